@@ -1,0 +1,213 @@
+/*
+ * pt_hip.h - C ABI of libpt_hip.so: the MI355X (gfx950) implementation of the
+ * Point-Teacher teacher->student training hot path.
+ *
+ * The reference (ZhuHaoranEIS/Point-Teacher) is 100 % Python; what its hot path
+ * calls natively are `mmcv.ops` (un-vendored) and long chains of small torch kernels.
+ * Every entry point below replaces ONE such call site; the comment above each names
+ * it as file:line relative to /root/reference/HBB_TOD/mmdet/.  INTEGRATION.md shows
+ * the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (HBM) unless marked [host]; fp32 / int32,
+ *     densely packed, row-major; nothing is allocated or freed inside a call;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls
+ *     only enqueue work - no host synchronisation, safe under hipGraph capture;
+ *   - return value: 0 on success, a negative PT_E* code on a rejected argument,
+ *     a positive hipError_t if a launch failed; pt_last_error() gives the text;
+ *   - images of a batch are concatenated; `off[B+1]` (int32, device) holds the
+ *     prefix offsets of per-image ground truths (off[0] = 0);
+ *   - index outputs use 0 = background / i+1 = gt i of that image
+ *     (AssignResult.gt_inds convention, core/bbox/assigners/assign_result.py).
+ */
+#ifndef PT_HIP_H
+#define PT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_OK 0
+#define PT_EINVAL (-1)  /* bad size / null pointer / unsupported parameter */
+#define PT_ELIMIT (-2)  /* size above a compiled-in limit (message says which) */
+
+const char* pt_last_error(void);
+/* ABI version, bumped when a signature changes. */
+int pt_abi_version(void);
+
+/* ------------------------------------------------------------------ assigners --
+ * TopkAssigner.assign with num_pre <= topk (every shipped config), i.e.
+ * core/bbox/assigners/topk_assigner.py:120-144: per gt the `num_pre` L1-nearest
+ * points (PointCost, match_costs/match_cost.py:188-214), later gt wins.
+ * points[P,2]; gt_xy[sumG,2]; off[B+1]; out gt_inds[B*P] (int32).
+ * If cand != NULL it receives the candidate rows [sumG,num_pre] (int32).
+ * Ties in distance are broken towards the LOWEST point index. num_pre <= 8. */
+int pt_topk_assign(const float* points, int P, const float* gt_xy, const int32_t* off, int B,
+                   int sumG, int num_pre, int32_t* gt_inds, int32_t* cand, void* stream);
+
+/* FUSETopkAssigner.assign (core/bbox/assigners/fuse_topk_assigner.py:91-118) fed the
+ * way _gnerate_pseudo_single does (dense_heads/fcos_head_p2b_ts.py:747-752):
+ * reg[B*P,4] are (l,t,r,b) distances decoded with `points`; cls[B*P,C] logits;
+ * cost = FocalLossCost*cls_w (match_cost.py:54-99) + InsiderCost*loc_w (:217-252).
+ * num_pre <= 8, topk < num_pre or >= num_pre (then every candidate is taken).
+ * cand[sumG,num_pre] (int32, required) receives the stage-1 candidates. */
+int pt_fuse_assign(const float* points, int P, const float* reg, const float* cls, int C,
+                   const float* gt_xy, const int32_t* gt_labels, const int32_t* off, int B,
+                   int sumG, int num_pre, int topk, float cls_w, float reg_w, float loc_w,
+                   int32_t* gt_inds, int32_t* cand, void* stream);
+
+/* Score-weighted pseudo-box fusion, fcos_head_p2b_ts.py:763-789.
+ * Uses gt_inds/cand from pt_fuse_assign.  Outputs per gt: pseudo_bboxes[sumG,4]
+ * (8x8 box around the point when no grid point was assigned), pseudo_points[sumG,2],
+ * pseudo_scores[sumG], nassigned[sumG] (int32) and iou_with_gt[sumG] (IoU with
+ * gt_bboxes, 0 where nassigned == 0; its mean over assigned gts is `mean_ious_pred`). */
+int pt_pseudo_boxes(const float* points, int P, const float* reg, const float* cls, int C,
+                    const float* gt_xy, const int32_t* gt_labels, const float* gt_bboxes,
+                    const int32_t* off, int B, int sumG, int num_pre, const int32_t* gt_inds,
+                    const int32_t* cand, float* pseudo_bboxes, float* pseudo_points,
+                    float* pseudo_scores, int32_t* nassigned, float* iou_with_gt, void* stream);
+
+/* FCOS target build, fcos_head_p2b_ts.py:586-603 and :669-706: labels[B*P] (int32,
+ * background = num_classes) and bbox_targets[B*P,4] = (l,t,r,b) w.r.t. the assigned
+ * box (box 0 of the image for unassigned points, zeros when the image has no box).
+ * If ctr_target != NULL it receives centerness_target (:1019-1038) for assigned
+ * points and 0 elsewhere. */
+int pt_fcos_targets(const float* points, int P, const int32_t* gt_inds, const float* boxes,
+                    const int32_t* box_labels, const int32_t* off, int B, int num_classes,
+                    int32_t* labels, float* bbox_targets, float* ctr_target, void* stream);
+
+/* ---------------------------------------------------------------------- losses --
+ * mmcv.ops.sigmoid_focal_loss, call site models/losses/focal_loss.py:85 (the
+ * importable twin py_sigmoid_focal_loss :11-56 is the oracle): element-wise
+ * loss[N,C]; labels[N] int32 in [0,C] (C = background); weight[N] may be NULL.
+ * fwd writes loss[N,C] (if non-NULL) and block partial sums partial[pt_focal_nblocks(N,C)];
+ * bwd writes grad[N,C] = scale[0] * weight[n] * dloss/dlogit (scale: device scalar). */
+int pt_focal_nblocks(int N, int C);
+int pt_sigmoid_focal_loss_fwd(const float* logits, const int32_t* labels, const float* weight,
+                              int N, int C, float gamma, float alpha, float* loss,
+                              float* partial, void* stream);
+int pt_sigmoid_focal_loss_bwd(const float* logits, const int32_t* labels, const float* weight,
+                              const float* scale, int N, int C, float gamma, float alpha,
+                              float* grad, void* stream);
+
+/* diou_loss (models/losses/iou_loss.py:139-189) and the min-over-9-shifted-targets
+ * part of DN_diou_loss (:414-463) in one pass over pred/target[N,4] (xyxy):
+ * diou[N] and dnmin[N] (dnmin may be NULL).  bwd: grad_pred[N,4] =
+ * g_diou[n]*d diou/d pred + g_dn[n]*d dnmin/d pred (either g may be NULL).
+ * torch autograd tie conventions are kept (max/min ties split 0.5, clamp passes at 0). */
+int pt_diou_fwd(const float* pred, const float* target, int N, float eps, float hyper,
+                float* diou, float* dnmin, void* stream);
+int pt_diou_bwd(const float* pred, const float* target, const float* g_diou, const float* g_dn,
+                int N, float eps, float hyper, float* grad_pred, void* stream);
+
+/* bbox_overlaps (core/bbox/iou_calculators/iou2d_calculator.py:74-260).
+ * mode 0 iou, 1 iof, 2 giou.  aligned: out[M]; pairwise: out[M,N]. */
+int pt_bbox_overlaps_aligned(const float* a, const float* b, int M, int mode, float eps,
+                             float* out, void* stream);
+int pt_bbox_overlaps_pairwise(const float* a, const float* b, int M, int N, int mode, float eps,
+                              float* out, void* stream);
+
+/* DeltaXYWHBBoxCoder.decode with means 0 / stds 1 (coder/delta_xywh_bbox_coder.py:144-270,
+ * call site fcos_head_p2b_ts.py:1210) fwd and bwd (w.r.t. deltas).  max_h/max_w <= 0: no clip. */
+int pt_delta2bbox_fwd(const float* rois, const float* deltas, int N, float max_h, float max_w,
+                      float wh_ratio_clip, float* out, void* stream);
+int pt_delta2bbox_bwd(const float* rois, const float* deltas, const float* grad_out, int N,
+                      float max_h, float max_w, float wh_ratio_clip, float* grad_deltas,
+                      void* stream);
+
+/* -------------------------------------------------------------------- RoIAlign --
+ * mmcv.ops.RoIAlign(output_size, spatial_scale, sampling_ratio=0, pool_mode='avg',
+ * aligned=True), built models/roi_heads/roi_extractors/base_roi_extractor.py:53-58,
+ * called fcos_head_p2b_ts.py:1202,1243,1268.  rois[K,5] = (batch, x1,y1,x2,y2).
+ * feat is [B,C,H,W] when channels_last == 0 and [B,H,W,C] when 1 (same for grad_feat);
+ * out / grad_out are always [K,C,out,out] (the layout the FC stack flattens).
+ * bwd ACCUMULATES into grad_feat (zero it first). C % 64 == 0 for channels_last. */
+int pt_roi_align_fwd(const float* feat, const float* rois, int B, int C, int H, int W, int K,
+                     int out_size, float spatial_scale, int sampling_ratio, int aligned,
+                     int channels_last, float* out, void* stream);
+int pt_roi_align_bwd(const float* grad_out, const float* rois, int B, int C, int H, int W, int K,
+                     int out_size, float spatial_scale, int sampling_ratio, int aligned,
+                     int channels_last, float* grad_feat, void* stream);
+
+/* ------------------------------------------------------------------ MIL bags --
+ * fine_proposals_from_cfg (detectors/syn_images_generator_v2.py:262-324) for a batch:
+ * boxes[sumG,4] -> props[sumG*U,4], valid[sumG*U] (uint8, IoF with the image > 0.7),
+ * U = R*R*(1+4*S) with R = n_ratios, S = n_shake.  ratios/shake are [host] arrays. */
+int pt_fine_proposals(const float* boxes, int sumG, const float* ratios, int n_ratios,
+                      const float* shake, int n_shake, float min_scale, float img_h, float img_w,
+                      float* props, uint8_t* valid, void* stream);
+
+/* gen_negative_proposals (syn_images_generator_v2.py:234-259): u[B,4,n] uniforms
+ * (the four torch.rand draws), pos[sum_pos,4] with pos_off[B+1];
+ * neg[B*n,4], neg_ok[B*n] (uint8: IoU < thr with every positive of its image). */
+int pt_negative_proposals(const float* u, int B, int n, const float* pos, const int32_t* pos_off,
+                          float img_h, float img_w, float iou_thr, float* neg, uint8_t* neg_ok,
+                          void* stream);
+
+/* mil_bag_training + gfocal_loss (fcos_head_p2b_ts.py:1147-1180, :1074-1078).
+ * cls/ins[NB,U2,C] (NB = num_gt*U1 bags), valid[NB*U2] uint8, labels[NB] int32.
+ * fwd: bag_loss[NB] (weighted gfocal summed over classes, 0 for empty bags) and
+ * bag_valid[NB] (uint8).  bwd: grads = scale[0] * d(sum bag_loss)/d(cls, ins). U2 <= 1024. */
+int pt_mil_bag_loss_fwd(const float* cls, const float* ins, const uint8_t* valid,
+                        const int32_t* labels, int NB, int U2, int C, float* bag_loss,
+                        uint8_t* bag_valid, void* stream);
+int pt_mil_bag_loss_bwd(const float* cls, const float* ins, const uint8_t* valid,
+                        const int32_t* labels, const float* scale, int NB, int U2, int C,
+                        float* grad_cls, float* grad_ins, void* stream);
+/* negative bags, same file :1169-1179: loss[M] = gfocal(sigmoid(x), 0, w) summed over C. */
+int pt_mil_neg_loss_fwd(const float* neg_cls, const uint8_t* neg_w, int M, int C, float* loss,
+                        void* stream);
+int pt_mil_neg_loss_bwd(const float* neg_cls, const uint8_t* neg_w, const float* scale, int M,
+                        int C, float* grad, void* stream);
+
+/* mil_bag_selection (+_single) fcos_head_p2b_ts.py:1112-1145, :1092-1110: per gt the
+ * top-k of sigmoid(cls)[label]*norm-softmax(ins)[label] over the whole U1*U2 bag,
+ * weighted box mean, clamp to the image, (1-beta)*box + beta*pseudo. topk <= 8. */
+int pt_mil_bag_select(const float* cls, const float* ins, const uint8_t* valid,
+                      const int32_t* labels, const float* bags, const float* pseudo, int NG,
+                      int U1, int U2, int C, int topk, float beta, float img_h, float img_w,
+                      float* merged, void* stream);
+
+/* ------------------------------------------------------- EMA / optimizer step --
+ * update_teacher_model (detectors/fcos_p2b_teacher_student.py:254-257) over ONE flat
+ * parameter buffer: teacher = alpha*teacher + one_minus_alpha*student (the caller rounds
+ * 1-alpha from double exactly like `t.mul_(a).add_(1 - a, s)` does). */
+int pt_ema_update(float* teacher, const float* student, int64_t n, float alpha,
+                  float one_minus_alpha, void* stream);
+/* squared L2 norm of a flat gradient buffer -> partial[pt_sqnorm_nblocks(n)] */
+int pt_sqnorm_nblocks(int64_t n);
+int pt_sqnorm_partial(const float* g, int64_t n, float* partial, void* stream);
+/* mmcv OptimizerHook grad-clip (max_norm, L2) + torch.optim.SGD(momentum, weight_decay)
+ * with the paramwise_cfg of aitodv2_point_teacher_0%.py:212-215 (bias lr x2, bias decay 0):
+ * elements [0,split) are weights, [split,n) biases.  sqnorm[0] = total squared grad
+ * norm (device scalar, already reduced over ranks if any); lr is a device scalar. */
+int pt_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, int64_t split,
+                const float* lr, float momentum, float weight_decay, float bias_lr_mult,
+                float bias_decay_mult, const float* sqnorm, float max_norm, int first_step,
+                void* stream);
+
+/* ------------------------------------------------------------------------ NMS --
+ * mmcv.ops.nms (offset 0), call site core/post_processing/bbox_nms.py:76 through
+ * batched_nms: boxes[N,4] must be sorted by descending score; class-aware when
+ * class_id != NULL.  keep[N] uint8.  N <= 8192. mask_ws: N*ceil(N/64) uint64 workspace. */
+int pt_nms_sorted(const float* boxes, const int32_t* class_id, int N, float iou_thr,
+                  uint64_t* mask_ws, uint8_t* keep, void* stream);
+/* mmcv.ops.box_iou_rotated (OBB rotate_iou2d_calculator; syn_images_generator_v2.py:667 via
+ * nms_rotated): boxes (cx,cy,w,h,angle[rad]). aligned: out[M]; else out[M,N]. */
+int pt_box_iou_rotated(const float* a, const float* b, int M, int N, int aligned, float* out,
+                       void* stream);
+/* mmcv.ops.nms_rotated: dets[N,5] sorted by descending score; keep[N] uint8. N <= 8192. */
+int pt_nms_rotated_sorted(const float* dets, int N, float iou_thr, uint64_t* mask_ws,
+                          uint8_t* keep, void* stream);
+/* the 255-mask of generate_black_paper (syn_images_generator_v2.py:678-688): every pixel
+ * inside or on the boundary of one of the quads[Q,8] (vertices truncated to int32 like
+ * polygon.astype(np.int32)) with alive[q] != 0 is set to `value` in img[C,H,W]. */
+int pt_fill_quads(float* img, int C, int H, int W, const float* quads, const uint8_t* alive,
+                  int Q, float value, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_HIP_H */

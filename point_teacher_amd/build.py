@@ -1,0 +1,68 @@
+"""Build libpt_hip.so (gfx950) in-tree with hipcc.  `python -m point_teacher_amd.build`.
+
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels to the GPU box
+with the gpurun snapshot."""
+import concurrent.futures
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OUT = os.path.join(HERE, 'libpt_hip.so')
+SOURCES = ['assign.hip', 'losses.hip', 'roi_align.hip', 'mil.hip', 'optim.hip', 'nms.hip']
+# -ffp-contract=off: index decisions (top-k, insider test) must see the same fp32 roundings
+# as the reference's un-fused torch ops; kernels that want FMA ask for it with fmaf().
+FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-ffp-contract=off', '-Wall',
+         '-Wno-unused-function', '-Wno-unused-variable']
+
+
+def hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError('hipcc not found')
+
+
+def _newer(src, dst):
+    return (not os.path.exists(dst)) or os.path.getmtime(src) > os.path.getmtime(dst)
+
+
+def build(force=False, verbose=True):
+    cc = hipcc()
+    objdir = os.path.join(HERE, 'build')
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(CSRC, 'pt_common.h'), os.path.join(HERE, '..', 'include', 'pt_hip.h')]
+    jobs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, s.replace('.hip', '.o'))
+        if force or _newer(src, obj) or any(_newer(h, obj) for h in hdrs):
+            jobs.append((src, obj))
+
+    def compile_one(job):
+        src, obj = job
+        cmd = [cc] + FLAGS + ['-c', src, '-o', obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return job, r
+    with concurrent.futures.ThreadPoolExecutor(max_workers=6) as ex:
+        for (src, obj), r in ex.map(compile_one, jobs):
+            if verbose and r.stderr.strip():
+                print(r.stderr, file=sys.stderr)
+            if r.returncode != 0:
+                raise RuntimeError(f'hipcc failed on {src}:\n{r.stderr}')
+            if verbose:
+                print('compiled', os.path.basename(src))
+    objs = [os.path.join(objdir, s.replace('.hip', '.o')) for s in SOURCES]
+    if jobs or force or not os.path.exists(OUT):
+        cmd = [cc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'link failed:\n{r.stderr}')
+        if verbose:
+            print('linked', OUT)
+    return OUT
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

@@ -1,0 +1,246 @@
+// NMS, rotated IoU / rotated NMS and the step-1 quad rasteriser for gfx950.
+// NMS is the classic 64x64 bitmask formulation: one workgroup of 64 threads per
+// (row-block, col-block) tile writes a 64-bit suppression word per row; a single
+// wavefront then walks the rows in score order keeping the "removed" bit-set in registers
+// (one or two 64-bit words per lane) - no host round trip.
+#include "pt_common.h"
+
+namespace pt {
+
+constexpr int NMS_MAXN = 8192;
+
+__device__ __forceinline__ float iou_xyxy(const float4 a, const float4 b) {
+  const float w = fmaxf(fminf(a.z, b.z) - fmaxf(a.x, b.x), 0.f);
+  const float h = fmaxf(fminf(a.w, b.w) - fmaxf(a.y, b.y), 0.f);
+  const float inter = w * h;
+  const float ua = (a.z - a.x) * (a.w - a.y) + (b.z - b.x) * (b.w - b.y) - inter;
+  return inter / ua;
+}
+
+// --------------------------------------------------------------- rotated IoU --
+struct P2 {
+  float x, y;
+};
+
+__device__ __forceinline__ void rbox_corners(const float* b, P2* p) {
+  const float c = cosf(b[4]), s = sinf(b[4]);
+  const float hw = b[2] * 0.5f, hh = b[3] * 0.5f;
+  const float dx[4] = {-hw, hw, hw, -hw}, dy[4] = {-hh, -hh, hh, hh};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    p[i].x = b[0] + dx[i] * c - dy[i] * s;
+    p[i].y = b[1] + dx[i] * s + dy[i] * c;
+  }
+}
+
+// Convex clip of `poly` (n vertices, CCW or CW consistent with the clip box) by the
+// half-plane on the left of a->b.  Sutherland-Hodgman; at most n+1 output vertices.
+__device__ __forceinline__ int clip_edge(const P2* in, int n, P2 a, P2 b, P2* out) {
+  int m = 0;
+  const float ex = b.x - a.x, ey = b.y - a.y;
+  for (int i = 0; i < n; ++i) {
+    const P2 p = in[i], q = in[(i + 1 == n) ? 0 : i + 1];
+    const float sp = ex * (p.y - a.y) - ey * (p.x - a.x);
+    const float sq = ex * (q.y - a.y) - ey * (q.x - a.x);
+    if (sp >= 0.f) out[m++] = p;
+    if ((sp > 0.f && sq < 0.f) || (sp < 0.f && sq > 0.f)) {
+      const float t = sp / (sp - sq);
+      out[m].x = p.x + t * (q.x - p.x);
+      out[m].y = p.y + t * (q.y - p.y);
+      ++m;
+    }
+  }
+  return m;
+}
+
+__device__ float rotated_iou(const float* b1, const float* b2) {
+  const float a1 = b1[2] * b1[3], a2 = b2[2] * b2[3];
+  if (a1 < 1e-14f || a2 < 1e-14f) return 0.f;
+  // translate to the first centre to keep fp32 precision (as mmcv's kernel does)
+  float c1[5] = {0.f, 0.f, b1[2], b1[3], b1[4]};
+  float c2[5] = {b2[0] - b1[0], b2[1] - b1[1], b2[2], b2[3], b2[4]};
+  P2 p1[4], p2[4], bufA[12], bufB[12];
+  rbox_corners(c1, p1);
+  rbox_corners(c2, p2);
+  int n = 4;
+  for (int i = 0; i < 4; ++i) bufA[i] = p1[i];
+  P2* cur = bufA;
+  P2* nxt = bufB;
+  for (int e = 0; e < 4 && n > 0; ++e) {
+    n = clip_edge(cur, n, p2[e], p2[(e + 1) & 3], nxt);
+    P2* t = cur; cur = nxt; nxt = t;
+  }
+  float inter = 0.f;
+  for (int i = 0; i < n; ++i) {
+    const P2 p = cur[i], q = cur[(i + 1 == n) ? 0 : i + 1];
+    inter += p.x * q.y - q.x * p.y;
+  }
+  inter = fabsf(inter) * 0.5f;
+  return inter / (a1 + a2 - inter);
+}
+
+__global__ void box_iou_rotated_kernel(const float* __restrict__ a, const float* __restrict__ b, int M, int N,
+                                       int aligned, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = aligned ? M : (long)M * N;
+  if (i >= total) return;
+  const int m = aligned ? (int)i : (int)(i / N), n = aligned ? (int)i : (int)(i % N);
+  float x[5], y[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { x[k] = a[(size_t)m * 5 + k]; y[k] = b[(size_t)n * 5 + k]; }
+  out[i] = rotated_iou(x, y);
+}
+
+// ------------------------------------------------------------------ bitmask ---
+template <bool ROT>
+__global__ void __launch_bounds__(64)
+    nms_mask_kernel(const float* __restrict__ boxes, const int32_t* __restrict__ cls, int N, float thr,
+                    unsigned long long* __restrict__ mask) {
+  const int rb = blockIdx.y, cb = blockIdx.x;
+  if (cb < rb) return;  // only the upper triangle is ever read
+  const int cols = cdiv(N, 64);
+  constexpr int D = ROT ? 5 : 4;
+  __shared__ float cbox[64 * 5];
+  __shared__ int ccls[64];
+  const int j = cb * 64 + threadIdx.x;
+  if (j < N) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) cbox[threadIdx.x * 5 + k] = boxes[(size_t)j * D + k];
+    ccls[threadIdx.x] = cls ? cls[j] : 0;
+  }
+  __syncthreads();
+  const int i = rb * 64 + threadIdx.x;
+  if (i >= N) return;
+  float me[5];
+#pragma unroll
+  for (int k = 0; k < D; ++k) me[k] = boxes[(size_t)i * D + k];
+  const int mycls = cls ? cls[i] : 0;
+  unsigned long long bits = 0ull;
+  const int nc = min(64, N - cb * 64);
+  const int start = (rb == cb) ? threadIdx.x + 1 : 0;
+  for (int t = start; t < nc; ++t) {
+    if (ccls[t] != mycls) continue;
+    float v;
+    if (ROT) {
+      v = rotated_iou(me, &cbox[t * 5]);
+    } else {
+      v = iou_xyxy(make_float4(me[0], me[1], me[2], me[3]),
+                   make_float4(cbox[t * 5], cbox[t * 5 + 1], cbox[t * 5 + 2], cbox[t * 5 + 3]));
+    }
+    if (v > thr) bits |= 1ull << t;
+  }
+  mask[(size_t)i * cols + cb] = bits;
+}
+
+// One wavefront: lane l owns removed-words l and l+64.
+__global__ void __launch_bounds__(64)
+    nms_scan_kernel(const unsigned long long* __restrict__ mask, int N, uint8_t* __restrict__ keep) {
+  const int cols = cdiv(N, 64);
+  const int lane = threadIdx.x;
+  unsigned long long r0 = 0ull, r1 = 0ull;
+  for (int i = 0; i < N; ++i) {
+    const int wd = i >> 6;
+    const unsigned long long src = (wd < 64) ? r0 : r1;
+    const unsigned lo = __shfl((unsigned)(src & 0xffffffffu), wd & 63, 64);
+    const unsigned hi = __shfl((unsigned)(src >> 32), wd & 63, 64);
+    const unsigned long long word = ((unsigned long long)hi << 32) | lo;
+    const bool removed = (word >> (i & 63)) & 1ull;
+    if (lane == 0) keep[i] = removed ? 0 : 1;
+    if (!removed) {
+      // row i only has valid words for columns >= i/64
+      if (lane < cols && lane >= wd) r0 |= mask[(size_t)i * cols + lane];
+      if (lane + 64 < cols && lane + 64 >= wd) r1 |= mask[(size_t)i * cols + lane + 64];
+    }
+  }
+}
+
+// ------------------------------------------------------------- quad fill -----
+__global__ void __launch_bounds__(256)
+    fill_quads_kernel(float* __restrict__ img, int C, int H, int W, const float* __restrict__ quads,
+                      const uint8_t* __restrict__ alive, float value) {
+  const int q = blockIdx.x;
+  if (alive && !alive[q]) return;
+  long long vx[4], vy[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    vx[i] = (long long)(int)quads[(size_t)q * 8 + 2 * i];       // astype(np.int32): truncation
+    vy[i] = (long long)(int)quads[(size_t)q * 8 + 2 * i + 1];
+  }
+  long long area2 = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) area2 += vx[i] * vy[(i + 1) & 3] - vx[(i + 1) & 3] * vy[i];
+  if (area2 == 0) return;
+  const long long sgn = area2 > 0 ? 1 : -1;
+  long long x0 = vx[0], x1 = vx[0], y0 = vy[0], y1 = vy[0];
+#pragma unroll
+  for (int i = 1; i < 4; ++i) {
+    x0 = vx[i] < x0 ? vx[i] : x0; x1 = vx[i] > x1 ? vx[i] : x1;
+    y0 = vy[i] < y0 ? vy[i] : y0; y1 = vy[i] > y1 ? vy[i] : y1;
+  }
+  x0 = x0 < 0 ? 0 : x0; y0 = y0 < 0 ? 0 : y0;
+  x1 = x1 > W - 1 ? W - 1 : x1; y1 = y1 > H - 1 ? H - 1 : y1;
+  if (x1 < x0 || y1 < y0) return;
+  const int bw = (int)(x1 - x0 + 1), bh = (int)(y1 - y0 + 1);
+  for (int t = threadIdx.x; t < bw * bh; t += blockDim.x) {
+    const long long x = x0 + t % bw, y = y0 + t / bw;
+    bool in = true;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long long cr = (vx[(i + 1) & 3] - vx[i]) * (y - vy[i]) - (vy[(i + 1) & 3] - vy[i]) * (x - vx[i]);
+      in = in && (cr * sgn >= 0);
+    }
+    if (in)
+      for (int c = 0; c < C; ++c) img[((size_t)c * H + y) * W + x] = value;
+  }
+}
+
+}  // namespace pt
+
+using namespace pt;
+
+template <bool ROT>
+static int nms_impl(const char* fn, const float* boxes, const int32_t* cls, int N, float thr, uint64_t* ws,
+                    uint8_t* keep, void* stream) {
+  if (N == 0) return PT_OK;
+  PT_REQUIRE(boxes && ws && keep && N > 0, PT_EINVAL, "%s: bad argument", fn);
+  PT_REQUIRE(N <= NMS_MAXN, PT_ELIMIT, "%s: N=%d above %d", fn, N, NMS_MAXN);
+  const int cols = cdiv(N, 64);
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(nms_mask_kernel<ROT>, dim3(cols, cols), dim3(64), 0, s, boxes, cls, N, thr,
+                     reinterpret_cast<unsigned long long*>(ws));
+  PT_LAUNCH_CHECK(fn);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<const unsigned long long*>(ws), N,
+                     keep);
+  PT_LAUNCH_CHECK(fn);
+  return PT_OK;
+}
+
+extern "C" int pt_nms_sorted(const float* boxes, const int32_t* class_id, int N, float iou_thr, uint64_t* mask_ws,
+                             uint8_t* keep, void* stream) {
+  return nms_impl<false>("pt_nms_sorted", boxes, class_id, N, iou_thr, mask_ws, keep, stream);
+}
+
+extern "C" int pt_nms_rotated_sorted(const float* dets, int N, float iou_thr, uint64_t* mask_ws, uint8_t* keep,
+                                     void* stream) {
+  return nms_impl<true>("pt_nms_rotated_sorted", dets, nullptr, N, iou_thr, mask_ws, keep, stream);
+}
+
+extern "C" int pt_box_iou_rotated(const float* a, const float* b, int M, int N, int aligned, float* out,
+                                  void* stream) {
+  if (M == 0 || N == 0) return PT_OK;
+  PT_REQUIRE(a && b && out && M > 0 && N > 0 && (!aligned || M == N), PT_EINVAL, "pt_box_iou_rotated: bad argument");
+  const long total = aligned ? M : (long)M * N;
+  hipLaunchKernelGGL(box_iou_rotated_kernel, dim3(cdiv(total, 128)), dim3(128), 0, as_stream(stream), a, b, M, N,
+                     aligned, out);
+  PT_LAUNCH_CHECK("pt_box_iou_rotated");
+  return PT_OK;
+}
+
+extern "C" int pt_fill_quads(float* img, int C, int H, int W, const float* quads, const uint8_t* alive, int Q,
+                             float value, void* stream) {
+  if (Q == 0) return PT_OK;
+  PT_REQUIRE(img && quads && C > 0 && H > 0 && W > 0 && Q > 0, PT_EINVAL, "pt_fill_quads: bad argument");
+  hipLaunchKernelGGL(fill_quads_kernel, dim3(Q), dim3(256), 0, as_stream(stream), img, C, H, W, quads, alive, value);
+  PT_LAUNCH_CHECK("pt_fill_quads");
+  return PT_OK;
+}

@@ -1,0 +1,72 @@
+// Shared helpers for the gfx950 kernels of libpt_hip.so (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/pt_hip.h"
+
+namespace pt {
+
+void set_error(const char* fmt, ...);
+
+#define PT_REQUIRE(cond, code, ...)      \
+  do {                                   \
+    if (!(cond)) {                       \
+      pt::set_error(__VA_ARGS__);        \
+      return (code);                     \
+    }                                    \
+  } while (0)
+
+// Check the launch that was just enqueued (no synchronisation).
+#define PT_LAUNCH_CHECK(name)                                                  \
+  do {                                                                         \
+    hipError_t _e = hipGetLastError();                                         \
+    if (_e != hipSuccess) {                                                    \
+      pt::set_error("%s: launch failed: %s", name, hipGetErrorString(_e));     \
+      return (int)_e;                                                          \
+    }                                                                          \
+  } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+__host__ __device__ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+constexpr int WAVE = 64;
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned long long t = __shfl_xor(v, o, 64);
+    v = t < v ? t : v;
+  }
+  return v;
+}
+
+// Block-wide sum for blockDim.x <= 1024 (multiple of 64); result valid in every thread.
+// `sm` must hold >= 17 floats.
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  float t = (lane < nw) ? sm[lane] : 0.f;
+  t = wave_sum(t);
+  return t;
+}
+
+// sigmoid exactly as torch's CPU/CUDA kernels compute it: 1 / (1 + exp(-x))
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+}  // namespace pt

@@ -1,0 +1,407 @@
+"""Tensor-level wrappers (and autograd Functions) over the C ABI in include/pt_hip.h.
+
+Everything here runs on the HIP device through libpt_hip.so; there is no torch/CPU
+fallback.  Batched inputs follow the C ABI convention: per-image ground truths are
+concatenated and described by an int32 offsets tensor `off[B+1]` on the device.
+"""
+import numpy as np
+import torch
+
+from . import hip
+
+f32, i32, u8 = torch.float32, torch.int32, torch.uint8
+
+
+def _f(x):
+    return x.contiguous().to(f32)
+
+
+def make_offsets(counts, device):
+    """Host list of per-image counts -> (off int32 [B+1] on device, total)."""
+    off = np.zeros(len(counts) + 1, np.int32)
+    off[1:] = np.cumsum(counts)
+    return torch.from_numpy(off).to(device, non_blocking=True), int(off[-1])
+
+
+# ------------------------------------------------------------------ assigners --
+
+def topk_assign(points, gt_xy, off, B, num_pre, want_cand=False):
+    """pt_topk_assign.  points [P,2]; gt_xy [sumG,>=2] (first two columns used).
+    Returns gt_inds int32 [B,P] (and cand int32 [sumG,num_pre])."""
+    P = points.shape[0]
+    sumG = gt_xy.shape[0]
+    gt_inds = torch.empty((B, P), dtype=i32, device=points.device)
+    cand = torch.empty((sumG, num_pre), dtype=i32, device=points.device) if want_cand else None
+    xy = _f(gt_xy[:, :2]) if sumG else None
+    hip.call('pt_topk_assign', _f(points), P, xy, off, B, sumG, num_pre, gt_inds, cand)
+    return (gt_inds, cand) if want_cand else gt_inds
+
+
+def fuse_assign(points, reg, cls, gt_xy, gt_labels, off, B, num_pre=5, topk=3, cls_w=1.0, reg_w=1.0, loc_w=1.0):
+    """pt_fuse_assign.  reg [B*P,4] distances, cls [B*P,C] logits."""
+    P = points.shape[0]
+    sumG = gt_xy.shape[0]
+    C = cls.shape[-1]
+    gt_inds = torch.empty((B, P), dtype=i32, device=points.device)
+    cand = torch.empty((sumG, num_pre), dtype=i32, device=points.device)
+    hip.call('pt_fuse_assign', _f(points), P, _f(reg), _f(cls), C, _f(gt_xy[:, :2]) if sumG else None,
+             gt_labels.to(i32).contiguous() if sumG else None, off, B, sumG, num_pre, topk,
+             float(cls_w), float(reg_w), float(loc_w), gt_inds, cand)
+    return gt_inds, cand
+
+
+def pseudo_boxes(points, reg, cls, gt_xy, gt_labels, gt_bboxes, off, B, gt_inds, cand):
+    """pt_pseudo_boxes -> dict(bboxes, points, scores, nassigned, iou)."""
+    P, sumG, C = points.shape[0], gt_xy.shape[0], cls.shape[-1]
+    dev = points.device
+    out = dict(bboxes=torch.empty((sumG, 4), dtype=f32, device=dev), points=torch.empty((sumG, 2), dtype=f32, device=dev),
+               scores=torch.empty((sumG,), dtype=f32, device=dev), nassigned=torch.empty((sumG,), dtype=i32, device=dev),
+               iou=torch.empty((sumG,), dtype=f32, device=dev))
+    if sumG:
+        hip.call('pt_pseudo_boxes', _f(points), P, _f(reg), _f(cls), C, _f(gt_xy[:, :2]), gt_labels.to(i32).contiguous(),
+                 _f(gt_bboxes) if gt_bboxes is not None else None, off, B, sumG, cand.shape[1], gt_inds, cand,
+                 out['bboxes'], out['points'], out['scores'], out['nassigned'], out['iou'] if gt_bboxes is not None else None)
+    return out
+
+
+def fcos_targets(points, gt_inds, boxes, box_labels, off, B, num_classes, want_ctr=True):
+    """pt_fcos_targets -> labels int32 [B*P], bbox_targets [B*P,4], ctr_target [B*P]."""
+    P = points.shape[0]
+    dev = points.device
+    labels = torch.empty((B * P,), dtype=i32, device=dev)
+    tg = torch.empty((B * P, 4), dtype=f32, device=dev)
+    ctr = torch.empty((B * P,), dtype=f32, device=dev) if want_ctr else None
+    nb = boxes.shape[0] if boxes is not None else 0
+    hip.call('pt_fcos_targets', _f(points), P, gt_inds.contiguous(), _f(boxes) if nb else None,
+             box_labels.to(i32).contiguous() if (box_labels is not None and nb) else None, off, B, num_classes,
+             labels, tg, ctr)
+    return labels, tg, ctr
+
+
+# ---------------------------------------------------------------------- losses --
+
+class _FocalSum(torch.autograd.Function):
+    """sum_n,c weight[n] * focal(logit[n,c]) (un-normalised)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, weight, gamma, alpha):
+        N, C = logits.shape
+        logits = _f(logits)
+        nb = hip.call('pt_focal_nblocks', N, C)
+        partial = torch.empty((nb,), dtype=f32, device=logits.device)
+        hip.call('pt_sigmoid_focal_loss_fwd', logits, labels, weight, N, C, float(gamma), float(alpha), None, partial)
+        ctx.save_for_backward(logits, labels, weight)
+        ctx.ga = (float(gamma), float(alpha))
+        return partial.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels, weight = ctx.saved_tensors
+        N, C = logits.shape
+        grad = torch.empty_like(logits)
+        hip.call('pt_sigmoid_focal_loss_bwd', logits, labels, weight, g.reshape(1).contiguous().to(f32), N, C,
+                 ctx.ga[0], ctx.ga[1], grad)
+        return grad, None, None, None, None
+
+
+def sigmoid_focal_loss_sum(logits, labels, weight=None, gamma=2.0, alpha=0.25):
+    labels = labels.to(i32).contiguous()
+    weight = _f(weight) if weight is not None else None
+    return _FocalSum.apply(logits, labels, weight, gamma, alpha)
+
+
+def sigmoid_focal_loss_elem(logits, labels, gamma=2.0, alpha=0.25):
+    """Element-wise loss [N,C] (no grad), as mmcv.ops.sigmoid_focal_loss(..., 'none')."""
+    N, C = logits.shape
+    out = torch.empty((N, C), dtype=f32, device=logits.device)
+    nb = hip.call('pt_focal_nblocks', N, C)
+    partial = torch.empty((nb,), dtype=f32, device=logits.device)
+    hip.call('pt_sigmoid_focal_loss_fwd', _f(logits.detach()), labels.to(i32).contiguous(), None, N, C, float(gamma),
+             float(alpha), out, partial)
+    return out
+
+
+class _DiouPair(torch.autograd.Function):
+    """(diou[N], dnmin[N]) of pred/target [N,4]."""
+
+    @staticmethod
+    def forward(ctx, pred, target, eps, hyper, want_dn):
+        pred, target = _f(pred), _f(target)
+        N = pred.shape[0]
+        diou = torch.empty((N,), dtype=f32, device=pred.device)
+        dn = torch.empty((N,), dtype=f32, device=pred.device) if want_dn else None
+        hip.call('pt_diou_fwd', pred, target, N, float(eps), float(hyper), diou, dn)
+        ctx.save_for_backward(pred, target)
+        ctx.cfg = (float(eps), float(hyper), want_dn)
+        if want_dn:
+            return diou, dn
+        dummy = diou.new_zeros(())
+        ctx.mark_non_differentiable(dummy)
+        return diou, dummy
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        pred, target = ctx.saved_tensors
+        eps, hyper, want_dn = ctx.cfg
+        N = pred.shape[0]
+        grad = torch.empty_like(pred)
+        hip.call('pt_diou_bwd', pred, target, _f(g1) if g1 is not None else None,
+                 _f(g2) if (want_dn and g2 is not None) else None, N, eps, hyper, grad)
+        return grad, None, None, None, None
+
+
+def diou_loss_elem(pred, target, eps=1e-6):
+    return _DiouPair.apply(pred, target, eps, 0.0, False)[0]
+
+
+def dn_diou_pair(pred, target, hyper, eps=1e-6):
+    return _DiouPair.apply(pred, target, eps, hyper, True)
+
+
+_MODE = {'iou': 0, 'iof': 1, 'giou': 2}
+
+
+def bbox_overlaps(b1, b2, mode='iou', is_aligned=False, eps=1e-6):
+    """Same contract as mmdet's bbox_overlaps (iou2d_calculator.py:74)."""
+    M, N = b1.shape[0], b2.shape[0]
+    if is_aligned:
+        assert M == N
+        out = torch.empty((M,), dtype=f32, device=b1.device)
+        hip.call('pt_bbox_overlaps_aligned', _f(b1), _f(b2), M, _MODE[mode], float(eps), out)
+    else:
+        out = torch.empty((M, N), dtype=f32, device=b1.device)
+        hip.call('pt_bbox_overlaps_pairwise', _f(b1), _f(b2), M, N, _MODE[mode], float(eps), out)
+    return out
+
+
+class _Delta2BBox(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rois, deltas, max_h, max_w, clip):
+        rois, deltas = _f(rois), _f(deltas)
+        N = rois.shape[0]
+        out = torch.empty((N, 4), dtype=f32, device=rois.device)
+        hip.call('pt_delta2bbox_fwd', rois, deltas, N, float(max_h), float(max_w), float(clip), out)
+        ctx.save_for_backward(rois, deltas)
+        ctx.cfg = (float(max_h), float(max_w), float(clip))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        rois, deltas = ctx.saved_tensors
+        N = rois.shape[0]
+        gd = torch.empty_like(deltas)
+        hip.call('pt_delta2bbox_bwd', rois, deltas, _f(g), N, *ctx.cfg, gd)
+        return None, gd, None, None, None
+
+
+def delta2bbox(rois, deltas, max_shape=None, wh_ratio_clip=16 / 1000):
+    mh, mw = (float(max_shape[0]), float(max_shape[1])) if max_shape is not None else (0.0, 0.0)
+    return _Delta2BBox.apply(rois, deltas, mh, mw, wh_ratio_clip)
+
+
+# -------------------------------------------------------------------- RoIAlign --
+
+class _RoIAlign(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, rois, out_size, scale, sampling_ratio, aligned):
+        B, C, H, W = feat.shape
+        cl = feat.is_contiguous(memory_format=torch.channels_last) and not feat.is_contiguous()
+        if cl:
+            fbuf = feat.permute(0, 2, 3, 1)            # a contiguous [B,H,W,C] view
+        else:
+            fbuf = feat.contiguous()
+        rois = _f(rois)
+        K = rois.shape[0]
+        out = torch.empty((K, C, out_size, out_size), dtype=f32, device=feat.device)
+        hip.call('pt_roi_align_fwd', fbuf, rois, B, C, H, W, K, out_size, float(scale), sampling_ratio,
+                 int(aligned), int(cl), out)
+        ctx.save_for_backward(rois)
+        ctx.cfg = (B, C, H, W, out_size, float(scale), sampling_ratio, int(aligned), cl)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        rois, = ctx.saved_tensors
+        B, C, H, W, out_size, scale, sr, aligned, cl = ctx.cfg
+        K = rois.shape[0]
+        if cl:
+            gbuf = torch.zeros((B, H, W, C), dtype=f32, device=g.device)
+        else:
+            gbuf = torch.zeros((B, C, H, W), dtype=f32, device=g.device)
+        hip.call('pt_roi_align_bwd', _f(g), rois, B, C, H, W, K, out_size, scale, sr, aligned, int(cl), gbuf)
+        gfeat = gbuf.permute(0, 3, 1, 2) if cl else gbuf
+        return gfeat, None, None, None, None, None
+
+
+def roi_align(feat, rois, output_size=7, spatial_scale=1.0, sampling_ratio=0, aligned=True):
+    """mmcv.ops.roi_align(input, rois, output_size, spatial_scale, sampling_ratio, 'avg', aligned)."""
+    return _RoIAlign.apply(feat, rois, int(output_size), spatial_scale, int(sampling_ratio), bool(aligned))
+
+
+# ------------------------------------------------------------------ MIL bags --
+
+def fine_proposals(boxes, base_ratios, shake_ratio, min_scale, img_hw):
+    """boxes [sumG,4] -> (props [sumG*U,4], valid uint8 [sumG*U])."""
+    sumG = boxes.shape[0]
+    shake = list(shake_ratio) if shake_ratio is not None else []
+    U = len(base_ratios) ** 2 * (1 + 4 * len(shake))
+    props = torch.empty((sumG * U, 4), dtype=f32, device=boxes.device)
+    valid = torch.empty((sumG * U,), dtype=u8, device=boxes.device)
+    hip.call('pt_fine_proposals', _f(boxes), sumG, hip.host_floats(base_ratios), len(base_ratios),
+             hip.host_floats(shake), len(shake), float(min_scale), float(img_hw[0]), float(img_hw[1]), props, valid)
+    return props, valid
+
+
+def negative_proposals(u, pos, pos_off, img_hw, iou_thr=0.3):
+    """u [B,4,n] uniforms -> (neg [B*n,4], ok uint8 [B*n])."""
+    B, _, n = u.shape
+    neg = torch.empty((B * n, 4), dtype=f32, device=u.device)
+    ok = torch.empty((B * n,), dtype=u8, device=u.device)
+    hip.call('pt_negative_proposals', _f(u), B, n, _f(pos), pos_off, float(img_hw[0]), float(img_hw[1]),
+             float(iou_thr), neg, ok)
+    return neg, ok
+
+
+class _MilBagLoss(torch.autograd.Function):
+    """sum over bags of the weighted gfocal bag loss; also returns #valid bags."""
+
+    @staticmethod
+    def forward(ctx, cls, ins, valid, labels):
+        NB, U2, C = cls.shape
+        cls, ins = _f(cls), _f(ins)
+        bl = torch.empty((NB,), dtype=f32, device=cls.device)
+        bv = torch.empty((NB,), dtype=u8, device=cls.device)
+        hip.call('pt_mil_bag_loss_fwd', cls, ins, valid, labels, NB, U2, C, bl, bv)
+        ctx.save_for_backward(cls, ins, valid, labels)
+        nvalid = bv.sum().to(f32)
+        ctx.mark_non_differentiable(nvalid)
+        return bl.sum(), nvalid
+
+    @staticmethod
+    def backward(ctx, g, _):
+        cls, ins, valid, labels = ctx.saved_tensors
+        NB, U2, C = cls.shape
+        gc, gi = torch.empty_like(cls), torch.empty_like(ins)
+        hip.call('pt_mil_bag_loss_bwd', cls, ins, valid, labels, g.reshape(1).contiguous().to(f32), NB, U2, C, gc, gi)
+        return gc, gi, None, None
+
+
+def mil_bag_loss_sum(cls, ins, valid, labels):
+    """cls/ins [NB,U2,C]; valid uint8 [NB*U2]; labels [NB] -> (sum loss, n valid bags)."""
+    return _MilBagLoss.apply(cls, ins, valid.to(u8).contiguous(), labels.to(i32).contiguous())
+
+
+class _MilNegLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        M, C = x.shape
+        x = _f(x)
+        out = torch.empty((M,), dtype=f32, device=x.device)
+        hip.call('pt_mil_neg_loss_fwd', x, w, M, C, out)
+        ctx.save_for_backward(x, w)
+        return out.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        M, C = x.shape
+        gx = torch.empty_like(x)
+        hip.call('pt_mil_neg_loss_bwd', x, w, g.reshape(1).contiguous().to(f32), M, C, gx)
+        return gx, None
+
+
+def mil_neg_loss_sum(neg_cls, neg_w):
+    return _MilNegLoss.apply(neg_cls, neg_w.to(u8).contiguous())
+
+
+def mil_bag_select(cls, ins, valid, labels, bags, pseudo, U1, U2, topk, beta, img_hw):
+    """cls/ins [NG,U1,U2,C] (any view of that size) -> merged boxes [NG,4]."""
+    NG = pseudo.shape[0]
+    C = cls.shape[-1]
+    merged = torch.empty((NG, 4), dtype=f32, device=cls.device)
+    hip.call('pt_mil_bag_select', _f(cls.detach()), _f(ins.detach()), valid.to(u8).contiguous(),
+             labels.to(i32).contiguous(), _f(bags), _f(pseudo), NG, U1, U2, C, int(topk), float(beta),
+             float(img_hw[0]), float(img_hw[1]), merged)
+    return merged
+
+
+# ------------------------------------------------------- EMA / optimizer step --
+
+def ema_update_(teacher_flat, student_flat, alpha):
+    hip.call('pt_ema_update', teacher_flat, student_flat, teacher_flat.numel(), float(alpha), float(1 - alpha))
+
+
+def grad_sqnorm(flat_grad):
+    nb = hip.call('pt_sqnorm_nblocks', flat_grad.numel())
+    partial = torch.empty((nb,), dtype=f32, device=flat_grad.device)
+    hip.call('pt_sqnorm_partial', flat_grad, flat_grad.numel(), partial)
+    return partial.sum().reshape(1)
+
+
+def sgd_step_(param, grad, mom, split, lr_t, momentum, weight_decay, bias_lr_mult, bias_decay_mult, sqnorm,
+              max_norm, first_step):
+    hip.call('pt_sgd_step', param, grad, mom, param.numel(), int(split), lr_t, float(momentum), float(weight_decay),
+             float(bias_lr_mult), float(bias_decay_mult), sqnorm, float(max_norm if max_norm else 0.0),
+             int(bool(first_step)))
+
+
+# ------------------------------------------------------------------------ NMS --
+
+def nms(boxes, scores, iou_threshold, class_ids=None):
+    """mmcv.ops.nms contract: returns (dets [M,5], keep [M]) in descending score order."""
+    N = boxes.shape[0]
+    if N == 0:
+        return torch.cat([boxes, scores[:, None]], 1), torch.empty((0,), dtype=torch.long, device=boxes.device)
+    order = torch.sort(scores, descending=True, stable=True)[1]
+    sb = _f(boxes[order])
+    cid = class_ids[order].to(i32).contiguous() if class_ids is not None else None
+    ws = torch.empty((N * ((N + 63) // 64),), dtype=torch.int64, device=boxes.device)
+    keep_m = torch.empty((N,), dtype=u8, device=boxes.device)
+    hip.call('pt_nms_sorted', sb, cid, N, float(iou_threshold), ws, keep_m)
+    keep = order[keep_m.bool()]
+    return torch.cat([boxes[keep], scores[keep, None]], 1), keep
+
+
+def batched_nms(boxes, scores, idxs, nms_cfg):
+    """mmcv.ops.batched_nms (class-aware) for nms_cfg = dict(type='nms', iou_threshold=...)."""
+    return nms(boxes, scores, nms_cfg.get('iou_threshold', 0.5), class_ids=idxs)
+
+
+def box_iou_rotated(b1, b2, aligned=False):
+    M, N = b1.shape[0], b2.shape[0]
+    out = torch.empty((M,) if aligned else (M, N), dtype=f32, device=b1.device)
+    hip.call('pt_box_iou_rotated', _f(b1), _f(b2), M, N, int(aligned), out)
+    return out
+
+
+def nms_rotated(dets, scores, iou_threshold):
+    """mmcv.ops.nms_rotated contract: (dets [M,6], keep [M])."""
+    N = dets.shape[0]
+    if N == 0:
+        return torch.cat([dets, scores[:, None]], 1), torch.empty((0,), dtype=torch.long, device=dets.device)
+    order = torch.sort(scores, descending=True, stable=True)[1]
+    sd = _f(dets[order][:, :5])
+    ws = torch.empty((N * ((N + 63) // 64),), dtype=torch.int64, device=dets.device)
+    keep_m = torch.empty((N,), dtype=u8, device=dets.device)
+    hip.call('pt_nms_rotated_sorted', sd, N, float(iou_threshold), ws, keep_m)
+    keep = order[keep_m.bool()]
+    return torch.cat([dets[keep], scores[keep, None]], 1), keep
+
+
+def nms_rotated_mask(dets_sorted, iou_threshold):
+    """Sync-free form: dets already sorted by descending score -> keep mask (uint8 [N])."""
+    N = dets_sorted.shape[0]
+    ws = torch.empty((max(N, 1) * ((N + 63) // 64 + 1),), dtype=torch.int64, device=dets_sorted.device)
+    keep_m = torch.ones((N,), dtype=u8, device=dets_sorted.device)
+    if N:
+        hip.call('pt_nms_rotated_sorted', _f(dets_sorted[:, :5]), N, float(iou_threshold), ws, keep_m)
+    return keep_m
+
+
+def fill_quads_(img, quads, alive, value=255.0):
+    """img [C,H,W] float (in place); quads [Q,8]; alive uint8 [Q] or None."""
+    C, H, W = img.shape
+    Q = quads.shape[0]
+    hip.call('pt_fill_quads', img, C, H, W, _f(quads), alive.to(u8).contiguous() if alive is not None else None, Q,
+             float(value))
+    return img

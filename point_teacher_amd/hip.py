@@ -1,0 +1,104 @@
+"""ctypes binding of libpt_hip.so - the ONLY place the native library is loaded.
+
+The prototypes are read from include/pt_hip.h, so the Python side can never drift from
+the C ABI.  There is no CPU fallback: if the library is missing, importing this module
+raises, and every wrapper refuses non-CUDA tensors.
+"""
+import ctypes
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libpt_hip.so')
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'pt_hip.h')
+
+_CT = {
+    'int': ctypes.c_int, 'float': ctypes.c_float, 'int64_t': ctypes.c_int64,
+    'void': None,
+}
+
+
+def parse_header(path=HEADER_PATH):
+    """-> {name: (restype, [(ctype, argname), ...])} for every function the header declares."""
+    txt = open(path).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    txt = re.sub(r'//[^\n]*', '', txt)
+    protos = {}
+    for m in re.finditer(r'(const\s+char\s*\*|int)\s+(pt_\w+)\s*\(([^)]*)\)\s*;', txt):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        restype = ctypes.c_char_p if 'char' in ret else ctypes.c_int
+        argl = []
+        for a in [x.strip() for x in args.split(',') if x.strip() and x.strip() != 'void']:
+            if '*' in a:
+                argl.append((ctypes.c_void_p, a.split('*')[-1].strip()))
+            else:
+                typ, an = a.rsplit(None, 1)
+                argl.append((_CT[typ.replace('const', '').strip()], an))
+        protos[name] = (restype, argl)
+    return protos
+
+
+PROTOS = parse_header()
+
+if not os.path.exists(LIB_PATH):
+    raise RuntimeError(
+        f'{LIB_PATH} not found: build it with `python -m point_teacher_amd.build` '
+        '(hipcc --offload-arch=gfx950).  point_teacher_amd has no CPU fallback.')
+_lib = ctypes.CDLL(LIB_PATH)
+for _n, (_r, _a) in PROTOS.items():
+    _f = getattr(_lib, _n)          # AttributeError here == header/library mismatch
+    _f.restype = _r
+    _f.argtypes = [t for t, _ in _a]
+
+ABI_VERSION = _lib.pt_abi_version()
+
+
+def last_error():
+    return _lib.pt_last_error().decode()
+
+
+_DT = {'float': torch.float32, 'int32_t': torch.int32, 'uint8_t': torch.uint8, 'uint64_t': torch.int64}
+
+
+def _ptr(x, name):
+    if x is None:
+        return None
+    if isinstance(x, torch.Tensor):
+        if not x.is_cuda:
+            raise RuntimeError(f'{name}: expected a CUDA/HIP tensor (point_teacher_amd has no CPU path)')
+        if not x.is_contiguous():
+            raise RuntimeError(f'{name}: tensor must be contiguous')
+        return x.data_ptr()
+    if isinstance(x, (ctypes.Array,)):
+        return ctypes.cast(x, ctypes.c_void_p)
+    if isinstance(x, int):
+        return x
+    raise TypeError(f'{name}: cannot pass {type(x)} as a pointer')
+
+
+def call(fn, *args):
+    """Call a libpt_hip entry point.  Tensors become device pointers; the trailing `stream`
+    argument is filled with torch's current stream when omitted."""
+    restype, proto = PROTOS[fn]
+    args = list(args)
+    auto_stream = len(args) == len(proto) - 1 and proto[-1][1] == 'stream'
+    if len(args) + int(auto_stream) != len(proto):
+        raise TypeError(f'{fn}: expected {len(proto)} arguments, got {len(args)}')
+    conv = []
+    for a, (ct, an) in zip(args, proto):
+        conv.append(_ptr(a, f'{fn}.{an}') if ct is ctypes.c_void_p else a)
+    if auto_stream:
+        conv.append(torch.cuda.current_stream().cuda_stream)
+    rc = getattr(_lib, fn)(*conv)
+    if restype is ctypes.c_int and fn not in ('pt_abi_version', 'pt_focal_nblocks', 'pt_sqnorm_nblocks') and rc != 0:
+        raise RuntimeError(f'{fn} failed (code {rc}): {last_error()}')
+    return rc
+
+
+def host_floats(vals):
+    arr = (ctypes.c_float * max(len(vals), 1))()
+    for i, v in enumerate(vals):
+        arr[i] = float(v)
+    return arr

@@ -1,0 +1,341 @@
+"""GPU parity tests: every kernel behind include/pt_hip.h against the CPU oracle
+(oracle/ref_ops.py) on seeded inputs and against the golden fixtures captured from the
+reference.  Index outputs bit-exact; fp32 outputs within 1e-3 relative (north_star's
+tolerance; most are ~1e-6).  All calls go through the C ABI (point_teacher_amd.hip)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+RT = 1e-3     # north_star: within 1e-3 relative on fp32
+
+
+def F():
+    from point_teacher_amd import functional
+    return functional
+
+
+def close(a, b, rtol=RT, atol=1e-5):
+    a = torch.as_tensor(a).detach().cpu().double()
+    b = torch.as_tensor(np.asarray(b) if not isinstance(b, torch.Tensor) else b.detach().cpu()).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    torch.testing.assert_close(a, b, rtol=rtol, atol=atol, equal_nan=True)
+
+
+def cu(x):
+    return x.to(DEV)
+
+
+def off1(n):
+    return torch.tensor([0, n], dtype=torch.int32, device=DEV)
+
+
+@pytest.mark.parametrize('name', ['g0', 'g1', 'g7', 'g40', 'clustered', 'full'])
+def test_assigners_vs_golden(name):
+    g = load_golden('assign_' + name)
+    f = F()
+    pts, cls, reg = g.t('in_points'), g.t('in_cls'), g.t('in_reg')
+    gtb, lab = g.t('in_gt_bboxes'), g.t('in_gt_labels')
+    G = gtb.shape[0]
+    gcx = R.bbox_xyxy_to_cxcywh(gtb) if G else torch.zeros(0, 4)
+    off = off1(G)
+    for k, key in ((1, 'out_a11_gt_inds'), (3, 'out_a33_gt_inds')):
+        gi = f.topk_assign(cu(pts), cu(gcx), off, 1, k)
+        assert torch.equal(gi.cpu().long().reshape(-1), g.t(key)), key
+    gi, cand = f.fuse_assign(cu(pts), cu(reg), cu(cls), cu(gcx[:, :2].contiguous()), cu(lab), off, 1, 5, 3)
+    assert torch.equal(gi.cpu().long().reshape(-1), g.t('out_fuse_gt_inds'))
+    # labels follow from gt_inds
+    if G:
+        lab_out = torch.where(gi.cpu().reshape(-1) > 0, lab[(gi.cpu().reshape(-1).long() - 1).clamp(min=0)],
+                              torch.full((pts.shape[0],), -1, dtype=torch.long))
+        assert torch.equal(lab_out, g.t('out_fuse_labels'))
+
+
+def test_assign_batched_and_tie_rule():
+    """Two images in one launch + exact distance ties (gt on a grid point / cell centre):
+    the documented rule is lowest point index, identical to the oracle."""
+    f = F()
+    H = W = 40
+    ys, xs = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing='ij')
+    pts = torch.stack([xs.reshape(-1) * 8 + 4, ys.reshape(-1) * 8 + 4], 1)
+    g = torch.Generator().manual_seed(5)
+    gts = [torch.round(torch.rand(57, 2, generator=g) * 300 * 2) / 2, torch.round(torch.rand(31, 2, generator=g) * 300)]
+    labs = [torch.randint(0, 8, (57,), generator=g), torch.randint(0, 8, (31,), generator=g)]
+    off, tot = f.make_offsets([57, 31], DEV)
+    allg = torch.cat(gts)
+    for k in (1, 3, 5):
+        gi = f.topk_assign(cu(pts), cu(allg), off, 2, k).cpu().long()
+        for b in range(2):
+            exp, _ = R.topk_assign(pts, gts[b], labs[b], k)
+            assert torch.equal(gi[b], exp), (k, b)
+    cls = torch.randn(2, H * W, 8, generator=g)
+    reg = torch.rand(2, H * W, 4, generator=g) * 20
+    gi, _ = f.fuse_assign(cu(pts), cu(reg.reshape(-1, 4)), cu(cls.reshape(-1, 8)), cu(allg), cu(torch.cat(labs)), off, 2)
+    for b in range(2):
+        dcx = R.bbox_xyxy_to_cxcywh(R.distance2bbox(pts, reg[b]))
+        exp, _ = R.fuse_topk_assign(dcx, pts, cls[b], gts[b], labs[b])
+        assert torch.equal(gi.cpu().long()[b], exp), b
+
+
+@pytest.mark.parametrize('name', ['small', 'mid'])
+def test_pseudo_and_targets_vs_golden(name):
+    g = load_golden('pseudo_' + name)
+    f = F()
+    pts, cls, reg = cu(g.t('in_points')), cu(g.t('in_cls')), cu(g.t('in_reg'))
+    gp, gl, gb = cu(g.t('in_gt_points')), cu(g.t('in_gt_labels')), cu(g.t('in_gt_bboxes'))
+    G = gp.shape[0]
+    off = off1(G)
+    gi, cand = f.fuse_assign(pts, reg, cls, gp, gl, off, 1)
+    ps = f.pseudo_boxes(pts, reg, cls, gp, gl, gb, off, 1, gi, cand)
+    close(ps['bboxes'], g['out_pseudo_bboxes'], atol=1e-3)
+    close(ps['points'], g['out_pseudo_points'], atol=1e-3)
+    nz = ps['nassigned'] > 0
+    close(ps['iou'][nz].mean(), g['out_mean_iou'])
+    assert np.array_equal(torch.nonzero(nz).reshape(-1).cpu().numpy(), g['out_valid_inds'])
+    pb = cu(g.t('out_pseudo_bboxes'))
+    gi1 = f.topk_assign(pts, gp, off, 1, 1)
+    labels, _, _ = f.fcos_targets(pts, gi1, None, gl, off, 1, 8, want_ctr=False)
+    assert torch.equal(labels.cpu().long(), g.t('out_labels'))
+    gi3 = f.topk_assign(pts, R.bbox_xyxy_to_cxcywh(pb.cpu()).to(DEV), off, 1, 3)
+    lr, bt, ctr = f.fcos_targets(pts, gi3, pb, gl, off, 1, 8)
+    assert torch.equal(lr.cpu().long(), g.t('out_labels_reg'))
+    close(bt, g['out_bbox_targets'], atol=1e-4)
+    close(ctr[lr < 8], g['out_ctr_target'], atol=1e-5)
+    gis = f.topk_assign(pts, R.bbox_xyxy_to_cxcywh(gb.cpu()).to(DEV), off, 1, 3)
+    sl, sbt, _ = f.fcos_targets(pts, gis, gb, None, off, 1, 8)
+    assert torch.equal(sl.cpu().long(), g.t('out_syn_labels'))
+    close(sbt, g['out_syn_bbox_targets'], atol=1e-4)
+
+
+def test_focal_loss():
+    g = load_golden('loss_focal')
+    f = F()
+    x = cu(g.t('in_logits')).requires_grad_(True)
+    l = f.sigmoid_focal_loss_sum(x, cu(g.t('in_labels')), cu(g.t('in_weight'))) / float(g['avg_factor'])
+    close(l, g['out_loss'])
+    l.backward()
+    close(x.grad, g['out_grad'], atol=1e-7)
+    close(f.sigmoid_focal_loss_elem(x, cu(g.t('in_labels'))), g['out_elem'], atol=1e-7)
+    # full size (B*P = 20000 points, 8 classes) against the oracle
+    gen = torch.Generator().manual_seed(1)
+    X = torch.randn(20000, 8, generator=gen) * 3
+    L = torch.randint(0, 9, (20000,), generator=gen)
+    xr = X.clone().requires_grad_(True)
+    lo = R.sigmoid_focal_loss(xr, L, None, avg_factor=311.0)
+    lo.backward()
+    xg = cu(X).requires_grad_(True)
+    lg = f.sigmoid_focal_loss_sum(xg, cu(L)) / 311.0
+    lg.backward()
+    close(lg, lo)
+    close(xg.grad, xr.grad, atol=1e-8)
+
+
+def test_diou_and_dn_diou():
+    g = load_golden('loss_diou')
+    f = F()
+    tgt, w, af = cu(g.t('in_target')), cu(g.t('in_weight')), float(g['avg_factor'])
+    pred = cu(g.t('in_pred')).requires_grad_(True)
+    d = f.diou_loss_elem(pred, tgt)
+    close(d, g['out_diou_none'], atol=1e-6)
+    l = (d * w).sum() / af
+    close(l, g['out_diou_loss'])
+    close(torch.autograd.grad(l, pred)[0], g['out_diou_grad'], atol=1e-6)
+    for hyper, tag in ((0.1, '01'), (0.2, '02')):
+        d, dn = f.dn_diou_pair(pred, tgt, hyper)
+        le = (d.mean() + dn) / 2                     # the DN quirk, iou_loss.py:412,463-464
+        close(le, g[f'out_dn{tag}_none'], atol=1e-6)
+        l = (le * w).sum() / af
+        close(l, g[f'out_dn{tag}_loss'])
+        close(torch.autograd.grad(l, pred)[0], g[f'out_dn{tag}_grad'], atol=1e-6)
+
+
+def test_bbox_math():
+    g = load_golden('bbox_math')
+    f = F()
+    a, b, b2 = cu(g.t('in_a')), cu(g.t('in_b')), cu(g.t('in_b2'))
+    for mode in ('iou', 'iof', 'giou'):
+        close(f.bbox_overlaps(a, b, mode), g[f'out_pair_{mode}'], atol=1e-6)
+        close(f.bbox_overlaps(a, b2, mode, True), g[f'out_align_{mode}'], atol=1e-6)
+    k1 = torch.FloatTensor([[0, 0, 10, 10], [10, 10, 20, 20], [32, 32, 38, 42]])
+    k2 = torch.FloatTensor([[0, 0, 10, 20], [0, 10, 10, 19], [10, 10, 20, 20]])
+    close(f.bbox_overlaps(cu(k1), cu(k2), 'giou', True), torch.tensor([0.5000, -0.0500, -0.8214]), atol=1e-4)
+    assert tuple(f.bbox_overlaps(cu(torch.zeros(0, 4)), cu(k1)).shape) == (0, 3)
+    close(f.delta2bbox(a, cu(g.t('in_deltas')), (300, 300, 3)), g['out_delta_decode'], atol=1e-3)
+    rois = torch.Tensor([[0., 0., 1., 1.], [0., 0., 1., 1.], [0., 0., 1., 1.], [5., 5., 5., 5.]])
+    deltas = torch.Tensor([[0., 0., 0., 0.], [1., 1., 1., 1.], [0., 0., 2., -1.], [0.7, -1.9, -0.5, 0.3]])
+    close(f.delta2bbox(cu(rois), cu(deltas), (32, 32)), g['known_delta2bbox'], atol=1e-4)
+    # gradient of the decode against autograd through the oracle
+    dl = g.t('in_deltas').clone().requires_grad_(True)
+    wgt = torch.randn(64, 4, generator=torch.Generator().manual_seed(0))
+    (R.delta2bbox(g.t('in_a'), dl, (300, 300, 3)) * wgt).sum().backward()
+    dg = cu(g.t('in_deltas')).requires_grad_(True)
+    (f.delta2bbox(a, dg, (300, 300, 3)) * cu(wgt)).sum().backward()
+    close(dg.grad, dl.grad, atol=1e-4)
+
+
+CFGS = [([1.0], None, 0), ([1.0, 1.2, 1.3, 0.8, 0.7], None, 4), ([1.0, 1.2, 1.3, 0.8, 0.7], [0.1], 16),
+        ([1.0, 1.3, 0.8], None, 0), ([1.0, 1.3, 0.7], [0.1], 4)]
+
+
+def test_proposals():
+    g = load_golden('proposals')
+    f = F()
+    hw = tuple(int(v) for v in g['img_hw'])
+    boxes = torch.cat([g.t('in_boxes0'), g.t('in_boxes1')])
+    n0 = g.t('in_boxes0').shape[0]
+    for ci, (ratios, shake, ms) in enumerate(CFGS):
+        p, v = f.fine_proposals(cu(boxes), ratios, shake, ms, hw)
+        U = p.shape[0] // boxes.shape[0]
+        exp_p = np.concatenate([g[f'out_c{ci}_prop0'], g[f'out_c{ci}_prop1']])
+        exp_v = np.concatenate([g[f'out_c{ci}_valid0'], g[f'out_c{ci}_valid1']]).reshape(-1)
+        close(p, exp_p, rtol=1e-6, atol=1e-4)
+        assert np.array_equal(v.cpu().numpy().astype(bool), exp_v), ci
+        assert U * n0 == g[f'out_c{ci}_prop0'].shape[0]
+    pos, _ = f.fine_proposals(cu(boxes), *CFGS[0], hw)
+    poff, _ = f.make_offsets([n0, boxes.shape[0] - n0], DEV)
+    neg, ok = f.negative_proposals(cu(g.t('in_u')), pos, poff, hw)
+    close(neg, np.concatenate([g['out_neg0'], g['out_neg1']]), atol=1e-5)
+    assert np.array_equal(ok.cpu().numpy().astype(bool), np.concatenate([g['out_negw0'], g['out_negw1']]))
+
+
+@pytest.mark.parametrize('name', ['u1x25_k1', 'u9x45_k3', 'full_k1'])
+def test_mil_bags(name):
+    g = load_golden('mil_' + name)
+    f = F()
+    N, U1, U2, C = g['in_cls'].shape
+    cls = cu(g.t('in_cls')).requires_grad_(True)
+    ins = cu(g.t('in_ins')).requires_grad_(True)
+    neg = cu(g.t('in_neg_cls')).requires_grad_(True)
+    valid = cu(g.t('in_valid')).reshape(-1)
+    lab = cu(g.t('in_labels'))
+    lab_b = lab[:, None].repeat(1, U1).reshape(-1)
+    s, nv = f.mil_bag_loss_sum(cls.reshape(N * U1, U2, C), ins.reshape(N * U1, U2, C), valid, lab_b)
+    ns = nv.clamp(min=1.0)
+    l = s / ns + f.mil_neg_loss_sum(neg, cu(g.t('in_neg_w'))) / ns
+    close(l, g['out_loss'])
+    gc, gi, gn = torch.autograd.grad(l, [cls, ins, neg])
+    close(gc, g['out_grad_cls'], atol=1e-7)
+    close(gi, g['out_grad_ins'], atol=1e-7)
+    close(gn, g['out_grad_neg'], atol=1e-7)
+    m = f.mil_bag_select(cls, ins, valid, lab, cu(g.t('in_bags')), cu(g.t('in_pseudo')), U1, U2, int(g['topk']),
+                         float(g['beta']), (800, 800))
+    close(m, g['out_merged'], atol=1e-2)
+
+
+def _rois(gen, K, B, size):
+    c = torch.rand(K, 2, generator=gen) * size
+    wh = torch.exp(torch.randn(K, 2, generator=gen) * 0.8 + np.log(14.))
+    bi = torch.randint(0, B, (K, 1), generator=gen).float()
+    return torch.cat([bi, c - wh / 2, c + wh / 2], 1)
+
+
+@pytest.mark.parametrize('channels_last', [False, True])
+def test_roi_align_vs_oracle(channels_last):
+    f = F()
+    gen = torch.Generator().manual_seed(7)
+    B, C, H, W = 2, 64, 25, 25
+    feat = torch.randn(B, C, H, W, generator=gen)
+    rois = _rois(gen, 96, B, 200)
+    rois[0, 1:] = torch.tensor([-30., -30., -20., -20.])      # entirely outside
+    rois[1, 1:] = torch.tensor([150., 150., 260., 260.])      # crosses the border, big (grid > 1)
+    rois[2, 1:] = torch.tensor([50., 50., 50., 50.])          # zero size
+    fr = feat.clone().requires_grad_(True)
+    out_ref = R.roi_align(fr, rois, 7, 0.125)
+    wgt = torch.randn(out_ref.shape, generator=gen)
+    (out_ref * wgt).sum().backward()
+    fg = cu(feat)
+    if channels_last:
+        fg = fg.contiguous(memory_format=torch.channels_last)
+    fg.requires_grad_(True)
+    out = f.roi_align(fg, cu(rois), 7, 0.125)
+    close(out, out_ref, atol=1e-5)
+    (out * cu(wgt)).sum().backward()
+    close(fg.grad, fr.grad, atol=1e-4)
+
+
+def test_roi_align_full_size_properties():
+    """BASELINE size (K = 5000 RoIs, [2,256,100,100]): constant map -> constant; linearity."""
+    f = F()
+    gen = torch.Generator().manual_seed(9)
+    B, C, H, W = 2, 256, 100, 100
+    rois = cu(_rois(gen, 5000, B, 800))
+    rois[:, 1:3].clamp_(min=8)
+    rois[:, 3:5].clamp_(max=790)
+    rois[:, 3:5] = torch.maximum(rois[:, 3:5], rois[:, 1:3] + 1)
+    const = torch.full((B, C, H, W), 1.75, device=DEV).contiguous(memory_format=torch.channels_last)
+    out = f.roi_align(const, rois, 7, 0.125)
+    assert out.shape == (5000, 256, 7, 7)
+    close(out, torch.full_like(out, 1.75), atol=1e-5)
+    a = torch.randn(B, C, H, W, device=DEV).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(B, C, H, W, device=DEV).contiguous(memory_format=torch.channels_last)
+    lhs = f.roi_align(2 * a + 3 * b, rois, 7, 0.125)
+    rhs = 2 * f.roi_align(a, rois, 7, 0.125) + 3 * f.roi_align(b, rois, 7, 0.125)
+    close(lhs, rhs, atol=1e-4)
+    # both layouts agree
+    close(f.roi_align(a.contiguous(), rois, 7, 0.125), f.roi_align(a, rois, 7, 0.125), atol=1e-5)
+
+
+def test_ema_sgd_norm():
+    g = load_golden('ema')
+    f = F()
+    t = cu(g.t('in_teacher')).clone()
+    f.ema_update_(t, cu(g.t('in_student')), float(g['alpha']))
+    close(t, g['out_teacher'], rtol=1e-6, atol=1e-7)
+    gen = torch.Generator().manual_seed(3)
+    n = 1_000_003
+    p, gr, m = (torch.randn(n, generator=gen) for _ in range(3))
+    gr *= 0.05
+    split = 900_000
+    sq = f.grad_sqnorm(cu(gr))
+    close(sq, (gr.double() ** 2).sum().float().reshape(1), rtol=1e-4)
+    coef = min(1.0, 35.0 / (float(sq.sqrt()) + 1e-6))
+    lr = torch.tensor([0.005], device=DEV)
+    pg, mg = cu(p).clone(), cu(m).clone()
+    f.sgd_step_(pg, cu(gr), mg, split, lr, 0.9, 1e-4, 2.0, 0.0, sq, 35.0, False)
+    pw, mw = R.sgd_momentum_step(p[:split], gr[:split], m[:split], 0.005, 0.9, 1e-4, coef)
+    pb, mb = R.sgd_momentum_step(p[split:], gr[split:], m[split:], 0.01, 0.9, 0.0, coef)
+    close(pg, torch.cat([pw, pb]), rtol=1e-5, atol=1e-6)
+    close(mg, torch.cat([mw, mb]), rtol=1e-5, atol=1e-6)
+
+
+def test_nms_and_rotated():
+    f = F()
+    gen = torch.Generator().manual_seed(11)
+    N = 3000
+    c = torch.rand(N, 2, generator=gen) * 400
+    wh = torch.rand(N, 2, generator=gen) * 30 + 4
+    boxes = torch.cat([c - wh / 2, c + wh / 2], 1)
+    scores = torch.rand(N, generator=gen)
+    ids = torch.randint(0, 8, (N,), generator=gen)
+    dets, keep = f.nms(cu(boxes), cu(scores), 0.5)
+    assert torch.equal(keep.cpu(), R.nms(boxes, scores, 0.5))
+    close(dets[:, 4], scores[keep.cpu()], rtol=0, atol=0)
+    _, keep = f.batched_nms(cu(boxes), cu(scores), cu(ids), dict(type='nms', iou_threshold=0.5))
+    exp = torch.cat([torch.nonzero(ids == k).reshape(-1)[R.nms(boxes[ids == k], scores[ids == k], 0.5)] for k in range(8)])
+    assert sorted(keep.cpu().tolist()) == sorted(exp.tolist())
+    M = 300
+    rb = torch.cat([torch.rand(M, 2, generator=gen) * 200, torch.rand(M, 2, generator=gen) * 40 + 3,
+                    (torch.rand(M, 1, generator=gen) - 0.5) * np.pi], 1)
+    iou = f.box_iou_rotated(cu(rb[:60]), cu(rb[60:140]))
+    close(iou, R.box_iou_rotated(rb[:60], rb[60:140]), atol=2e-4)
+    rs = torch.rand(M, generator=gen)
+    _, keep = f.nms_rotated(cu(rb), cu(rs), 0.05)
+    assert torch.equal(keep.cpu(), R.nms_rotated(rb, rs, 0.05))
+
+
+def test_fill_quads():
+    f = F()
+    gen = torch.Generator().manual_seed(13)
+    obb = torch.cat([torch.rand(40, 2, generator=gen) * 180 + 10, torch.rand(40, 2, generator=gen) * 40 + 2,
+                     (torch.rand(40, 1, generator=gen) - 0.5) * np.pi], 1)
+    quads = R.obb2poly_le90(obb)
+    alive = torch.rand(40, generator=gen) > 0.2
+    img = torch.zeros(3, 200, 200, device=DEV)
+    f.fill_quads_(img, cu(quads), cu(alive), 255.0)
+    exp = R.fill_convex_quads(quads[alive].numpy().astype(np.int32), 200, 200)
+    assert np.array_equal((img[0] == 255).cpu().numpy(), exp.astype(bool))
+    assert torch.equal(img[0], img[2])
