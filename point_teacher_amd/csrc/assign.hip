@@ -259,15 +259,17 @@ __global__ void fcos_targets_kernel(const float* __restrict__ points, int P, con
   float l = 0.f, t = 0.f, r = 0.f, bt = 0.f, c = 0.f;
   int lab = num_classes;
   if (G > 0) {
-    const int idx = gi > 0 ? gi - 1 : 0;
-    const float* bx = boxes + (size_t)(g0 + idx) * 4;
-    const float px = points[2 * p], py = points[2 * p + 1];
-    l = px - bx[0]; t = py - bx[1]; r = bx[2] - px; bt = bx[3] - py;
-    if (gi > 0) {
-      lab = box_labels ? box_labels[g0 + gi - 1] : 0;
-      const float a = fmaxf(fminf(l, r), 0.01f) / fmaxf(l, r);
-      const float d = fmaxf(fminf(t, bt), 0.01f) / fmaxf(t, bt);
-      c = sqrtf(a * d);
+    if (gi > 0) lab = box_labels ? box_labels[g0 + gi - 1] : 0;
+    if (boxes) {
+      const int idx = gi > 0 ? gi - 1 : 0;
+      const float* bx = boxes + (size_t)(g0 + idx) * 4;
+      const float px = points[2 * p], py = points[2 * p + 1];
+      l = px - bx[0]; t = py - bx[1]; r = bx[2] - px; bt = bx[3] - py;
+      if (gi > 0) {
+        const float a = fmaxf(fminf(l, r), 0.01f) / fmaxf(l, r);
+        const float d = fmaxf(fminf(t, bt), 0.01f) / fmaxf(t, bt);
+        c = sqrtf(a * d);
+      }
     }
   }
   labels[i] = lab;
@@ -338,6 +340,8 @@ extern "C" int pt_fcos_targets(const float* points, int P, const int32_t* gt_ind
                                const int32_t* box_labels, const int32_t* off, int B, int num_classes,
                                int32_t* labels, float* bbox_targets, float* ctr_target, void* stream) {
   PT_REQUIRE(points && gt_inds && off && labels && P > 0 && B > 0, PT_EINVAL, "pt_fcos_targets: bad argument");
+  PT_REQUIRE(boxes || (!bbox_targets && !ctr_target), PT_EINVAL,
+             "pt_fcos_targets: bbox_targets/ctr_target requested without boxes");
   const size_t n = (size_t)B * P;
   hipLaunchKernelGGL(fcos_targets_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), points, P, gt_inds,
                      boxes, box_labels, off, B, num_classes, labels, bbox_targets, ctr_target);

@@ -69,12 +69,15 @@ def fcos_targets(points, gt_inds, boxes, box_labels, off, B, num_classes, want_c
     P = points.shape[0]
     dev = points.device
     labels = torch.empty((B * P,), dtype=i32, device=dev)
-    tg = torch.empty((B * P, 4), dtype=f32, device=dev)
-    ctr = torch.empty((B * P,), dtype=f32, device=dev) if want_ctr else None
     nb = boxes.shape[0] if boxes is not None else 0
+    if boxes is None:                      # labels only (classification branch)
+        tg, ctr = None, None
+    else:
+        tg = torch.zeros((B * P, 4), dtype=f32, device=dev)
+        ctr = torch.zeros((B * P,), dtype=f32, device=dev) if want_ctr else None
     hip.call('pt_fcos_targets', _f(points), P, gt_inds.contiguous(), _f(boxes) if nb else None,
-             box_labels.to(i32).contiguous() if (box_labels is not None and nb) else None, off, B, num_classes,
-             labels, tg, ctr)
+             box_labels.to(i32).contiguous() if (box_labels is not None and box_labels.numel()) else None,
+             off, B, num_classes, labels, tg if nb else None, ctr if nb else None)
     return labels, tg, ctr
 
 
