@@ -43,9 +43,13 @@ int pt_abi_version(void);
  * points (PointCost, match_costs/match_cost.py:188-214), later gt wins.
  * points[P,2]; gt_xy[sumG,2]; off[B+1]; out gt_inds[B*P] (int32).
  * If cand != NULL it receives the candidate rows [sumG,num_pre] (int32).
+ * gt_valid (uint8[sumG], may be NULL): gts with 0 are skipped but keep their index, which
+ * equals assigning the order-preserving filtered list (strong_augmentation drops gts that
+ * leave the crop, detectors/syn_images_generator_v2.py:77-90) without a host round trip.
  * Ties in distance are broken towards the LOWEST point index. num_pre <= 8. */
-int pt_topk_assign(const float* points, int P, const float* gt_xy, const int32_t* off, int B,
-                   int sumG, int num_pre, int32_t* gt_inds, int32_t* cand, void* stream);
+int pt_topk_assign(const float* points, int P, const float* gt_xy, const uint8_t* gt_valid,
+                   const int32_t* off, int B, int sumG, int num_pre, int32_t* gt_inds,
+                   int32_t* cand, void* stream);
 
 /* FUSETopkAssigner.assign (core/bbox/assigners/fuse_topk_assigner.py:91-118) fed the
  * way _gnerate_pseudo_single does (dense_heads/fcos_head_p2b_ts.py:747-752):

@@ -1,0 +1,13 @@
+"""point_teacher_amd - MI355X-native implementation of the Point-Teacher teacher->student
+training hot path behind the reference's registry surface.
+
+Importing the package loads libpt_hip.so (through .hip) and registers every class under the
+name the reference's configs use.  There is no CPU compute path."""
+from . import hip                      # noqa: F401  (raises loudly when the HIP library is missing)
+from . import functional               # noqa: F401
+from .registry import (BACKBONES, BBOX_ASSIGNERS, BBOX_CODERS, DETECTORS, HEADS, LOSSES, MATCH_COST, NECKS,  # noqa: F401
+                       ROI_EXTRACTORS, Config, build_assigner, build_detector, build_from_cfg, build_loss)
+from . import core, losses, nn_modules, head, detectors   # noqa: F401,E402  (populate the registries)
+from .runtime import Trainer           # noqa: F401,E402
+
+__version__ = '0.1.0'

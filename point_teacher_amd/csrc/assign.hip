@@ -91,12 +91,17 @@ __device__ __forceinline__ int image_of(const int32_t* off, int B, int g) {
 
 __global__ void __launch_bounds__(256) topk_assign_kernel(const float* __restrict__ points, int P,
                                                           const float* __restrict__ gt_xy,
+                                                          const uint8_t* __restrict__ gt_valid,
                                                           const int32_t* __restrict__ off, int B, int k,
                                                           int32_t* __restrict__ gt_inds,
                                                           int32_t* __restrict__ cand) {
   __shared__ unsigned long long red_sm[4];
   __shared__ int rows_sm[KMAX];
   const int g = blockIdx.x;
+  if (gt_valid && !gt_valid[g]) {  // workgroup-uniform exit
+    if (cand && threadIdx.x < k) cand[(size_t)g * k + threadIdx.x] = -1;
+    return;
+  }
   const int b = image_of(off, B, g);
   const int local = g - off[b];
   nearest_k(points, P, gt_xy[2 * g], gt_xy[2 * g + 1], 1.0f, k, red_sm, rows_sm);
@@ -284,8 +289,9 @@ using namespace pt;
 extern "C" const char* pt_last_error(void) { return pt::g_err; }
 extern "C" int pt_abi_version(void) { return 1; }
 
-extern "C" int pt_topk_assign(const float* points, int P, const float* gt_xy, const int32_t* off, int B,
-                              int sumG, int num_pre, int32_t* gt_inds, int32_t* cand, void* stream) {
+extern "C" int pt_topk_assign(const float* points, int P, const float* gt_xy, const uint8_t* gt_valid,
+                              const int32_t* off, int B, int sumG, int num_pre, int32_t* gt_inds, int32_t* cand,
+                              void* stream) {
   PT_REQUIRE(points && off && gt_inds && P > 0 && B > 0 && sumG >= 0, PT_EINVAL, "pt_topk_assign: bad argument");
   PT_REQUIRE(num_pre >= 1 && num_pre <= KMAX, PT_ELIMIT, "pt_topk_assign: num_pre=%d outside [1,%d]", num_pre, KMAX);
   PT_REQUIRE(num_pre <= P, PT_EINVAL, "pt_topk_assign: num_pre > P");
@@ -294,7 +300,8 @@ extern "C" int pt_topk_assign(const float* points, int P, const float* gt_xy, co
   if (e != hipSuccess) { set_error("pt_topk_assign: memset: %s", hipGetErrorString(e)); return (int)e; }
   if (sumG == 0) return PT_OK;
   PT_REQUIRE(gt_xy, PT_EINVAL, "pt_topk_assign: gt_xy is NULL");
-  hipLaunchKernelGGL(topk_assign_kernel, dim3(sumG), dim3(256), 0, s, points, P, gt_xy, off, B, num_pre, gt_inds, cand);
+  hipLaunchKernelGGL(topk_assign_kernel, dim3(sumG), dim3(256), 0, s, points, P, gt_xy, gt_valid, off, B, num_pre, gt_inds,
+                     cand);
   PT_LAUNCH_CHECK("pt_topk_assign");
   return PT_OK;
 }

@@ -1,0 +1,415 @@
+"""Student_FCOS and TS_P2B_FCOS - the teacher->student detector of Point-Teacher, mirroring
+/root/reference/HBB_TOD/mmdet/models/detectors/{fcos_student,fcos_p2b_teacher_student,
+single_stage,base}.py.  Same registry names, constructor keywords, `train_step` /
+`forward(return_loss=...)` contract and per-iteration order of operations (Appendix A of
+SURVEY.md); the per-image python loops, CPU round trips and host synchronisations of the
+reference are replaced by batched launches into libpt_hip.so."""
+from collections import OrderedDict
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import functional as F
+from .core import bbox2result, bbox_overlaps, bbox_xyxy_to_cxcywh
+from .proposals import (MIL_gen_proposals_from_cfg, gen_negative_proposals, generate_black_paper_masked,
+                        load_basic_shape, random_point_in_quadrilateral, strong_augmentation_masked)
+from .registry import DETECTORS, build_backbone, build_detector, build_head, build_neck
+
+
+class LazyLogVars(OrderedDict):
+    """log_vars whose values stay on the device until somebody reads them.  The reference
+    calls `.item()` on ~12 scalars every iteration (base.py:201-207); here that cost is paid
+    only when a logger actually looks (every `log_config.interval` iterations)."""
+
+    def materialize(self):
+        keys = list(self.keys())
+        if not keys:
+            return {}
+        vals = torch.stack([super(LazyLogVars, self).__getitem__(k).detach().float().reshape(()) for k in keys])
+        if dist.is_available() and dist.is_initialized():
+            vals = vals / dist.get_world_size()
+            dist.all_reduce(vals)                      # ONE coalesced all-reduce instead of one per key
+        host = vals.cpu().tolist()
+        return OrderedDict(zip(keys, host))
+
+    def __getitem__(self, k):
+        v = super().__getitem__(k)
+        return v.item() if isinstance(v, torch.Tensor) else v
+
+
+class BaseDetector(nn.Module):
+    """detectors/base.py: forward dispatch, _parse_losses, train_step."""
+
+    def __init__(self, init_cfg=None):
+        super().__init__()
+        self.fp16_enabled = False
+
+    @property
+    def with_neck(self):
+        return hasattr(self, 'neck') and self.neck is not None
+
+    def forward(self, img, img_metas, return_loss=True, **kwargs):
+        """base.py:156-173"""
+        if return_loss:
+            return self.forward_train(img, img_metas, **kwargs)
+        return self.forward_test(img, img_metas, **kwargs)
+
+    def forward_test(self, imgs, img_metas, **kwargs):
+        if isinstance(imgs, torch.Tensor):
+            imgs, img_metas = [imgs], [img_metas]
+        assert len(imgs) == 1, 'test-time augmentation is not on the Point-Teacher path'
+        return self.simple_test(imgs[0], img_metas[0], **kwargs)
+
+    def _parse_losses(self, losses):
+        """base.py:175-208: every key containing 'loss' is summed; all keys are logged."""
+        log_vars = LazyLogVars()
+        for name, value in losses.items():
+            if isinstance(value, torch.Tensor):
+                log_vars[name] = value.mean()
+            elif isinstance(value, list):
+                log_vars[name] = sum(v.mean() for v in value)
+            else:
+                raise TypeError(f'{name} is not a tensor or list of tensors')
+        loss = sum(v for k, v in OrderedDict.items(log_vars) if 'loss' in k)
+        log_vars['loss'] = loss
+        return loss, log_vars
+
+    def train_step(self, data, optimizer=None):
+        """base.py:210-243"""
+        losses = self(**data)
+        loss, log_vars = self._parse_losses(losses)
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(data['img_metas']))
+
+
+@DETECTORS.register_module()
+class Student_FCOS(BaseDetector):
+    """detectors/fcos_student.py:8-50 over single_stage.py:10-60 (backbone -> neck -> neck_agg -> head)."""
+
+    def __init__(self, backbone, neck=None, neck_agg=None, bbox_head=None, roi_head=None, train_cfg=None, test_cfg=None,
+                 pretrained=None, init_cfg=None):
+        super().__init__(init_cfg)
+        self.backbone = build_backbone(backbone)
+        if neck is not None:
+            self.neck = build_neck(neck)
+        if neck_agg is not None:
+            self.neck_agg = build_neck(neck_agg)
+        bbox_head = dict(bbox_head)
+        bbox_head.update(train_cfg=train_cfg, test_cfg=test_cfg)
+        self.bbox_head = build_head(bbox_head)
+        self.roi_head = build_head(roi_head) if roi_head is not None else None
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+
+    @property
+    def with_neck_agg(self):
+        return hasattr(self, 'neck_agg') and self.neck_agg is not None
+
+    def extract_feat(self, img):
+        x = self.backbone(img)
+        if self.with_neck:
+            x = self.neck(x)
+        if self.with_neck_agg:
+            x = self.neck_agg(x)
+        return x
+
+    def forward_dummy(self, img):
+        return self.bbox_head(self.extract_feat(img))
+
+    def simple_test(self, img, img_metas, rescale=False):
+        res = self.bbox_head.simple_test(self.extract_feat(img), img_metas, rescale=rescale)
+        return [bbox2result(b, l, self.bbox_head.num_classes) for b, l in res]
+
+
+@DETECTORS.register_module()
+class TS_P2B_FCOS(BaseDetector):
+    """detectors/fcos_p2b_teacher_student.py:36-519."""
+
+    def __init__(self, _model_, _point_='random', num_stages=2, num_refine=500, num_training_burninstep1=512,
+                 num_training_burninstep2=512, ema_alpha=0.999, filter_score=0.8, burn_in_step=10000, lamda=1.0,
+                 alpha=[0.1, 1.0],
+                 shape_list=[[20, 20, 0.5, 0.5], [30, 120, 0.5, 0.5], [10, 20, 0.5, 0.5], [20, 50, 0.5, 0.5],
+                             [30, 20, 0.5, 0.5]],
+                 MIL_head=None, train_cfg=None, test_cfg=None, pretrained=None, init_cfg=None):
+        super().__init__(init_cfg)
+        self.teacher = build_detector(_model_, train_cfg, test_cfg)       # two independently initialised copies (:60-61)
+        self.student = build_detector(_model_, train_cfg, test_cfg)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.gt_bboxes_point, self.refined_gt_bboxes_point = {}, {}
+        self.count, self.ema_alpha = 0, ema_alpha
+        self.epoch, self.epoch_dict, self.max_epoch = 0, {}, 12
+        self.lamda = lamda
+        self.pattern, self.prior_size = load_basic_shape(shape_list)
+        self.scale_ratio, self.filter_score, self.burn_in_step, self.alpha = 1.0, filter_score, burn_in_step, alpha
+        self.num_stages, self.num_refine = num_stages, num_refine
+        self.num_training_burninstep1, self.num_training_burninstep2 = num_training_burninstep1, num_training_burninstep2
+        self._point_ = _point_
+        if self.train_cfg is not None:
+            self.fine_proposal_cfg = list(self.train_cfg['fine_proposal_cfg'])
+            self.fine_proposal_extensive_cfg = list(self.train_cfg['fine_proposal_extensive_cfg'])
+        # Set by runtime.FlatParams: (teacher_flat, student_flat) so the EMA is ONE launch.  The
+        # teacher never receives gradients (the reference defines freeze() :110-113 but never calls
+        # it, which only wastes optimizer/DDP work); here its parameters are frozen explicitly.
+        self._flat = None
+        for p in self.teacher.parameters():
+            p.requires_grad = False
+        # hooks for tests: inject the random draws of one iteration
+        self._inject = {}
+
+    # the reference keeps count/point dictionaries as plain attributes, so they are lost on resume
+    # (SURVEY section 5); persisting them is a documented deviation.
+    def get_extra_state(self):
+        return dict(count=self.count, epoch=self.epoch,
+                    gt_bboxes_point={k: v.cpu() for k, v in self.gt_bboxes_point.items()},
+                    refined_gt_bboxes_point={k: v.cpu() for k, v in self.refined_gt_bboxes_point.items()})
+
+    def set_extra_state(self, state):
+        if not state:
+            return
+        dev = next(self.parameters()).device
+        self.count, self.epoch = state.get('count', 0), state.get('epoch', 0)
+        self.gt_bboxes_point = {k: v.to(dev) for k, v in state.get('gt_bboxes_point', {}).items()}
+        self.refined_gt_bboxes_point = {k: v.to(dev) for k, v in state.get('refined_gt_bboxes_point', {}).items()}
+
+    def extract_feat(self, img, model=None):
+        return model.extract_feat(img)
+
+    def forward_dummy(self, img, model=None):
+        return model.forward_dummy(img)
+
+    def freeze(self, model):
+        model.eval()
+        for p in model.parameters():
+            p.requires_grad = False
+
+    # ------------------------------------------------------------------ training --
+    def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None):
+        """:116-139"""
+        img = img.to(torch.float)
+        num_img = len(img_metas)
+        self.update_teacher_model(self.teacher, self.student, self.ema_alpha)
+        self.update_epoch(num_img, img_metas)
+        gt_points, img_list, img = self.genrate_points(num_img, img, img_metas, gt_bboxes)
+        if self.count <= self.burn_in_step:
+            losses = self.forward_train_burn_in_step1(num_img, img, img_list, img_metas, gt_bboxes, gt_points, gt_labels,
+                                                      gt_bboxes_ignore, img.device)
+        else:
+            losses = self.forward_train_burn_in_step2(num_img, img, img_list, img_metas, gt_bboxes, gt_points, gt_labels,
+                                                      gt_bboxes_ignore, img.device)
+        self.count += 1
+        return losses
+
+    def update_teacher_model(self, teacher_model, student_model, ema_decay=0.999):
+        """:254-257: over parameters() only (buffers untouched), at the START of the iteration."""
+        with torch.no_grad():
+            if self._flat is not None:
+                F.ema_update_(self._flat[0], self._flat[1], ema_decay)
+            else:   # parameters not flattened yet (unit tests / CPU construction): per-tensor form
+                for t, s in zip(teacher_model.parameters(), student_model.parameters()):
+                    t.data.mul_(ema_decay).add_(s.data, alpha=1 - ema_decay)
+
+    def update_epoch(self, num_img, img_metas):
+        """:259-264"""
+        if img_metas[0]['ori_filename'] in self.epoch_dict:
+            self.epoch += 1
+            self.epoch_dict = {}
+        for i in range(num_img):
+            self.epoch_dict[img_metas[i]['ori_filename']] = 1
+
+    def update_points(self, num_img, img_metas, pseudo_bboxes):
+        """:266-274"""
+        out = []
+        for i in range(num_img):
+            pc = bbox_xyxy_to_cxcywh(pseudo_bboxes[i])[:, :2]
+            oc = self.gt_bboxes_point[img_metas[i]['ori_filename']]
+            rc = (1 - self.lamda) * pc + self.lamda * oc
+            out.append(rc)
+            self.refined_gt_bboxes_point[img_metas[i]['ori_filename']] = rc
+        return out
+
+    def genrate_points(self, num_img, img, img_metas, gt_bboxes):
+        """:504-519"""
+        gt_points, img_list = [], []
+        for i in range(num_img):
+            name = img_metas[i]['ori_filename']
+            if name in self.refined_gt_bboxes_point:
+                gt_points.append(self.refined_gt_bboxes_point[name])
+            else:
+                u = self._inject.get('point_u')
+                pts = random_point_in_quadrilateral(gt_bboxes[i], self._point_, *(u[i] if u is not None else (None, None)))
+                gt_points.append(pts)
+                self.gt_bboxes_point[name] = pts
+            img_list.append(img[i])
+        return gt_points, img_list, img
+
+    def _teacher_pseudo(self, img, img_metas, img_list, gt_points, gt_labels, gt_bboxes, gt_bboxes_ignore):
+        with torch.no_grad():
+            feat = self.extract_feat(img, self.teacher)
+            outs = self.teacher.bbox_head(feat)
+            return self.teacher.bbox_head.get_pseudo_bbox(*outs, gt_points, gt_labels, gt_bboxes, self.filter_score,
+                                                          img_metas, img_list, gt_bboxes_ignore)
+
+    def _refined_points_distance(self, gt_points, gt_bboxes):
+        real = bbox_xyxy_to_cxcywh(torch.cat(gt_bboxes, dim=0))
+        return (torch.sqrt((torch.cat(gt_points) - real[:, :2]) ** 2) / torch.sqrt((real[:, 2:] / 2) ** 2)).mean()
+
+    def _student_aug_loss(self, img, img_metas, gt_points, gt_labels, pseudo_points, pseudo_labels, pseudo_bboxes,
+                          gt_bboxes_ignore):
+        aug = strong_augmentation_masked(img, gt_points, gt_labels, pseudo_points, pseudo_labels, pseudo_bboxes,
+                                         params=self._inject.get('aug'))
+        img_aug, img_aug_list, gp, gl, pp, pl, pb, gv, pv = aug
+        outs = self.student.bbox_head(self.extract_feat(img_aug, self.student))
+        return self.student.bbox_head.loss_pseudo(*outs, gp, gl, pp, pl, pb, [None] * len(img_metas), img_metas,
+                                                  img_aug_list, self.count <= self.burn_in_step, gt_bboxes_ignore,
+                                                  gt_valid=gv, pseudo_valid=pv)
+
+    def forward_train_burn_in_step2(self, num_img, img, img_list, img_metas, gt_bboxes, gt_points, gt_labels,
+                                    gt_bboxes_ignore, device):
+        """:213-252"""
+        losses = {}
+        pb_c, pp_c, pl_c, _, _ = self._teacher_pseudo(img, img_metas, img_list, gt_points, gt_labels, gt_bboxes,
+                                                      gt_bboxes_ignore)
+        feat = self.extract_feat(img, self.student)
+        mil_feat = self.student.bbox_head.forward_mil(feat)
+        pb_r, pp_r, mil_losses = self.forward_mil_head_burn_in_step2(num_img, pb_c, pp_c, pl_c, gt_bboxes, img_metas,
+                                                                     mil_feat)
+        if mil_losses is not None:
+            losses.update(mil_losses)
+        del feat, mil_feat
+        gt_points = self.update_points(num_img, img_metas, pb_r)
+        losses['refined_points_distance'] = self._refined_points_distance(gt_points, gt_bboxes)
+        lc, lb, lt = self._student_aug_loss(img, img_metas, gt_points, gt_labels, pp_r, pl_c, pb_r, gt_bboxes_ignore)
+        losses['loss_cls'], losses['loss_bbox'], losses['loss_centerness'] = lc, lb, lt
+        return losses
+
+    def forward_mil_head_burn_in_step2(self, num_img, pseudo_bboxes, pseudo_points, pseudo_labels, gt_bboxes, img_metas,
+                                       x_ori):
+        """:425-466"""
+        n = self.num_training_burninstep2
+        losses = {}
+        pb_t = [b[:n].clone() for b in pseudo_bboxes]
+        gb_t = [b[:n].clone() for b in gt_bboxes]
+        pp_t = [p[:n].clone() for p in pseudo_points]
+        pl_t = [l[:n].clone() for l in pseudo_labels]
+        refined_b = [b.clone() for b in pseudo_bboxes]
+        refined_p = [p.clone() for p in pseudo_points]
+        gb_cat = torch.cat(gb_t, dim=0)
+        losses['coarse_bboxes_iou'] = bbox_overlaps(torch.cat(pb_t, dim=0), gb_cat, is_aligned=True).mean()
+        head = self.student.bbox_head
+        for stage in range(self.num_stages):
+            cfg = self.fine_proposal_cfg[stage]
+            pr, pv, pref, preal = MIL_gen_proposals_from_cfg(pp_t, pb_t, cfg, gb_t, img_meta=img_metas)
+            neg, negw = gen_negative_proposals(pp_t, cfg, pr, img_meta=img_metas, uniforms=self._inject.get(f'neg{stage}'))
+            mil_loss, pb_t = head.MIL_head_burn_in_step2(x_ori, img_metas, pr, pv, pref, preal, neg, negw, pb_t, pl_t,
+                                                         self.fine_proposal_extensive_cfg[stage], stage)
+            losses[f'stage{stage}_refine_bboxes_iou'] = bbox_overlaps(torch.cat(pb_t, dim=0), gb_cat, is_aligned=True).mean()
+            mil_loss[f'stage{stage}_loss_mil_bbox'] = mil_loss[f'stage{stage}_loss_mil_bbox'] * self.alpha[0]
+            mil_loss[f'stage{stage}_loss_mil_bags'] = mil_loss[f'stage{stage}_loss_mil_bags'] * self.alpha[1]
+            losses.update(mil_loss)
+        for i in range(num_img):
+            k = pb_t[i].shape[0]
+            refined_b[i][:k] = pb_t[i]
+            refined_p[i][:k] = bbox_xyxy_to_cxcywh(pb_t[i])[:, :2]
+        return refined_b, refined_p, losses
+
+    # --------------------------------------------------------------- burn-in step 1 --
+    def genrate_syn(self, num_img, img_list, gt_bboxes, gt_labels):
+        """:469-502 on the device: (img_syn [B,C,H,W], list, syn boxes list, alive masks list)."""
+        imgs, boxes, alive = [], [], []
+        draws = self._inject.get('syn')
+        for i in range(num_img):
+            C, H, W = img_list[i].shape
+            im, bx, al = generate_black_paper_masked(img_list[i], gt_bboxes[i], self.prior_size,
+                                                     range(int(len(self.pattern) / 2)), min(H, W),
+                                                     draws=draws[i] if draws is not None else None)
+            imgs.append(im); boxes.append(bx); alive.append(al)
+        return torch.stack(imgs, dim=0), imgs, boxes, alive
+
+    def forward_train_burn_in_step1(self, num_img, img, img_list, img_metas, gt_bboxes, gt_points, gt_labels,
+                                    gt_bboxes_ignore, device):
+        """:141-211.  The synthetic boxes are carried as fixed-size lists + `alive` masks."""
+        losses = {}
+        img_syn, _, syn_boxes, syn_alive = self.genrate_syn(num_img, img_list, gt_bboxes, gt_labels)
+        head = self.student.bbox_head
+        feat_all = self.extract_feat(torch.cat([img_syn, img], dim=0), self.student)
+        mil_all = head.forward_mil(feat_all)
+        feat_syn = [f[:num_img] for f in feat_all]
+        mil_syn = [m[:num_img] for m in mil_all]
+        mil_ori = [m[num_img:] for m in mil_all]
+        outs_syn = head(feat_syn)
+        loss_syn = head.loss(*outs_syn, syn_boxes, img_metas, gt_bboxes_ignore, gt_valid=syn_alive)
+        pb_c, pp_c, pl_c, _, _ = self._teacher_pseudo(img, img_metas, img_list, gt_points, gt_labels, gt_bboxes,
+                                                      gt_bboxes_ignore)
+        _, _, mil_losses = self.forward_mil_head_burn_in_step1(num_img, syn_boxes, syn_alive, pb_c, pp_c, pl_c, gt_bboxes,
+                                                               img_metas, mil_syn, mil_ori, img)
+        pb_r, pp_r = pb_c, pp_c                                   # the MIL output is discarded in step 1 (:187)
+        if mil_losses is not None:
+            losses.update(mil_losses)
+            gt_points = self.update_points(num_img, img_metas, pb_r)
+            losses['refined_points_distance'] = self._refined_points_distance(gt_points, gt_bboxes)
+        lc, _, _ = self._student_aug_loss(img, img_metas, gt_points, gt_labels, pp_r, pl_c, pb_r, gt_bboxes_ignore)
+        losses['loss_cls'] = lc
+        losses['loss_bbox'], losses['loss_centerness'] = loss_syn
+        return losses
+
+    def _compact_alive(self, boxes, alive, n):
+        """First `n` alive rows of `boxes` without a host round trip: (compacted [n,4], weight [n]).
+        Rows beyond the number of alive boxes are a harmless dummy box with weight 0."""
+        out = boxes.new_zeros((n + 1, 4))
+        out[:, 2:] = 8.0
+        w = boxes.new_zeros(n + 1)
+        if boxes.shape[0]:
+            rank = torch.cumsum(alive.int(), 0) - 1
+            take = alive & (rank < n)
+            idx = torch.where(take, rank, torch.full_like(rank, n)).long()   # everything else -> dump slot n
+            out.index_copy_(0, idx, boxes)
+            w.index_copy_(0, idx, take.to(w.dtype))
+        return out[:n].contiguous(), w[:n].contiguous()
+
+    def forward_mil_head_burn_in_step1(self, num_img, synthetic_bboxes, synthetic_alive, pseudo_bboxes, pseudo_points,
+                                       pseudo_labels, gt_bboxes, img_metas, x_synthetic, x_ori, img):
+        """:365-423.  Deviation (documented): when an image ends with zero synthetic boxes the
+        reference drops the MIL loss keys for that iteration (a DDP hazard); here
+        the keys are always present and such an image simply contributes zero-weight bags."""
+        n = self.num_training_burninstep1
+        losses = {}
+        syn_t, syn_w = zip(*[self._compact_alive(b, a, n) for b, a in zip(synthetic_bboxes, synthetic_alive)])
+        syn_t, syn_w = list(syn_t), list(syn_w)
+        syn_p = [bbox_xyxy_to_cxcywh(b)[:, :2] for b in syn_t]
+        pb_t = [b[:n] for b in pseudo_bboxes]
+        gb_t = [b[:n] for b in gt_bboxes]
+        pp_t = [p[:n] for p in pseudo_points]
+        pl_t = [l[:n] for l in pseudo_labels]
+        refined_b = [b.clone() for b in pseudo_bboxes]
+        refined_p = [p.clone() for p in pseudo_points]
+        gb_cat = torch.cat(gb_t, dim=0)
+        losses['coarse_bboxes_iou'] = bbox_overlaps(torch.cat(pb_t, dim=0), gb_cat, is_aligned=True).mean()
+        head = self.student.bbox_head
+        for stage in range(self.num_stages):
+            cfg = self.fine_proposal_cfg[stage]
+            ext = self.fine_proposal_extensive_cfg[stage]
+            pr, pv, pref, preal = MIL_gen_proposals_from_cfg(pp_t, pb_t, cfg, gb_t, img_meta=img_metas)
+            spr, spv, spref, spreal = MIL_gen_proposals_from_cfg(syn_p, syn_t, cfg, syn_t, img_meta=img_metas)
+            neg, negw = gen_negative_proposals(pp_t, cfg, pr, img_meta=img_metas, uniforms=self._inject.get(f'neg{stage}'))
+            U1 = len(cfg['base_ratios']) ** 2 * (1 + 4 * len(cfg['shake_ratio'] or []))
+            U2 = len(ext['base_ratios']) ** 2 * (1 + 4 * len(ext['shake_ratio'] or []))
+            bag_w = [w.repeat_interleave(U1 * U2) for w in syn_w]
+            mil_loss, pb_t = head.MIL_head_burn_in_step1(x_ori, x_synthetic, img_metas, pr, pv, pref, preal, spr, spv,
+                                                         spref, spreal, neg, negw, syn_t, pb_t, pl_t, ext, stage,
+                                                         syn_bag_weight=bag_w)
+            losses[f'stage{stage}_refine_bboxes_iou'] = bbox_overlaps(torch.cat(pb_t, dim=0), gb_cat, is_aligned=True).mean()
+            mil_loss[f'stage{stage}_loss_mil_bbox'] = mil_loss[f'stage{stage}_loss_mil_bbox'] * self.alpha[0]
+            mil_loss[f'stage{stage}_loss_mil_bags'] = mil_loss[f'stage{stage}_loss_mil_bags'] * self.alpha[1]
+            losses.update(mil_loss)
+        for i in range(num_img):
+            k = pb_t[i].shape[0]
+            refined_b[i][:k] = pb_t[i]
+            refined_p[i][:k] = bbox_xyxy_to_cxcywh(pb_t[i])[:, :2]
+        return refined_b, refined_p, losses
+
+    # ------------------------------------------------------------------- inference --
+    def simple_test(self, img, img_metas, rescale=False):
+        """:276-298: inference uses the TEACHER."""
+        img = img.to(torch.float)
+        feat = self.extract_feat(img, self.teacher)
+        res = self.teacher.bbox_head.simple_test(feat, img_metas, rescale=rescale)
+        return [bbox2result(b, l, self.teacher.bbox_head.num_classes) for b, l in res]

@@ -16,24 +16,66 @@ def _f(x):
     return x.contiguous().to(f32)
 
 
+class _PinnedRing:
+    """Persistent pinned staging ring for small host->device index uploads (offsets, batch
+    ids).  A fresh pageable upload would serialise the host behind the stream every
+    iteration; copies from this ring are truly asynchronous.  The ring is large enough
+    (256K words) that a slot is reused only thousands of iterations after the GPU consumed it."""
+
+    def __init__(self, words=1 << 18):
+        self.words = words
+        self.buf = None
+        self.pos = 0
+
+    def upload(self, arr, device, dtype):
+        arr = np.ascontiguousarray(arr)
+        n = arr.size
+        if self.buf is None:
+            self.buf = torch.empty(self.words, dtype=torch.int32).pin_memory()
+        if n > self.words:
+            return torch.from_numpy(arr).to(device)
+        if self.pos + n > self.words:
+            self.pos = 0
+        view = self.buf[self.pos:self.pos + n]
+        self.pos += n
+        if dtype == torch.int32:
+            view.numpy()[:] = arr.astype(np.int32).reshape(-1)
+            return view.to(device, non_blocking=True).reshape(arr.shape)
+        fv = view.view(torch.float32)
+        fv.numpy()[:] = arr.astype(np.float32).reshape(-1)
+        return fv.to(device, non_blocking=True).reshape(arr.shape)
+
+
+_ring = _PinnedRing()
+
+
+def upload_i32(values, device):
+    return _ring.upload(np.asarray(values, dtype=np.int32), device, torch.int32)
+
+
+def upload_f32(values, device):
+    return _ring.upload(np.asarray(values, dtype=np.float32), device, torch.float32)
+
+
 def make_offsets(counts, device):
     """Host list of per-image counts -> (off int32 [B+1] on device, total)."""
     off = np.zeros(len(counts) + 1, np.int32)
     off[1:] = np.cumsum(counts)
-    return torch.from_numpy(off).to(device, non_blocking=True), int(off[-1])
+    return upload_i32(off, device), int(off[-1])
 
 
 # ------------------------------------------------------------------ assigners --
 
-def topk_assign(points, gt_xy, off, B, num_pre, want_cand=False):
-    """pt_topk_assign.  points [P,2]; gt_xy [sumG,>=2] (first two columns used).
-    Returns gt_inds int32 [B,P] (and cand int32 [sumG,num_pre])."""
+def topk_assign(points, gt_xy, off, B, num_pre, want_cand=False, gt_valid=None):
+    """pt_topk_assign.  points [P,2]; gt_xy [sumG,>=2] (first two columns used);
+    gt_valid optional uint8/bool [sumG].  Returns gt_inds int32 [B,P] (and cand [sumG,num_pre])."""
     P = points.shape[0]
     sumG = gt_xy.shape[0]
     gt_inds = torch.empty((B, P), dtype=i32, device=points.device)
     cand = torch.empty((sumG, num_pre), dtype=i32, device=points.device) if want_cand else None
     xy = _f(gt_xy[:, :2]) if sumG else None
-    hip.call('pt_topk_assign', _f(points), P, xy, off, B, sumG, num_pre, gt_inds, cand)
+    gv = gt_valid.to(u8).contiguous() if (gt_valid is not None and sumG) else None
+    hip.call('pt_topk_assign', _f(points), P, xy, gv, off, B, sumG, num_pre, gt_inds, cand)
     return (gt_inds, cand) if want_cand else gt_inds
 
 

@@ -1,0 +1,440 @@
+"""TS_P2BFCOSHead - the FCOS-style dense head with the MIL refinement branch, mirroring
+/root/reference/HBB_TOD/mmdet/models/dense_heads/fcos_head_p2b_ts.py (+ anchor_free_head.py)
+method for method.  Label assignment, target build, pseudo-box fusion, focal / DN-DIoU
+losses, RoIAlign, bag scoring and bag selection all run in libpt_hip.so; images of a batch
+are processed in ONE launch per op and no method synchronises the host (the reference
+syncs on every `.nonzero()`, `len(pos_inds)`, `.item()` and `.tolist()`).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as TF
+
+from . import functional as F
+from .core import (bbox2roi, bbox_cxcywh_to_xyxy, bbox_overlaps, bbox_xyxy_to_cxcywh, distance2bbox, multi_apply,
+                   multiclass_nms, reduce_mean)
+from .losses import diou_forward_masked
+from .nn_modules import ConvModule, Scale
+from .proposals import MIL_gen_proposals_from_cfg
+from .registry import HEADS, build_assigner, build_bbox_coder, build_loss, build_roi_extractor
+
+INF = 1e8
+
+
+def _cat(ts, dim=0):
+    return torch.cat(list(ts), dim) if len(ts) else None
+
+
+@HEADS.register_module()
+class TS_P2BFCOSHead(nn.Module):
+    """Constructor keywords as fcos_head_p2b_ts.py:80-146 / anchor_free_head.py:35-70."""
+
+    def __init__(self, num_classes, in_channels, feat_channels=256, stacked_convs=4, strides=(4, 8, 16, 32, 64),
+                 dcn_on_last_conv=False, conv_bias='auto', center_sampling=False, center_sample_radius=1.5,
+                 norm_on_bbox=False, centerness_on_reg=False, mil_stack_conv=1, beta=0.25, top_k=3, num_stages=2,
+                 bbox_roi_extractor=None,
+                 loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+                 loss_bbox_burn1=dict(type='DIoULoss', loss_weight=1.0),
+                 loss_bbox_burn2=dict(type='DN_DIoULoss', loss_weight=1.0, hyper=0.1),
+                 loss_bbox_denosing=dict(type='DN_DIoULoss', loss_weight=1.0, hyper=0.3),
+                 loss_centerness=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
+                 conv_cfg=None, norm_cfg=dict(type='GN', num_groups=32, requires_grad=True), train_cfg=None,
+                 test_cfg=None, init_cfg=None, regress_ranges=None, **kwargs):
+        super().__init__()
+        assert norm_cfg is None, 'the Point-Teacher configs use norm_cfg=None in the head'
+        assert not dcn_on_last_conv, 'dcn_on_last_conv=False in every Point-Teacher config (DCN is a later row)'
+        self.num_classes = self.cls_out_channels = num_classes
+        self.in_channels, self.feat_channels, self.stacked_convs = in_channels, feat_channels, stacked_convs
+        self.strides = list(strides)
+        self.dcn_on_last_conv = dcn_on_last_conv
+        assert conv_bias == 'auto' or isinstance(conv_bias, bool)
+        self.conv_bias = True if conv_bias == 'auto' else conv_bias
+        self.center_sampling, self.center_sample_radius = center_sampling, center_sample_radius
+        self.norm_on_bbox, self.centerness_on_reg = norm_on_bbox, centerness_on_reg
+        self.mil_stack_conv, self.num_stages = mil_stack_conv, num_stages
+        self.loss_cls = build_loss(loss_cls)
+        self.loss_bbox = build_loss(loss_bbox_burn1)
+        self.loss_centerness = build_loss(loss_centerness)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        if train_cfg:
+            assert 'assigner' in train_cfg, 'assigner should be provided when train_cfg is set.'
+            self.assigner = build_assigner(train_cfg['assigner'])
+            self.fuse_assigner = build_assigner(train_cfg['fuse_assigner'])
+            self.syn_assigner = build_assigner(train_cfg['syn_assigner'])
+            self.pseudo_assigner = build_assigner(train_cfg['pseudo_assigner'])
+        # MIL head (fcos_head_p2b_ts.py:174-187)
+        self.beta, self.topk = beta, top_k
+        self.bbox_roi_extractor = build_roi_extractor(bbox_roi_extractor)
+        self.loss_mil_iou = build_loss(dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=0.25))
+        self.loss_mil_bbox = build_loss(dict(type='SmoothL1Loss', beta=1.0, loss_weight=0.25))
+        self.mil_bbox_decoder = build_bbox_coder(dict(type='DeltaXYWHBBoxCoder', target_means=[.0, .0, .0, .0],
+                                                      target_stds=[1.0, 1.0, 1.0, 1.0]))
+        self.loss_bbox_denosing = build_loss(loss_bbox_denosing)
+        self.loss_bbox_burn2 = build_loss(loss_bbox_burn2)
+        self.smoothl1 = build_loss(dict(type='SmoothL1Loss', beta=1.0, loss_weight=1.0))
+        self._init_layers()
+        self.init_weights()
+        self._points_cache = {}
+
+    # ------------------------------------------------------------------ layers --
+    def _init_layers(self):
+        """anchor_free_head.py:86-135 + fcos_head_p2b_ts.py:189-263 (same parameter names)."""
+        def stack(n, cin):
+            return nn.ModuleList([ConvModule(cin if i == 0 else self.feat_channels, self.feat_channels, 3, padding=1,
+                                             bias=self.conv_bias) for i in range(n)])
+        self.cls_convs = stack(self.stacked_convs, self.in_channels)
+        self.reg_convs = stack(self.stacked_convs, self.in_channels)
+        self.conv_cls = nn.Conv2d(self.feat_channels, self.cls_out_channels, 3, padding=1)
+        self.conv_reg = nn.Conv2d(self.feat_channels, 4, 3, padding=1)
+        self.conv_centerness = nn.Conv2d(self.feat_channels, 1, 3, padding=1)
+        self.scales = nn.ModuleList([Scale(1.0) for _ in self.strides])
+        self.conv_mil = stack(self.mil_stack_conv, self.in_channels)
+        self.num_shared_fcs, self.fc_out_channels, self.roi_feat_area = 2, 1024, 7 * 7
+
+        def fcs():
+            d = self.in_channels * self.roi_feat_area
+            return nn.ModuleList([nn.Linear(d if i == 0 else self.fc_out_channels, self.fc_out_channels)
+                                  for i in range(self.num_shared_fcs)])
+        self.shared_fcs, self.shared_fcs_refine = fcs(), fcs()            # built but unused at train time (:219-222)
+        self.cls_fcs, self.ins_fcs = nn.ModuleList(), nn.ModuleList()
+        self.relu = nn.ReLU(inplace=True)
+        self.fc_cls, self.fc_ins, self.fc_reg, self.fc_iou = (nn.ModuleList() for _ in range(4))
+        self.shared_fcs_bag, self.shared_fcs_reg = nn.ModuleList(), nn.ModuleList()
+        for _ in range(self.num_stages):
+            self.shared_fcs_bag.append(fcs())
+            self.shared_fcs_reg.append(fcs())
+            self.fc_cls.append(nn.Linear(self.fc_out_channels, self.num_classes))
+            self.fc_ins.append(nn.Linear(self.fc_out_channels, self.num_classes))
+            self.fc_reg.append(nn.Linear(self.fc_out_channels, 4))
+            self.fc_iou.append(nn.Linear(self.fc_out_channels, 1))
+
+    def init_weights(self):
+        """init_cfg of fcos_head_p2b_ts.py:137-145: Normal(std .01) on convs, conv_cls bias_prob .01."""
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.normal_(m.weight, 0, 0.01)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+        nn.init.constant_(self.conv_cls.bias, float(-torch.log(torch.tensor((1 - 0.01) / 0.01))))
+
+    # ----------------------------------------------------------------- forward --
+    def get_points(self, featmap_sizes, dtype, device, flatten=False):
+        """anchor_free_head.py:318-335 + fcos_head_p2b_ts.py:1007-1017 (cached per size)."""
+        out = []
+        for (h, w), s in zip(featmap_sizes, self.strides):
+            key = (int(h), int(w), s, str(device), dtype)
+            if key not in self._points_cache:
+                ys, xs = torch.meshgrid(torch.arange(h, device=device).to(dtype), torch.arange(w, device=device).to(dtype),
+                                        indexing='ij')
+                self._points_cache[key] = torch.stack((xs.reshape(-1) * s, ys.reshape(-1) * s), dim=-1) + s // 2
+            out.append(self._points_cache[key])
+        return out
+
+    def forward(self, feats):
+        """fcos_head_p2b_ts.py:302-324 -> (cls_scores, bbox_preds, centernesses, points) lists per level."""
+        sizes = [f.size()[-2:] for f in feats]
+        pts = self.get_points(sizes, feats[0].dtype if feats[0].dtype == torch.float32 else torch.float32,
+                              feats[0].device)
+        return multi_apply(self.forward_single, feats, self.scales, self.strides, pts)
+
+    def forward_single(self, x, scale, stride, points):
+        """fcos_head_p2b_ts.py:326-353"""
+        cls_feat = reg_feat = x
+        for l in self.cls_convs:
+            cls_feat = l(cls_feat)
+        cls_score = self.conv_cls(cls_feat)
+        for l in self.reg_convs:
+            reg_feat = l(reg_feat)
+        bbox_pred = self.conv_reg(reg_feat)
+        centerness = self.conv_centerness(reg_feat if self.centerness_on_reg else cls_feat)
+        bbox_pred = scale(bbox_pred).float()
+        if self.norm_on_bbox:
+            bbox_pred = bbox_pred.clamp(min=0) * stride
+        else:
+            bbox_pred = bbox_pred.exp()
+        return cls_score, bbox_pred, centerness, points
+
+    def forward_mil(self, feats):
+        """:1080-1090"""
+        outs = []
+        for x in feats:
+            m = x
+            for l in self.conv_mil:
+                m = l(m)
+            outs.append(m)
+        return outs
+
+    # --------------------------------------------------------------- flattening --
+    def _flat(self, cls_scores, bbox_preds, centernesses):
+        """[B,C,H,W] per level -> [B, P, C] (all levels concatenated, image-major)."""
+        B = cls_scores[0].size(0)
+        fc = torch.cat([c.permute(0, 2, 3, 1).reshape(B, -1, self.cls_out_channels) for c in cls_scores], 1)
+        fr = torch.cat([r.permute(0, 2, 3, 1).reshape(B, -1, 4) for r in bbox_preds], 1)
+        ft = torch.cat([t.permute(0, 2, 3, 1).reshape(B, -1) for t in centernesses], 1)
+        return fc.float().contiguous(), fr.float().contiguous(), ft.float().contiguous()
+
+    # -------------------------------------------------------------- pseudo boxes --
+    def get_pseudo_bbox(self, cls_scores, bbox_preds, centernesses, all_level_points, gt_points, gt_labels, gt_bboxes,
+                        filter_scores, img_metas, img_list, gt_bboxes_ignore=None):
+        """:357-375 -> (pseudo_bboxes, pseudo_points, pseudo_labels, mean_ious_pred, valid_masks).
+        The last item is a list of boolean masks (the reference returns index tensors built
+        through python sets, :791; nothing downstream reads them)."""
+        assert len(cls_scores) == len(bbox_preds) == len(centernesses)
+        fc, fr, _ = self._flat(cls_scores, bbox_preds, centernesses)
+        B, P = fc.shape[:2]
+        points = torch.cat(all_level_points, 0)
+        counts = [int(l.shape[0]) for l in gt_labels]
+        dev = fc.device
+        off, tot = F.make_offsets(counts, dev)
+        a = self.fuse_assigner
+        gp, gl, gb = torch.cat(gt_points), torch.cat(gt_labels), torch.cat(gt_bboxes)
+        gi, cand = F.fuse_assign(points, fr.reshape(-1, 4), fc.reshape(-1, self.cls_out_channels), gp, gl, off, B,
+                                 a.num_pre, a.topk, a.cls_cost.weight, a.reg_cost.weight, a.location_cost.weight)
+        ps = F.pseudo_boxes(points, fr.reshape(-1, 4), fc.reshape(-1, self.cls_out_channels), gp, gl, gb, off, B, gi, cand)
+        nz = ps['nassigned'] > 0
+        valid = nz & (ps['scores'] >= filter_scores)
+        ious, nzs = torch.split(ps['iou'], counts), torch.split(nz, counts)
+        mean_iou = sum((i.sum() / z.sum()) if c else i.new_zeros(()) for i, z, c in zip(ious, nzs, counts)) / B
+        return (list(torch.split(ps['bboxes'], counts)), list(torch.split(ps['points'], counts)), list(gt_labels),
+                mean_iou, list(torch.split(valid, counts)))
+
+    # --------------------------------------------------------------------- losses --
+    def _reg_branch(self, points, B, fr, ft, gi_reg, boxes, box_labels, off, loss_mod, dn):
+        """Shared tail of loss_pseudo (:436-463) and loss (:502-532): targets, centerness-weighted
+        (DN-)DIoU and centerness BCE, dense over all B*P points with the positive mask."""
+        P = points.shape[0]
+        labels_reg, tg, ctr_t = F.fcos_targets(points, gi_reg, boxes, box_labels, off, B, self.num_classes)
+        pos = labels_reg < self.num_classes
+        num_pos = reduce_mean(pos.sum().float()).clamp(min=1.0)
+        ctr_den = reduce_mean(ctr_t.sum().detach()).clamp(min=1e-6)
+        pts = points.repeat(B, 1)
+        pred = distance2bbox(pts, fr.reshape(-1, 4))
+        tgt = distance2bbox(pts, tg)
+        if dn:
+            loss_bbox = loss_mod.forward_masked(pred, tgt, pos, ctr_t, ctr_den)
+        else:
+            loss_bbox = diou_forward_masked(loss_mod, pred, tgt, pos, ctr_t, ctr_den)
+        bce = TF.binary_cross_entropy_with_logits(ft.reshape(-1), ctr_t, reduction='none')
+        loss_ctr = self.loss_centerness.loss_weight * torch.where(pos, bce, torch.zeros_like(bce)).sum() / num_pos
+        return loss_bbox, loss_ctr
+
+    def loss_pseudo(self, cls_scores, bbox_preds, centernesses, all_level_points, gt_points, gt_labels, pseudo_points,
+                    pseudo_labels, pseudo_bboxes, gt_augument_ignore, img_metas, img_list, burn_in_step1,
+                    gt_bboxes_ignore=None, gt_valid=None, pseudo_valid=None):
+        """:380-465.  gt_valid / pseudo_valid: optional per-image boolean masks (see
+        proposals.strong_augmentation_masked); without them the lists are used as given."""
+        assert len(cls_scores) == len(bbox_preds) == len(centernesses)
+        fc, fr, ft = self._flat(cls_scores, bbox_preds, centernesses)
+        B, P = fc.shape[:2]
+        points = torch.cat(all_level_points, 0)
+        dev = fc.device
+        # classification labels: assigner (1,1) on the points (:665-670)
+        gcounts = [int(p.shape[0]) for p in gt_points]
+        goff, _ = F.make_offsets(gcounts, dev)
+        gi_cls = F.topk_assign(points, torch.cat(gt_points), goff, B, self.assigner.num_pre,
+                               gt_valid=_cat(gt_valid) if gt_valid is not None else None)
+        labels, _, _ = F.fcos_targets(points, gi_cls, None, torch.cat(gt_labels), goff, B, self.num_classes)
+        num_pos = reduce_mean((labels < self.num_classes).sum().float()).clamp(min=1.0)
+        loss_cls = self.loss_cls(fc.reshape(-1, self.cls_out_channels), labels, weight=None, avg_factor=num_pos)
+        # regression: pseudo_assigner (3,3) on the pseudo-box centres (:683-706)
+        pcounts = [int(b.shape[0]) for b in pseudo_bboxes]
+        poff, _ = F.make_offsets(pcounts, dev)
+        pb = torch.cat(pseudo_bboxes)
+        gi_reg = F.topk_assign(points, bbox_xyxy_to_cxcywh(pb), poff, B, self.pseudo_assigner.num_pre,
+                               gt_valid=_cat(pseudo_valid) if pseudo_valid is not None else None)
+        loss_bbox, loss_ctr = self._reg_branch(points, B, fr, ft, gi_reg, pb, torch.cat(pseudo_labels), poff,
+                                               self.loss_bbox_burn2, dn=True)
+        return loss_cls, loss_bbox, loss_ctr
+
+    def loss(self, cls_scores, bbox_preds, centernesses, all_level_points, gt_bboxes, img_metas, gt_bboxes_ignore=None,
+             gt_valid=None):
+        """:470-534 (burn-in step 1: synthetic rectangles, syn_assigner (3,3), plain DIoU)."""
+        fc, fr, ft = self._flat(cls_scores, bbox_preds, centernesses)
+        B = fc.shape[0]
+        points = torch.cat(all_level_points, 0)
+        counts = [int(b.shape[0]) for b in gt_bboxes]
+        off, _ = F.make_offsets(counts, fc.device)
+        gb = torch.cat(gt_bboxes)
+        gi = F.topk_assign(points, bbox_xyxy_to_cxcywh(gb), off, B, self.syn_assigner.num_pre,
+                           gt_valid=_cat(gt_valid) if gt_valid is not None else None)
+        return self._reg_branch(points, B, fr, ft, gi, gb, None, off, self.loss_bbox, dn=False)
+
+    def centerness_target(self, pos_bbox_targets):
+        """:1019-1038"""
+        lr, tb = pos_bbox_targets[:, [0, 2]], pos_bbox_targets[:, [1, 3]]
+        if len(lr) == 0:
+            return lr[..., 0]
+        c = (lr.min(dim=-1)[0].clamp(min=0.01) / lr.max(dim=-1)[0]) * (tb.min(dim=-1)[0].clamp(min=0.01) / tb.max(dim=-1)[0])
+        return torch.sqrt(c)
+
+    def gfocal_loss(self, p, q, w=1.0, eps=1e-6):
+        """:1074-1078 (torch form, kept for API parity; training uses the fused kernel)."""
+        return -(((p - q) ** 2) * (q * (p + eps).log() + (1 - q) * (1 - p + eps).log()) * w).sum(dim=-1)
+
+    # ----------------------------------------------------------------- MIL head --
+    def _fc_stack(self, fcs, x):
+        for fc in fcs:
+            x = TF.relu(fc(x), inplace=True)
+        return x
+
+    def mil_bag_extensive(self, num_gt, num_gt_pre_image, x, img_metas, proposals_list, proposals_valid_list,
+                          proposals_reference_list, proposals_real_list, bbox_results, fine_proposal_cfg, stage,
+                          bag_weight=None):
+        """:1182-1236.  bag_weight (optional, per image [n_i*U1*U2] float) multiplies the validity
+        weights - used by step 1 where padded synthetic boxes must not count."""
+        U1 = sum(p.shape[0] for p in proposals_list) // max(num_gt, 1)      # :1185 (same U1 for every image)
+        bbox_results['base_shaking_num'] = U1
+        points_list = [bbox_xyxy_to_cxcywh(p)[:, :2] for p in proposals_list]
+        ext, ext_valid, _, ext_ref = MIL_gen_proposals_from_cfg(points_list, proposals_list, fine_proposal_cfg,
+                                                               proposals_reference_list, img_metas)
+        num_aug = len(fine_proposal_cfg['base_ratios']) ** 2 * (1 + 4 * len(fine_proposal_cfg['shake_ratio'] or []))
+        ext_real = [r.unsqueeze(1).repeat(1, num_aug, 1).reshape(-1, 4) for r in proposals_real_list]
+        bbox_results['base_bags'], bbox_results['base_bags_valid'] = proposals_list, proposals_valid_list
+        bags, real, ref = torch.cat(ext), torch.cat(ext_real), torch.cat(ext_ref)
+        valid = torch.cat(ext_valid).reshape(-1)
+        K = bags.shape[0]
+        if bag_weight is None:
+            bbox_results['coarse_bags_iou'] = bbox_overlaps(bags, real, is_aligned=True).mean()
+            wgt, avg = valid.float(), float(max(K, 1))
+            wsum = None
+        else:
+            bw = torch.cat(bag_weight)
+            wsum = bw.sum().clamp(min=1.0)
+            bbox_results['coarse_bags_iou'] = (bbox_overlaps(bags, real, is_aligned=True) * bw).sum() / wsum
+            wgt, avg = valid.float() * bw, wsum
+        bbox_results['extensive_shaking_num'] = U2 = num_aug
+        rois = bbox2roi(ext)
+        feats = self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois).flatten(1)
+        bbox_pred = self.fc_reg[stage](self._fc_stack(self.shared_fcs_reg[stage], feats))
+        del feats
+        bbox_pred = self.mil_bbox_decoder.decode(bags, bbox_pred, max_shape=img_metas[0]['img_shape'])
+        pred_d = bbox_pred.detach()
+        bbox_results['loss_mil_bbox'] = self.loss_bbox_denosing(bbox_pred, ref, weight=wgt, avg_factor=avg)
+        ri = bbox_overlaps(pred_d, real, is_aligned=True)
+        bbox_results['refine_bags_iou'] = ri.mean() if wsum is None else (ri * torch.cat(bag_weight)).sum() / wsum
+        sizes = [e.shape[0] for e in ext]
+        bbox_results['extensive_bags'] = list(torch.split(pred_d, sizes))
+        bbox_results['extensive_bags_valid'] = ext_valid
+        bbox_results['extensive_bags_reference'] = ext_ref
+        bbox_results['extensive_bags_real'] = ext_real
+
+    def mil_bag_classifier(self, num_gt, x, bbox_results, stage):
+        """:1240-1256"""
+        rois = bbox2roi(bbox_results['extensive_bags'])
+        feats = self._fc_stack(self.shared_fcs_bag[stage],
+                               self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois).flatten(1))
+        U1, U2 = bbox_results['base_shaking_num'], bbox_results['extensive_shaking_num']
+        bbox_results['cls_score'] = self.fc_cls[stage](feats).view(num_gt, U1, U2, -1)
+        bbox_results['ins_score'] = self.fc_ins[stage](feats).view(num_gt, U1, U2, -1)
+
+    def forward_mil_head(self, num_gt, num_gt_pre_image, x, proposals_list, proposals_valid_list,
+                         proposals_reference_list, proposals_real_list, img_metas, fine_proposal_cfg, stage,
+                         neg_proposal_list=None, neg_weight_list=None, bag_weight=None):
+        """:1259-1277"""
+        bbox_results = {}
+        self.mil_bag_extensive(num_gt, num_gt_pre_image, x, img_metas, proposals_list, proposals_valid_list,
+                               proposals_reference_list, proposals_real_list, bbox_results, fine_proposal_cfg, stage,
+                               bag_weight=bag_weight)
+        self.mil_bag_classifier(num_gt, x, bbox_results, stage)
+        if neg_proposal_list is not None:
+            rois = bbox2roi(neg_proposal_list)
+            feats = self._fc_stack(self.shared_fcs_bag[stage],
+                                   self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois).flatten(1))
+            bbox_results['neg_cls_score'] = self.fc_cls[stage](feats)
+        return bbox_results
+
+    def mil_bag_training(self, bbox_results, gt_labels, neg_weight_list):
+        """:1147-1180 through the fused bag-loss kernels."""
+        cls, ins = bbox_results['cls_score'], bbox_results['ins_score']
+        N, U1, U2, C = cls.shape
+        labels = torch.cat(gt_labels).unsqueeze(1).repeat(1, U1).reshape(-1)
+        valid = torch.cat(bbox_results['extensive_bags_valid'], 0).reshape(-1)
+        total, nvalid = F.mil_bag_loss_sum(cls.reshape(N * U1, U2, C), ins.reshape(N * U1, U2, C), valid, labels)
+        num_sample = nvalid.clamp(min=1.0)
+        loss = total / num_sample
+        if neg_weight_list is not None:
+            loss = loss + F.mil_neg_loss_sum(bbox_results['neg_cls_score'], torch.cat(neg_weight_list)) / num_sample
+        return loss
+
+    def mil_bag_selection(self, bbox_results, img_metas, pseudo_bboxes, pseudo_labels):
+        """:1112-1145 (+ _single :1092-1110) in one launch for the whole batch."""
+        cls, ins = bbox_results['cls_score'], bbox_results['ins_score']
+        N, U1, U2, C = cls.shape
+        h, w, _ = img_metas[0]['img_shape']
+        merged = F.mil_bag_select(cls, ins, torch.cat(bbox_results['extensive_bags_valid'], 0).reshape(-1),
+                                  torch.cat(pseudo_labels), torch.cat(bbox_results['extensive_bags'], 0),
+                                  torch.cat(pseudo_bboxes), U1, U2, self.topk, self.beta, (h, w))
+        return list(torch.split(merged, [len(b) for b in pseudo_bboxes]))
+
+    def MIL_head_burn_in_step2(self, x, img_metas, proposals_list, proposals_valid_list, proposals_reference_list,
+                               proposals_real_list, neg_proposal_list, neg_weight_list, pseudo_bboxes, pseudo_labels,
+                               fine_proposal_cfg, stage):
+        """:1318-1344"""
+        num_gt = sum(b.shape[0] for b in pseudo_bboxes)
+        npi = [b.shape[0] for b in pseudo_bboxes]
+        r = self.forward_mil_head(num_gt, npi, x, proposals_list, proposals_valid_list, proposals_reference_list,
+                                  proposals_real_list, img_metas, fine_proposal_cfg, stage, neg_proposal_list,
+                                  neg_weight_list)
+        losses = {f'stage{stage}_loss_mil_bbox': r['loss_mil_bbox'],
+                  f'stage{stage}_loss_mil_bags': self.mil_bag_training(r, pseudo_labels, neg_weight_list),
+                  f'stage{stage}_coarse_bags_iou': r['coarse_bags_iou'],
+                  f'stage{stage}_refine_bags_iou': r['refine_bags_iou']}
+        return losses, self.mil_bag_selection(r, img_metas, pseudo_bboxes, pseudo_labels)
+
+    def MIL_head_burn_in_step1(self, x_ori, x_synethic, img_metas, proposals_list, proposals_valid_list,
+                               proposals_reference_list, proposals_real_list, syn_proposals_list,
+                               syn_proposals_valid_list, syn_proposals_reference_list, syn_proposals_real_list,
+                               neg_proposal_list, neg_weight_list, synthetic_bboxes, pseudo_bboxes, pseudo_labels,
+                               fine_proposal_cfg, stage, syn_bag_weight=None):
+        """:1279-1316: the regression branch trains on the SYNTHETIC bags, the bag classifier on the real ones."""
+        num_syn = sum(b.shape[0] for b in synthetic_bboxes)
+        nsi = [b.shape[0] for b in synthetic_bboxes]
+        num_gt = sum(b.shape[0] for b in pseudo_bboxes)
+        npi = [b.shape[0] for b in pseudo_bboxes]
+        losses = {}
+        rs = self.forward_mil_head(num_syn, nsi, x_synethic, syn_proposals_list, syn_proposals_valid_list,
+                                   syn_proposals_reference_list, syn_proposals_real_list, img_metas, fine_proposal_cfg,
+                                   stage, bag_weight=syn_bag_weight)
+        losses[f'stage{stage}_loss_mil_bbox'] = rs['loss_mil_bbox']
+        del rs
+        r = self.forward_mil_head(num_gt, npi, x_ori, proposals_list, proposals_valid_list, proposals_reference_list,
+                                  proposals_real_list, img_metas, fine_proposal_cfg, stage, neg_proposal_list,
+                                  neg_weight_list)
+        losses[f'stage{stage}_loss_mil_bags'] = self.mil_bag_training(r, pseudo_labels, neg_weight_list)
+        losses[f'stage{stage}_coarse_bags_iou'] = r['coarse_bags_iou']
+        losses[f'stage{stage}_refine_bags_iou'] = r['refine_bags_iou']
+        return losses, self.mil_bag_selection(r, img_metas, pseudo_bboxes, pseudo_labels)
+
+    # ------------------------------------------------------------------ inference --
+    def simple_test(self, feats, img_metas, rescale=False):
+        return self.get_bboxes(*self.forward(feats), img_metas, rescale=rescale)
+
+    def get_bboxes(self, cls_scores, bbox_preds, centernesses, all_level_points, img_metas, cfg=None, rescale=False,
+                   with_nms=True):
+        """:796-1005 (non-ONNX path)."""
+        cfg = self.test_cfg if cfg is None else cfg
+        B = cls_scores[0].shape[0]
+        img_shapes = [m['img_shape'] for m in img_metas]
+        nms_pre = cfg.get('nms_pre', -1)
+        mb, ms, mc = [], [], []
+        for cls_score, bbox_pred, ctr, points in zip(cls_scores, bbox_preds, centernesses, all_level_points):
+            scores = cls_score.detach().permute(0, 2, 3, 1).reshape(B, -1, self.cls_out_channels).sigmoid()
+            ctr = ctr.detach().permute(0, 2, 3, 1).reshape(B, -1).sigmoid()
+            bbox_pred = bbox_pred.detach().permute(0, 2, 3, 1).reshape(B, -1, 4)
+            points = points.expand(B, -1, 2)
+            if 0 < nms_pre < bbox_pred.shape[1]:
+                max_scores, _ = (scores * ctr[..., None]).max(-1)
+                _, topk_inds = max_scores.topk(nms_pre)
+                bi = torch.arange(B, device=scores.device).view(-1, 1).expand_as(topk_inds)
+                points, bbox_pred = points[bi, topk_inds, :], bbox_pred[bi, topk_inds, :]
+                scores, ctr = scores[bi, topk_inds, :], ctr[bi, topk_inds]
+            mb.append(distance2bbox(points, bbox_pred, max_shape=img_shapes))
+            ms.append(scores)
+            mc.append(ctr)
+        bb, sc, ct = torch.cat(mb, 1), torch.cat(ms, 1), torch.cat(mc, 1)
+        if rescale:
+            bb = bb / bb.new_tensor([m['scale_factor'] for m in img_metas]).unsqueeze(1)
+        sc = torch.cat([sc, sc.new_zeros(B, sc.shape[1], 1)], dim=-1)
+        if not with_nms:
+            return [tuple(t) for t in zip(bb, sc, ct)]
+        return [multiclass_nms(b, s, cfg['score_thr'], cfg['nms'], cfg['max_per_img'], score_factors=c)
+                for b, s, c in zip(bb, sc, ct)]

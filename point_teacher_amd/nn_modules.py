@@ -1,0 +1,310 @@
+"""Backbone / neck / RoI modules with the reference's registry names, constructor keywords
+and parameter names (so mmdet checkpoints load): ResNet (caffe style), FPN, PSAGG, Scale,
+RoIAlign, SingleRoIExtractor.  The convolutions are plain torch (MIOpen on ROCm) - the
+contraction work belongs on the matrix cores via the vendor library; everything specific to
+Point-Teacher around them is in libpt_hip.so.
+
+Citations: /root/reference/HBB_TOD/mmdet/models/backbones/resnet.py,
+necks/fpn.py, necks/ps_fpn.py, roi_heads/roi_extractors/*.py.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as TF
+
+from . import functional as F
+from .registry import BACKBONES, NECKS, ROI_EXTRACTORS
+
+
+class ConvModule(nn.Module):
+    """The subset of mmcv.cnn.ConvModule on this path: conv (+ReLU).  Parameter path `.conv`."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, act=True):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=bias)
+        self.with_activation = act
+
+    def forward(self, x):
+        x = self.conv(x)
+        return TF.relu(x, inplace=True) if self.with_activation else x
+
+
+class Scale(nn.Module):
+    """mmcv.cnn.Scale"""
+
+    def __init__(self, scale=1.0):
+        super().__init__()
+        self.scale = nn.Parameter(torch.tensor(scale, dtype=torch.float))
+
+    def forward(self, x):
+        return x * self.scale
+
+
+# ------------------------------------------------------------------------ ResNet --
+class Bottleneck(nn.Module):
+    """backbones/resnet.py:96-303; `caffe` style puts the stride on conv1 (:153-158)."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, style='pytorch'):
+        super().__init__()
+        assert style in ('pytorch', 'caffe')
+        s1, s2 = (1, stride) if style == 'pytorch' else (stride, 1)
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, stride=s1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=s2, padding=dilation, dilation=dilation, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x
+        out = TF.relu(self.bn1(self.conv1(x)), inplace=True)
+        out = TF.relu(self.bn2(self.conv2(out)), inplace=True)
+        out = self.bn3(self.conv3(out))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        out += identity
+        return TF.relu(out, inplace=True)
+
+
+@BACKBONES.register_module()
+class ResNet(nn.Module):
+    """backbones/resnet.py:305-658 for depth 50/101/152 (Bottleneck)."""
+    arch_settings = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+
+    def __init__(self, depth, in_channels=3, num_stages=4, strides=(1, 2, 2, 2), dilations=(1, 1, 1, 1),
+                 out_indices=(0, 1, 2, 3), style='pytorch', frozen_stages=-1, norm_cfg=dict(type='BN', requires_grad=True),
+                 norm_eval=True, zero_init_residual=True, pretrained=None, init_cfg=None, **unused):
+        super().__init__()
+        if depth not in self.arch_settings:
+            raise KeyError(f'invalid depth {depth} for resnet')
+        blocks = self.arch_settings[depth][:num_stages]
+        self.out_indices, self.frozen_stages, self.norm_eval = out_indices, frozen_stages, norm_eval
+        self.conv1 = nn.Conv2d(in_channels, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        inplanes = 64
+        self.res_layers = []
+        for i, nb in enumerate(blocks):
+            planes = 64 * 2 ** i
+            layers = []
+            for j in range(nb):
+                stride = strides[i] if j == 0 else 1
+                ds = None
+                if j == 0 and (stride != 1 or inplanes != planes * 4):
+                    ds = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False),
+                                       nn.BatchNorm2d(planes * 4))
+                layers.append(Bottleneck(inplanes, planes, stride, dilations[i], ds, style))
+                inplanes = planes * 4
+            name = f'layer{i + 1}'
+            self.add_module(name, nn.Sequential(*layers))
+            self.res_layers.append(name)
+        if not norm_cfg.get('requires_grad', True):
+            for m in self.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    for p in m.parameters():
+                        p.requires_grad = False
+        self._freeze_stages()
+        self.init_weights()
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _freeze_stages(self):
+        """resnet.py:612-628"""
+        if self.frozen_stages >= 0:
+            self.bn1.eval()
+            for m in (self.conv1, self.bn1):
+                for p in m.parameters():
+                    p.requires_grad = False
+        for i in range(1, self.frozen_stages + 1):
+            m = getattr(self, f'layer{i}')
+            m.eval()
+            for p in m.parameters():
+                p.requires_grad = False
+
+    def forward(self, x):
+        x = self.maxpool(TF.relu(self.bn1(self.conv1(x)), inplace=True))
+        outs = []
+        for i, name in enumerate(self.res_layers):
+            x = getattr(self, name)(x)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
+
+    def train(self, mode=True):
+        """resnet.py:647-658: re-freeze and force every BN to eval when norm_eval."""
+        super().train(mode)
+        self._freeze_stages()
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.eval()
+        return self
+
+
+# --------------------------------------------------------------------------- FPN --
+def _xavier_uniform_(module):
+    for m in module.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.xavier_uniform_(m.weight)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+
+
+@NECKS.register_module()
+class FPN(nn.Module):
+    """necks/fpn.py:10-202 (no norm / no activation, as in the Point-Teacher configs)."""
+
+    def __init__(self, in_channels, out_channels, num_outs, start_level=0, end_level=-1, add_extra_convs=False,
+                 relu_before_extra_convs=False, no_norm_on_lateral=False, conv_cfg=None, norm_cfg=None, act_cfg=None,
+                 upsample_cfg=dict(mode='nearest'), init_cfg=None):
+        super().__init__()
+        assert isinstance(in_channels, list) and norm_cfg is None and conv_cfg is None
+        self.in_channels, self.out_channels, self.num_outs = in_channels, out_channels, num_outs
+        self.num_ins = len(in_channels)
+        self.relu_before_extra_convs = relu_before_extra_convs
+        self.upsample_cfg = dict(upsample_cfg)
+        if end_level == -1:
+            self.backbone_end_level = self.num_ins
+            assert num_outs >= self.num_ins - start_level
+        else:
+            self.backbone_end_level = end_level
+            assert end_level <= len(in_channels) and num_outs == end_level - start_level
+        self.start_level, self.end_level = start_level, end_level
+        assert isinstance(add_extra_convs, (str, bool))
+        if isinstance(add_extra_convs, str):
+            assert add_extra_convs in ('on_input', 'on_lateral', 'on_output')
+        elif add_extra_convs:
+            add_extra_convs = 'on_input'
+        self.add_extra_convs = add_extra_convs
+        act = act_cfg is not None
+        self.lateral_convs, self.fpn_convs = nn.ModuleList(), nn.ModuleList()
+        for i in range(self.start_level, self.backbone_end_level):
+            self.lateral_convs.append(ConvModule(in_channels[i], out_channels, 1, act=act))
+            self.fpn_convs.append(ConvModule(out_channels, out_channels, 3, padding=1, act=act))
+        extra_levels = num_outs - self.backbone_end_level + self.start_level
+        if self.add_extra_convs and extra_levels >= 1:
+            for i in range(extra_levels):
+                cin = self.in_channels[self.backbone_end_level - 1] if (i == 0 and self.add_extra_convs == 'on_input') \
+                    else out_channels
+                self.fpn_convs.append(ConvModule(cin, out_channels, 3, stride=2, padding=1, act=act))
+        _xavier_uniform_(self)
+
+    def forward(self, inputs):
+        assert len(inputs) == len(self.in_channels)
+        laterals = [l(inputs[i + self.start_level]) for i, l in enumerate(self.lateral_convs)]
+        n = len(laterals)
+        for i in range(n - 1, 0, -1):
+            if 'scale_factor' in self.upsample_cfg:
+                laterals[i - 1] = laterals[i - 1] + TF.interpolate(laterals[i], **self.upsample_cfg)
+            else:
+                laterals[i - 1] = laterals[i - 1] + TF.interpolate(laterals[i], size=laterals[i - 1].shape[2:],
+                                                                   **self.upsample_cfg)
+        outs = [self.fpn_convs[i](laterals[i]) for i in range(n)]
+        if self.num_outs > len(outs):
+            if not self.add_extra_convs:
+                for i in range(self.num_outs - n):
+                    outs.append(TF.max_pool2d(outs[-1], 1, stride=2))
+            else:
+                if self.add_extra_convs == 'on_input':
+                    src = inputs[self.backbone_end_level - 1]
+                elif self.add_extra_convs == 'on_lateral':
+                    src = laterals[-1]
+                else:
+                    src = outs[-1]
+                outs.append(self.fpn_convs[n](src))
+                for i in range(n + 1, self.num_outs):
+                    outs.append(self.fpn_convs[i](TF.relu(outs[-1]) if self.relu_before_extra_convs else outs[-1]))
+        return tuple(outs)
+
+
+@NECKS.register_module()
+class PSAGG(nn.Module):
+    """necks/ps_fpn.py:8-75: collapse the pyramid top-down into ONE stride-8 map."""
+
+    def __init__(self, num_aggregation, in_channels, out_channels, conv_cfg=None, norm_cfg=None, act_cfg=None,
+                 upsample_cfg=dict(mode='nearest'), init_cfg=None):
+        super().__init__()
+        assert norm_cfg is None and conv_cfg is None
+        self.num_aggregation, self.in_channels, self.out_channels = num_aggregation, in_channels, out_channels
+        self.upsample_cfg = dict(upsample_cfg)
+        self.lateral_convs = nn.ModuleList()
+        for i in range(num_aggregation):
+            cout = in_channels if i != num_aggregation - 1 else out_channels
+            self.lateral_convs.append(ConvModule(in_channels, cout, 1, act=act_cfg is not None))
+        _xavier_uniform_(self)
+
+    def forward(self, inputs):
+        inputs = list(inputs)
+        inputs[-1] = self.lateral_convs[0](inputs[-1])
+        for i in range(self.num_aggregation):
+            index = self.num_aggregation - i - 1
+            if index != 0:
+                if 'scale_factor' in self.upsample_cfg:
+                    up = TF.interpolate(inputs[index], **self.upsample_cfg)
+                else:
+                    up = TF.interpolate(inputs[index], size=inputs[index - 1].shape[2:], **self.upsample_cfg)
+                inputs[index - 1] = self.lateral_convs[i + 1](inputs[index - 1] + up)
+        return tuple([inputs[0]])
+
+
+# ---------------------------------------------------------------- RoI extraction --
+class RoIAlign(nn.Module):
+    """mmcv.ops.RoIAlign (constructor defaults of mmcv 1.x: sampling_ratio=0, pool_mode='avg',
+    aligned=True), built at roi_extractors/base_roi_extractor.py:53-58."""
+
+    def __init__(self, output_size, spatial_scale=1.0, sampling_ratio=0, pool_mode='avg', aligned=True,
+                 use_torchvision=False):
+        super().__init__()
+        assert pool_mode == 'avg', "only pool_mode='avg' is on the Point-Teacher path"
+        self.output_size = output_size if isinstance(output_size, int) else output_size[0]
+        self.spatial_scale, self.sampling_ratio, self.aligned = float(spatial_scale), int(sampling_ratio), aligned
+
+    def forward(self, input, rois):
+        return F.roi_align(input, rois, self.output_size, self.spatial_scale, self.sampling_ratio, self.aligned)
+
+
+_ROI_LAYERS = {'RoIAlign': RoIAlign}
+
+
+@ROI_EXTRACTORS.register_module()
+class SingleRoIExtractor(nn.Module):
+    """roi_extractors/single_level_roi_extractor.py:9-110 + base_roi_extractor.py (single level used)."""
+
+    def __init__(self, roi_layer, out_channels, featmap_strides, finest_scale=56, init_cfg=None):
+        super().__init__()
+        cfg = dict(roi_layer)
+        layer_cls = _ROI_LAYERS[cfg.pop('type')]
+        self.roi_layers = nn.ModuleList([layer_cls(spatial_scale=1 / s, **cfg) for s in featmap_strides])
+        self.out_channels, self.featmap_strides, self.finest_scale = out_channels, featmap_strides, finest_scale
+
+    @property
+    def num_inputs(self):
+        return len(self.featmap_strides)
+
+    def map_roi_levels(self, rois, num_levels):
+        scale = torch.sqrt((rois[:, 3] - rois[:, 1]) * (rois[:, 4] - rois[:, 2]))
+        lvls = torch.floor(torch.log2(scale / self.finest_scale + 1e-6))
+        return lvls.clamp(min=0, max=num_levels - 1).long()
+
+    def forward(self, feats, rois, roi_scale_factor=None):
+        assert roi_scale_factor is None
+        if len(feats) == 1:
+            if rois.shape[0] == 0:
+                o = self.roi_layers[0].output_size
+                return feats[0].new_zeros(0, self.out_channels, o, o)
+            return self.roi_layers[0](feats[0], rois)
+        out_size = self.roi_layers[0].output_size
+        roi_feats = feats[0].new_zeros(rois.size(0), self.out_channels, out_size, out_size)
+        lvls = self.map_roi_levels(rois, len(feats))
+        for i in range(len(feats)):
+            inds = (lvls == i).nonzero(as_tuple=False).squeeze(1)
+            if inds.numel() > 0:
+                roi_feats[inds] = self.roi_layers[i](feats[i], rois[inds])
+        return roi_feats

@@ -1,0 +1,32 @@
+"""The registry/config boundary: our loader parses the reference's own config files (when the
+reference tree is present - never on the GPU box) to the same dictionary as the shipped mirrors."""
+import os
+
+import pytest
+
+from point_teacher_amd.registry import Config
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MINE = os.path.join(ROOT, 'point_teacher_amd', 'configs', 'point_teacher')
+REF = '/root/reference/HBB_TOD/configs/point_teacher'
+
+
+@pytest.mark.parametrize('p', [0, 30, 60, 100])
+def test_shipped_config_loads(p):
+    cfg = Config.fromfile(os.path.join(MINE, f'aitodv2_point_teacher_{p}.py'))
+    assert cfg.model.type == 'TS_P2B_FCOS'
+    assert cfg.model._model_.type == 'Student_FCOS'
+    assert cfg.model._model_.bbox_head.type == 'TS_P2BFCOSHead'
+    assert cfg.optimizer.type == 'SGD' and cfg.optimizer.lr == 0.005 and cfg.optimizer.momentum == 0.9
+    assert cfg.optimizer_config == dict(grad_clip=dict(max_norm=35, norm_type=2))      # _delete_ honoured
+    assert cfg.lr_config.warmup == 'constant' and cfg.lr_config.warmup_iters == 10000
+    assert cfg.data.train.type == 'AITODDataset'                                         # merged with the base
+    assert len(cfg.model.train_cfg.fine_proposal_cfg) == 2
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference tree not present (GPU box)')
+@pytest.mark.parametrize('p', [0, 30, 60, 100])
+def test_reference_config_loads_and_matches_mirror(p):
+    ref = Config.fromfile(os.path.join(REF, f'aitodv2_point_teacher_{p}%.py')).to_dict()
+    mine = Config.fromfile(os.path.join(MINE, f'aitodv2_point_teacher_{p}.py')).to_dict()
+    assert ref == mine
