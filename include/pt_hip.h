@@ -127,13 +127,15 @@ int pt_delta2bbox_bwd(const float* rois, const float* deltas, const float* grad_
  * called fcos_head_p2b_ts.py:1202,1243,1268.  rois[K,5] = (batch, x1,y1,x2,y2).
  * feat is [B,C,H,W] when channels_last == 0 and [B,H,W,C] when 1 (same for grad_feat);
  * out / grad_out are always [K,C,out,out] (the layout the FC stack flattens).
- * bwd ACCUMULATES into grad_feat (zero it first). C % 64 == 0 for channels_last. */
+ * bwd ACCUMULATES into grad_feat (zero it first).  `group` (>= 1) is a locality hint for
+ * the channels_last backward: that many CONSECUTIVE RoIs (the U2 boxes of one MIL bag)
+ * are reduced on chip before touching HBM; any value gives the same result. */
 int pt_roi_align_fwd(const float* feat, const float* rois, int B, int C, int H, int W, int K,
                      int out_size, float spatial_scale, int sampling_ratio, int aligned,
                      int channels_last, float* out, void* stream);
 int pt_roi_align_bwd(const float* grad_out, const float* rois, int B, int C, int H, int W, int K,
                      int out_size, float spatial_scale, int sampling_ratio, int aligned,
-                     int channels_last, float* grad_feat, void* stream);
+                     int channels_last, int group, float* grad_feat, void* stream);
 
 /* ------------------------------------------------------------------ MIL bags --
  * fine_proposals_from_cfg (detectors/syn_images_generator_v2.py:262-324) for a batch:

@@ -248,8 +248,10 @@ def delta2bbox(rois, deltas, max_shape=None, wh_ratio_clip=16 / 1000):
 
 class _RoIAlign(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feat, rois, out_size, scale, sampling_ratio, aligned):
+    def forward(ctx, feat, rois, out_size, scale, sampling_ratio, aligned, group):
         B, C, H, W = feat.shape
+        in_dtype = feat.dtype
+        feat = feat.float()                       # bf16/fp16 maps (autocast) are widened: kernels are fp32
         cl = feat.is_contiguous(memory_format=torch.channels_last) and not feat.is_contiguous()
         if cl:
             fbuf = feat.permute(0, 2, 3, 1)            # a contiguous [B,H,W,C] view
@@ -261,26 +263,27 @@ class _RoIAlign(torch.autograd.Function):
         hip.call('pt_roi_align_fwd', fbuf, rois, B, C, H, W, K, out_size, float(scale), sampling_ratio,
                  int(aligned), int(cl), out)
         ctx.save_for_backward(rois)
-        ctx.cfg = (B, C, H, W, out_size, float(scale), sampling_ratio, int(aligned), cl)
+        ctx.cfg = (B, C, H, W, out_size, float(scale), sampling_ratio, int(aligned), cl, int(group), in_dtype)
         return out
 
     @staticmethod
     def backward(ctx, g):
         rois, = ctx.saved_tensors
-        B, C, H, W, out_size, scale, sr, aligned, cl = ctx.cfg
+        B, C, H, W, out_size, scale, sr, aligned, cl, group, in_dtype = ctx.cfg
         K = rois.shape[0]
         if cl:
             gbuf = torch.zeros((B, H, W, C), dtype=f32, device=g.device)
         else:
             gbuf = torch.zeros((B, C, H, W), dtype=f32, device=g.device)
-        hip.call('pt_roi_align_bwd', _f(g), rois, B, C, H, W, K, out_size, scale, sr, aligned, int(cl), gbuf)
+        hip.call('pt_roi_align_bwd', _f(g), rois, B, C, H, W, K, out_size, scale, sr, aligned, int(cl), group, gbuf)
         gfeat = gbuf.permute(0, 3, 1, 2) if cl else gbuf
-        return gfeat, None, None, None, None, None
+        return gfeat.to(in_dtype), None, None, None, None, None, None
 
 
-def roi_align(feat, rois, output_size=7, spatial_scale=1.0, sampling_ratio=0, aligned=True):
-    """mmcv.ops.roi_align(input, rois, output_size, spatial_scale, sampling_ratio, 'avg', aligned)."""
-    return _RoIAlign.apply(feat, rois, int(output_size), spatial_scale, int(sampling_ratio), bool(aligned))
+def roi_align(feat, rois, output_size=7, spatial_scale=1.0, sampling_ratio=0, aligned=True, group=1):
+    """mmcv.ops.roi_align(input, rois, output_size, spatial_scale, sampling_ratio, 'avg', aligned).
+    `group`: locality hint for the backward (consecutive RoIs that overlap, e.g. one MIL bag)."""
+    return _RoIAlign.apply(feat, rois, int(output_size), spatial_scale, int(sampling_ratio), bool(aligned), int(group))
 
 
 # ------------------------------------------------------------------ MIL bags --

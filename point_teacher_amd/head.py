@@ -276,6 +276,11 @@ class TS_P2BFCOSHead(nn.Module):
             x = TF.relu(fc(x), inplace=True)
         return x
 
+    @staticmethod
+    def _bag_group(U1, U2):
+        """All U1*U2 boxes of one gt are consecutive and overlap; the kernel takes at most 64 per workgroup."""
+        return U1 * U2 if U1 * U2 <= 64 else (U2 if U2 <= 64 else 1)
+
     def mil_bag_extensive(self, num_gt, num_gt_pre_image, x, img_metas, proposals_list, proposals_valid_list,
                           proposals_reference_list, proposals_real_list, bbox_results, fine_proposal_cfg, stage,
                           bag_weight=None):
@@ -303,7 +308,7 @@ class TS_P2BFCOSHead(nn.Module):
             wgt, avg = valid.float() * bw, wsum
         bbox_results['extensive_shaking_num'] = U2 = num_aug
         rois = bbox2roi(ext)
-        feats = self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois).flatten(1)
+        feats = self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois, group=self._bag_group(U1, U2)).flatten(1)
         bbox_pred = self.fc_reg[stage](self._fc_stack(self.shared_fcs_reg[stage], feats))
         del feats
         bbox_pred = self.mil_bbox_decoder.decode(bags, bbox_pred, max_shape=img_metas[0]['img_shape'])
@@ -320,9 +325,10 @@ class TS_P2BFCOSHead(nn.Module):
     def mil_bag_classifier(self, num_gt, x, bbox_results, stage):
         """:1240-1256"""
         rois = bbox2roi(bbox_results['extensive_bags'])
-        feats = self._fc_stack(self.shared_fcs_bag[stage],
-                               self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois).flatten(1))
         U1, U2 = bbox_results['base_shaking_num'], bbox_results['extensive_shaking_num']
+        feats = self._fc_stack(self.shared_fcs_bag[stage],
+                               self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois,
+                                                       group=self._bag_group(U1, U2)).flatten(1))
         bbox_results['cls_score'] = self.fc_cls[stage](feats).view(num_gt, U1, U2, -1)
         bbox_results['ins_score'] = self.fc_ins[stage](feats).view(num_gt, U1, U2, -1)
 
@@ -331,6 +337,9 @@ class TS_P2BFCOSHead(nn.Module):
                          neg_proposal_list=None, neg_weight_list=None, bag_weight=None):
         """:1259-1277"""
         bbox_results = {}
+        # the RoIAlign kernels want the [B,H,W,C] layout (1 KiB coalesced rows, full-rate atomics);
+        # one 20 MB layout change here is shared by the three RoIAlign calls of this stage
+        x = [f.float().contiguous(memory_format=torch.channels_last) for f in x[:self.bbox_roi_extractor.num_inputs]]
         self.mil_bag_extensive(num_gt, num_gt_pre_image, x, img_metas, proposals_list, proposals_valid_list,
                                proposals_reference_list, proposals_real_list, bbox_results, fine_proposal_cfg, stage,
                                bag_weight=bag_weight)

@@ -20,6 +20,9 @@ _CT = {
 }
 
 
+PTR_DTYPES = {}      # {fn: {argname: C element type}} filled by parse_header
+
+
 def parse_header(path=HEADER_PATH):
     """-> {name: (restype, [(ctype, argname), ...])} for every function the header declares."""
     txt = open(path).read()
@@ -32,6 +35,8 @@ def parse_header(path=HEADER_PATH):
         argl = []
         for a in [x.strip() for x in args.split(',') if x.strip() and x.strip() != 'void']:
             if '*' in a:
+                base = a.split('*')[0].replace('const', '').strip()
+                PTR_DTYPES.setdefault(name, {})[a.split('*')[-1].strip()] = base
                 argl.append((ctypes.c_void_p, a.split('*')[-1].strip()))
             else:
                 typ, an = a.rsplit(None, 1)
@@ -62,7 +67,7 @@ def last_error():
 _DT = {'float': torch.float32, 'int32_t': torch.int32, 'uint8_t': torch.uint8, 'uint64_t': torch.int64}
 
 
-def _ptr(x, name):
+def _ptr(x, name, ctype=None):
     if x is None:
         return None
     if isinstance(x, torch.Tensor):
@@ -70,6 +75,9 @@ def _ptr(x, name):
             raise RuntimeError(f'{name}: expected a CUDA/HIP tensor (point_teacher_amd has no CPU path)')
         if not x.is_contiguous():
             raise RuntimeError(f'{name}: tensor must be contiguous')
+        want = _DT.get(ctype)
+        if want is not None and x.dtype != want:      # a wrong element size would read out of bounds
+            raise TypeError(f'{name}: expected {want}, got {x.dtype}')
         return x.data_ptr()
     if isinstance(x, (ctypes.Array,)):
         return ctypes.cast(x, ctypes.c_void_p)
@@ -88,7 +96,7 @@ def call(fn, *args):
         raise TypeError(f'{fn}: expected {len(proto)} arguments, got {len(args)}')
     conv = []
     for a, (ct, an) in zip(args, proto):
-        conv.append(_ptr(a, f'{fn}.{an}') if ct is ctypes.c_void_p else a)
+        conv.append(_ptr(a, f'{fn}.{an}', PTR_DTYPES.get(fn, {}).get(an)) if ct is ctypes.c_void_p else a)
     if auto_stream:
         conv.append(torch.cuda.current_stream().cuda_stream)
     rc = getattr(_lib, fn)(*conv)

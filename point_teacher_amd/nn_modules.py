@@ -266,8 +266,8 @@ class RoIAlign(nn.Module):
         self.output_size = output_size if isinstance(output_size, int) else output_size[0]
         self.spatial_scale, self.sampling_ratio, self.aligned = float(spatial_scale), int(sampling_ratio), aligned
 
-    def forward(self, input, rois):
-        return F.roi_align(input, rois, self.output_size, self.spatial_scale, self.sampling_ratio, self.aligned)
+    def forward(self, input, rois, group=1):
+        return F.roi_align(input, rois, self.output_size, self.spatial_scale, self.sampling_ratio, self.aligned, group)
 
 
 _ROI_LAYERS = {'RoIAlign': RoIAlign}
@@ -293,13 +293,14 @@ class SingleRoIExtractor(nn.Module):
         lvls = torch.floor(torch.log2(scale / self.finest_scale + 1e-6))
         return lvls.clamp(min=0, max=num_levels - 1).long()
 
-    def forward(self, feats, rois, roi_scale_factor=None):
+    def forward(self, feats, rois, roi_scale_factor=None, group=1):
+        """`group`: how many consecutive RoIs overlap (one MIL bag) - a locality hint for the backward."""
         assert roi_scale_factor is None
         if len(feats) == 1:
             if rois.shape[0] == 0:
                 o = self.roi_layers[0].output_size
                 return feats[0].new_zeros(0, self.out_channels, o, o)
-            return self.roi_layers[0](feats[0], rois)
+            return self.roi_layers[0](feats[0], rois, group)
         out_size = self.roi_layers[0].output_size
         roi_feats = feats[0].new_zeros(rois.size(0), self.out_channels, out_size, out_size)
         lvls = self.map_roi_levels(rois, len(feats))

@@ -37,3 +37,28 @@ class SyntheticTiles:
         sel = [self.items[(it * B + j) % len(self.items)] for j in range(B)]
         return dict(img=torch.stack([s[0] for s in sel]), img_metas=[s[3] for s in sel],
                     gt_bboxes=[s[1] for s in sel], gt_labels=[s[2] for s in sel])
+
+
+def benchmark_init_(model, phase2=False):
+    """Random-init stand-in for the pretrained state the recipe starts from.  There is no
+    network here for `open-mmlab://detectron/resnet50_caffe`; a Kaiming-initialised stem fed
+    raw 0-255 pixels produces activations in the hundreds and the first SGD steps diverge
+    (in the reference as well).  Scaling the stem filters by 1/64 gives O(1) features, i.e. the
+    regime real training runs in; it changes no shape and no amount of work.  With
+    `phase2=True` the regression bias is set to +1 (8 px boxes): phase 2 only starts after
+    4000 burn-in iterations, when the regression branch no longer emits the all-zero
+    distances of a cold start (zero-area pseudo boxes make the centerness target 0.01/0).
+    The MIL box-refinement layer `fc_reg` is scaled by 0.01 so that refined bags stay near the
+    coarse boxes as they do in a trained model; torch's default Linear init makes it emit
+    |dw| ~ 4 deltas, i.e. 60x larger boxes clipped to the whole image, which turns every RoI
+    into a 100x100-pixel crop with a 15x15 sampling grid per bin (225x the realistic RoIAlign work)."""
+    import torch
+    with torch.no_grad():
+        for m in (model.student, model.teacher):
+            m.backbone.conv1.weight.mul_(1.0 / 64.0)
+            for fc in m.bbox_head.fc_reg:
+                fc.weight.mul_(0.01)
+                fc.bias.zero_()
+            if phase2:
+                m.bbox_head.conv_reg.bias.fill_(1.0)
+    return model
