@@ -313,7 +313,11 @@ class TS_P2BFCOSHead(nn.Module):
         del feats
         bbox_pred = self.mil_bbox_decoder.decode(bags, bbox_pred, max_shape=img_metas[0]['img_shape'])
         pred_d = bbox_pred.detach()
-        bbox_results['loss_mil_bbox'] = self.loss_bbox_denosing(bbox_pred, ref, weight=wgt, avg_factor=avg)
+        if bag_weight is None:
+            bbox_results['loss_mil_bbox'] = self.loss_bbox_denosing(bbox_pred, ref, weight=wgt, avg_factor=avg)
+        else:   # padded rows must not enter the batch-mean term of DN-DIoU (iou_loss.py:412) either
+            bbox_results['loss_mil_bbox'] = self.loss_bbox_denosing.forward_masked(
+                bbox_pred, ref, torch.cat(bag_weight) > 0, valid.float(), avg)
         ri = bbox_overlaps(pred_d, real, is_aligned=True)
         bbox_results['refine_bags_iou'] = ri.mean() if wsum is None else (ri * torch.cat(bag_weight)).sum() / wsum
         sizes = [e.shape[0] for e in ext]

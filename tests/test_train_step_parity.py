@@ -1,0 +1,141 @@
+"""Whole-iteration parity on the GPU: the product's `TS_P2B_FCOS.train_step` (HIP kernels +
+MIOpen convs) against the CPU oracle `oracle/ref_model.py` on the SAME weights, inputs and
+injected random draws.  Every entry of the loss dict within 1e-3 relative (north_star),
+gradients of representative parameters by cosine similarity."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_model as M
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build(dev, phase2):
+    import point_teacher_amd as pta
+    from point_teacher_amd.synthetic import benchmark_init_
+    torch.manual_seed(3)
+    cfg = pta.Config.fromfile(os.path.join(ROOT, 'point_teacher_amd', 'configs', 'point_teacher', 'aitodv2_point_teacher_0.py'))
+    cfg.model['burn_in_step'] = -1 if phase2 else 10 ** 9
+    model = pta.build_detector(cfg.model).to(dev)
+    benchmark_init_(model, phase2=True)
+    model.train()
+    return pta, cfg, model
+
+
+def _data(dev, size=256, n_obj=(23, 17), seed=5):
+    g = torch.Generator().manual_seed(seed)
+    img = (torch.rand(2, 3, size, size, generator=g) * 90 + 60).round()
+    boxes, labels = [], []
+    for n in n_obj:
+        c = torch.rand(n, 2, generator=g) * (size - 48) + 24
+        # keep centres off the symmetric tie positions of the stride-8 grid
+        c = c + 0.37
+        wh = torch.exp(torch.randn(n, 2, generator=g) * 0.4 + np.log(14.0)).clamp(4, 40)
+        boxes.append(torch.cat([c - wh / 2, c + wh / 2], 1))
+        labels.append(torch.randint(0, 8, (n,), generator=g))
+    metas = [dict(ori_filename=f't{i}.png', img_shape=(size, size, 3), scale_factor=np.ones(4, np.float32)) for i in range(2)]
+    return img, boxes, labels, metas
+
+
+def _strip(sd, prefix):
+    return {k[len(prefix):]: v.detach().cpu().clone() for k, v in sd.items() if k.startswith(prefix)}
+
+
+def _check(losses_gpu, losses_ref, keys=None):
+    keys = keys or losses_ref.keys()
+    for k in keys:
+        a, b = float(losses_gpu[k]), float(losses_ref[k])
+        assert abs(a - b) <= 1e-3 * max(abs(b), 1e-2) + 1e-5, (k, a, b)
+
+
+def _cos(a, b):
+    a, b = a.double().reshape(-1), b.double().reshape(-1)
+    return float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+
+
+GRAD_KEYS = ['bbox_head.conv_cls.weight', 'bbox_head.conv_reg.weight', 'bbox_head.reg_convs.3.conv.weight',
+             'bbox_head.fc_cls.0.weight', 'bbox_head.fc_ins.0.weight', 'bbox_head.fc_reg.0.weight',
+             'bbox_head.shared_fcs_bag.0.1.weight', 'neck_agg.lateral_convs.4.conv.weight',
+             'neck.fpn_convs.0.conv.weight', 'backbone.layer4.2.conv3.weight', 'backbone.layer2.0.conv1.weight']
+
+
+def test_step2_loss_dict_and_grads():
+    dev = torch.device('cuda:0')
+    pta, cfg, model = _build(dev, phase2=True)
+    img, boxes, labels, metas = _data(dev)
+    g = torch.Generator().manual_seed(11)
+    neg_u = torch.rand(2, 4, 200, generator=g)
+    aug = (['horizontal', 'diagonal'], [0.9, 1.1])
+    model._inject = dict(neg0=neg_u.to(dev), aug=aug)
+    sd_s0 = _strip(model.state_dict(), 'student.')
+    sd_t0 = _strip(model.state_dict(), 'teacher.')
+    data = dict(img=img.to(dev), img_metas=metas, gt_bboxes=[b.to(dev) for b in boxes], gt_labels=[l.to(dev) for l in labels])
+    out = model.train_step(data, None)
+    out['loss'].backward()
+    lv = out['log_vars'].materialize()
+    # ---- oracle on the same weights --------------------------------------------
+    torch.set_num_threads(8)
+    params = {k: (v.clone().requires_grad_(True) if M.trainable(k) else v) for k, v in sd_s0.items()}
+    sd_t = M.ema(sd_t0, sd_s0)                                     # the EMA runs first (:126)
+    gp = [R.bbox_xyxy_to_cxcywh(b)[:, :2] for b in boxes]          # _point_ = 0.0 -> box centres
+    cfgm = dict(M.MODEL_CFG)
+    ref, _ = M.forward_train_step2(params, sd_t, img, boxes, labels, gp, cfgm, dict(neg0=neg_u, aug=aug))
+    ref['loss'] = M.total_loss(ref)
+    assert set(ref.keys()) == set(lv.keys()), set(ref.keys()) ^ set(lv.keys())
+    _check(lv, ref)
+    # teacher after EMA
+    t_gpu = _strip(model.state_dict(), 'teacher.')
+    for k in ('bbox_head.conv_cls.weight', 'backbone.layer3.1.conv2.weight', 'backbone.bn1.weight'):
+        torch.testing.assert_close(t_gpu[k], sd_t[k], rtol=1e-6, atol=1e-7)
+    names = [k for k in GRAD_KEYS]
+    gr = torch.autograd.grad(ref['loss'], [params[k] for k in names])
+    gs = dict(model.student.named_parameters())
+    for k, gref in zip(names, gr):
+        c = _cos(gs[k].grad.cpu(), gref)
+        assert c > 0.999, (k, c)
+        ratio = float(gs[k].grad.cpu().norm() / (gref.norm() + 1e-30))
+        assert abs(ratio - 1) < 2e-2, (k, ratio)
+    for n, p in model.teacher.named_parameters():
+        assert p.grad is None, n                                     # the teacher never receives gradients
+
+
+def test_step1_loss_dict():
+    dev = torch.device('cuda:0')
+    pta, cfg, model = _build(dev, phase2=False)
+    img, boxes, labels, metas = _data(dev, seed=6)
+    g = torch.Generator().manual_seed(12)
+    neg_u = torch.rand(2, 4, 200, generator=g)
+    aug = (['vertical', 'None'], [1.2, 0.8])
+    model._inject = dict(neg0=neg_u.to(dev), aug=aug)
+    sd_s0 = _strip(model.state_dict(), 'student.')
+    sd_t0 = _strip(model.state_dict(), 'teacher.')
+    data = dict(img=img.to(dev), img_metas=metas, gt_bboxes=[b.to(dev) for b in boxes], gt_labels=[l.to(dev) for l in labels])
+    # capture what the GPU generator produced so the oracle sees the same synthetic images/boxes
+    captured = {}
+    orig = model.genrate_syn
+
+    def spy(*a, **k):
+        r = orig(*a, **k)
+        captured['img_syn'], captured['boxes'], captured['alive'] = r[0], r[2], r[3]
+        return r
+    model.genrate_syn = spy
+    out = model.train_step(data, None)
+    lv = out['log_vars'].materialize()
+    n = cfg.model['num_training_burninstep1']
+    syn = [b[a].cpu() for b, a in zip(captured['boxes'], captured['alive'])]
+    assert all(0 < s.shape[0] for s in syn)
+    # the white rectangles really are in the image
+    assert float((captured['img_syn'] == 255).float().mean()) > float((data['img'] == 255).float().mean())
+    params = {k: (v.clone().requires_grad_(True) if M.trainable(k) else v) for k, v in sd_s0.items()}
+    sd_t = M.ema(sd_t0, sd_s0)
+    gp = [R.bbox_xyxy_to_cxcywh(b)[:, :2] for b in boxes]
+    ref, _ = M.forward_train_step1(params, sd_t, img, boxes, labels, gp, dict(M.MODEL_CFG),
+                                   dict(neg0=neg_u, aug=aug, img_syn=captured['img_syn'].cpu(), syn_boxes=syn))
+    ref['loss'] = M.total_loss(ref)
+    assert set(ref.keys()) == set(lv.keys()), set(ref.keys()) ^ set(lv.keys())
+    _check(lv, ref)
