@@ -63,35 +63,83 @@ __device__ __forceinline__ Bilin bilin(float y, float x, int H, int W) {
 constexpr int MAX_BINS = 49;  // out_size <= 7
 
 // ------------------------------------------------------------ channels_last --
-template <int CPT>  // channels per thread (C = 256 * CPT / ... ) handled by looping
+// Separable form.  The samples of a bin lie on a product grid ys x xs and bilinear
+// interpolation (and the "outside the map" test) is separable, so
+//     out[ph][pw][c] = 1/count * sum_py sum_px  Ay[ph][py] * Ax[pw][px] * feat[y0+py][x0+px][c]
+// with per-axis weight vectors Ay[ph][.] / Ax[pw][.] that are non-zero only on the band of
+// pixel rows / columns bin ph / pw touches.  A bin with a g x g sampling grid needs (g+1)^2
+// pixel reads instead of 4 g^2 taps, the weights are computed once per RoI (not per channel)
+// and every index is wave-uniform.  AxisW lives in LDS.
+constexpr int MAXR = 256;   // largest supported map extent (H, W <= 256)
+constexpr int NB = 7;       // out_size <= 7
+
+struct AxisW {
+  float w[NB][MAXR];  // dense [bin][pixel - o]; zero outside the band
+  int lo[NB], hi[NB];  // inclusive band of each bin (hi < lo: empty)
+  int o, e;            // first / last pixel touched by any bin (e < o: nothing)
+};
+
+// Block-cooperative.  Mirrors bilin(): v <= 0 -> 0; lo >= L-1 -> lo = hi = L-1, frac 0.
+__device__ void axis_weights(float start, float bin, int grid, int L, int out_size, AxisW* A) {
+  for (int i = threadIdx.x; i < NB * MAXR; i += blockDim.x) (&A->w[0][0])[i] = 0.f;
+  if (threadIdx.x < NB) { A->lo[threadIdx.x] = 1 << 30; A->hi[threadIdx.x] = -1; }
+  if (threadIdx.x == 0) { A->o = 1 << 30; A->e = -1; }
+  __syncthreads();
+  const int n = out_size * grid;
+  for (int t = threadIdx.x; t < n; t += blockDim.x) {   // pass 1: extent
+    const int p = t / grid, i = t - p * grid;
+    float v = start + p * bin + (i + .5f) * bin / (float)grid;
+    if (v < -1.0f || v > (float)L) continue;
+    if (v <= 0.f) v = 0.f;
+    int l = (int)v, h;
+    if (l >= L - 1) { h = l = L - 1; } else { h = l + 1; }
+    atomicMin(&A->o, l);
+    atomicMax(&A->e, h);
+  }
+  __syncthreads();
+  const int o = A->o;
+  for (int t = threadIdx.x; t < n; t += blockDim.x) {   // pass 2: weights and bands
+    const int p = t / grid, i = t - p * grid;
+    float v = start + p * bin + (i + .5f) * bin / (float)grid;
+    if (v < -1.0f || v > (float)L) continue;
+    if (v <= 0.f) v = 0.f;
+    int l = (int)v, h;
+    if (l >= L - 1) { h = l = L - 1; v = (float)l; } else { h = l + 1; }
+    const float fl = v - (float)l, fh = 1.f - fl;
+    atomicAdd(&A->w[p][l - o], fh);
+    atomicAdd(&A->w[p][h - o], fl);
+    atomicMin(&A->lo[p], l - o);
+    atomicMax(&A->hi[p], h - o);
+  }
+  __syncthreads();
+}
+
 __global__ void __launch_bounds__(256)
     roi_align_fwd_cl(const float* __restrict__ feat, const float* __restrict__ rois, int B, int C, int H, int W,
                      int out_size, float scale, int sampling_ratio, int aligned, float* __restrict__ out) {
   extern __shared__ float tile[];  // [bins][C+1]
+  __shared__ AxisW AX, AY;
   const int k = blockIdx.x;
   const RoiGeom g = roi_geom(rois + (size_t)k * 5, out_size, scale, sampling_ratio, aligned, B);
   const int bins = out_size * out_size;
   const int ld = C + 1;
+  for (int i = threadIdx.x; i < bins * ld; i += blockDim.x) tile[i] = 0.f;
+  axis_weights(g.start_w, g.bin_w, g.grid_w, W, out_size, &AX);
+  axis_weights(g.start_h, g.bin_h, g.grid_h, H, out_size, &AY);
   const float* fb = feat + (size_t)g.b * H * W * C;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    for (int ph = 0; ph < out_size; ++ph) {
-      for (int pw = 0; pw < out_size; ++pw) {
-        float acc = 0.f;
-        for (int iy = 0; iy < g.grid_h; ++iy) {
-          const float y = g.start_h + ph * g.bin_h + (iy + .5f) * g.bin_h / (float)g.grid_h;
-          for (int ix = 0; ix < g.grid_w; ++ix) {
-            const float x = g.start_w + pw * g.bin_w + (ix + .5f) * g.bin_w / (float)g.grid_w;
-            const Bilin q = bilin(y, x, H, W);
-            if (q.valid) {
-              const float v1 = fb[((size_t)q.y0 * W + q.x0) * C + c];
-              const float v2 = fb[((size_t)q.y0 * W + q.x1) * C + c];
-              const float v3 = fb[((size_t)q.y1 * W + q.x0) * C + c];
-              const float v4 = fb[((size_t)q.y1 * W + q.x1) * C + c];
-              acc += q.w1 * v1 + q.w2 * v2 + q.w3 * v3 + q.w4 * v4;
-            }
-          }
+  const int ny = AY.e - AY.o + 1;
+  if (AX.e >= AX.o && ny > 0) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      for (int py = 0; py < ny; ++py) {
+        const float* row = fb + ((size_t)(AY.o + py) * W + AX.o) * C + c;
+        for (int pw = 0; pw < out_size; ++pw) {
+          const int xl = AX.lo[pw], xh = AX.hi[pw];
+          if (xh < xl) continue;
+          float t = 0.f;
+          for (int px = xl; px <= xh; ++px) t += AX.w[pw][px] * row[(size_t)px * C];
+          for (int ph = 0; ph < out_size; ++ph)
+            if (AY.lo[ph] <= py && py <= AY.hi[ph]) tile[(ph * out_size + pw) * ld + c] += AY.w[ph][py] * t;
         }
-        tile[(ph * out_size + pw) * ld + c] = acc / g.inv_count;
       }
     }
   }
@@ -99,16 +147,17 @@ __global__ void __launch_bounds__(256)
   float* ob = out + (size_t)k * C * bins;
   for (int o = threadIdx.x; o < C * bins; o += blockDim.x) {
     const int c = o / bins, bin = o - c * bins;
-    ob[o] = tile[bin * ld + c];
+    ob[o] = tile[bin * ld + c] / g.inv_count;
   }
 }
 
 // Backward, channels_last.  One workgroup owns `group` CONSECUTIVE RoIs (the U2 jittered boxes
 // of one MIL bag sit next to each other and cover the same few feature pixels).  Threads own
 // channels, so the union footprint of the group (<= FOOT_MAXPIX pixels) is accumulated in LDS
-// without any atomics and flushed with ONE f32 atomic per (pixel, channel): ~300x fewer global
-// atomics than scattering every bilinear tap, and no same-address serialisation between the
-// members of a bag.  Groups whose union footprint is larger fall back to per-tap atomics.
+// without atomics and flushed with ONE f32 atomic per (pixel, channel); with the separable
+// weights a RoI issues (rows x cols of its footprint) updates instead of 4 per tap.  Groups
+// whose union footprint is larger go straight to global atomics (256 contiguous bytes per
+// wave instruction - the full-rate shape), still one per footprint pixel.
 constexpr int FOOT_MAXPIX = 25;
 
 __global__ void __launch_bounds__(256)
@@ -116,6 +165,7 @@ __global__ void __launch_bounds__(256)
                      int group, int out_size, float scale, int sampling_ratio, int aligned,
                      float* __restrict__ gfeat) {
   extern __shared__ float smem[];  // [bins][C+1] grad tile, [FOOT_MAXPIX][C] footprint, 8 ints of bounds
+  __shared__ AxisW AX, AY;
   const int bins = out_size * out_size;
   const int ld = C + 1;
   float* tile = smem;
@@ -144,37 +194,39 @@ __global__ void __launch_bounds__(256)
   for (int k = k0; k < k1; ++k) {
     const RoiGeom g = roi_geom(rois + (size_t)k * 5, out_size, scale, sampling_ratio, aligned, B);
     const float* gb = gout + (size_t)k * C * bins;
-    __syncthreads();   // previous RoI's tile fully consumed (and foot zeroed on the first trip)
+    __syncthreads();   // previous RoI's tile and weights fully consumed (and foot zeroed on the first trip)
     for (int o = threadIdx.x; o < C * bins; o += blockDim.x) {
       const int c = o / bins, bin = o - c * bins;
       tile[bin * ld + c] = gb[o];
     }
-    __syncthreads();
+    axis_weights(g.start_w, g.bin_w, g.grid_w, W, out_size, &AX);   // ends with a barrier
+    axis_weights(g.start_h, g.bin_h, g.grid_h, H, out_size, &AY);
+    const int ny = AY.e - AY.o + 1, nx = AX.e - AX.o + 1;
+    if (ny <= 0 || nx <= 0) continue;
     float* fb = gfeat + (size_t)g.b * H * W * C;
+    const bool in = use_foot && AX.o >= ux0 && AX.e < ux0 + uw && AY.o >= uy0 && AY.e < uy0 + uh;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-      for (int ph = 0; ph < out_size; ++ph) {
-        for (int pw = 0; pw < out_size; ++pw) {
-          const float gv = tile[(ph * out_size + pw) * ld + c] / g.inv_count;
-          for (int iy = 0; iy < g.grid_h; ++iy) {
-            const float y = g.start_h + ph * g.bin_h + (iy + .5f) * g.bin_h / (float)g.grid_h;
-            for (int ix = 0; ix < g.grid_w; ++ix) {
-              const float x = g.start_w + pw * g.bin_w + (ix + .5f) * g.bin_w / (float)g.grid_w;
-              const Bilin q = bilin(y, x, H, W);
-              if (!q.valid) continue;
-              const bool in = use_foot && q.x0 >= ux0 && q.x1 < ux0 + uw && q.y0 >= uy0 && q.y1 < uy0 + uh;
-              if (in) {   // wave-uniform branch; thread-private column c of the footprint
-                const int r0 = (q.y0 - uy0) * uw, r1 = (q.y1 - uy0) * uw;
-                foot[(r0 + q.x0 - ux0) * C + c] += gv * q.w1;
-                foot[(r0 + q.x1 - ux0) * C + c] += gv * q.w2;
-                foot[(r1 + q.x0 - ux0) * C + c] += gv * q.w3;
-                foot[(r1 + q.x1 - ux0) * C + c] += gv * q.w4;
-              } else {
-                atomicAdd(&fb[((size_t)q.y0 * W + q.x0) * C + c], gv * q.w1);
-                atomicAdd(&fb[((size_t)q.y0 * W + q.x1) * C + c], gv * q.w2);
-                atomicAdd(&fb[((size_t)q.y1 * W + q.x0) * C + c], gv * q.w3);
-                atomicAdd(&fb[((size_t)q.y1 * W + q.x1) * C + c], gv * q.w4);
-              }
-            }
+      for (int py = 0; py < ny; ++py) {
+        float S[NB];
+#pragma unroll
+        for (int pw = 0; pw < NB; ++pw) S[pw] = 0.f;
+        for (int ph = 0; ph < out_size; ++ph) {
+          if (AY.lo[ph] > py || py > AY.hi[ph]) continue;
+          const float wy = AY.w[ph][py] / g.inv_count;
+#pragma unroll
+          for (int pw = 0; pw < NB; ++pw)
+            if (pw < out_size) S[pw] += wy * tile[(ph * out_size + pw) * ld + c];
+        }
+        for (int px = 0; px < nx; ++px) {
+          float v = 0.f;
+#pragma unroll
+          for (int pw = 0; pw < NB; ++pw)
+            if (pw < out_size) v += AX.w[pw][px] * S[pw];
+          if (v == 0.f) continue;
+          if (in) {   // wave-uniform branch; thread-private column c of the footprint
+            foot[((AY.o + py - uy0) * uw + (AX.o + px - ux0)) * C + c] += v;
+          } else {
+            atomicAdd(&fb[((size_t)(AY.o + py) * W + AX.o + px) * C + c], v);
           }
         }
       }
@@ -251,9 +303,12 @@ static int roi_check(const char* fn, const void* a, const void* rois, const void
   PT_REQUIRE(a && rois && o, PT_EINVAL, "%s: NULL pointer", fn);
   PT_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && K > 0, PT_EINVAL, "%s: bad size", fn);
   PT_REQUIRE(out_size >= 1 && out_size * out_size <= MAX_BINS, PT_ELIMIT, "%s: out_size=%d above 7", fn, out_size);
-  if (channels_last)
-    PT_REQUIRE((size_t)(C + 1) * out_size * out_size * 4 <= 160 * 1024, PT_ELIMIT,
+  if (channels_last) {
+    PT_REQUIRE((size_t)(C + 1) * out_size * out_size * 4 + 2 * sizeof(pt::AxisW) <= 150 * 1024, PT_ELIMIT,
                "%s: C=%d too large for the LDS tile", fn, C);
+    PT_REQUIRE(H <= pt::MAXR && W <= pt::MAXR, PT_ELIMIT, "%s: channels_last path supports maps up to %dx%d", fn,
+               pt::MAXR, pt::MAXR);
+  }
   return PT_OK;
 }
 
@@ -268,12 +323,12 @@ extern "C" int pt_roi_align_fwd(const float* feat, const float* rois, int B, int
     const size_t lds = (size_t)(C + 1) * out_size * out_size * sizeof(float);
     static size_t attr_bytes = 0;
     if (lds > attr_bytes) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_cl<1>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_cl),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) { set_error("pt_roi_align_fwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
       attr_bytes = lds;
     }
-    hipLaunchKernelGGL(roi_align_fwd_cl<1>, dim3(K), dim3(256), lds, s, feat, rois, B, C, H, W, out_size, spatial_scale,
+    hipLaunchKernelGGL(roi_align_fwd_cl, dim3(K), dim3(256), lds, s, feat, rois, B, C, H, W, out_size, spatial_scale,
                        sampling_ratio, aligned, out);
   } else {
     const long total = (long)K * C * out_size * out_size;
@@ -295,7 +350,7 @@ extern "C" int pt_roi_align_bwd(const float* grad_out, const float* rois, int B,
   hipStream_t s = as_stream(stream);
   if (channels_last) {
     const size_t lds = ((size_t)(C + 1) * out_size * out_size + (size_t)FOOT_MAXPIX * C + 8) * sizeof(float);
-    PT_REQUIRE(lds <= 160 * 1024, PT_ELIMIT, "pt_roi_align_bwd: C=%d too large for the LDS tiles", C);
+    PT_REQUIRE(lds + 2 * sizeof(AxisW) <= 160 * 1024, PT_ELIMIT, "pt_roi_align_bwd: C=%d too large for the LDS tiles", C);
     static size_t attr_bytes = 0;
     if (lds > attr_bytes) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_bwd_cl),

@@ -81,6 +81,37 @@ class FlatParams:
         return True
 
 
+class GradReducer:
+    """Mean of a flat gradient buffer over the data-parallel ranks: `chunks` large all-reduces
+    (RCCL over xGMI on the GPU, on a side stream; gloo in the CPU tests).  No data-path
+    collective other than this one exists on the path (images shard independently)."""
+
+    def __init__(self, chunks=4, device=None):
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.chunks = max(int(chunks), 1)
+        self.stream = torch.cuda.Stream(device=device) if (self.world > 1 and device is not None
+                                                           and device.type == 'cuda') else None
+
+    def reduce_(self, g):
+        if self.world == 1:
+            return g
+        n = g.numel()
+        step = (n + self.chunks - 1) // self.chunks
+        if self.stream is None:
+            g.div_(self.world)
+            for s in range(0, n, step):
+                dist.all_reduce(g[s:s + step])
+            return g
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            g.div_(self.world)
+            for s in range(0, n, step):
+                dist.all_reduce(g[s:s + step])
+        cur.wait_stream(self.stream)
+        return g
+
+
 class StepLR:
     """mmcv StepLrUpdaterHook with warm-up, by_epoch=True (lr_config of the configs)."""
 
@@ -126,8 +157,7 @@ class Trainer:
         self._lr_host = None
         self.iter = 0
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        self.grad_chunks = max(int(grad_chunks), 1)
-        self.comm_stream = torch.cuda.Stream(device=dev) if (self.world > 1 and dev.type == 'cuda') else None
+        self.reducer = GradReducer(grad_chunks, dev)
         self.autocast_dtype = autocast_dtype
         self._broadcast_initial_state()
 
@@ -142,23 +172,6 @@ class Trainer:
             self.lr_t.fill_(lr)
             self._lr_host = lr
 
-    def _allreduce_grads(self):
-        """Mean of the flat gradient over ranks in `grad_chunks` large RCCL all-reduces on a side stream."""
-        g = self.flat.grad_flat
-        if self.comm_stream is None:
-            g.div_(self.world)
-            dist.all_reduce(g)
-            return
-        cur = torch.cuda.current_stream()
-        self.comm_stream.wait_stream(cur)
-        with torch.cuda.stream(self.comm_stream):
-            g.div_(self.world)
-            n = g.numel()
-            step = (n + self.grad_chunks - 1) // self.grad_chunks
-            for s in range(0, n, step):
-                dist.all_reduce(g[s:s + step])
-        cur.wait_stream(self.comm_stream)
-
     def step(self, data):
         """One training iteration: zero grads, train_step (EMA happens inside, at its start),
         backward, gradient exchange, clip + SGD.  Returns train_step's dict."""
@@ -170,8 +183,7 @@ class Trainer:
         else:
             out = self.model.train_step(data, None)
         out['loss'].backward()
-        if self.world > 1:
-            self._allreduce_grads()
+        self.reducer.reduce_(self.flat.grad_flat)
         f = self.flat
         sq = F.grad_sqnorm(f.grad_flat) if self.max_norm > 0 else None
         F.sgd_step_(f.student_flat[:f.n_train], f.grad_flat, f.mom_flat, f.n_weights, self.lr_t, self.momentum,
