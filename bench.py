@@ -34,6 +34,9 @@ def parse():
     ap.add_argument('--objects', type=int, default=300)
     ap.add_argument('--percent', type=int, default=0, choices=[0, 30, 60, 100])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--channels-last', type=int, default=1)
+    ap.add_argument('--miopen-find', type=int, default=1)
+    ap.add_argument('--fold-bn', type=int, default=0)
     ap.add_argument('--cpu-baseline-iters', type=int, default=1)
     ap.add_argument('--roofline-kernel', default='auto')
     return ap.parse_args()
@@ -69,6 +72,7 @@ def main():
     from point_teacher_amd import hip
     from point_teacher_amd.synthetic import SyntheticTiles
 
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)      # MIOpen find mode
     torch.manual_seed(1234)           # same initial weights on every rank (also broadcast by the Trainer)
     cfg = pta.Config.fromfile(os.path.join(ROOT, 'point_teacher_amd', 'configs', 'point_teacher',
                                            f'aitodv2_point_teacher_{args.percent}.py'))
@@ -79,7 +83,12 @@ def main():
     benchmark_init_(model, phase2=(args.workload == 'step2'))     # see its docstring: same shapes, same work
     model.train()
     trainer = pta.Trainer(model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config, iters_per_epoch=5000,
-                          autocast_dtype=torch.bfloat16 if args.dtype == 'bf16' else None)
+                          autocast_dtype=torch.bfloat16 if args.dtype == 'bf16' else None,
+                          channels_last=bool(args.channels_last))
+    if args.fold_bn:
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.fold_into_conv = True
     data = SyntheticTiles(n=8, size=args.size, mean_objects=args.objects, seed=7, device=dev, rank=rank, world=world)
 
     def barrier():

@@ -128,14 +128,17 @@ int pt_delta2bbox_bwd(const float* rois, const float* deltas, const float* grad_
  * feat is [B,C,H,W] when channels_last == 0 and [B,H,W,C] when 1 (same for grad_feat);
  * out / grad_out are always [K,C,out,out] (the layout the FC stack flattens).
  * bwd ACCUMULATES into grad_feat (zero it first).  `group` (>= 1) is a locality hint for
- * the channels_last backward: that many CONSECUTIVE RoIs (the U2 boxes of one MIL bag)
- * are reduced on chip before touching HBM; any value gives the same result. */
+ * the channels_last kernels: that many CONSECUTIVE RoIs (the U1*U2 boxes of one MIL bag)
+ * share a workgroup; bags whose taps fall on <= 5x5 feature pixels take a register-resident
+ * fast path, the rest the generic kernel.  group_ws: K int32 of workspace (may be NULL:
+ * generic kernel only).  Any group value gives the same result. */
 int pt_roi_align_fwd(const float* feat, const float* rois, int B, int C, int H, int W, int K,
                      int out_size, float spatial_scale, int sampling_ratio, int aligned,
-                     int channels_last, float* out, void* stream);
+                     int channels_last, int group, int32_t* group_ws, float* out, void* stream);
 int pt_roi_align_bwd(const float* grad_out, const float* rois, int B, int C, int H, int W, int K,
                      int out_size, float spatial_scale, int sampling_ratio, int aligned,
-                     int channels_last, int group, float* grad_feat, void* stream);
+                     int channels_last, int group, int32_t* group_ws, float* grad_feat,
+                     void* stream);
 
 /* ------------------------------------------------------------------ MIL bags --
  * fine_proposals_from_cfg (detectors/syn_images_generator_v2.py:262-324) for a batch:

@@ -116,10 +116,12 @@ __device__ void axis_weights(float start, float bin, int grid, int L, int out_si
 
 __global__ void __launch_bounds__(256)
     roi_align_fwd_cl(const float* __restrict__ feat, const float* __restrict__ rois, int B, int C, int H, int W,
-                     int out_size, float scale, int sampling_ratio, int aligned, float* __restrict__ out) {
+                     int out_size, float scale, int sampling_ratio, int aligned, float* __restrict__ out,
+                     const int* __restrict__ fallback, int group) {
   extern __shared__ float tile[];  // [bins][C+1]
   __shared__ AxisW AX, AY;
   const int k = blockIdx.x;
+  if (fallback && !fallback[k]) return;   // this RoI was done by the small-footprint kernel
   const RoiGeom g = roi_geom(rois + (size_t)k * 5, out_size, scale, sampling_ratio, aligned, B);
   const int bins = out_size * out_size;
   const int ld = C + 1;
@@ -151,94 +153,245 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// Backward, channels_last.  One workgroup owns `group` CONSECUTIVE RoIs (the U2 jittered boxes
-// of one MIL bag sit next to each other and cover the same few feature pixels).  Threads own
-// channels, so the union footprint of the group (<= FOOT_MAXPIX pixels) is accumulated in LDS
-// without atomics and flushed with ONE f32 atomic per (pixel, channel); with the separable
-// weights a RoI issues (rows x cols of its footprint) updates instead of 4 per tap.  Groups
-// whose union footprint is larger go straight to global atomics (256 contiguous bytes per
-// wave instruction - the full-rate shape), still one per footprint pixel.
-constexpr int FOOT_MAXPIX = 25;
-
+// Backward, channels_last, generic: one workgroup per RoI; with the separable weights a RoI issues
+// ONE f32 atomic per footprint pixel and channel (256 contiguous bytes per wave instruction - the
+// full-rate shape) instead of 4 per bilinear tap.  RoIs whose bag was reduced on chip by the
+// small-footprint kernel below are skipped through `fallback`.
 __global__ void __launch_bounds__(256)
     roi_align_bwd_cl(const float* __restrict__ gout, const float* __restrict__ rois, int B, int C, int H, int W, int K,
                      int group, int out_size, float scale, int sampling_ratio, int aligned,
-                     float* __restrict__ gfeat) {
-  extern __shared__ float smem[];  // [bins][C+1] grad tile, [FOOT_MAXPIX][C] footprint, 8 ints of bounds
+                     float* __restrict__ gfeat, const int* __restrict__ fallback) {
+  extern __shared__ float tile[];  // [bins][C+1] grad tile
   __shared__ AxisW AX, AY;
+  const int k = blockIdx.x;
+  if (fallback && !fallback[k / group]) return;   // done by the small-footprint kernel
   const int bins = out_size * out_size;
   const int ld = C + 1;
-  float* tile = smem;
-  float* foot = smem + (size_t)bins * ld;
-  int* ub = reinterpret_cast<int*>(foot + (size_t)FOOT_MAXPIX * C);  // x0,y0,x1,y1 (inclusive), batch (-2 = mixed)
-  const int k0 = blockIdx.x * group, k1 = min(k0 + group, K);
-  if (threadIdx.x == 0) { ub[0] = 1 << 30; ub[1] = 1 << 30; ub[2] = -1; ub[3] = -1; ub[4] = -1; }
+  const RoiGeom g = roi_geom(rois + (size_t)k * 5, out_size, scale, sampling_ratio, aligned, B);
+  const float* gb = gout + (size_t)k * C * bins;
+  for (int o = threadIdx.x; o < C * bins; o += blockDim.x) {
+    const int c = o / bins, bin = o - c * bins;
+    tile[bin * ld + c] = gb[o];
+  }
+  axis_weights(g.start_w, g.bin_w, g.grid_w, W, out_size, &AX);   // ends with a barrier
+  axis_weights(g.start_h, g.bin_h, g.grid_h, H, out_size, &AY);
+  const int ny = AY.e - AY.o + 1, nx = AX.e - AX.o + 1;
+  if (ny <= 0 || nx <= 0) return;
+  float* fb = gfeat + (size_t)g.b * H * W * C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    for (int py = 0; py < ny; ++py) {
+      float S[NB];
+#pragma unroll
+      for (int pw = 0; pw < NB; ++pw) S[pw] = 0.f;
+      for (int ph = 0; ph < out_size; ++ph) {
+        if (AY.lo[ph] > py || py > AY.hi[ph]) continue;
+        const float wy = AY.w[ph][py] / g.inv_count;
+#pragma unroll
+        for (int pw = 0; pw < NB; ++pw)
+          if (pw < out_size) S[pw] += wy * tile[(ph * out_size + pw) * ld + c];
+      }
+      for (int px = 0; px < nx; ++px) {
+        float v = 0.f;
+#pragma unroll
+        for (int pw = 0; pw < NB; ++pw)
+          if (pw < out_size) v += AX.w[pw][px] * S[pw];
+        if (v != 0.f) atomicAdd(&fb[((size_t)(AY.o + py) * W + AX.o + px) * C + c], v);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------ small-footprint bag fast path --
+// The U2 jittered boxes of one MIL bag of a tiny object (the common case: AI-TOD objects are
+// ~12 px = 1.5 feature pixels) all fall on the same <= 5x5 feature pixels.  One workgroup owns
+// the bag: the 25 footprint pixels of channel c live in 25 REGISTERS of thread c (loaded once
+// for the whole bag), the separable per-axis weights of every member are precomputed into LDS
+// by the first threads (one thread per (member, axis, bin): no atomics), and each member costs
+// 420 register FMAs per thread - no barriers, no LDS tile, no per-tap memory traffic.  The
+// backward keeps the 25 footprint accumulators in registers across the whole bag and issues 25
+// coalesced atomics per thread at the end.  A workgroup falls back to the generic kernels
+// (flag in `fallback[blockIdx]`) when its union footprint is larger or spans two images.
+constexpr int SF = 5;            // footprint side
+constexpr int SMALL_GROUP = 32;  // members per workgroup (>= U1*U2 of the 0 % config)
+
+struct SmallW {
+  float ax[SMALL_GROUP][NB][SF];
+  float ay[SMALL_GROUP][NB][SF];   // already divided by the sample count
+  int ub[6];                       // x0, y0, x1, y1, batch, ok
+};
+
+__device__ __forceinline__ void small_tap(float v, int L, int& l, int& h, float& fl, bool& valid) {
+  valid = !(v < -1.0f || v > (float)L);
+  if (v <= 0.f) v = 0.f;
+  l = (int)v;
+  if (l >= L - 1) { h = l = L - 1; v = (float)l; } else { h = l + 1; }
+  fl = v - (float)l;
+}
+
+// Fills S for RoIs [k0,k1).  Returns (via S->ub[5]) whether the fast path applies.
+__device__ void small_setup(const float* __restrict__ rois, int k0, int k1, int B, int H, int W, int out_size,
+                            float scale, int sampling_ratio, int aligned, SmallW* S) {
+  if (threadIdx.x == 0) { S->ub[0] = 1 << 30; S->ub[1] = 1 << 30; S->ub[2] = -1; S->ub[3] = -1; S->ub[4] = -1; S->ub[5] = 1; }
   __syncthreads();
-  for (int k = k0 + threadIdx.x; k < k1; k += blockDim.x) {
-    const RoiGeom g = roi_geom(rois + (size_t)k * 5, out_size, scale, sampling_ratio, aligned, B);
-    const float xe = g.start_w + g.bin_w * out_size, ye = g.start_h + g.bin_h * out_size;
-    // taps of a sample at x touch floor(x) and floor(x)+1 (clamped); samples lie in [start, end]
-    const int x0 = min(max((int)floorf(fminf(g.start_w, xe)), 0), W - 1);
-    const int y0 = min(max((int)floorf(fminf(g.start_h, ye)), 0), H - 1);
-    const int x1 = min(max((int)floorf(fmaxf(g.start_w, xe)) + 1, 0), W - 1);
-    const int y1 = min(max((int)floorf(fmaxf(g.start_h, ye)) + 1, 0), H - 1);
-    atomicMin(&ub[0], x0); atomicMin(&ub[1], y0); atomicMax(&ub[2], x1); atomicMax(&ub[3], y1);
-    const int old = atomicCAS(&ub[4], -1, g.b);
-    if (old != -1 && old != g.b) ub[4] = -2;
+  const int n = (k1 - k0) * 2 * out_size;
+  for (int t = threadIdx.x; t < n; t += blockDim.x) {      // pass 1: exact union of the taps
+    const int r = t / (2 * out_size), a = (t / out_size) & 1, p = t % out_size;
+    const RoiGeom g = roi_geom(rois + (size_t)(k0 + r) * 5, out_size, scale, sampling_ratio, aligned, B);
+    const float start = a ? g.start_h : g.start_w, bin = a ? g.bin_h : g.bin_w;
+    const int grid = a ? g.grid_h : g.grid_w, L = a ? H : W;
+    if (grid > 8) S->ub[5] = 0;
+    for (int i = 0; i < grid && i < 8; ++i) {
+      int l, h; float fl; bool valid;
+      small_tap(start + p * bin + (i + .5f) * bin / (float)grid, L, l, h, fl, valid);
+      if (!valid) continue;
+      atomicMin(&S->ub[a], l);
+      atomicMax(&S->ub[2 + a], h);
+    }
+    if (a == 0 && p == 0) {
+      const int old = atomicCAS(&S->ub[4], -1, g.b);
+      if (old != -1 && old != g.b) S->ub[5] = 0;
+    }
   }
   __syncthreads();
-  const int ux0 = ub[0], uy0 = ub[1], uw = ub[2] - ub[0] + 1, uh = ub[3] - ub[1] + 1;
-  const bool use_foot = (ub[4] >= 0) && (uw > 0) && (uh > 0) && (uw * uh <= FOOT_MAXPIX);
-  if (use_foot)
-    for (int i = threadIdx.x; i < uw * uh * C; i += blockDim.x) foot[i] = 0.f;
-  for (int k = k0; k < k1; ++k) {
-    const RoiGeom g = roi_geom(rois + (size_t)k * 5, out_size, scale, sampling_ratio, aligned, B);
-    const float* gb = gout + (size_t)k * C * bins;
-    __syncthreads();   // previous RoI's tile and weights fully consumed (and foot zeroed on the first trip)
-    for (int o = threadIdx.x; o < C * bins; o += blockDim.x) {
-      const int c = o / bins, bin = o - c * bins;
-      tile[bin * ld + c] = gb[o];
+  const int ox = S->ub[0], oy = S->ub[1];
+  const bool ok = S->ub[5] && (S->ub[2] - ox < SF) && (S->ub[3] - oy < SF);
+  __syncthreads();
+  if (threadIdx.x == 0) S->ub[5] = ok ? 1 : 0;
+  if (ok) {
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {    // pass 2: one thread per (member, axis, bin)
+      const int r = t / (2 * out_size), a = (t / out_size) & 1, p = t % out_size;
+      const RoiGeom g = roi_geom(rois + (size_t)(k0 + r) * 5, out_size, scale, sampling_ratio, aligned, B);
+      const float start = a ? g.start_h : g.start_w, bin = a ? g.bin_h : g.bin_w;
+      const int grid = a ? g.grid_h : g.grid_w, L = a ? H : W, o = a ? oy : ox;
+      float* w = a ? S->ay[r][p] : S->ax[r][p];
+#pragma unroll
+      for (int i = 0; i < SF; ++i) w[i] = 0.f;
+      for (int i = 0; i < grid; ++i) {
+        int l, h; float fl; bool valid;
+        small_tap(start + p * bin + (i + .5f) * bin / (float)grid, L, l, h, fl, valid);
+        if (!valid) continue;
+        w[l - o] += 1.f - fl;
+        w[h - o] += fl;
+      }
+      if (a) {
+#pragma unroll
+        for (int i = 0; i < SF; ++i) w[i] = w[i] / g.inv_count;
+      }
     }
-    axis_weights(g.start_w, g.bin_w, g.grid_w, W, out_size, &AX);   // ends with a barrier
-    axis_weights(g.start_h, g.bin_h, g.grid_h, H, out_size, &AY);
-    const int ny = AY.e - AY.o + 1, nx = AX.e - AX.o + 1;
-    if (ny <= 0 || nx <= 0) continue;
-    float* fb = gfeat + (size_t)g.b * H * W * C;
-    const bool in = use_foot && AX.o >= ux0 && AX.e < ux0 + uw && AY.o >= uy0 && AY.e < uy0 + uh;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-      for (int py = 0; py < ny; ++py) {
-        float S[NB];
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(256)
+    roi_align_small_fwd(const float* __restrict__ feat, const float* __restrict__ rois, int B, int C, int H, int W,
+                        int K, int group, int out_size, float scale, int sampling_ratio, int aligned,
+                        float* __restrict__ out, int* __restrict__ fallback) {
+  __shared__ SmallW S;
+  group = 1;   // the forward has nothing to share between bag members: one RoI per workgroup for parallelism
+  const int k0 = blockIdx.x * group, k1 = min(k0 + group, K);
+  small_setup(rois, k0, k1, B, H, W, out_size, scale, sampling_ratio, aligned, &S);
+  if (!S.ub[5]) { if (threadIdx.x == 0) fallback[blockIdx.x] = 1; return; }
+  if (threadIdx.x == 0) fallback[blockIdx.x] = 0;
+  const int ox = S.ub[0], oy = S.ub[1], b = S.ub[4];
+  const int bins = out_size * out_size;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float f[SF][SF];
 #pragma unroll
-        for (int pw = 0; pw < NB; ++pw) S[pw] = 0.f;
-        for (int ph = 0; ph < out_size; ++ph) {
-          if (AY.lo[ph] > py || py > AY.hi[ph]) continue;
-          const float wy = AY.w[ph][py] / g.inv_count;
+    for (int y = 0; y < SF; ++y)
 #pragma unroll
-          for (int pw = 0; pw < NB; ++pw)
-            if (pw < out_size) S[pw] += wy * tile[(ph * out_size + pw) * ld + c];
+      for (int x = 0; x < SF; ++x) {
+        const int yy = min(oy + y, H - 1), xx = min(ox + x, W - 1);   // rows/cols beyond the union have zero weight
+        f[y][x] = feat[(((size_t)b * H + yy) * W + xx) * C + c];
+      }
+    for (int k = k0; k < k1; ++k) {
+      const int r = k - k0;
+      float* ob = out + ((size_t)k * C + c) * bins;
+      float T[SF][NB];
+#pragma unroll
+      for (int y = 0; y < SF; ++y)
+#pragma unroll
+        for (int pw = 0; pw < NB; ++pw) {
+          float t = 0.f;
+          if (pw < out_size) {
+#pragma unroll
+            for (int x = 0; x < SF; ++x) t = fmaf(S.ax[r][pw][x], f[y][x], t);
+          }
+          T[y][pw] = t;
         }
-        for (int px = 0; px < nx; ++px) {
-          float v = 0.f;
 #pragma unroll
-          for (int pw = 0; pw < NB; ++pw)
-            if (pw < out_size) v += AX.w[pw][px] * S[pw];
-          if (v == 0.f) continue;
-          if (in) {   // wave-uniform branch; thread-private column c of the footprint
-            foot[((AY.o + py - uy0) * uw + (AX.o + px - ux0)) * C + c] += v;
-          } else {
-            atomicAdd(&fb[((size_t)(AY.o + py) * W + AX.o + px) * C + c], v);
+      for (int ph = 0; ph < NB; ++ph) {
+        if (ph < out_size) {
+#pragma unroll
+          for (int pw = 0; pw < NB; ++pw) {
+            if (pw < out_size) {
+              float v = 0.f;
+#pragma unroll
+              for (int y = 0; y < SF; ++y) v = fmaf(S.ay[r][ph][y], T[y][pw], v);
+              ob[ph * out_size + pw] = v;
+            }
           }
         }
       }
     }
   }
-  if (use_foot) {
-    // each thread flushes the columns it accumulated itself: no barrier needed
-    float* fb = gfeat + (size_t)ub[4] * H * W * C;
-    for (int c = threadIdx.x; c < C; c += blockDim.x)
-      for (int p = 0; p < uw * uh; ++p) {
-        const float v = foot[p * C + c];
-        if (v != 0.f) atomicAdd(&fb[((size_t)(uy0 + p / uw) * W + (ux0 + p % uw)) * C + c], v);
+}
+
+__global__ void __launch_bounds__(256)
+    roi_align_small_bwd(const float* __restrict__ gout, const float* __restrict__ rois, int B, int C, int H, int W,
+                        int K, int group, int out_size, float scale, int sampling_ratio, int aligned,
+                        float* __restrict__ gfeat, int* __restrict__ fallback) {
+  __shared__ SmallW S;
+  const int k0 = blockIdx.x * group, k1 = min(k0 + group, K);
+  small_setup(rois, k0, k1, B, H, W, out_size, scale, sampling_ratio, aligned, &S);
+  if (!S.ub[5]) { if (threadIdx.x == 0) fallback[blockIdx.x] = 1; return; }
+  if (threadIdx.x == 0) fallback[blockIdx.x] = 0;
+  const int ox = S.ub[0], oy = S.ub[1], b = S.ub[4];
+  const int bins = out_size * out_size;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float acc[SF][SF];
+#pragma unroll
+    for (int y = 0; y < SF; ++y)
+#pragma unroll
+      for (int x = 0; x < SF; ++x) acc[y][x] = 0.f;
+    for (int k = k0; k < k1; ++k) {
+      const int r = k - k0;
+      const float* gb = gout + ((size_t)k * C + c) * bins;
+      float Sy[SF][NB];
+#pragma unroll
+      for (int y = 0; y < SF; ++y)
+#pragma unroll
+        for (int pw = 0; pw < NB; ++pw) Sy[y][pw] = 0.f;
+#pragma unroll
+      for (int ph = 0; ph < NB; ++ph) {
+        if (ph < out_size) {
+#pragma unroll
+          for (int pw = 0; pw < NB; ++pw) {
+            if (pw < out_size) {
+              const float g = gb[ph * out_size + pw];
+#pragma unroll
+              for (int y = 0; y < SF; ++y) Sy[y][pw] = fmaf(S.ay[r][ph][y], g, Sy[y][pw]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int y = 0; y < SF; ++y)
+#pragma unroll
+        for (int x = 0; x < SF; ++x) {
+          float v = acc[y][x];
+#pragma unroll
+          for (int pw = 0; pw < NB; ++pw)
+            if (pw < out_size) v = fmaf(S.ax[r][pw][x], Sy[y][pw], v);
+          acc[y][x] = v;
+        }
+    }
+#pragma unroll
+    for (int y = 0; y < SF; ++y)
+#pragma unroll
+      for (int x = 0; x < SF; ++x) {
+        const float v = acc[y][x];
+        if (v != 0.f && oy + y < H && ox + x < W)
+          atomicAdd(&gfeat[(((size_t)b * H + oy + y) * W + ox + x) * C + c], v);
       }
   }
 }
@@ -313,8 +466,8 @@ static int roi_check(const char* fn, const void* a, const void* rois, const void
 }
 
 extern "C" int pt_roi_align_fwd(const float* feat, const float* rois, int B, int C, int H, int W, int K, int out_size,
-                                float spatial_scale, int sampling_ratio, int aligned, int channels_last, float* out,
-                                void* stream) {
+                                float spatial_scale, int sampling_ratio, int aligned, int channels_last, int group,
+                                int32_t* group_ws, float* out, void* stream) {
   if (K == 0) return PT_OK;
   int rc = roi_check("pt_roi_align_fwd", feat, rois, out, B, C, H, W, K, out_size, channels_last);
   if (rc) return rc;
@@ -328,8 +481,16 @@ extern "C" int pt_roi_align_fwd(const float* feat, const float* rois, int B, int
       if (e != hipSuccess) { set_error("pt_roi_align_fwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
       attr_bytes = lds;
     }
+    const int* fb = nullptr;
+    if (group < 1) group = 1;
+    if (group_ws && out_size <= NB) {
+      hipLaunchKernelGGL(roi_align_small_fwd, dim3(K), dim3(256), 0, s, feat, rois, B, C, H, W, K, 1,
+                         out_size, spatial_scale, sampling_ratio, aligned, out, group_ws);
+      PT_LAUNCH_CHECK("pt_roi_align_fwd(small)");
+      fb = group_ws;
+    }
     hipLaunchKernelGGL(roi_align_fwd_cl, dim3(K), dim3(256), lds, s, feat, rois, B, C, H, W, out_size, spatial_scale,
-                       sampling_ratio, aligned, out);
+                       sampling_ratio, aligned, out, fb, group);
   } else {
     const long total = (long)K * C * out_size * out_size;
     int nb = cdiv(total, 256);
@@ -343,13 +504,13 @@ extern "C" int pt_roi_align_fwd(const float* feat, const float* rois, int B, int
 
 extern "C" int pt_roi_align_bwd(const float* grad_out, const float* rois, int B, int C, int H, int W, int K,
                                 int out_size, float spatial_scale, int sampling_ratio, int aligned,
-                                int channels_last, int group, float* grad_feat, void* stream) {
+                                int channels_last, int group, int32_t* group_ws, float* grad_feat, void* stream) {
   if (K == 0) return PT_OK;
   int rc = roi_check("pt_roi_align_bwd", grad_out, rois, grad_feat, B, C, H, W, K, out_size, channels_last);
   if (rc) return rc;
   hipStream_t s = as_stream(stream);
   if (channels_last) {
-    const size_t lds = ((size_t)(C + 1) * out_size * out_size + (size_t)FOOT_MAXPIX * C + 8) * sizeof(float);
+    const size_t lds = (size_t)(C + 1) * out_size * out_size * sizeof(float);
     PT_REQUIRE(lds + 2 * sizeof(AxisW) <= 160 * 1024, PT_ELIMIT, "pt_roi_align_bwd: C=%d too large for the LDS tiles", C);
     static size_t attr_bytes = 0;
     if (lds > attr_bytes) {
@@ -360,8 +521,15 @@ extern "C" int pt_roi_align_bwd(const float* grad_out, const float* rois, int B,
     }
     if (group < 1) group = 1;
     if (group > 64) group = 64;
-    hipLaunchKernelGGL(roi_align_bwd_cl, dim3(cdiv(K, group)), dim3(256), lds, s, grad_out, rois, B, C, H, W, K, group,
-                       out_size, spatial_scale, sampling_ratio, aligned, grad_feat);
+    const int* fb = nullptr;
+    if (group_ws && group > 1 && group <= SMALL_GROUP && out_size <= NB) {
+      hipLaunchKernelGGL(roi_align_small_bwd, dim3(cdiv(K, group)), dim3(256), 0, s, grad_out, rois, B, C, H, W, K,
+                         group, out_size, spatial_scale, sampling_ratio, aligned, grad_feat, group_ws);
+      PT_LAUNCH_CHECK("pt_roi_align_bwd(small)");
+      fb = group_ws;
+    }
+    hipLaunchKernelGGL(roi_align_bwd_cl, dim3(K), dim3(256), lds, s, grad_out, rois, B, C, H, W, K, group,
+                       out_size, spatial_scale, sampling_ratio, aligned, grad_feat, fb);
   } else {
     const long total = (long)K * C * out_size * out_size;
     int nb = cdiv(total, 256);

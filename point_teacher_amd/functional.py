@@ -260,8 +260,9 @@ class _RoIAlign(torch.autograd.Function):
         rois = _f(rois)
         K = rois.shape[0]
         out = torch.empty((K, C, out_size, out_size), dtype=f32, device=feat.device)
+        ws = torch.empty((K,), dtype=i32, device=feat.device) if cl else None
         hip.call('pt_roi_align_fwd', fbuf, rois, B, C, H, W, K, out_size, float(scale), sampling_ratio,
-                 int(aligned), int(cl), out)
+                 int(aligned), int(cl), int(group), ws, out)
         ctx.save_for_backward(rois)
         ctx.cfg = (B, C, H, W, out_size, float(scale), sampling_ratio, int(aligned), cl, int(group), in_dtype)
         return out
@@ -275,7 +276,8 @@ class _RoIAlign(torch.autograd.Function):
             gbuf = torch.zeros((B, H, W, C), dtype=f32, device=g.device)
         else:
             gbuf = torch.zeros((B, C, H, W), dtype=f32, device=g.device)
-        hip.call('pt_roi_align_bwd', _f(g), rois, B, C, H, W, K, out_size, scale, sr, aligned, int(cl), group, gbuf)
+        ws = torch.empty((K,), dtype=i32, device=g.device) if (cl and group > 1) else None
+        hip.call('pt_roi_align_bwd', _f(g), rois, B, C, H, W, K, out_size, scale, sr, aligned, int(cl), group, ws, gbuf)
         gfeat = gbuf.permute(0, 3, 1, 2) if cl else gbuf
         return gfeat.to(in_dtype), None, None, None, None, None, None
 

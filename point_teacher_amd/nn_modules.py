@@ -40,6 +40,31 @@ class Scale(nn.Module):
 
 
 # ------------------------------------------------------------------------ ResNet --
+def conv_bn(x, conv, bn, relu):
+    """conv -> BatchNorm -> (ReLU).  When the BN is in eval mode with a frozen affine (the only
+    mode on this path: norm_eval=True, requires_grad=False, resnet.py:647-658) the normalisation
+    is a per-channel affine map and is folded into the convolution:
+        y = conv(x, w * s) + (beta - mean * s),   s = gamma / sqrt(var + eps)
+    which removes one full read+write pass over the activation in the forward and one in the
+    backward per convolution.  s and the bias are cached (they never change while frozen).
+    Measured on MI355X (r01, phase 2 fp32): 53.6 ms folded vs 51.9 ms un-folded - MIOpen adds the
+    bias in a separate pass, so nothing is saved; folding is therefore OFF unless a BN module
+    carries `fold_into_conv = True`."""
+    if bn.training or bn.weight.requires_grad or not getattr(bn, 'fold_into_conv', False):
+        y = bn(conv(x))
+    else:
+        cache = getattr(bn, '_folded', None)
+        ver = (bn.weight._version, bn.bias._version, bn.running_var._version, bn.running_mean._version,
+               bn.weight.data_ptr())
+        if cache is None or cache[0] != ver:
+            with torch.no_grad():
+                sc = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+                cache = (ver, sc.view(-1, 1, 1, 1).contiguous(), (bn.bias - bn.running_mean * sc).contiguous())
+            bn._folded = cache
+        y = TF.conv2d(x, conv.weight * cache[1], cache[2], conv.stride, conv.padding, conv.dilation, conv.groups)
+    return TF.relu(y, inplace=True) if relu else y
+
+
 class Bottleneck(nn.Module):
     """backbones/resnet.py:96-303; `caffe` style puts the stride on conv1 (:153-158)."""
     expansion = 4
@@ -58,11 +83,11 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         identity = x
-        out = TF.relu(self.bn1(self.conv1(x)), inplace=True)
-        out = TF.relu(self.bn2(self.conv2(out)), inplace=True)
-        out = self.bn3(self.conv3(out))
+        out = conv_bn(x, self.conv1, self.bn1, True)
+        out = conv_bn(out, self.conv2, self.bn2, True)
+        out = conv_bn(out, self.conv3, self.bn3, False)
         if self.downsample is not None:
-            identity = self.downsample(x)
+            identity = conv_bn(x, self.downsample[0], self.downsample[1], False)
         out += identity
         return TF.relu(out, inplace=True)
 
@@ -129,7 +154,7 @@ class ResNet(nn.Module):
                 p.requires_grad = False
 
     def forward(self, x):
-        x = self.maxpool(TF.relu(self.bn1(self.conv1(x)), inplace=True))
+        x = self.maxpool(conv_bn(x, self.conv1, self.bn1, True))
         outs = []
         for i, name in enumerate(self.res_layers):
             x = getattr(self, name)(x)

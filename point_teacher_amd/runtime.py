@@ -27,8 +27,12 @@ from . import functional as F
 class FlatParams:
     """Re-homes the parameters of `model.student` / `model.teacher` into flat buffers."""
 
-    def __init__(self, model):
+    def __init__(self, model, channels_last=False):
+        """channels_last=True stores 4-D (convolution) weights in [O,H,W,I] order inside the flat
+        buffers and exposes them as channels_last-strided views, so MIOpen's NHWC kernels run
+        without per-call layout transposes; the flat-buffer kernels are order-agnostic."""
         self.model = model
+        self.channels_last = channels_last
         student = list(model.student.named_parameters())
         teacher = dict(model.teacher.named_parameters())
         assert [n for n, _ in student] == list(teacher.keys()), 'teacher/student parameter lists differ'
@@ -57,12 +61,22 @@ class FlatParams:
             for name, p in self.order:
                 n = p.numel()
                 t = teacher[name]
-                self.student_flat[off:off + n].copy_(p.data.reshape(-1))
-                self.teacher_flat[off:off + n].copy_(t.data.reshape(-1))
-                p.data = self.student_flat[off:off + n].view(p.shape)
-                t.data = self.teacher_flat[off:off + n].view(t.shape)
+                if channels_last and p.dim() == 4:
+                    O, I, KH, KW = p.shape
+
+                    def view(buf):
+                        return buf[off:off + n].view(O, KH, KW, I).permute(0, 3, 1, 2)
+                    view(self.student_flat).copy_(p.data)
+                    view(self.teacher_flat).copy_(t.data)
+                else:
+                    def view(buf):
+                        return buf[off:off + n].view(p.shape)
+                    self.student_flat[off:off + n].copy_(p.data.reshape(-1))
+                    self.teacher_flat[off:off + n].copy_(t.data.reshape(-1))
+                p.data = view(self.student_flat)
+                t.data = view(self.teacher_flat)
                 if p.requires_grad:
-                    p.grad = self.grad_flat[off:off + n].view(p.shape)
+                    p.grad = view(self.grad_flat)
                 self.slices[name] = (off, n)
                 off += (n + 3) // 4 * 4
         model._flat = (self.teacher_flat, self.student_flat)
@@ -137,10 +151,11 @@ class Trainer:
     """One object = model + flat storage + optimizer + (optional) data-parallel exchange."""
 
     def __init__(self, model, optimizer_cfg, optimizer_config=None, lr_config=None, iters_per_epoch=1000,
-                 grad_chunks=4, autocast_dtype=None):
+                 grad_chunks=4, autocast_dtype=None, channels_last=False):
         assert optimizer_cfg.get('type', 'SGD') == 'SGD', 'the Point-Teacher recipe is SGD'
         self.model = model
-        self.flat = FlatParams(model)
+        self.flat = FlatParams(model, channels_last=channels_last)
+        self.channels_last = channels_last
         self.momentum = optimizer_cfg.get('momentum', 0.0)
         self.weight_decay = optimizer_cfg.get('weight_decay', 0.0)
         pw = optimizer_cfg.get('paramwise_cfg', {}) or {}
@@ -177,6 +192,8 @@ class Trainer:
         backward, gradient exchange, clip + SGD.  Returns train_step's dict."""
         self._set_lr()
         self.flat.zero_grad()
+        if self.channels_last:
+            data = dict(data, img=data['img'].contiguous(memory_format=torch.channels_last))
         if self.autocast_dtype is not None:
             with torch.autocast('cuda', dtype=self.autocast_dtype):
                 out = self.model.train_step(data, None)

@@ -339,3 +339,35 @@ def test_fill_quads():
     exp = R.fill_convex_quads(quads[alive].numpy().astype(np.int32), 200, 200)
     assert np.array_equal((img[0] == 255).cpu().numpy(), exp.astype(bool))
     assert torch.equal(img[0], img[2])
+
+
+def test_roi_align_bag_fast_path():
+    """Bags of jittered tiny boxes (group = 25) take the register-resident small-footprint kernels;
+    bags with a large member or spanning two images fall back to the generic kernel inside the same
+    call.  Both must equal the oracle (forward and backward)."""
+    f = F()
+    gen = torch.Generator().manual_seed(21)
+    B, C, H, W = 2, 64, 40, 40
+    feat = torch.randn(B, C, H, W, generator=gen)
+    n_gt, U = 12, 25
+    c = torch.rand(n_gt, 2, generator=gen) * 280 + 20
+    wh = torch.exp(torch.randn(n_gt, 2, generator=gen) * 0.5 + np.log(11.))
+    wh[3] = torch.tensor([150., 90.])                      # one big object -> generic path for its bag
+    c[5] = torch.tensor([1.0, 318.0])                      # on the border -> clamped taps
+    base = torch.cat([c - wh / 2, c + wh / 2], 1)
+    props, _ = R.fine_proposals(base, [1.0, 1.2, 1.3, 0.8, 0.7], None, 4, (320, 320))
+    bi = (torch.arange(n_gt).repeat_interleave(U) % 2).float()[:, None]
+    bi[7 * U + 3] = 1 - bi[7 * U + 3]                      # a bag that spans two images -> fallback
+    rois = torch.cat([bi, props], 1)
+    fr = feat.clone().requires_grad_(True)
+    out_ref = R.roi_align(fr, rois, 7, 0.125)
+    wgt = torch.randn(out_ref.shape, generator=gen)
+    (out_ref * wgt).sum().backward()
+    fg = cu(feat).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    out = f.roi_align(fg, cu(rois), 7, 0.125, 0, True, U)
+    close(out, out_ref, atol=1e-5)
+    (out * cu(wgt)).sum().backward()
+    close(fg.grad, fr.grad, atol=1e-4)
+    # group hint must not change the result
+    out1 = f.roi_align(fg.detach(), cu(rois), 7, 0.125, 0, True, 1)
+    close(out1, out, rtol=1e-5, atol=1e-5)
