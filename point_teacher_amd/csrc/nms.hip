@@ -56,6 +56,11 @@ __device__ __forceinline__ int clip_edge(const P2* in, int n, P2 a, P2 b, P2* ou
 __device__ float rotated_iou(const float* b1, const float* b2) {
   const float a1 = b1[2] * b1[3], a2 = b2[2] * b2[3];
   if (a1 < 1e-14f || a2 < 1e-14f) return 0.f;
+  {  // bounding circles apart -> the polygons cannot intersect (exact 0, skips the clip for most pairs)
+    const float dx = b2[0] - b1[0], dy = b2[1] - b1[1];
+    const float r = 0.5f * (sqrtf(b1[2] * b1[2] + b1[3] * b1[3]) + sqrtf(b2[2] * b2[2] + b2[3] * b2[3]));
+    if (dx * dx + dy * dy > r * r * 1.0001f) return 0.f;
+  }
   // translate to the first centre to keep fp32 precision (as mmcv's kernel does)
   float c1[5] = {0.f, 0.f, b1[2], b1[3], b1[4]};
   float c2[5] = {b2[0] - b1[0], b2[1] - b1[1], b2[2], b2[3], b2[4]};
