@@ -437,12 +437,28 @@ def _synthetic_batch(batch, size, objects, seed=7):
     return img, boxes, labels
 
 
+def effective_cpus():
+    """Cores this process may actually use: min(affinity mask, cgroup CPU quota).  The GPU boxes
+    expose 256 logical CPUs but cap the container at 16; sizing thread pools by os.cpu_count()
+    there oversubscribes 16x and the CPU leg takes minutes."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(workload='step1', batch=2, size=800, objects=300, iters=1):
     """Time the oracle's full iteration (forward + backward + clip + SGD + EMA) on the host
     cores for `iters` iterations after one untimed warm-up at a reduced size.  Returns the
     dict bench.py puts under "cpu_baseline"."""
-    cores = os.cpu_count() or 1
+    cores = effective_cpus()
     torch.set_num_threads(cores)
+    import sys
+    print(f'[cpu_baseline] timing {iters} oracle iteration(s) on {cores} host threads ...', file=sys.stderr, flush=True)
     g = torch.Generator().manual_seed(0)
     sd_s = init_detector_state(1)
     sd_t = init_detector_state(2)
