@@ -197,6 +197,19 @@ int pt_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n,
                 float bias_decay_mult, const float* sqnorm, float max_norm, int first_step,
                 void* stream);
 
+/* Frozen BatchNorm (+ residual add) (+ ReLU) in one pass each way.  Every BatchNorm on the path
+ * is in eval mode with a frozen affine (models/backbones/resnet.py:647-658, config
+ * norm_cfg=dict(type='BN', requires_grad=False), norm_eval=True), i.e. y = x*scale[c] + shift[c]
+ * with scale = gamma/sqrt(var+eps), shift = beta - mean*scale; the Bottleneck tail
+ * (resnet.py:262-303) adds the identity and applies ReLU.  inner = H*W for NCHW tensors, 1 for
+ * channels_last; y may alias x.  bwd: m = relu ? (y > 0) : 1; grad_res = g*m (may be NULL);
+ * grad_x = g*m*scale[c] (may be NULL).  n % 4 == 0. */
+int pt_affine_relu_fwd(const float* x, const float* scale, const float* shift,
+                       const float* residual, int64_t n, int C, int64_t inner, int relu, float* y,
+                       void* stream);
+int pt_affine_relu_bwd(const float* grad_y, const float* y, const float* scale, int64_t n, int C,
+                       int64_t inner, int relu, float* grad_x, float* grad_res, void* stream);
+
 /* ------------------------------------------------------------------------ NMS --
  * mmcv.ops.nms (offset 0), call site core/post_processing/bbox_nms.py:76 through
  * batched_nms: boxes[N,4] must be sorted by descending score; class-aware when

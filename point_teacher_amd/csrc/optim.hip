@@ -108,3 +108,101 @@ extern "C" int pt_sgd_step(float* param, const float* grad, float* momentum_buf,
   PT_LAUNCH_CHECK("pt_sgd_step");
   return PT_OK;
 }
+
+// ----------------------------------------------------------------------------------------------
+// Frozen-BatchNorm epilogue.  On this path every BatchNorm runs in eval mode with a frozen affine
+// (backbones/resnet.py:647-658: norm_eval=True, requires_grad=False), i.e. it is the per-channel map
+// y = x*scale[c] + shift[c].  torch runs it as 2-3 separate full passes over the activation (BN,
+// residual add, ReLU) forward and 3 more backward; these kernels do each direction in ONE pass:
+//   fwd: y = [relu]( x*scale[c] + shift[c] [+ residual] )           (in place on x allowed)
+//   bwd: m = relu ? (y > 0) : 1 ;  grad_res = g*m ;  grad_x = g*m*scale[c]
+// `inner` = H*W for NCHW tensors and 1 for channels_last ones (channel = (i / inner) % C).
+namespace pt {
+
+__global__ void __launch_bounds__(256)
+    affine_relu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                           const float* __restrict__ shift, const float* __restrict__ res, long n4, int C,
+                           long inner, int relu, float* __restrict__ y) {
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  const float4* r4 = reinterpret_cast<const float4*>(res);
+  float4* y4 = reinterpret_cast<float4*>(y);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 v = x4[i];
+    const long e = i << 2;
+    float s[4], b[4];
+    if (inner == 1) {              // channels_last: 4 consecutive channels (C % 4 == 0)
+      const int c = (int)(e % C);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { s[k] = scale[c + k]; b[k] = shift[c + k]; }
+    } else {                       // NCHW: inner % 4 == 0 -> one channel for the whole float4
+      const int c = (int)((e / inner) % C);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { s[k] = scale[c]; b[k] = shift[c]; }
+    }
+    v.x = v.x * s[0] + b[0]; v.y = v.y * s[1] + b[1]; v.z = v.z * s[2] + b[2]; v.w = v.w * s[3] + b[3];
+    if (res) { const float4 r = r4[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    y4[i] = v;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    affine_relu_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ scale,
+                           long n4, int C, long inner, int relu, float* __restrict__ gx, float* __restrict__ gres) {
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  const float4* y4 = reinterpret_cast<const float4*>(y);
+  float4* gx4 = reinterpret_cast<float4*>(gx);
+  float4* gr4 = reinterpret_cast<float4*>(gres);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 v = g4[i];
+    if (relu) {
+      const float4 o = y4[i];
+      v.x = o.x > 0.f ? v.x : 0.f; v.y = o.y > 0.f ? v.y : 0.f; v.z = o.z > 0.f ? v.z : 0.f; v.w = o.w > 0.f ? v.w : 0.f;
+    }
+    if (gres) gr4[i] = v;
+    if (gx) {
+      const long e = i << 2;
+      if (inner == 1) {
+        const int c = (int)(e % C);
+        v.x *= scale[c]; v.y *= scale[c + 1]; v.z *= scale[c + 2]; v.w *= scale[c + 3];
+      } else {
+        const float s = scale[(int)((e / inner) % C)];
+        v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+      }
+      gx4[i] = v;
+    }
+  }
+}
+
+}  // namespace pt
+
+static int affine_check(const char* fn, int64_t n, int C, int64_t inner) {
+  PT_REQUIRE(n > 0 && C > 0 && inner > 0 && n % 4 == 0, PT_EINVAL, "%s: bad size (n must be a multiple of 4)", fn);
+  PT_REQUIRE((inner == 1 && C % 4 == 0) || (inner > 1 && inner % 4 == 0), PT_EINVAL,
+             "%s: need C %% 4 == 0 (channels_last) or H*W %% 4 == 0 (NCHW)", fn);
+  return PT_OK;
+}
+
+extern "C" int pt_affine_relu_fwd(const float* x, const float* scale, const float* shift, const float* residual,
+                                  int64_t n, int C, int64_t inner, int relu, float* y, void* stream) {
+  if (n == 0) return PT_OK;
+  PT_REQUIRE(x && scale && shift && y, PT_EINVAL, "pt_affine_relu_fwd: NULL pointer");
+  int rc = affine_check("pt_affine_relu_fwd", n, C, inner);
+  if (rc) return rc;
+  hipLaunchKernelGGL(affine_relu_fwd_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, as_stream(stream), x, scale, shift,
+                     residual, (long)(n / 4), C, (long)inner, relu, y);
+  PT_LAUNCH_CHECK("pt_affine_relu_fwd");
+  return PT_OK;
+}
+
+extern "C" int pt_affine_relu_bwd(const float* grad_y, const float* y, const float* scale, int64_t n, int C,
+                                  int64_t inner, int relu, float* grad_x, float* grad_res, void* stream) {
+  if (n == 0) return PT_OK;
+  PT_REQUIRE(grad_y && scale && (grad_x || grad_res) && (!relu || y), PT_EINVAL, "pt_affine_relu_bwd: NULL pointer");
+  int rc = affine_check("pt_affine_relu_bwd", n, C, inner);
+  if (rc) return rc;
+  hipLaunchKernelGGL(affine_relu_bwd_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, as_stream(stream), grad_y, y,
+                     scale, (long)(n / 4), C, (long)inner, relu, grad_x, grad_res);
+  PT_LAUNCH_CHECK("pt_affine_relu_bwd");
+  return PT_OK;
+}

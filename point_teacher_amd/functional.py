@@ -395,6 +395,52 @@ def sgd_step_(param, grad, mom, split, lr_t, momentum, weight_decay, bias_lr_mul
              int(bool(first_step)))
 
 
+class _AffineReLU(torch.autograd.Function):
+    """y = [relu](x*scale[c] + shift[c] [+ residual]) in place on x (x is a fresh conv output)."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, residual, relu):
+        cl = x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+        C = x.shape[1]
+        inner = 1 if cl else x.shape[2] * x.shape[3]
+        xb = x.permute(0, 2, 3, 1) if cl else x
+        rb = None
+        if residual is not None:
+            rb = (residual.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1) if cl
+                  else residual.contiguous())
+        hip.call('pt_affine_relu_fwd', xb, scale, shift, rb, x.numel(), C, inner, int(relu), xb)
+        ctx.mark_dirty(x)
+        ctx.save_for_backward(x if relu else None, scale)
+        ctx.cfg = (cl, C, inner, bool(relu), residual is not None)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        y, scale = ctx.saved_tensors
+        cl, C, inner, relu, has_res = ctx.cfg
+        if cl:
+            g = g.contiguous(memory_format=torch.channels_last)
+            gb = g.permute(0, 2, 3, 1)
+            yb = y.permute(0, 2, 3, 1) if y is not None else None
+        else:
+            g = g.contiguous()
+            gb, yb = g, y
+        need_x = ctx.needs_input_grad[0]
+        gx = torch.empty_like(g) if need_x else None
+        gres = torch.empty_like(g) if (has_res and ctx.needs_input_grad[3]) else None
+        if gx is None and gres is None:
+            return None, None, None, None, None
+        hip.call('pt_affine_relu_bwd', gb, yb, scale, g.numel(), C, inner, int(relu),
+                 (gx.permute(0, 2, 3, 1) if cl else gx) if gx is not None else None,
+                 (gres.permute(0, 2, 3, 1) if cl else gres) if gres is not None else None)
+        return gx, None, None, gres, None
+
+
+def affine_relu_(x, scale, shift, residual=None, relu=True):
+    """Frozen-BN epilogue (pt_affine_relu_*): x must be fp32, 4-D, dense NCHW or channels_last."""
+    return _AffineReLU.apply(x, scale, shift, residual, relu)
+
+
 # ------------------------------------------------------------------------ NMS --
 
 def nms(boxes, scores, iou_threshold, class_ids=None):

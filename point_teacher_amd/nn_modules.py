@@ -40,28 +40,35 @@ class Scale(nn.Module):
 
 
 # ------------------------------------------------------------------------ ResNet --
-def conv_bn(x, conv, bn, relu):
-    """conv -> BatchNorm -> (ReLU).  When the BN is in eval mode with a frozen affine (the only
-    mode on this path: norm_eval=True, requires_grad=False, resnet.py:647-658) the normalisation
-    is a per-channel affine map and is folded into the convolution:
-        y = conv(x, w * s) + (beta - mean * s),   s = gamma / sqrt(var + eps)
-    which removes one full read+write pass over the activation in the forward and one in the
-    backward per convolution.  s and the bias are cached (they never change while frozen).
-    Measured on MI355X (r01, phase 2 fp32): 53.6 ms folded vs 51.9 ms un-folded - MIOpen adds the
-    bias in a separate pass, so nothing is saved; folding is therefore OFF unless a BN module
-    carries `fold_into_conv = True`."""
-    if bn.training or bn.weight.requires_grad or not getattr(bn, 'fold_into_conv', False):
-        y = bn(conv(x))
-    else:
-        cache = getattr(bn, '_folded', None)
-        ver = (bn.weight._version, bn.bias._version, bn.running_var._version, bn.running_mean._version,
-               bn.weight.data_ptr())
-        if cache is None or cache[0] != ver:
-            with torch.no_grad():
-                sc = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
-                cache = (ver, sc.view(-1, 1, 1, 1).contiguous(), (bn.bias - bn.running_mean * sc).contiguous())
-            bn._folded = cache
-        y = TF.conv2d(x, conv.weight * cache[1], cache[2], conv.stride, conv.padding, conv.dilation, conv.groups)
+def _bn_affine(bn):
+    """(scale, shift) of a frozen eval-mode BatchNorm, cached until its tensors change."""
+    cache = getattr(bn, '_affine', None)
+    ver = (bn.weight._version, bn.bias._version, bn.running_var._version, bn.running_mean._version,
+           bn.weight.data_ptr(), bn.weight.device)
+    if cache is None or cache[0] != ver:
+        with torch.no_grad():
+            sc = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).float().contiguous()
+            cache = (ver, sc, (bn.bias - bn.running_mean * sc).float().contiguous())
+        bn._affine = cache
+    return cache[1], cache[2]
+
+
+def conv_bn(x, conv, bn, relu, residual=None):
+    """conv -> BatchNorm (-> + residual) (-> ReLU).  Every BatchNorm on this path is in eval mode
+    with a frozen affine (norm_eval=True, requires_grad=False, resnet.py:647-658), i.e. a
+    per-channel affine map; BN, the residual add and the ReLU then run as ONE pass over the
+    activation in each direction (pt_affine_relu_fwd/bwd) instead of three."""
+    y = conv(x)
+    fused = (not bn.training and not bn.weight.requires_grad and y.dtype == torch.float32 and y.is_cuda
+             and getattr(bn, 'fuse_epilogue', True) and y.numel() % 4 == 0
+             and (y.shape[1] % 4 == 0 if (y.is_contiguous(memory_format=torch.channels_last) and not y.is_contiguous())
+                  else (y.is_contiguous() and (y.shape[2] * y.shape[3]) % 4 == 0)))
+    if fused:
+        sc, sh = _bn_affine(bn)
+        return F.affine_relu_(y, sc, sh, residual, relu)
+    y = bn(y)
+    if residual is not None:
+        y = y + residual
     return TF.relu(y, inplace=True) if relu else y
 
 
@@ -85,11 +92,9 @@ class Bottleneck(nn.Module):
         identity = x
         out = conv_bn(x, self.conv1, self.bn1, True)
         out = conv_bn(out, self.conv2, self.bn2, True)
-        out = conv_bn(out, self.conv3, self.bn3, False)
         if self.downsample is not None:
             identity = conv_bn(x, self.downsample[0], self.downsample[1], False)
-        out += identity
-        return TF.relu(out, inplace=True)
+        return conv_bn(out, self.conv3, self.bn3, True, residual=identity)
 
 
 @BACKBONES.register_module()

@@ -371,3 +371,34 @@ def test_roi_align_bag_fast_path():
     # group hint must not change the result
     out1 = f.roi_align(fg.detach(), cu(rois), 7, 0.125, 0, True, 1)
     close(out1, out, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('channels_last', [False, True])
+@pytest.mark.parametrize('relu,with_res', [(True, False), (True, True), (False, False)])
+def test_frozen_bn_epilogue(channels_last, relu, with_res):
+    """pt_affine_relu_* == eval-mode BatchNorm (+ identity) (+ ReLU) of torch, values and gradients."""
+    f = F()
+    gen = torch.Generator().manual_seed(31)
+    N, C, H, W = 2, 64, 12, 20
+    x = torch.randn(N, C, H, W, generator=gen)
+    res = torch.randn(N, C, H, W, generator=gen)
+    bn = torch.nn.BatchNorm2d(C).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=gen) + 0.5); bn.bias.copy_(torch.randn(C, generator=gen))
+        bn.running_mean.copy_(torch.randn(C, generator=gen)); bn.running_var.copy_(torch.rand(C, generator=gen) + 0.2)
+    xr, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    y = bn(xr) + (rr if with_res else 0)
+    y = torch.relu(y) if relu else y
+    wgt = torch.randn(y.shape, generator=gen)
+    (y * wgt).sum().backward()
+    mf = torch.channels_last if channels_last else torch.contiguous_format
+    xg = cu(x).contiguous(memory_format=mf).requires_grad_(True)
+    rg = cu(res).contiguous(memory_format=mf).requires_grad_(True)
+    sc = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).detach()
+    sh = (bn.bias - bn.running_mean * sc).detach()
+    out = f.affine_relu_(xg * 1.0, cu(sc), cu(sh), rg if with_res else None, relu)
+    close(out, y, atol=1e-5)
+    (out * cu(wgt)).sum().backward()
+    close(xg.grad, xr.grad, atol=1e-5)
+    if with_res:
+        close(rg.grad, rr.grad, atol=1e-6)
