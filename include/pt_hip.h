@@ -229,6 +229,26 @@ int pt_nms_rotated_sorted(const float* dets, int N, float iou_thr, uint64_t* mas
 int pt_fill_quads(float* img, int C, int H, int W, const float* quads, const uint8_t* alive,
                   int Q, float value, void* stream);
 
+/* ------------------------------------------------- oriented boxes (OBB variant) --
+ * mmcv.ops.diff_iou_rotated_2d, call sites OBB_TOD/mmrotate/models/losses/rotated_iou_loss.py:47,90
+ * (RotatedIoULoss / DN_IoULoss): aligned IoU of boxes (cx,cy,w,h,angle[rad]) [N,5], differentiable
+ * w.r.t. boxes1 (the prediction; the reference detaches the target).  bwd: grad_boxes1[N,5] =
+ * grad_iou[n] * d iou / d boxes1[n]. */
+int pt_diff_iou_rotated_fwd(const float* boxes1, const float* boxes2, int N, float* iou,
+                            void* stream);
+int pt_diff_iou_rotated_bwd(const float* boxes1, const float* boxes2, const float* grad_iou, int N,
+                            float* grad_boxes1, void* stream);
+/* mmcv.ops.RoIAlignRotated(out_size, spatial_scale, sample_num, aligned=True, clockwise), cfg
+ * OBB_TOD/configs/point teacher/sodaa_fcos_pointteacher_1x.py:71-80, called
+ * OBB_TOD/mmrotate/models/roi_heads/roi_extractors/rotate_single_level_roi_extractor.py:126.
+ * rois[K,6] = (batch, cx, cy, w, h, theta); layouts as pt_roi_align_*; bwd accumulates. */
+int pt_roi_align_rotated_fwd(const float* feat, const float* rois, int B, int C, int H, int W,
+                             int K, int out_size, float spatial_scale, int sample_num, int aligned,
+                             int clockwise, int channels_last, float* out, void* stream);
+int pt_roi_align_rotated_bwd(const float* grad_out, const float* rois, int B, int C, int H, int W,
+                             int K, int out_size, float spatial_scale, int sample_num, int aligned,
+                             int clockwise, int channels_last, float* grad_feat, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

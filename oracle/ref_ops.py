@@ -818,3 +818,73 @@ def sgd_momentum_step(p, g, buf, lr, momentum=0.9, weight_decay=1e-4, clip_coef=
     g = g * clip_coef + weight_decay * p
     buf = momentum * buf + g
     return p - lr * buf, buf
+
+
+# ----------------------------------------------------------------------------
+# Oriented-box ops of the OBB variant (mmcv.ops.diff_iou_rotated_2d / RoIAlignRotated) -
+# PARITY UNPINNED (mmcv-full absent): published algorithms, checked by invariants.
+# ----------------------------------------------------------------------------
+
+
+def diff_iou_rotated_grad(b1, b2, h=1e-4):
+    """(iou [N], d iou / d b1 [N,5]) by central differences of the fp64 polygon-clip IoU."""
+    N = b1.shape[0]
+    iou = np.zeros(N)
+    grad = np.zeros((N, 5))
+    a, b = b1.double().numpy(), b2.double().numpy()
+    for n in range(N):
+        iou[n] = rotated_iou_single(a[n], b[n])
+        for k in range(5):
+            p, m = a[n].copy(), a[n].copy()
+            p[k] += h; m[k] -= h
+            grad[n, k] = (rotated_iou_single(p, b[n]) - rotated_iou_single(m, b[n])) / (2 * h)
+    return torch.from_numpy(iou).float(), torch.from_numpy(grad).float()
+
+
+def roi_align_rotated(feat, rois, out_size=7, spatial_scale=0.125, sample_num=2, aligned=True, clockwise=True):
+    """Published mmcv algorithm (roi_align_rotated_cuda_kernel.cuh): the sampling grid of each bin is
+    rotated by theta about the RoI centre.  torch gathers -> autograd supplies the backward."""
+    K = rois.shape[0]
+    B, C, H, W = feat.shape
+    out = feat.new_zeros((K, C, out_size, out_size))
+    flat = feat.reshape(B, C, H * W)
+    off = 0.5 if aligned else 0.0
+    for k in range(K):
+        b = int(rois[k, 0])
+        cw, ch = float(rois[k, 1]) * spatial_scale - off, float(rois[k, 2]) * spatial_scale - off
+        rw, rh = float(rois[k, 3]) * spatial_scale, float(rois[k, 4]) * spatial_scale
+        th = -float(rois[k, 5]) if clockwise else float(rois[k, 5])
+        if not aligned:
+            rw, rh = max(rw, 1.0), max(rh, 1.0)
+        gh = sample_num if sample_num > 0 else int(math.ceil(rh / out_size))
+        gw = sample_num if sample_num > 0 else int(math.ceil(rw / out_size))
+        if gh <= 0 or gw <= 0:
+            continue
+        bh, bw = np.float32(rh / out_size), np.float32(rw / out_size)
+        ph = torch.arange(out_size, dtype=torch.float32)
+        yy = (np.float32(-rh / 2) + ph[:, None] * bh + (torch.arange(gh, dtype=torch.float32)[None] + 0.5) * bh / gh).reshape(-1)
+        xx = (np.float32(-rw / 2) + ph[:, None] * bw + (torch.arange(gw, dtype=torch.float32)[None] + 0.5) * bw / gw).reshape(-1)
+        c, s = np.float32(math.cos(th)), np.float32(math.sin(th))
+        Y = yy[:, None] * c - xx[None, :] * s + np.float32(ch)
+        X = yy[:, None] * s + xx[None, :] * c + np.float32(cw)
+        oob = (Y < -1.0) | (Y > H) | (X < -1.0) | (X > W)
+
+        def prep(v, L):
+            v = v.clamp(min=0)
+            lo = v.floor().long()
+            hc = lo >= L - 1
+            lo = torch.where(hc, torch.full_like(lo, L - 1), lo)
+            hi = torch.where(hc, lo, lo + 1)
+            v = torch.where(hc, lo.float(), v)
+            l = v - lo.float()
+            return lo, hi, l, 1 - l
+        ylo, yhi, ly, hy = prep(Y, H)
+        xlo, xhi, lx, hx = prep(X, W)
+        f = flat[b]
+
+        def g(yi, xi):
+            return f[:, (yi * W + xi).reshape(-1)].reshape(C, *Y.shape)
+        val = g(ylo, xlo) * (hy * hx) + g(ylo, xhi) * (hy * lx) + g(yhi, xlo) * (ly * hx) + g(yhi, xhi) * (ly * lx)
+        val = val * (~oob).to(val.dtype)
+        out[k] = val.reshape(C, out_size, gh, out_size, gw).sum((2, 4)) / max(gh * gw, 1)
+    return out

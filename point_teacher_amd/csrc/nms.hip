@@ -97,8 +97,10 @@ __global__ void box_iou_rotated_kernel(const float* __restrict__ a, const float*
 }
 
 // ------------------------------------------------------------------ bitmask ---
+// 256 threads per 64x64 tile: thread (r = tid & 63, q = tid >> 6) tests row r against columns
+// [16q, 16q+16); the four partial words of a row are OR-ed through LDS.
 template <bool ROT>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
     nms_mask_kernel(const float* __restrict__ boxes, const int32_t* __restrict__ cls, int N, float thr,
                     unsigned long long* __restrict__ mask) {
   const int rb = blockIdx.y, cb = blockIdx.x;
@@ -107,34 +109,41 @@ __global__ void __launch_bounds__(64)
   constexpr int D = ROT ? 5 : 4;
   __shared__ float cbox[64 * 5];
   __shared__ int ccls[64];
-  const int j = cb * 64 + threadIdx.x;
-  if (j < N) {
+  __shared__ unsigned long long part[4][64];
+  const int r = threadIdx.x & 63, q = threadIdx.x >> 6;
+  if (q == 0) {
+    const int j = cb * 64 + r;
+    if (j < N) {
 #pragma unroll
-    for (int k = 0; k < D; ++k) cbox[threadIdx.x * 5 + k] = boxes[(size_t)j * D + k];
-    ccls[threadIdx.x] = cls ? cls[j] : 0;
+      for (int k = 0; k < D; ++k) cbox[r * 5 + k] = boxes[(size_t)j * D + k];
+      ccls[r] = cls ? cls[j] : 0;
+    }
   }
   __syncthreads();
-  const int i = rb * 64 + threadIdx.x;
-  if (i >= N) return;
-  float me[5];
-#pragma unroll
-  for (int k = 0; k < D; ++k) me[k] = boxes[(size_t)i * D + k];
-  const int mycls = cls ? cls[i] : 0;
+  const int i = rb * 64 + r;
   unsigned long long bits = 0ull;
-  const int nc = min(64, N - cb * 64);
-  const int start = (rb == cb) ? threadIdx.x + 1 : 0;
-  for (int t = start; t < nc; ++t) {
-    if (ccls[t] != mycls) continue;
-    float v;
-    if (ROT) {
-      v = rotated_iou(me, &cbox[t * 5]);
-    } else {
-      v = iou_xyxy(make_float4(me[0], me[1], me[2], me[3]),
-                   make_float4(cbox[t * 5], cbox[t * 5 + 1], cbox[t * 5 + 2], cbox[t * 5 + 3]));
+  if (i < N) {
+    float me[5];
+#pragma unroll
+    for (int k = 0; k < D; ++k) me[k] = boxes[(size_t)i * D + k];
+    const int mycls = cls ? cls[i] : 0;
+    const int nc = min(64, N - cb * 64);
+    const int lo = max(q * 16, (rb == cb) ? r + 1 : 0), hi = min(q * 16 + 16, nc);
+    for (int t = lo; t < hi; ++t) {
+      if (ccls[t] != mycls) continue;
+      float v;
+      if (ROT) {
+        v = rotated_iou(me, &cbox[t * 5]);
+      } else {
+        v = iou_xyxy(make_float4(me[0], me[1], me[2], me[3]),
+                     make_float4(cbox[t * 5], cbox[t * 5 + 1], cbox[t * 5 + 2], cbox[t * 5 + 3]));
+      }
+      if (v > thr) bits |= 1ull << t;
     }
-    if (v > thr) bits |= 1ull << t;
   }
-  mask[(size_t)i * cols + cb] = bits;
+  part[q][r] = bits;
+  __syncthreads();
+  if (q == 0 && i < N) mask[(size_t)i * cols + cb] = part[0][r] | part[1][r] | part[2][r] | part[3][r];
 }
 
 // One wavefront: lane l owns removed-words l and l+64.
@@ -211,7 +220,7 @@ static int nms_impl(const char* fn, const float* boxes, const int32_t* cls, int 
   PT_REQUIRE(N <= NMS_MAXN, PT_ELIMIT, "%s: N=%d above %d", fn, N, NMS_MAXN);
   const int cols = cdiv(N, 64);
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(nms_mask_kernel<ROT>, dim3(cols, cols), dim3(64), 0, s, boxes, cls, N, thr,
+  hipLaunchKernelGGL(nms_mask_kernel<ROT>, dim3(cols, cols), dim3(256), 0, s, boxes, cls, N, thr,
                      reinterpret_cast<unsigned long long*>(ws));
   PT_LAUNCH_CHECK(fn);
   hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<const unsigned long long*>(ws), N,

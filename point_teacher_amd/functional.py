@@ -501,3 +501,61 @@ def fill_quads_(img, quads, alive, value=255.0):
     hip.call('pt_fill_quads', img, C, H, W, _f(quads), alive.to(u8).contiguous() if alive is not None else None, Q,
              float(value))
     return img
+
+
+# ------------------------------------------------- oriented boxes (OBB variant) --
+class _DiffIoURotated(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, b1, b2):
+        b1, b2 = _f(b1), _f(b2)
+        N = b1.shape[0]
+        iou = torch.empty((N,), dtype=f32, device=b1.device)
+        hip.call('pt_diff_iou_rotated_fwd', b1, b2, N, iou)
+        ctx.save_for_backward(b1, b2)
+        return iou
+
+    @staticmethod
+    def backward(ctx, g):
+        b1, b2 = ctx.saved_tensors
+        gb = torch.empty_like(b1)
+        hip.call('pt_diff_iou_rotated_bwd', b1, b2, _f(g), b1.shape[0], gb)
+        return gb, None
+
+
+def diff_iou_rotated_2d(box1, box2):
+    """mmcv.ops.diff_iou_rotated_2d contract: box1/box2 [B,N,5] -> IoU [B,N]; gradients flow to
+    box1 only (the reference's losses detach the target)."""
+    B, N = box1.shape[:2]
+    return _DiffIoURotated.apply(box1.reshape(-1, 5), box2.detach().reshape(-1, 5)).reshape(B, N)
+
+
+class _RoIAlignRotated(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, rois, out_size, scale, sample_num, aligned, clockwise):
+        B, C, H, W = feat.shape
+        in_dtype = feat.dtype
+        feat = feat.float()
+        cl = feat.is_contiguous(memory_format=torch.channels_last) and not feat.is_contiguous()
+        fbuf = feat.permute(0, 2, 3, 1) if cl else feat.contiguous()
+        rois = _f(rois)
+        K = rois.shape[0]
+        out = torch.empty((K, C, out_size, out_size), dtype=f32, device=feat.device)
+        hip.call('pt_roi_align_rotated_fwd', fbuf, rois, B, C, H, W, K, out_size, float(scale), int(sample_num),
+                 int(aligned), int(clockwise), int(cl), out)
+        ctx.save_for_backward(rois)
+        ctx.cfg = (B, C, H, W, out_size, float(scale), int(sample_num), int(aligned), int(clockwise), cl, in_dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        rois, = ctx.saved_tensors
+        B, C, H, W, out_size, scale, sn, aligned, cw, cl, in_dtype = ctx.cfg
+        gbuf = torch.zeros((B, H, W, C) if cl else (B, C, H, W), dtype=f32, device=g.device)
+        hip.call('pt_roi_align_rotated_bwd', _f(g), rois, B, C, H, W, rois.shape[0], out_size, scale, sn, aligned, cw,
+                 int(cl), gbuf)
+        return (gbuf.permute(0, 3, 1, 2) if cl else gbuf).to(in_dtype), None, None, None, None, None, None
+
+
+def roi_align_rotated(feat, rois, out_size, spatial_scale, sample_num=0, aligned=True, clockwise=False):
+    """mmcv.ops.roi_align_rotated: rois [K,6] = (batch, cx, cy, w, h, theta)."""
+    return _RoIAlignRotated.apply(feat, rois, int(out_size), spatial_scale, int(sample_num), bool(aligned), bool(clockwise))

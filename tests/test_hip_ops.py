@@ -402,3 +402,56 @@ def test_frozen_bn_epilogue(channels_last, relu, with_res):
     close(xg.grad, xr.grad, atol=1e-5)
     if with_res:
         close(rg.grad, rr.grad, atol=1e-6)
+
+
+def test_diff_iou_rotated():
+    f = F()
+    gen = torch.Generator().manual_seed(41)
+    N = 200
+    b2 = torch.cat([torch.rand(N, 2, generator=gen) * 100 + 50, torch.rand(N, 2, generator=gen) * 40 + 6,
+                    (torch.rand(N, 1, generator=gen) - 0.5) * np.pi], 1)
+    b1 = b2 + torch.cat([torch.randn(N, 2, generator=gen) * 4, torch.randn(N, 2, generator=gen) * 3,
+                         torch.randn(N, 1, generator=gen) * 0.2], 1)
+    b1[:, 2:4] = b1[:, 2:4].clamp(min=3)
+    b1[0] = torch.tensor([500., 500., 10., 10., 0.1])              # disjoint -> IoU 0, zero gradient
+    iou_ref, grad_ref = R.diff_iou_rotated_grad(b1, b2)
+    x = cu(b1).requires_grad_(True)
+    iou = f.diff_iou_rotated_2d(x[None], cu(b2)[None])[0]
+    close(iou, iou_ref, atol=2e-4)
+    close(iou, f.box_iou_rotated(cu(b1), cu(b2), aligned=True), atol=1e-5)
+    wgt = torch.rand(N, generator=gen)
+    (iou * cu(wgt)).sum().backward()
+    close(x.grad, grad_ref * wgt[:, None], rtol=2e-2, atol=2e-3)
+    # theta = 0: equals the axis-aligned IoU
+    hb = torch.cat([b1[:, :4], torch.zeros(N, 1)], 1), torch.cat([b2[:, :4], torch.zeros(N, 1)], 1)
+    close(f.diff_iou_rotated_2d(cu(hb[0])[None], cu(hb[1])[None])[0],
+          R.bbox_overlaps(R.bbox_cxcywh_to_xyxy(hb[0][:, :4]), R.bbox_cxcywh_to_xyxy(hb[1][:, :4]), is_aligned=True), atol=1e-4)
+
+
+@pytest.mark.parametrize('channels_last', [False, True])
+def test_roi_align_rotated(channels_last):
+    f = F()
+    gen = torch.Generator().manual_seed(43)
+    B, C, H, W = 2, 32, 30, 30
+    feat = torch.randn(B, C, H, W, generator=gen)
+    K = 40
+    rois = torch.cat([torch.randint(0, B, (K, 1), generator=gen).float(), torch.rand(K, 2, generator=gen) * 220 + 10,
+                      torch.rand(K, 2, generator=gen) * 60 + 4, (torch.rand(K, 1, generator=gen) - 0.5) * np.pi], 1)
+    rois[0, 1:3] = torch.tensor([-40., -40.])                     # outside the map
+    fr = feat.clone().requires_grad_(True)
+    ref = R.roi_align_rotated(fr, rois, 7, 0.125, 2, True, True)
+    wgt = torch.randn(ref.shape, generator=gen)
+    (ref * wgt).sum().backward()
+    fg = cu(feat)
+    if channels_last:
+        fg = fg.contiguous(memory_format=torch.channels_last)
+    fg.requires_grad_(True)
+    out = f.roi_align_rotated(fg, cu(rois), 7, 0.125, 2, True, True)
+    close(out, ref, atol=1e-5)
+    (out * cu(wgt)).sum().backward()
+    close(fg.grad, fr.grad, atol=1e-4)
+    # theta = 0, adaptive grid: identical to the axis-aligned RoIAlign
+    r0 = rois.clone(); r0[:, 5] = 0
+    xyxy = torch.cat([r0[:, :1], r0[:, 1:3] - r0[:, 3:5] / 2, r0[:, 1:3] + r0[:, 3:5] / 2], 1)
+    close(f.roi_align_rotated(fg.detach(), cu(r0), 7, 0.125, 0, True, True), f.roi_align(fg.detach(), cu(xyxy), 7, 0.125),
+          atol=1e-4)
