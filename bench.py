@@ -62,10 +62,16 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU path)'
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)          # (rehearsals put several gloo ranks on one card)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)     # 'nccl' is RCCL on ROCm
+        backend = os.environ.get('PT_DIST_BACKEND', 'nccl')     # 'nccl' is RCCL on ROCm
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     import point_teacher_amd as pta

@@ -888,3 +888,52 @@ def roi_align_rotated(feat, rois, out_size=7, spatial_scale=0.125, sample_num=2,
         val = val * (~oob).to(val.dtype)
         out[k] = val.reshape(C, out_size, gh, out_size, gw).sum((2, 4)) / max(gh * gw, 1)
     return out
+
+
+def distance2obb(points, distance, angle_version='le90'):
+    """OBB_TOD/mmrotate/core/bbox/coder/distance_angle_point_coder.py:93-111"""
+    d, angle = distance.split([4, 1], dim=1)
+    c, s = torch.cos(angle), torch.sin(angle)
+    rot = torch.cat([c, -s, s, c], dim=1).reshape(-1, 2, 2)
+    wh = d[:, :2] + d[:, 2:]
+    off = torch.bmm(rot, ((d[:, 2:] - d[:, :2]) / 2).unsqueeze(2)).squeeze(2)
+    if angle_version == 'le90':
+        angle = (angle + np.pi / 2) % np.pi - np.pi / 2
+    elif angle_version == 'le135':
+        angle = (angle + np.pi / 4) % np.pi - np.pi / 4
+    return torch.cat([points + off, wh, angle], dim=-1)
+
+
+def rotated_targets_single(points, gt_inds, boxes5):
+    """OBB_TOD/mmrotate/models/dense_heads/rotated_fcos_head_p2rb_ts.py:671-716 through the dense
+    [P,G] construction the reference uses."""
+    P, G = points.shape[0], boxes5.shape[0]
+    pts = points[:, None, :].expand(P, G, 2)
+    gb = boxes5[None].expand(P, G, 5)
+    ctr, wh, ang = torch.split(gb, [2, 2, 1], dim=2)
+    c, s = torch.cos(ang), torch.sin(ang)
+    rot = torch.cat([c, s, -s, c], dim=-1).reshape(P, G, 2, 2)
+    off = torch.matmul(rot, (pts - ctr)[..., None]).squeeze(-1)
+    w, h = wh[..., 0], wh[..., 1]
+    t = torch.stack((w / 2 + off[..., 0], h / 2 + off[..., 1], w / 2 - off[..., 0], h / 2 - off[..., 1]), -1)
+    idx = torch.where(gt_inds > 0, gt_inds - 1, torch.zeros_like(gt_inds))
+    ar = torch.arange(P)
+    return t[ar, idx], ang[ar, idx]
+
+
+def dn_iou_loss_values(pred, target, hyper=0.2, eps=1e-6, mode='log'):
+    """OBB_TOD/mmrotate/models/losses/rotated_iou_loss.py:105-147 (values only; fp64 polygon clip)."""
+    def loss_of(t):
+        i = box_iou_rotated(pred, t, aligned=True).clamp(min=eps)
+        return -i.log() if mode == 'log' else (1 - i if mode == 'linear' else 1 - i ** 2)
+    base = loss_of(target)
+    anx = hyper / 2
+    w, h = target[:, 2], target[:, 3]
+    bank = []
+    for i in (-1, 0, 1):
+        for j in (-1, 0, 1):
+            t = target.clone()
+            t[:, 2] = t[:, 2] - anx * w * i
+            t[:, 3] = t[:, 3] - anx * h * j
+            bank.append(loss_of(t))
+    return (base + torch.stack(bank, 1).min(1)[0]) / 2

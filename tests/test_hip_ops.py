@@ -455,3 +455,55 @@ def test_roi_align_rotated(channels_last):
     xyxy = torch.cat([r0[:, :1], r0[:, 1:3] - r0[:, 3:5] / 2, r0[:, 1:3] + r0[:, 3:5] / 2], 1)
     close(f.roi_align_rotated(fg.detach(), cu(r0), 7, 0.125, 0, True, True), f.roi_align(fg.detach(), cu(xyxy), 7, 0.125),
           atol=1e-4)
+
+
+def test_obb_building_blocks():
+    """DistanceAnglePointCoder, rotated FCOS targets, RotatedIoULoss / DN_IoULoss, rbbox2roi,
+    RotatedSingleRoIExtractor and multiclass_nms_rotated of the OBB variant against the oracle."""
+    import point_teacher_amd as pta
+    from point_teacher_amd import obb
+    gen = torch.Generator().manual_seed(51)
+    P = 300
+    pts = torch.rand(P, 2, generator=gen) * 400
+    dist = torch.cat([torch.rand(P, 4, generator=gen) * 30, (torch.rand(P, 1, generator=gen) - 0.5) * 4], 1)
+    coder = pta.registry.build_bbox_coder(dict(type='DistanceAnglePointCoder', angle_version='le90'))
+    dec = coder.decode(cu(pts), cu(dist))
+    close(dec, R.distance2obb(pts, dist, 'le90'), atol=1e-4)
+    # encode(decode(x)) round trip on the distances (angle already in range)
+    d2 = dist.clone(); d2[:, 4] = (torch.rand(P, generator=gen) - 0.5) * 3.0
+    rt = coder.encode(cu(pts), coder.decode(cu(pts), cu(d2)))
+    close(rt[:, :4], d2[:, :4], atol=1e-3)
+    G = 17
+    boxes5 = torch.cat([torch.rand(G, 2, generator=gen) * 400, torch.rand(G, 2, generator=gen) * 50 + 4,
+                        (torch.rand(G, 1, generator=gen) - 0.5) * np.pi], 1)
+    gi = torch.randint(0, G + 1, (P,), generator=gen)
+    tg, ang = obb.rotated_fcos_targets(cu(pts), cu(gi), cu(boxes5))
+    tr, ar = R.rotated_targets_single(pts, gi, boxes5)
+    close(tg, tr, atol=1e-3); close(ang, ar, atol=1e-6)
+    N = 120
+    tgt = torch.cat([torch.rand(N, 2, generator=gen) * 200 + 50, torch.rand(N, 2, generator=gen) * 40 + 8,
+                     (torch.rand(N, 1, generator=gen) - 0.5) * np.pi], 1)
+    pred = tgt + torch.cat([torch.randn(N, 2, generator=gen) * 3, torch.randn(N, 2, generator=gen) * 2,
+                            torch.randn(N, 1, generator=gen) * 0.15], 1)
+    w = torch.rand(N, generator=gen)
+    l1 = pta.registry.build_loss(dict(type='RotatedIoULoss', loss_weight=1.0))
+    l2 = pta.registry.build_loss(dict(type='DN_IoULoss', loss_weight=1.0, hyper=0.1))
+    x = cu(pred).requires_grad_(True)
+    v1 = l1(x, cu(tgt), weight=cu(w), avg_factor=10.0)
+    exp1 = (-R.box_iou_rotated(pred, tgt, aligned=True).clamp(min=1e-6).log() * w).sum() / 10.0
+    close(v1, exp1, rtol=2e-3)
+    v2 = l2(x, cu(tgt), weight=cu(w), avg_factor=10.0)
+    close(v2, (R.dn_iou_loss_values(pred, tgt, 0.1) * w).sum() / 10.0, rtol=2e-3)
+    v2.backward()
+    assert torch.isfinite(x.grad).all() and float(x.grad.abs().sum()) > 0
+    rois = obb.rbbox2roi([cu(tgt[:5]), cu(tgt[:0]), cu(tgt[5:9])])
+    assert rois.shape == (9, 6) and rois[:, 0].tolist() == [0.] * 5 + [2.] * 4
+    ext = pta.registry.build_roi_extractor(dict(type='RotatedSingleRoIExtractor', out_channels=16, featmap_strides=[8],
+                                                roi_layer=dict(type='RoIAlignRotated', out_size=7, sample_num=2, clockwise=True)))
+    feat = torch.randn(3, 16, 40, 40, generator=gen)
+    out = ext([cu(feat)], rois)
+    close(out, R.roi_align_rotated(feat, rois.cpu(), 7, 0.125, 2, True, True), atol=1e-5)
+    scores = torch.rand(N, 9, generator=gen); scores[:, -1] = 0
+    dets, labels = obb.multiclass_nms_rotated(cu(tgt), cu(scores), 0.3, dict(iou_thr=0.1), 50)
+    assert dets.shape[1] == 6 and dets.shape[0] == labels.shape[0] <= 50
+    assert bool((dets[:-1, 5] >= dets[1:, 5]).all())
