@@ -338,8 +338,10 @@ class TS_P2BFCOSHead(nn.Module):
 
     def forward_mil_head(self, num_gt, num_gt_pre_image, x, proposals_list, proposals_valid_list,
                          proposals_reference_list, proposals_real_list, img_metas, fine_proposal_cfg, stage,
-                         neg_proposal_list=None, neg_weight_list=None, bag_weight=None):
-        """:1259-1277"""
+                         neg_proposal_list=None, neg_weight_list=None, bag_weight=None, need_classifier=True):
+        """:1259-1277.  need_classifier=False skips mil_bag_classifier when the caller only consumes
+        `loss_mil_bbox` (the synthetic branch of step 1, :1301-1305: the reference computes the bag
+        scores there and throws them away)."""
         bbox_results = {}
         # the RoIAlign kernels want the [B,H,W,C] layout (1 KiB coalesced rows, full-rate atomics);
         # one 20 MB layout change here is shared by the three RoIAlign calls of this stage
@@ -347,7 +349,8 @@ class TS_P2BFCOSHead(nn.Module):
         self.mil_bag_extensive(num_gt, num_gt_pre_image, x, img_metas, proposals_list, proposals_valid_list,
                                proposals_reference_list, proposals_real_list, bbox_results, fine_proposal_cfg, stage,
                                bag_weight=bag_weight)
-        self.mil_bag_classifier(num_gt, x, bbox_results, stage)
+        if need_classifier:
+            self.mil_bag_classifier(num_gt, x, bbox_results, stage)
         if neg_proposal_list is not None:
             rois = bbox2roi(neg_proposal_list)
             feats = self._fc_stack(self.shared_fcs_bag[stage],
@@ -406,7 +409,7 @@ class TS_P2BFCOSHead(nn.Module):
         losses = {}
         rs = self.forward_mil_head(num_syn, nsi, x_synethic, syn_proposals_list, syn_proposals_valid_list,
                                    syn_proposals_reference_list, syn_proposals_real_list, img_metas, fine_proposal_cfg,
-                                   stage, bag_weight=syn_bag_weight)
+                                   stage, bag_weight=syn_bag_weight, need_classifier=False)
         losses[f'stage{stage}_loss_mil_bbox'] = rs['loss_mil_bbox']
         del rs
         r = self.forward_mil_head(num_gt, npi, x_ori, proposals_list, proposals_valid_list, proposals_reference_list,

@@ -139,3 +139,48 @@ def test_step1_loss_dict():
     ref['loss'] = M.total_loss(ref)
     assert set(ref.keys()) == set(lv.keys()), set(ref.keys()) ^ set(lv.keys())
     _check(lv, ref)
+
+
+def test_eval_path_detections():
+    """simple_test (fcos_p2b_teacher_student.py:276-298 -> get_bboxes :796-1005 -> multiclass_nms): the
+    teacher's detections on the GPU equal a restatement from the oracle pieces (sigmoid scores x
+    centerness, top-k, distance2bbox with clipping, class-aware greedy NMS)."""
+    dev = torch.device('cuda:0')
+    pta, cfg, model = _build(dev, phase2=True)
+    with torch.no_grad():          # make some logits confident so that detections exist
+        model.teacher.bbox_head.conv_cls.bias.fill_(-1.0)
+    img, boxes, labels, metas = _data(dev, seed=9)
+    model.eval()
+    with torch.no_grad():
+        res = model.simple_test(img.to(dev), metas, rescale=False)
+    assert len(res) == 2 and len(res[0]) == 8 and all(r.shape[1] == 5 for r in res[0])
+    sd_t = _strip(model.state_dict(), 'teacher.')
+    with torch.no_grad():
+        cls, reg, ctr = M.head_forward(sd_t, M.extract_feat(sd_t, img))
+    pts = M.grid_points(img.shape[2] // 8, img.shape[3] // 8)
+    tc = cfg.model['test_cfg']
+    for b in range(2):
+        sc = cls[b].permute(1, 2, 0).reshape(-1, 8).sigmoid()
+        ct = ctr[b].permute(1, 2, 0).reshape(-1).sigmoid()
+        bb = R.distance2bbox(pts, reg[b].permute(1, 2, 0).reshape(-1, 4), max_shape=metas[b]['img_shape'])
+        per_cls = []
+        for c in range(8):
+            m = sc[:, c] > tc['score_thr']
+            s = (sc[:, c] * ct)[m]
+            keep = R.nms(bb[m], s, tc['nms']['iou_threshold'])
+            per_cls.append((s[keep], bb[m][keep], torch.full((len(keep),), c)))
+        all_s = torch.cat([p[0] for p in per_cls]); all_b = torch.cat([p[1] for p in per_cls])
+        all_c = torch.cat([p[2] for p in per_cls])
+        order = torch.argsort(all_s, descending=True, stable=True)[:tc['max_per_img']]   # bbox_nms.py:83-85
+        all_s, all_b, all_c = all_s[order], all_b[order], all_c[order]
+        assert all_s.numel() > 0
+        for c in range(8):
+            got = torch.from_numpy(res[b][c])
+            rs, rb = all_s[all_c == c], all_b[all_c == c]
+            assert abs(got.shape[0] - rs.numel()) <= 2, (b, c, got.shape, rs.numel())
+            if got.shape[0] == rs.numel() and rs.numel():
+                torch.testing.assert_close(got[:, 4], rs, rtol=2e-3, atol=2e-4)
+                # near-equal scores may swap neighbours: compare the detections as a set (keyed by box centre)
+                kg = torch.argsort((got[:, 0] + got[:, 2]) * 4096 + (got[:, 1] + got[:, 3]))
+                kr = torch.argsort((rb[:, 0] + rb[:, 2]) * 4096 + (rb[:, 1] + rb[:, 3]))
+                torch.testing.assert_close(got[kg, :4], rb[kr], rtol=1e-3, atol=5e-2)
