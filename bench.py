@@ -155,8 +155,14 @@ def main():
     dom = args.roofline_kernel if args.roofline_kernel != 'auto' else max(timed, key=lambda k: timed[k]['total_ms'])
     d = timed[dom]
     achieved = d['bytes'] / (d['avg_ms'] * 1e-3) / 1e9
+    traffic = None          # HBM bytes per launch from the committed PMC passes (same workload), else null
+    try:
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01', 'pmc_traffic.json')))
+        traffic = pmc.get(args.workload, {}).get(dom, {}).get('traffic')
+    except Exception:
+        pass
     roofline = dict(bound='hbm', kernel=dom, achieved=round(achieved, 1), peak=8000.0, unit='GB/s',
-                    frac=round(achieved / 8000.0, 4), traffic=None, avg_launch_us=round(d['avg_ms'] * 1e3, 2),
+                    frac=round(achieved / 8000.0, 4), traffic=traffic, avg_launch_us=round(d['avg_ms'] * 1e3, 2),
                     launches=d['calls'], bytes_per_launch=int(d['bytes']))
 
     if rank == 0:
