@@ -213,14 +213,14 @@ int pt_affine_relu_bwd(const float* grad_y, const float* y, const float* scale, 
 /* ------------------------------------------------------------------------ NMS --
  * mmcv.ops.nms (offset 0), call site core/post_processing/bbox_nms.py:76 through
  * batched_nms: boxes[N,4] must be sorted by descending score; class-aware when
- * class_id != NULL.  keep[N] uint8.  N <= 8192. mask_ws: N*ceil(N/64) uint64 workspace. */
+ * class_id != NULL.  keep[N] uint8.  N <= 32768. mask_ws: N*ceil(N/64) uint64 workspace. */
 int pt_nms_sorted(const float* boxes, const int32_t* class_id, int N, float iou_thr,
                   uint64_t* mask_ws, uint8_t* keep, void* stream);
 /* mmcv.ops.box_iou_rotated (OBB rotate_iou2d_calculator; syn_images_generator_v2.py:667 via
  * nms_rotated): boxes (cx,cy,w,h,angle[rad]). aligned: out[M]; else out[M,N]. */
 int pt_box_iou_rotated(const float* a, const float* b, int M, int N, int aligned, float* out,
                        void* stream);
-/* mmcv.ops.nms_rotated: dets[N,5] sorted by descending score; keep[N] uint8. N <= 8192. */
+/* mmcv.ops.nms_rotated: dets[N,5] sorted by descending score; keep[N] uint8. N <= 32768. */
 int pt_nms_rotated_sorted(const float* dets, int N, float iou_thr, uint64_t* mask_ws,
                           uint8_t* keep, void* stream);
 /* the 255-mask of generate_black_paper (syn_images_generator_v2.py:678-688): every pixel
@@ -248,6 +248,39 @@ int pt_roi_align_rotated_fwd(const float* feat, const float* rois, int B, int C,
 int pt_roi_align_rotated_bwd(const float* grad_out, const float* rois, int B, int C, int H, int W,
                              int K, int out_size, float spatial_scale, int sample_num, int aligned,
                              int clockwise, int channels_last, float* grad_feat, void* stream);
+
+/* ---- teacher->student glue of the OBB head (TS_P2RBRotatedFCOSHead) ----------------
+ * FUSETopkAssigner as OBB_TOD/mmrotate/models/dense_heads/rotated_fcos_head_p2rb_ts.py:883-885
+ * calls it: `dec`[B*P,5] are the DistanceAnglePointCoder-decoded (cx,cy,w,h,a) boxes; InsiderCost
+ * (HBB_TOD/mmdet/core/bbox/match_costs/match_cost.py:235-241) reads columns 0-3 as an
+ * axis-aligned cxcywh box.  Everything else as pt_fuse_assign. */
+int pt_fuse_assign_obb(const float* points, int P, const float* dec, const float* cls, int C,
+                       const float* gt_xy, const int32_t* gt_labels, const int32_t* off, int B,
+                       int sumG, int num_pre, int topk, float cls_w, float reg_w, float loc_w,
+                       int32_t* gt_inds, int32_t* cand, void* stream);
+/* _gnerate_pseudo_single, rotated_fcos_head_p2rb_ts.py:899-917: score-weighted mean of the
+ * decoded 5-vectors (angle included) -> pseudo_bboxes[sumG,5]; (gx,gy,8,8,0) when nothing was
+ * assigned.  pseudo_points[sumG,2], pseudo_scores[sumG], nassigned[sumG]. */
+int pt_pseudo_boxes_obb(const float* dec, int P, const float* cls, int C, const float* gt_xy,
+                        const int32_t* gt_labels, const int32_t* off, int B, int sumG, int num_pre,
+                        const int32_t* gt_inds, const int32_t* cand, float* pseudo_bboxes,
+                        float* pseudo_points, float* pseudo_scores, int32_t* nassigned,
+                        void* stream);
+/* _get_target_single / _get_target_pseudo_single, rotated_fcos_head_p2rb_ts.py:671-716, :781-843
+ * (+ centerness_target :1118-1138): boxes[sumG,5]; out labels[B*P], bbox_targets[B*P,4] =
+ * (l,t,r,b) in the frame of the assigned box (box 0 of the image when unassigned),
+ * angle_targets[B*P], ctr_target[B*P] (0 when unassigned). */
+int pt_fcos_targets_obb(const float* points, int P, const int32_t* gt_inds, const float* boxes,
+                        const int32_t* box_labels, const int32_t* off, int B, int num_classes,
+                        int32_t* labels, float* bbox_targets, float* angle_targets,
+                        float* ctr_target, void* stream);
+/* mil_bag_selection(_single), rotated_fcos_head_p2rb_ts.py:1198-1250: as pt_mil_bag_select on
+ * (cx,cy,w,h,a) bags[NG*U1*U2,5] / pseudo[NG,5]; columns 0 and 1 are clamped to [0,w] and then
+ * to [0,h] (:1211-1212), w/h/a are left alone. */
+int pt_mil_bag_select_obb(const float* cls, const float* ins, const uint8_t* valid,
+                          const int32_t* labels, const float* bags, const float* pseudo, int NG,
+                          int U1, int U2, int C, int topk, float beta, float img_h, float img_w,
+                          float* merged, void* stream);
 
 #ifdef __cplusplus
 }

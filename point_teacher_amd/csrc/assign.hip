@@ -121,6 +121,11 @@ __device__ __forceinline__ float focal_cost(float x, float alpha, float gamma_is
   return pos - neg;
 }
 
+// DEC = false: `reg` holds (l,t,r,b) distances [B*P,4] that are decoded with `points` (HBB head).
+// DEC = true : `reg` holds DECODED oriented boxes (cx,cy,w,h,a) [B*P,5]; InsiderCost reads the first
+//              four columns as an axis-aligned cxcywh box and ignores the angle (match_cost.py:235-241),
+//              which is what the OBB head feeds it (rotated_fcos_head_p2rb_ts.py:883-885).
+template <bool DEC>
 __global__ void __launch_bounds__(256)
     fuse_assign_kernel(const float* __restrict__ points, int P, const float* __restrict__ reg,
                        const float* __restrict__ cls, int C, const float* __restrict__ gt_xy,
@@ -145,10 +150,16 @@ __global__ void __launch_bounds__(256)
     // per candidate: decoded box exactly as distance2bbox -> xyxy_to_cxcywh -> InsiderCost do
     if (threadIdx.x < k && rows_sm[threadIdx.x] >= 0) {
       const int row = rows_sm[threadIdx.x];
-      const float px = points[2 * row], py = points[2 * row + 1];
-      const float* d = reg + ((size_t)b * P + row) * 4;
-      const float x1 = px - d[0], y1 = py - d[1], x2 = px + d[2], y2 = py + d[3];
-      const float cx = (x1 + x2) / 2, cy = (y1 + y2) / 2, w = x2 - x1, h = y2 - y1;
+      float cx, cy, w, h;
+      if (DEC) {
+        const float* d = reg + ((size_t)b * P + row) * 5;
+        cx = d[0]; cy = d[1]; w = d[2]; h = d[3];
+      } else {
+        const float px = points[2 * row], py = points[2 * row + 1];
+        const float* d = reg + ((size_t)b * P + row) * 4;
+        const float x1 = px - d[0], y1 = py - d[1], x2 = px + d[2], y2 = py + d[3];
+        cx = (x1 + x2) / 2; cy = (y1 + y2) / 2; w = x2 - x1; h = y2 - y1;
+      }
       box_sm[threadIdx.x][0] = cx - w / 2;
       box_sm[threadIdx.x][1] = cy - h / 2;
       box_sm[threadIdx.x][2] = cx + w / 2;
@@ -282,6 +293,86 @@ __global__ void fcos_targets_kernel(const float* __restrict__ points, int P, con
   if (ctr) ctr[i] = c;
 }
 
+// _gnerate_pseudo_single of the OBB head (rotated_fcos_head_p2rb_ts.py:899-917): score-weighted mean of
+// the DECODED (cx,cy,w,h,a) boxes of the points assigned to each gt - the angle is averaged like any
+// other column - or (gx, gy, 8, 8, 0) when no point was assigned.
+__global__ void pseudo_boxes_obb_kernel(const float* __restrict__ dec, int P, const float* __restrict__ cls, int C,
+                                        const float* __restrict__ gt_xy, const int32_t* __restrict__ gt_labels,
+                                        const int32_t* __restrict__ off, int B, int sumG, int k,
+                                        const int32_t* __restrict__ gt_inds, const int32_t* __restrict__ cand,
+                                        float* __restrict__ pb, float* __restrict__ pp, float* __restrict__ ps,
+                                        int32_t* __restrict__ nass) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= sumG) return;
+  const int b = image_of(off, B, g);
+  const int local = g - off[b];
+  const int lab = gt_labels[g];
+  float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, ss = 0.f;
+  int n = 0;
+  for (int r = 0; r < k; ++r) {
+    const int row = cand[(size_t)g * k + r];
+    if (row < 0) continue;
+    const size_t q = (size_t)b * P + row;
+    if (gt_inds[q] != local + 1) continue;
+    const float sc = sigmoidf_(cls[q * C + lab]);
+    const float* d = dec + q * 5;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) s[c] += d[c] * sc;
+    ss += sc;
+    ++n;
+  }
+  float o[5];
+  float score = 0.f;
+  if (n > 0) {
+#pragma unroll
+    for (int c = 0; c < 5; ++c) o[c] = s[c] / ss;
+    score = ss / (float)n;
+  } else {
+    o[0] = gt_xy[2 * g]; o[1] = gt_xy[2 * g + 1]; o[2] = 8.f; o[3] = 8.f; o[4] = 0.f;
+  }
+#pragma unroll
+  for (int c = 0; c < 5; ++c) pb[5 * (size_t)g + c] = o[c];
+  pp[2 * g] = o[0]; pp[2 * g + 1] = o[1];
+  ps[g] = score;
+  nass[g] = n;
+}
+
+// _get_target_single / _get_target_pseudo_single of the OBB head (:671-716, :781-843): the (l,t,r,b)
+// distances of every point in the frame of its ASSIGNED oriented box (box 0 of the image when unassigned,
+// as `inds * 0` does), that box's angle, the label and the centerness target (:1118-1138).
+__global__ void fcos_targets_obb_kernel(const float* __restrict__ points, int P, const int32_t* __restrict__ gt_inds,
+                                        const float* __restrict__ boxes, const int32_t* __restrict__ box_labels,
+                                        const int32_t* __restrict__ off, int B, int num_classes,
+                                        int32_t* __restrict__ labels, float* __restrict__ tg,
+                                        float* __restrict__ ang, float* __restrict__ ctr) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * P) return;
+  const int b = (int)(i / P), p = (int)(i % P);
+  const int g0 = off[b], G = off[b + 1] - g0;
+  const int gi = gt_inds[i];
+  float l = 0.f, t = 0.f, r = 0.f, bt = 0.f, a = 0.f, c = 0.f;
+  int lab = num_classes;
+  if (G > 0) {
+    if (gi > 0) lab = box_labels ? box_labels[g0 + gi - 1] : 0;
+    const int idx = gi > 0 ? gi - 1 : 0;
+    const float* bx = boxes + (size_t)(g0 + idx) * 5;
+    a = bx[4];
+    const float ca = cosf(a), sa = sinf(a);
+    const float dx = points[2 * p] - bx[0], dy = points[2 * p + 1] - bx[1];
+    const float ox = ca * dx + sa * dy, oy = -sa * dx + ca * dy;
+    l = bx[2] / 2 + ox; r = bx[2] / 2 - ox; t = bx[3] / 2 + oy; bt = bx[3] / 2 - oy;
+    if (gi > 0) {
+      const float u = fmaxf(fminf(l, r), 0.01f) / fmaxf(l, r);
+      const float v = fmaxf(fminf(t, bt), 0.01f) / fmaxf(t, bt);
+      c = sqrtf(u * v);
+    }
+  }
+  labels[i] = lab;
+  tg[4 * i] = l; tg[4 * i + 1] = t; tg[4 * i + 2] = r; tg[4 * i + 3] = bt;
+  ang[i] = a;
+  ctr[i] = c;
+}
+
 }  // namespace pt
 
 using namespace pt;
@@ -320,9 +411,59 @@ extern "C" int pt_fuse_assign(const float* points, int P, const float* reg, cons
   if (e != hipSuccess) { set_error("pt_fuse_assign: memset: %s", hipGetErrorString(e)); return (int)e; }
   if (sumG == 0) return PT_OK;
   PT_REQUIRE(gt_xy && gt_labels && cand, PT_EINVAL, "pt_fuse_assign: NULL gt array");
-  hipLaunchKernelGGL(fuse_assign_kernel, dim3(sumG), dim3(256), 0, s, points, P, reg, cls, C, gt_xy, gt_labels, off,
-                     B, num_pre, topk, cls_w, reg_w, loc_w, gt_inds, cand);
+  hipLaunchKernelGGL(fuse_assign_kernel<false>, dim3(sumG), dim3(256), 0, s, points, P, reg, cls, C, gt_xy, gt_labels,
+                     off, B, num_pre, topk, cls_w, reg_w, loc_w, gt_inds, cand);
   PT_LAUNCH_CHECK("pt_fuse_assign");
+  return PT_OK;
+}
+
+extern "C" int pt_fuse_assign_obb(const float* points, int P, const float* dec, const float* cls, int C,
+                                  const float* gt_xy, const int32_t* gt_labels, const int32_t* off, int B, int sumG,
+                                  int num_pre, int topk, float cls_w, float reg_w, float loc_w, int32_t* gt_inds,
+                                  int32_t* cand, void* stream) {
+  PT_REQUIRE(points && dec && cls && off && gt_inds && P > 0 && B > 0 && sumG >= 0, PT_EINVAL,
+             "pt_fuse_assign_obb: bad argument");
+  PT_REQUIRE(num_pre >= 1 && num_pre <= KMAX, PT_ELIMIT, "pt_fuse_assign_obb: num_pre=%d outside [1,%d]", num_pre, KMAX);
+  PT_REQUIRE(C >= 1 && C <= 64, PT_ELIMIT, "pt_fuse_assign_obb: C=%d outside [1,64]", C);
+  PT_REQUIRE(topk >= 1 && num_pre <= P, PT_EINVAL, "pt_fuse_assign_obb: bad topk/num_pre");
+  hipStream_t s = as_stream(stream);
+  hipError_t e = hipMemsetAsync(gt_inds, 0, sizeof(int32_t) * (size_t)B * P, s);
+  if (e != hipSuccess) { set_error("pt_fuse_assign_obb: memset: %s", hipGetErrorString(e)); return (int)e; }
+  if (sumG == 0) return PT_OK;
+  PT_REQUIRE(gt_xy && gt_labels && cand, PT_EINVAL, "pt_fuse_assign_obb: NULL gt array");
+  hipLaunchKernelGGL(fuse_assign_kernel<true>, dim3(sumG), dim3(256), 0, s, points, P, dec, cls, C, gt_xy, gt_labels,
+                     off, B, num_pre, topk, cls_w, reg_w, loc_w, gt_inds, cand);
+  PT_LAUNCH_CHECK("pt_fuse_assign_obb");
+  return PT_OK;
+}
+
+extern "C" int pt_pseudo_boxes_obb(const float* dec, int P, const float* cls, int C, const float* gt_xy,
+                                   const int32_t* gt_labels, const int32_t* off, int B, int sumG, int num_pre,
+                                   const int32_t* gt_inds, const int32_t* cand, float* pseudo_bboxes,
+                                   float* pseudo_points, float* pseudo_scores, int32_t* nassigned, void* stream) {
+  if (sumG == 0) return PT_OK;
+  PT_REQUIRE(dec && cls && gt_xy && gt_labels && off && gt_inds && cand && pseudo_bboxes && pseudo_points &&
+                 pseudo_scores && nassigned,
+             PT_EINVAL, "pt_pseudo_boxes_obb: NULL argument");
+  PT_REQUIRE(P > 0 && B > 0 && C > 0 && num_pre >= 1 && num_pre <= KMAX, PT_EINVAL, "pt_pseudo_boxes_obb: bad size");
+  hipLaunchKernelGGL(pseudo_boxes_obb_kernel, dim3(cdiv(sumG, 64)), dim3(64), 0, as_stream(stream), dec, P, cls, C,
+                     gt_xy, gt_labels, off, B, sumG, num_pre, gt_inds, cand, pseudo_bboxes, pseudo_points,
+                     pseudo_scores, nassigned);
+  PT_LAUNCH_CHECK("pt_pseudo_boxes_obb");
+  return PT_OK;
+}
+
+extern "C" int pt_fcos_targets_obb(const float* points, int P, const int32_t* gt_inds, const float* boxes,
+                                   const int32_t* box_labels, const int32_t* off, int B, int num_classes,
+                                   int32_t* labels, float* bbox_targets, float* angle_targets, float* ctr_target,
+                                   void* stream) {
+  PT_REQUIRE(points && gt_inds && off && boxes && labels && bbox_targets && angle_targets && ctr_target && P > 0 &&
+                 B > 0,
+             PT_EINVAL, "pt_fcos_targets_obb: bad argument");
+  const size_t n = (size_t)B * P;
+  hipLaunchKernelGGL(fcos_targets_obb_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), points, P, gt_inds,
+                     boxes, box_labels, off, B, num_classes, labels, bbox_targets, angle_targets, ctr_target);
+  PT_LAUNCH_CHECK("pt_fcos_targets_obb");
   return PT_OK;
 }
 

@@ -198,11 +198,15 @@ __global__ void mil_neg_loss_kernel(const float* __restrict__ x, const uint8_t* 
 // ----------------------------------------------------------- bag selection ---
 constexpr int SEL_MAXU = 4096;
 
+// D = 4: xyxy bags, x clamped to [0,w] and y to [0,h] (fcos_head_p2b_ts.py:1092-1110).
+// D = 5: (cx,cy,w,h,a) bags; the OBB head clamps columns 0 AND 1 first to [0,w] and then to [0,h]
+//        (rotated_fcos_head_p2rb_ts.py:1211-1212) and leaves w, h, a alone.
+template <int D>
 __global__ void __launch_bounds__(64)
     mil_bag_select_kernel(const float* __restrict__ cls, const float* __restrict__ ins,
                           const uint8_t* __restrict__ valid, const int32_t* __restrict__ labels,
-                          const float4* __restrict__ bags, const float4* __restrict__ pseudo, int U1, int U2, int C,
-                          int topk, float beta, float img_h, float img_w, float4* __restrict__ merged) {
+                          const float* __restrict__ bags, const float* __restrict__ pseudo, int U1, int U2, int C,
+                          int topk, float beta, float img_h, float img_w, float* __restrict__ merged) {
   __shared__ float score[SEL_MAXU];
   const int g = blockIdx.x, lane = threadIdx.x;
   const int U = U1 * U2;
@@ -220,7 +224,7 @@ __global__ void __launch_bounds__(64)
     }
   }
   __syncthreads();
-  float sw = 0.f, bx = 0.f, by = 0.f, bz = 0.f, bw = 0.f;
+  float sw = 0.f;
   float sc_k[8];
   int id_k[8];
   unsigned long long last = 0ull;
@@ -241,16 +245,24 @@ __global__ void __launch_bounds__(64)
     sw += sc_k[r];
   }
   if (lane == 0) {
+    float acc[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) acc[c] = 0.f;
     for (int r = 0; r < topk; ++r) {
       const float wgt = sc_k[r] / (sw + 1e-8f);
-      const float4 q = bags[(size_t)g * U + id_k[r]];
-      bx += q.x * wgt; by += q.y * wgt; bz += q.z * wgt; bw += q.w * wgt;
+      const float* q = bags + ((size_t)g * U + id_k[r]) * D;
+#pragma unroll
+      for (int c = 0; c < D; ++c) acc[c] += q[c] * wgt;
     }
-    bx = fminf(fmaxf(bx, 0.f), img_w); bz = fminf(fmaxf(bz, 0.f), img_w);
-    by = fminf(fmaxf(by, 0.f), img_h); bw = fminf(fmaxf(bw, 0.f), img_h);
-    const float4 p = pseudo[g];
-    merged[g] = make_float4((1.f - beta) * bx + beta * p.x, (1.f - beta) * by + beta * p.y,
-                            (1.f - beta) * bz + beta * p.z, (1.f - beta) * bw + beta * p.w);
+    if (D == 4) {
+      acc[0] = fminf(fmaxf(acc[0], 0.f), img_w); acc[2] = fminf(fmaxf(acc[2], 0.f), img_w);
+      acc[1] = fminf(fmaxf(acc[1], 0.f), img_h); acc[3] = fminf(fmaxf(acc[3], 0.f), img_h);
+    } else {
+      acc[0] = fminf(fmaxf(fminf(fmaxf(acc[0], 0.f), img_w), 0.f), img_h);
+      acc[1] = fminf(fmaxf(fminf(fmaxf(acc[1], 0.f), img_w), 0.f), img_h);
+    }
+#pragma unroll
+    for (int c = 0; c < D; ++c) merged[(size_t)g * D + c] = (1.f - beta) * acc[c] + beta * pseudo[(size_t)g * D + c];
   }
 }
 
@@ -340,9 +352,22 @@ extern "C" int pt_mil_bag_select(const float* cls, const float* ins, const uint8
              PT_EINVAL, "pt_mil_bag_select: bad argument");
   PT_REQUIRE(topk >= 1 && topk <= 8 && topk <= U1 * U2, PT_ELIMIT, "pt_mil_bag_select: topk=%d outside [1,8]", topk);
   PT_REQUIRE(U1 * U2 <= SEL_MAXU, PT_ELIMIT, "pt_mil_bag_select: U1*U2=%d above %d", U1 * U2, SEL_MAXU);
-  hipLaunchKernelGGL(mil_bag_select_kernel, dim3(NG), dim3(64), 0, as_stream(stream), cls, ins, valid, labels,
-                     reinterpret_cast<const float4*>(bags), reinterpret_cast<const float4*>(pseudo), U1, U2, C, topk,
-                     beta, img_h, img_w, reinterpret_cast<float4*>(merged));
+  hipLaunchKernelGGL(mil_bag_select_kernel<4>, dim3(NG), dim3(64), 0, as_stream(stream), cls, ins, valid, labels, bags,
+                     pseudo, U1, U2, C, topk, beta, img_h, img_w, merged);
   PT_LAUNCH_CHECK("pt_mil_bag_select");
+  return PT_OK;
+}
+
+extern "C" int pt_mil_bag_select_obb(const float* cls, const float* ins, const uint8_t* valid, const int32_t* labels,
+                                     const float* bags, const float* pseudo, int NG, int U1, int U2, int C, int topk,
+                                     float beta, float img_h, float img_w, float* merged, void* stream) {
+  if (NG == 0) return PT_OK;
+  PT_REQUIRE(cls && ins && valid && labels && bags && pseudo && merged && NG > 0 && U1 > 0 && U2 > 0 && C > 0,
+             PT_EINVAL, "pt_mil_bag_select_obb: bad argument");
+  PT_REQUIRE(topk >= 1 && topk <= 8 && topk <= U1 * U2, PT_ELIMIT, "pt_mil_bag_select_obb: topk=%d outside [1,8]", topk);
+  PT_REQUIRE(U1 * U2 <= SEL_MAXU, PT_ELIMIT, "pt_mil_bag_select_obb: U1*U2=%d above %d", U1 * U2, SEL_MAXU);
+  hipLaunchKernelGGL(mil_bag_select_kernel<5>, dim3(NG), dim3(64), 0, as_stream(stream), cls, ins, valid, labels, bags,
+                     pseudo, U1, U2, C, topk, beta, img_h, img_w, merged);
+  PT_LAUNCH_CHECK("pt_mil_bag_select_obb");
   return PT_OK;
 }

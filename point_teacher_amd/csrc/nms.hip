@@ -7,7 +7,7 @@
 
 namespace pt {
 
-constexpr int NMS_MAXN = 8192;
+constexpr int NMS_MAXN = 32768;   // nms_pre (2000-3000) x classes (8-9) candidates of the test_cfgs fit
 
 __device__ __forceinline__ float iou_xyxy(const float4 a, const float4 b) {
   const float w = fmaxf(fminf(a.z, b.z) - fmaxf(a.x, b.x), 0.f);
@@ -146,15 +146,20 @@ __global__ void __launch_bounds__(256)
   if (q == 0 && i < N) mask[(size_t)i * cols + cb] = part[0][r] | part[1][r] | part[2][r] | part[3][r];
 }
 
-// One wavefront: lane l owns removed-words l and l+64.
+// One wavefront: lane l owns the removed-words l, l+64, ..., l+64*(WPL-1) (64*64*WPL candidates).
+template <int WPL>
 __global__ void __launch_bounds__(64)
     nms_scan_kernel(const unsigned long long* __restrict__ mask, int N, uint8_t* __restrict__ keep) {
   const int cols = cdiv(N, 64);
   const int lane = threadIdx.x;
-  unsigned long long r0 = 0ull, r1 = 0ull;
+  unsigned long long r[WPL];
+#pragma unroll
+  for (int k = 0; k < WPL; ++k) r[k] = 0ull;
   for (int i = 0; i < N; ++i) {
     const int wd = i >> 6;
-    const unsigned long long src = (wd < 64) ? r0 : r1;
+    unsigned long long src = r[0];
+#pragma unroll
+    for (int k = 1; k < WPL; ++k) src = ((wd >> 6) == k) ? r[k] : src;      // wd is wave-uniform
     const unsigned lo = __shfl((unsigned)(src & 0xffffffffu), wd & 63, 64);
     const unsigned hi = __shfl((unsigned)(src >> 32), wd & 63, 64);
     const unsigned long long word = ((unsigned long long)hi << 32) | lo;
@@ -162,8 +167,11 @@ __global__ void __launch_bounds__(64)
     if (lane == 0) keep[i] = removed ? 0 : 1;
     if (!removed) {
       // row i only has valid words for columns >= i/64
-      if (lane < cols && lane >= wd) r0 |= mask[(size_t)i * cols + lane];
-      if (lane + 64 < cols && lane + 64 >= wd) r1 |= mask[(size_t)i * cols + lane + 64];
+#pragma unroll
+      for (int k = 0; k < WPL; ++k) {
+        const int c = lane + 64 * k;
+        if (c < cols && c >= wd) r[k] |= mask[(size_t)i * cols + c];
+      }
     }
   }
 }
@@ -223,8 +231,12 @@ static int nms_impl(const char* fn, const float* boxes, const int32_t* cls, int 
   hipLaunchKernelGGL(nms_mask_kernel<ROT>, dim3(cols, cols), dim3(256), 0, s, boxes, cls, N, thr,
                      reinterpret_cast<unsigned long long*>(ws));
   PT_LAUNCH_CHECK(fn);
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<const unsigned long long*>(ws), N,
-                     keep);
+  if (N <= 8192)
+    hipLaunchKernelGGL(nms_scan_kernel<2>, dim3(1), dim3(64), 0, s, reinterpret_cast<const unsigned long long*>(ws), N,
+                       keep);
+  else
+    hipLaunchKernelGGL(nms_scan_kernel<8>, dim3(1), dim3(64), 0, s, reinterpret_cast<const unsigned long long*>(ws), N,
+                       keep);
   PT_LAUNCH_CHECK(fn);
   return PT_OK;
 }

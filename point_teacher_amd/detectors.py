@@ -124,6 +124,34 @@ class Student_FCOS(BaseDetector):
 class TS_P2B_FCOS(BaseDetector):
     """detectors/fcos_p2b_teacher_student.py:36-519."""
 
+    # Box-format hooks: everything below that depends on xyxy boxes goes through these, so that the
+    # oriented twin (obb_detectors.RotatedFCOS_TS) only swaps them.
+    _epoch_key = 'ori_filename'
+    _mil_gen = staticmethod(MIL_gen_proposals_from_cfg)
+    _neg_gen = staticmethod(gen_negative_proposals)
+
+    @staticmethod
+    def _aligned_iou(a, b):
+        return bbox_overlaps(a, b, is_aligned=True)
+
+    @staticmethod
+    def _cxcywh(boxes):
+        return bbox_xyxy_to_cxcywh(boxes)
+
+    def _strong_aug(self, img, gt_points, gt_labels, pseudo_points, pseudo_labels, pseudo_bboxes):
+        return strong_augmentation_masked(img, gt_points, gt_labels, pseudo_points, pseudo_labels, pseudo_bboxes,
+                                          params=self._inject.get('aug'))
+
+    def _black_paper(self, img, gt_bboxes, imgsize, draws):
+        return generate_black_paper_masked(img, gt_bboxes, self.prior_size, range(int(len(self.pattern) / 2)), imgsize,
+                                           draws=draws)
+
+    def _initial_points(self, gt_bboxes, u):
+        return random_point_in_quadrilateral(gt_bboxes, self._point_, *(u if u is not None else (None, None)))
+
+    def _to_results(self, dets, labels, num_classes):
+        return bbox2result(dets, labels, num_classes)
+
     def __init__(self, _model_, _point_='random', num_stages=2, num_refine=500, num_training_burninstep1=512,
                  num_training_burninstep2=512, ema_alpha=0.999, filter_score=0.8, burn_in_step=10000, lamda=1.0,
                  alpha=[0.1, 1.0],
@@ -209,17 +237,17 @@ class TS_P2B_FCOS(BaseDetector):
 
     def update_epoch(self, num_img, img_metas):
         """:259-264"""
-        if img_metas[0]['ori_filename'] in self.epoch_dict:
+        if img_metas[0][self._epoch_key] in self.epoch_dict:
             self.epoch += 1
             self.epoch_dict = {}
         for i in range(num_img):
-            self.epoch_dict[img_metas[i]['ori_filename']] = 1
+            self.epoch_dict[img_metas[i][self._epoch_key]] = 1
 
     def update_points(self, num_img, img_metas, pseudo_bboxes):
         """:266-274"""
         out = []
         for i in range(num_img):
-            pc = bbox_xyxy_to_cxcywh(pseudo_bboxes[i])[:, :2]
+            pc = self._cxcywh(pseudo_bboxes[i])[:, :2]
             oc = self.gt_bboxes_point[img_metas[i]['ori_filename']]
             rc = (1 - self.lamda) * pc + self.lamda * oc
             out.append(rc)
@@ -235,7 +263,7 @@ class TS_P2B_FCOS(BaseDetector):
                 gt_points.append(self.refined_gt_bboxes_point[name])
             else:
                 u = self._inject.get('point_u')
-                pts = random_point_in_quadrilateral(gt_bboxes[i], self._point_, *(u[i] if u is not None else (None, None)))
+                pts = self._initial_points(gt_bboxes[i], u[i] if u is not None else None)
                 gt_points.append(pts)
                 self.gt_bboxes_point[name] = pts
             img_list.append(img[i])
@@ -249,13 +277,12 @@ class TS_P2B_FCOS(BaseDetector):
                                                           img_metas, img_list, gt_bboxes_ignore)
 
     def _refined_points_distance(self, gt_points, gt_bboxes):
-        real = bbox_xyxy_to_cxcywh(torch.cat(gt_bboxes, dim=0))
-        return (torch.sqrt((torch.cat(gt_points) - real[:, :2]) ** 2) / torch.sqrt((real[:, 2:] / 2) ** 2)).mean()
+        real = self._cxcywh(torch.cat(gt_bboxes, dim=0))
+        return (torch.sqrt((torch.cat(gt_points) - real[:, :2]) ** 2) / torch.sqrt((real[:, 2:4] / 2) ** 2)).mean()
 
     def _student_aug_loss(self, img, img_metas, gt_points, gt_labels, pseudo_points, pseudo_labels, pseudo_bboxes,
                           gt_bboxes_ignore):
-        aug = strong_augmentation_masked(img, gt_points, gt_labels, pseudo_points, pseudo_labels, pseudo_bboxes,
-                                         params=self._inject.get('aug'))
+        aug = self._strong_aug(img, gt_points, gt_labels, pseudo_points, pseudo_labels, pseudo_bboxes)
         img_aug, img_aug_list, gp, gl, pp, pl, pb, gv, pv = aug
         outs = self.student.bbox_head(self.extract_feat(img_aug, self.student))
         return self.student.bbox_head.loss_pseudo(*outs, gp, gl, pp, pl, pb, [None] * len(img_metas), img_metas,
@@ -293,22 +320,22 @@ class TS_P2B_FCOS(BaseDetector):
         refined_b = [b.clone() for b in pseudo_bboxes]
         refined_p = [p.clone() for p in pseudo_points]
         gb_cat = torch.cat(gb_t, dim=0)
-        losses['coarse_bboxes_iou'] = bbox_overlaps(torch.cat(pb_t, dim=0), gb_cat, is_aligned=True).mean()
+        losses['coarse_bboxes_iou'] = self._aligned_iou(torch.cat(pb_t, dim=0), gb_cat).mean()
         head = self.student.bbox_head
         for stage in range(self.num_stages):
             cfg = self.fine_proposal_cfg[stage]
-            pr, pv, pref, preal = MIL_gen_proposals_from_cfg(pp_t, pb_t, cfg, gb_t, img_meta=img_metas)
-            neg, negw = gen_negative_proposals(pp_t, cfg, pr, img_meta=img_metas, uniforms=self._inject.get(f'neg{stage}'))
+            pr, pv, pref, preal = self._mil_gen(pp_t, pb_t, cfg, gb_t, img_meta=img_metas)
+            neg, negw = self._neg_gen(pp_t, cfg, pr, img_meta=img_metas, uniforms=self._inject.get(f'neg{stage}'))
             mil_loss, pb_t = head.MIL_head_burn_in_step2(x_ori, img_metas, pr, pv, pref, preal, neg, negw, pb_t, pl_t,
                                                          self.fine_proposal_extensive_cfg[stage], stage)
-            losses[f'stage{stage}_refine_bboxes_iou'] = bbox_overlaps(torch.cat(pb_t, dim=0), gb_cat, is_aligned=True).mean()
+            losses[f'stage{stage}_refine_bboxes_iou'] = self._aligned_iou(torch.cat(pb_t, dim=0), gb_cat).mean()
             mil_loss[f'stage{stage}_loss_mil_bbox'] = mil_loss[f'stage{stage}_loss_mil_bbox'] * self.alpha[0]
             mil_loss[f'stage{stage}_loss_mil_bags'] = mil_loss[f'stage{stage}_loss_mil_bags'] * self.alpha[1]
             losses.update(mil_loss)
         for i in range(num_img):
             k = pb_t[i].shape[0]
             refined_b[i][:k] = pb_t[i]
-            refined_p[i][:k] = bbox_xyxy_to_cxcywh(pb_t[i])[:, :2]
+            refined_p[i][:k] = self._cxcywh(pb_t[i])[:, :2]
         return refined_b, refined_p, losses
 
     # --------------------------------------------------------------- burn-in step 1 --
@@ -318,9 +345,7 @@ class TS_P2B_FCOS(BaseDetector):
         draws = self._inject.get('syn')
         for i in range(num_img):
             C, H, W = img_list[i].shape
-            im, bx, al = generate_black_paper_masked(img_list[i], gt_bboxes[i], self.prior_size,
-                                                     range(int(len(self.pattern) / 2)), min(H, W),
-                                                     draws=draws[i] if draws is not None else None)
+            im, bx, al = self._black_paper(img_list[i], gt_bboxes[i], min(H, W), draws[i] if draws is not None else None)
             imgs.append(im); boxes.append(bx); alive.append(al)
         return torch.stack(imgs, dim=0), imgs, boxes, alive
 
@@ -354,8 +379,8 @@ class TS_P2B_FCOS(BaseDetector):
     def _compact_alive(self, boxes, alive, n):
         """First `n` alive rows of `boxes` without a host round trip: (compacted [n,4], weight [n]).
         Rows beyond the number of alive boxes are a harmless dummy box with weight 0."""
-        out = boxes.new_zeros((n + 1, 4))
-        out[:, 2:] = 8.0
+        out = boxes.new_zeros((n + 1, boxes.shape[1]))
+        out[:, 2:4] = 8.0
         w = boxes.new_zeros(n + 1)
         if boxes.shape[0]:
             rank = torch.cumsum(alive.int(), 0) - 1
@@ -374,7 +399,7 @@ class TS_P2B_FCOS(BaseDetector):
         losses = {}
         syn_t, syn_w = zip(*[self._compact_alive(b, a, n) for b, a in zip(synthetic_bboxes, synthetic_alive)])
         syn_t, syn_w = list(syn_t), list(syn_w)
-        syn_p = [bbox_xyxy_to_cxcywh(b)[:, :2] for b in syn_t]
+        syn_p = [self._cxcywh(b)[:, :2] for b in syn_t]
         pb_t = [b[:n] for b in pseudo_bboxes]
         gb_t = [b[:n] for b in gt_bboxes]
         pp_t = [p[:n] for p in pseudo_points]
@@ -382,28 +407,28 @@ class TS_P2B_FCOS(BaseDetector):
         refined_b = [b.clone() for b in pseudo_bboxes]
         refined_p = [p.clone() for p in pseudo_points]
         gb_cat = torch.cat(gb_t, dim=0)
-        losses['coarse_bboxes_iou'] = bbox_overlaps(torch.cat(pb_t, dim=0), gb_cat, is_aligned=True).mean()
+        losses['coarse_bboxes_iou'] = self._aligned_iou(torch.cat(pb_t, dim=0), gb_cat).mean()
         head = self.student.bbox_head
         for stage in range(self.num_stages):
             cfg = self.fine_proposal_cfg[stage]
             ext = self.fine_proposal_extensive_cfg[stage]
-            pr, pv, pref, preal = MIL_gen_proposals_from_cfg(pp_t, pb_t, cfg, gb_t, img_meta=img_metas)
-            spr, spv, spref, spreal = MIL_gen_proposals_from_cfg(syn_p, syn_t, cfg, syn_t, img_meta=img_metas)
-            neg, negw = gen_negative_proposals(pp_t, cfg, pr, img_meta=img_metas, uniforms=self._inject.get(f'neg{stage}'))
+            pr, pv, pref, preal = self._mil_gen(pp_t, pb_t, cfg, gb_t, img_meta=img_metas)
+            spr, spv, spref, spreal = self._mil_gen(syn_p, syn_t, cfg, syn_t, img_meta=img_metas)
+            neg, negw = self._neg_gen(pp_t, cfg, pr, img_meta=img_metas, uniforms=self._inject.get(f'neg{stage}'))
             U1 = len(cfg['base_ratios']) ** 2 * (1 + 4 * len(cfg['shake_ratio'] or []))
             U2 = len(ext['base_ratios']) ** 2 * (1 + 4 * len(ext['shake_ratio'] or []))
             bag_w = [w.repeat_interleave(U1 * U2) for w in syn_w]
             mil_loss, pb_t = head.MIL_head_burn_in_step1(x_ori, x_synthetic, img_metas, pr, pv, pref, preal, spr, spv,
                                                          spref, spreal, neg, negw, syn_t, pb_t, pl_t, ext, stage,
                                                          syn_bag_weight=bag_w)
-            losses[f'stage{stage}_refine_bboxes_iou'] = bbox_overlaps(torch.cat(pb_t, dim=0), gb_cat, is_aligned=True).mean()
+            losses[f'stage{stage}_refine_bboxes_iou'] = self._aligned_iou(torch.cat(pb_t, dim=0), gb_cat).mean()
             mil_loss[f'stage{stage}_loss_mil_bbox'] = mil_loss[f'stage{stage}_loss_mil_bbox'] * self.alpha[0]
             mil_loss[f'stage{stage}_loss_mil_bags'] = mil_loss[f'stage{stage}_loss_mil_bags'] * self.alpha[1]
             losses.update(mil_loss)
         for i in range(num_img):
             k = pb_t[i].shape[0]
             refined_b[i][:k] = pb_t[i]
-            refined_p[i][:k] = bbox_xyxy_to_cxcywh(pb_t[i])[:, :2]
+            refined_p[i][:k] = self._cxcywh(pb_t[i])[:, :2]
         return refined_b, refined_p, losses
 
     # ------------------------------------------------------------------- inference --
@@ -412,4 +437,4 @@ class TS_P2B_FCOS(BaseDetector):
         img = img.to(torch.float)
         feat = self.extract_feat(img, self.teacher)
         res = self.teacher.bbox_head.simple_test(feat, img_metas, rescale=rescale)
-        return [bbox2result(b, l, self.teacher.bbox_head.num_classes) for b, l in res]
+        return [self._to_results(b, l, self.teacher.bbox_head.num_classes) for b, l in res]

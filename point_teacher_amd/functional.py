@@ -123,6 +123,47 @@ def fcos_targets(points, gt_inds, boxes, box_labels, off, B, num_classes, want_c
     return labels, tg, ctr
 
 
+def fuse_assign_obb(points, dec, cls, gt_xy, gt_labels, off, B, num_pre=5, topk=3, cls_w=1.0, reg_w=1.0, loc_w=1.0):
+    """pt_fuse_assign_obb.  dec [B*P,5] decoded (cx,cy,w,h,a), cls [B*P,C] logits."""
+    P = points.shape[0]
+    sumG = gt_xy.shape[0]
+    C = cls.shape[-1]
+    gt_inds = torch.empty((B, P), dtype=i32, device=points.device)
+    cand = torch.empty((sumG, num_pre), dtype=i32, device=points.device)
+    hip.call('pt_fuse_assign_obb', _f(points), P, _f(dec), _f(cls), C, _f(gt_xy[:, :2]) if sumG else None,
+             gt_labels.to(i32).contiguous() if sumG else None, off, B, sumG, num_pre, topk,
+             float(cls_w), float(reg_w), float(loc_w), gt_inds, cand)
+    return gt_inds, cand
+
+
+def pseudo_boxes_obb(P, dec, cls, gt_xy, gt_labels, off, B, gt_inds, cand):
+    """pt_pseudo_boxes_obb -> dict(bboxes [sumG,5], points, scores, nassigned)."""
+    sumG, C = gt_xy.shape[0], cls.shape[-1]
+    dev = dec.device
+    out = dict(bboxes=torch.empty((sumG, 5), dtype=f32, device=dev), points=torch.empty((sumG, 2), dtype=f32, device=dev),
+               scores=torch.empty((sumG,), dtype=f32, device=dev), nassigned=torch.empty((sumG,), dtype=i32, device=dev))
+    if sumG:
+        hip.call('pt_pseudo_boxes_obb', _f(dec), P, _f(cls), C, _f(gt_xy[:, :2]), gt_labels.to(i32).contiguous(), off, B,
+                 sumG, cand.shape[1], gt_inds, cand, out['bboxes'], out['points'], out['scores'], out['nassigned'])
+    return out
+
+
+def fcos_targets_obb(points, gt_inds, boxes5, box_labels, off, B, num_classes):
+    """pt_fcos_targets_obb -> labels int32 [B*P], bbox_targets [B*P,4], angle_targets [B*P,1], ctr_target [B*P]."""
+    P = points.shape[0]
+    dev = points.device
+    labels = torch.empty((B * P,), dtype=i32, device=dev)
+    tg = torch.empty((B * P, 4), dtype=f32, device=dev)
+    ang = torch.empty((B * P, 1), dtype=f32, device=dev)
+    ctr = torch.empty((B * P,), dtype=f32, device=dev)
+    if boxes5.shape[0] == 0:               # no box anywhere: every image takes the G == 0 branch
+        boxes5 = boxes5.new_zeros((1, 5))
+    hip.call('pt_fcos_targets_obb', _f(points), P, gt_inds.contiguous(), _f(boxes5[:, :5]),
+             box_labels.to(i32).contiguous() if (box_labels is not None and box_labels.numel()) else None,
+             off, B, num_classes, labels, tg, ang, ctr)
+    return labels, tg, ang, ctr
+
+
 # ---------------------------------------------------------------------- losses --
 
 class _FocalSum(torch.autograd.Function):
@@ -365,11 +406,13 @@ def mil_neg_loss_sum(neg_cls, neg_w):
 
 
 def mil_bag_select(cls, ins, valid, labels, bags, pseudo, U1, U2, topk, beta, img_hw):
-    """cls/ins [NG,U1,U2,C] (any view of that size) -> merged boxes [NG,4]."""
-    NG = pseudo.shape[0]
+    """cls/ins [NG,U1,U2,C] (any view of that size) -> merged boxes [NG,D]; D = 4 (xyxy) or 5 (cx,cy,w,h,a)."""
+    NG, D = pseudo.shape
     C = cls.shape[-1]
-    merged = torch.empty((NG, 4), dtype=f32, device=cls.device)
-    hip.call('pt_mil_bag_select', _f(cls.detach()), _f(ins.detach()), valid.to(u8).contiguous(),
+    assert D in (4, 5) and bags.shape[-1] == D
+    merged = torch.empty((NG, D), dtype=f32, device=cls.device)
+    hip.call('pt_mil_bag_select' if D == 4 else 'pt_mil_bag_select_obb', _f(cls.detach()), _f(ins.detach()),
+             valid.to(u8).contiguous(),
              labels.to(i32).contiguous(), _f(bags), _f(pseudo), NG, U1, U2, C, int(topk), float(beta),
              float(img_hw[0]), float(img_hw[1]), merged)
     return merged

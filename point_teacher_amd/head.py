@@ -40,14 +40,15 @@ class TS_P2BFCOSHead(nn.Module):
                  conv_cfg=None, norm_cfg=dict(type='GN', num_groups=32, requires_grad=True), train_cfg=None,
                  test_cfg=None, init_cfg=None, regress_ranges=None, **kwargs):
         super().__init__()
-        assert norm_cfg is None, 'the Point-Teacher configs use norm_cfg=None in the head'
+        assert norm_cfg is None or norm_cfg['type'] == 'GN', 'head norm is None (HBB configs) or GroupNorm (OBB config)'
+        self.norm_cfg = norm_cfg
         assert not dcn_on_last_conv, 'dcn_on_last_conv=False in every Point-Teacher config (DCN is a later row)'
         self.num_classes = self.cls_out_channels = num_classes
         self.in_channels, self.feat_channels, self.stacked_convs = in_channels, feat_channels, stacked_convs
         self.strides = list(strides)
         self.dcn_on_last_conv = dcn_on_last_conv
         assert conv_bias == 'auto' or isinstance(conv_bias, bool)
-        self.conv_bias = True if conv_bias == 'auto' else conv_bias
+        self.conv_bias = (norm_cfg is None) if conv_bias == 'auto' else conv_bias
         self.center_sampling, self.center_sample_radius = center_sampling, center_sample_radius
         self.norm_on_bbox, self.centerness_on_reg = norm_on_bbox, centerness_on_reg
         self.mil_stack_conv, self.num_stages = mil_stack_conv, num_stages
@@ -80,7 +81,7 @@ class TS_P2BFCOSHead(nn.Module):
         """anchor_free_head.py:86-135 + fcos_head_p2b_ts.py:189-263 (same parameter names)."""
         def stack(n, cin):
             return nn.ModuleList([ConvModule(cin if i == 0 else self.feat_channels, self.feat_channels, 3, padding=1,
-                                             bias=self.conv_bias) for i in range(n)])
+                                             bias=self.conv_bias, norm_cfg=self.norm_cfg) for i in range(n)])
         self.cls_convs = stack(self.stacked_convs, self.in_channels)
         self.reg_convs = stack(self.stacked_convs, self.in_channels)
         self.conv_cls = nn.Conv2d(self.feat_channels, self.cls_out_channels, 3, padding=1)

@@ -16,15 +16,27 @@ from .registry import BACKBONES, NECKS, ROI_EXTRACTORS
 
 
 class ConvModule(nn.Module):
-    """The subset of mmcv.cnn.ConvModule on this path: conv (+ReLU).  Parameter path `.conv`."""
+    """The subset of mmcv.cnn.ConvModule on this path: conv (+GroupNorm) (+ReLU).  Parameter paths
+    `.conv` and `.gn` (mmcv names the norm layer after its type); bias='auto' means "no bias when a
+    norm layer follows" (mmcv/cnn/bricks/conv_module.py:113-116)."""
 
-    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, act=True):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, act=True, norm_cfg=None):
         super().__init__()
+        if bias == 'auto':
+            bias = norm_cfg is None
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=bias)
         self.with_activation = act
+        self.with_norm = norm_cfg is not None
+        if self.with_norm:
+            assert norm_cfg['type'] == 'GN', 'GroupNorm is the only head norm on the Point-Teacher path'
+            self.gn = nn.GroupNorm(norm_cfg['num_groups'], out_channels)
+            for p in self.gn.parameters():
+                p.requires_grad = norm_cfg.get('requires_grad', True)
 
     def forward(self, x):
         x = self.conv(x)
+        if self.with_norm:
+            x = self.gn(x)
         return TF.relu(x, inplace=True) if self.with_activation else x
 
 

@@ -205,7 +205,8 @@ def strong_augmentation(img, gt_points, gt_labels, pseudo_points, pseudo_labels,
 
 
 # ------------------------------------------------- burn-in step 1: white rectangles --
-def generate_black_paper_masked(img, gt_bboxes, prior_size, dense_cls, imgsize, max_extra=10, draws=None):
+def generate_black_paper_masked(img, gt_bboxes, prior_size, dense_cls, imgsize, max_extra=10, draws=None, fill=255.0,
+                                return_obb=False):
     """GPU, sync-free form of generate_black_paper (syn_images_generator_v2.py:591-690) for ONE
     image [C,H,W] whose real objects are gt_bboxes [G,4] (xyxy).
 
@@ -219,7 +220,11 @@ def generate_black_paper_masked(img, gt_bboxes, prior_size, dense_cls, imgsize, 
     are in the order the reference's `bb[keep]` would have (descending score), `alive`
     marks the rows that exist in the reference's output.  The rasteriser contract is
     "pixels inside or on the int32-truncated quadrilateral" (cv2.fillPoly is not
-    available: parity unpinned at pixel level)."""
+    available: parity unpinned at pixel level).
+
+    fill='max' paints with the image maximum instead of 255 (the OBB generator,
+    OBB_TOD/.../syn_images_generator_v2.py:722, whose inputs are mean/std-normalised);
+    return_obb=True returns the rectangles as (cx,cy,w,h,a) rows instead of their hulls."""
     C, H, W = img.shape
     dev = img.device
     G = gt_bboxes.shape[0]
@@ -289,7 +294,13 @@ def generate_black_paper_masked(img, gt_bboxes, prior_size, dense_cls, imgsize, 
     inside = (xyxy.min(-1)[0] >= 0) & (xyxy.max(-1)[0] <= imgsize - 1)
     alive = keep & exist[order] & (sb[:, 5] < 1) & inside
     polys = obb2poly_le90(sb[:, :5])
-    img_syn = F.fill_quads_(img.clone().contiguous(), polys, alive, 255.0)
+    if fill == 'max':      # device-side value: rasterise a 0/1 mask, then select (no host read of img.max())
+        mask = F.fill_quads_(torch.zeros((1, H, W), dtype=img.dtype, device=dev), polys, alive, 1.0)
+        img_syn = torch.where(mask == 1, img.max(), img)
+    else:
+        img_syn = F.fill_quads_(img.clone().contiguous(), polys, alive, float(fill))
+    if return_obb:
+        return img_syn, sb[:, :5].contiguous(), alive
     hull = torch.stack([polys[:, 0::2].min(1)[0], polys[:, 1::2].min(1)[0], polys[:, 0::2].max(1)[0],
                         polys[:, 1::2].max(1)[0]], 1)
     return img_syn, hull, alive

@@ -327,6 +327,23 @@ def test_nms_and_rotated():
     assert torch.equal(keep.cpu(), R.nms_rotated(rb, rs, 0.05))
 
 
+def test_nms_large_candidate_sets():
+    """nms_pre x classes candidates of the shipped test_cfgs (up to 3000 x 8) exceed the two-word scan:
+    N = 20000 goes through the eight-word scan and still equals the greedy oracle; above 32768 the
+    entry point refuses loudly."""
+    f = F()
+    gen = torch.Generator().manual_seed(12)
+    N = 20000
+    c = torch.rand(N, 2, generator=gen) * 1500
+    wh = torch.rand(N, 2, generator=gen) * 30 + 4
+    boxes = torch.cat([c - wh / 2, c + wh / 2], 1)
+    scores = torch.rand(N, generator=gen)
+    _, keep = f.nms(cu(boxes), cu(scores), 0.5)
+    assert torch.equal(keep.cpu(), R.nms(boxes, scores, 0.5))
+    with pytest.raises(RuntimeError, match='above 32768'):
+        f.nms(cu(torch.zeros(32769, 4)), cu(torch.zeros(32769)), 0.5)
+
+
 def test_fill_quads():
     f = F()
     gen = torch.Generator().manual_seed(13)
