@@ -28,9 +28,11 @@ def parse():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='step1', choices=['step1', 'step2'])
+    ap.add_argument('--variant', default='hbb', choices=['hbb', 'obb'],
+                    help="hbb: AI-TOD-v2 configs (BASELINE configs[0-3]); obb: SODA-A oriented config (configs[4])")
     ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'])
     ap.add_argument('--batch', type=int, default=2)
-    ap.add_argument('--size', type=int, default=800)
+    ap.add_argument('--size', type=int, default=None, help='tile side; default 800 (hbb) / 1200 (obb, RResize of the config)')
     ap.add_argument('--objects', type=int, default=300)
     ap.add_argument('--percent', type=int, default=0, choices=[0, 30, 60, 100])
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -44,7 +46,7 @@ def parse():
 
 # algorithmic HBM bytes per launch of the custom kernels
 def algorithmic_bytes(name, shapes):
-    if name in ('pt_roi_align_fwd', 'pt_roi_align_bwd'):
+    if name in ('pt_roi_align_fwd', 'pt_roi_align_bwd', 'pt_roi_align_rotated_fwd', 'pt_roi_align_rotated_bwd'):
         K, C, o = shapes['K'], shapes['C'], shapes['out']
         return K * C * o * o * 4            # the [K,C,7,7] block written (fwd) / read (bwd); the map stays in L2/MALL
     if name == 'pt_ema_update':
@@ -58,6 +60,9 @@ def algorithmic_bytes(name, shapes):
 
 def main():
     args = parse()
+    obb = args.variant == 'obb'
+    if args.size is None:
+        args.size = 1200 if obb else 800
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -80,8 +85,12 @@ def main():
 
     torch.backends.cudnn.benchmark = bool(args.miopen_find)      # MIOpen find mode
     torch.manual_seed(1234)           # same initial weights on every rank (also broadcast by the Trainer)
-    cfg = pta.Config.fromfile(os.path.join(ROOT, 'point_teacher_amd', 'configs', 'point_teacher',
-                                           f'aitodv2_point_teacher_{args.percent}.py'))
+    if obb:
+        cfg = pta.Config.fromfile(os.path.join(ROOT, 'point_teacher_amd', 'configs', 'obb', 'point_teacher',
+                                               'sodaa_fcos_pointteacher_1x.py'))
+    else:
+        cfg = pta.Config.fromfile(os.path.join(ROOT, 'point_teacher_amd', 'configs', 'point_teacher',
+                                               f'aitodv2_point_teacher_{args.percent}.py'))
     # phase switch (fcos_p2b_teacher_student.py:133): count <= burn_in_step -> step 1
     cfg.model['burn_in_step'] = 10 ** 9 if args.workload == 'step1' else -1
     model = pta.build_detector(cfg.model).to(dev)
@@ -95,7 +104,8 @@ def main():
         for m in model.modules():
             if isinstance(m, torch.nn.BatchNorm2d):
                 m.fold_into_conv = True
-    data = SyntheticTiles(n=8, size=args.size, mean_objects=args.objects, seed=7, device=dev, rank=rank, world=world)
+    data = SyntheticTiles(n=8, size=args.size, mean_objects=args.objects, seed=7, device=dev, rank=rank, world=world,
+                          oriented=obb, num_classes=9 if obb else 8)
 
     def barrier():
         torch.cuda.synchronize()
@@ -119,7 +129,7 @@ def main():
             r = orig_call(fn, *a)
             e1.record()
             shp = None
-            if fn in ('pt_roi_align_fwd', 'pt_roi_align_bwd'):
+            if fn in ('pt_roi_align_fwd', 'pt_roi_align_bwd', 'pt_roi_align_rotated_fwd', 'pt_roi_align_rotated_bwd'):
                 shp = dict(K=a[6], C=a[3], out=a[7])
             elif fn in ('pt_ema_update', 'pt_sgd_step', 'pt_sqnorm_partial'):
                 shp = dict(n=a[2] if fn == 'pt_ema_update' else (a[3] if fn == 'pt_sgd_step' else a[1]))
@@ -158,7 +168,7 @@ def main():
     traffic = None          # HBM bytes per launch from the committed PMC passes (same workload), else null
     try:
         pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01', 'pmc_traffic.json')))
-        traffic = pmc.get(args.workload, {}).get(dom, {}).get('traffic')
+        traffic = pmc.get(('obb_' if obb else '') + args.workload, {}).get(dom, {}).get('traffic')
     except Exception:
         pass
     roofline = dict(bound='hbm', kernel=dom, achieved=round(achieved, 1), peak=8000.0, unit='GB/s',
@@ -167,7 +177,11 @@ def main():
 
     if rank == 0:
         cpu_baseline = None
-        if not args.no_cpu_baseline and world == 1:
+        if obb:
+            cpu_baseline = dict(value=None, unit='iters/s', cores=None, kind='port',
+                                sample='not timed for the oriented variant (its oracle, oracle/ref_obb.py, loops over RoIs '
+                                       'in python); the CPU leg is reported on the default hbb workload')
+        elif not args.no_cpu_baseline and world == 1:
             try:
                 from oracle import ref_model
                 cpu_baseline = ref_model.cpu_baseline(args.workload, args.batch, args.size, args.objects,
@@ -176,15 +190,17 @@ def main():
                 cpu_baseline = dict(value=None, unit='iters/s', cores=os.cpu_count(), kind='port',
                                     sample=f'failed: {type(e).__name__}: {e}')
         iters_s = args.steps * 1.0 / dt
-        flops_iter = 3.3e12 * (args.batch / 2)         # BASELINE.md section 3 (0 % config, B = 2)
+        # BASELINE.md section 3 (0 % config, B = 2, 800x800); the conv towers dominate, so other tile sizes scale by area
+        flops_iter = 3.3e12 * (args.batch / 2) * (args.size / 800.0) ** 2
         peak = 2.5e15 if args.dtype == 'bf16' else 157.3e12
         line = dict(
-            metric='train iters/sec (800x800, ~300 pts/img)', value=round(iters_s * world, 4), unit='iters/s',
+            metric=f'train iters/sec ({args.size}x{args.size}, ~{args.objects} pts/img)', value=round(iters_s * world, 4), unit='iters/s',
             n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),
             higher_is_better=True, scaling='weak', vs_baseline=None,
             dtype='f32' if args.dtype == 'fp32' else 'bf16', data='synthetic',
-            config=dict(workload=f'aitodv2_point_teacher_{args.percent}% {"burn-in phase 1" if args.workload == "step1" else "phase 2 (MIL on)"}, '
-                                 f'R50-FPN-PSAGG + TS_P2BFCOSHead, bs {args.batch}/GPU, {args.size}x{args.size}, '
+            config=dict(workload=(f'sodaa_fcos_pointteacher_1x (oriented) ' if obb else f'aitodv2_point_teacher_{args.percent}% ')
+                                 + f'{"burn-in phase 1" if args.workload == "step1" else "phase 2 (MIL on)"}, '
+                                 f'R50-FPN-PSAGG + {"TS_P2RBRotatedFCOSHead" if obb else "TS_P2BFCOSHead"}, bs {args.batch}/GPU, {args.size}x{args.size}, '
                                  f'~{args.objects} pts/img, {"fp32" if args.dtype == "fp32" else "bf16 autocast convs + fp32 head"}',
                         global_batch=args.batch * world, parallelism=f'dp{world}', phase=args.workload),
             roofline=roofline, cpu_baseline=cpu_baseline,

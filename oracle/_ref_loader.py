@@ -229,3 +229,68 @@ def ref(name):
     """Return a loaded reference module, e.g. ref('models.losses.iou_loss')."""
     install()
     return importlib.import_module('mmdet.' + name)
+
+
+# ------------------------------------------------------------------------------
+# Oriented-box tree (OBB_TOD/mmrotate): same technique.  The OBB tree imports the HBB fork's
+# `mmdet` for assigners / match costs / coders / losses, so `install()` runs first.
+# ------------------------------------------------------------------------------
+OBB = os.path.join(REF_ROOT, 'OBB_TOD')
+
+
+def install_obb():
+    """Register an empty `mmrotate` package tree over OBB_TOD/mmrotate and load the files of the
+    oriented path whose arithmetic is pure python/torch (idempotent)."""
+    install()
+    if 'mmrotate' in sys.modules and getattr(sys.modules['mmrotate'], '_pt_shim', False):
+        return
+    import torch.nn as nn
+    mr = os.path.join(OBB, 'mmrotate')
+    root = _pkg('mmrotate', mr)
+    root._pt_shim = True
+    core = _pkg('mmrotate.core', os.path.join(mr, 'core'), stub=True)
+    for sub in ['core/bbox', 'core/bbox/coder', 'models', 'models/losses', 'models/dense_heads', 'models/detectors']:
+        _pkg('mmrotate.' + sub.replace('/', '.'), os.path.join(mr, sub))
+    _pkg('mmrotate.core.bbox.iou_calculators', stub=True)          # rbbox_overlaps -> mmcv.ops (absent)
+    _pkg('mmrotate.core.visualization', stub=True)
+    _pkg('mmrotate.core.visualization.palette', stub=True)
+    _pkg('mmrotate.models.detectors.data_augument_bank', stub=True)  # plotting helpers (matplotlib/PIL)
+    for n in ('matplotlib', 'matplotlib.pyplot', 'matplotlib.patches', 'matplotlib.collections', 'PIL'):
+        if n not in sys.modules:
+            _pkg(n, stub=True)
+    # names the HBB shim did not need
+    mmcv_cnn = sys.modules['mmcv.cnn']
+    if getattr(mmcv_cnn, 'ConvModule', None) is None:
+        mmcv_cnn.ConvModule = nn.Module
+    _pkg('mmdet.core.anchor', stub=True)
+    _pkg('mmdet.core.anchor.point_generator', stub=True)
+    _pkg('mmdet.models.roi_heads', stub=True)
+    _pkg('mmdet.models.roi_heads.bbox_heads', stub=True)
+    _pkg('mmdet.models.roi_heads.bbox_heads.bbox_head', stub=True)
+    _pkg('mmdet.core.visualization', stub=True)
+    _pkg('mmdet.core.visualization.image', stub=True)
+    sys.modules['mmdet.core'].BaseBBoxCoder = importlib.import_module('mmdet.core.bbox.coder.base_bbox_coder').BaseBBoxCoder
+    sys.modules['mmdet.models.dense_heads'].AnchorFreeHead = importlib.import_module(
+        'mmdet.models.dense_heads.anchor_free_head').AnchorFreeHead
+    ls = sys.modules['mmdet.models.losses']
+    ls.accuracy = None
+    imp = importlib.import_module
+    tr = imp('mmrotate.core.bbox.transforms')
+    bld = imp('mmrotate.core.bbox.builder')
+    imp('mmrotate.core.bbox.coder.distance_angle_point_coder')
+    core.build_bbox_coder = bld.build_bbox_coder
+    core.build_assigner = bld.build_assigner
+    core.build_sampler = bld.build_sampler
+    core.obb2xyxy = tr.obb2xyxy
+    core.rbbox2result = tr.rbbox2result
+    core.rbbox2roi = tr.rbbox2roi
+    imp('mmrotate.models.builder')
+    imp('mmrotate.models.detectors.syn_images_generator_v2')
+    imp('mmrotate.models.dense_heads.rotated_anchor_free_head')
+    imp('mmrotate.models.dense_heads.rotated_fcos_head_p2rb_ts')
+
+
+def ref_obb(name):
+    """Return a loaded OBB reference module, e.g. ref_obb('core.bbox.transforms')."""
+    install_obb()
+    return importlib.import_module('mmrotate.' + name)

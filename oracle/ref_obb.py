@@ -51,6 +51,19 @@ def poly2obb_le90(polys):
     return torch.stack([(p1[:, 0] + p3[:, 0]) / 2.0, (p1[:, 1] + p3[:, 1]) / 2.0, torch.max(e1, e2), torch.min(e1, e2), ang], 1)
 
 
+def obb2distance(points, boxes5, max_dis=None, eps=None):
+    """core/bbox/coder/distance_angle_point_coder.py:73-91 (encode)."""
+    ctr, wh, ang = torch.split(boxes5, [2, 2, 1], dim=1)
+    c, s = torch.cos(ang), torch.sin(ang)
+    rot = torch.cat([c, s, -s, c], dim=1).reshape(-1, 2, 2)
+    off = torch.bmm(rot, (points - ctr)[..., None]).squeeze(-1)
+    w, h = wh[..., 0], wh[..., 1]
+    l, r, t, b = w / 2 + off[..., 0], w / 2 - off[..., 0], h / 2 + off[..., 1], h / 2 - off[..., 1]
+    if max_dis is not None:
+        l, t, r, b = [v.clamp(min=0, max=max_dis - eps) for v in (l, t, r, b)]
+    return torch.stack((l, t, r, b, ang[:, 0]), -1)
+
+
 # ----------------------------------------------------------- differentiable rotated IoU --
 class _RotIoU(torch.autograd.Function):
     """mmcv.ops.diff_iou_rotated_2d for aligned [N,5] boxes: value = fp64 polygon-clip IoU,

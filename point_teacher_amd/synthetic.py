@@ -24,11 +24,31 @@ def make_tile(idx, size=800, num_classes=8, mean_objects=300, seed=0, device='cp
     return img.to(device), boxes.to(device), labels.to(device), meta
 
 
+def make_tile_obb(idx, size=1200, num_classes=9, mean_objects=300, seed=0, device='cpu', max_objects=600):
+    """SODA-A-like tile of config 5: the same low-pass-noise picture after the config's Normalize
+    (mean [123.675, 116.28, 103.53], std [58.395, 57.12, 57.375]), oriented boxes (cx, cy, w, h, a) in the
+    le90 convention (w >= h, a in [-pi/2, pi/2)), 9 classes."""
+    img, boxes, _, meta = make_tile(idx, size, num_classes, mean_objects, seed, 'cpu', max_objects)
+    g = torch.Generator().manual_seed(seed * 1_000_003 + idx + 77)
+    mean = torch.tensor([123.675, 116.28, 103.53]).view(3, 1, 1)
+    std = torch.tensor([58.395, 57.12, 57.375]).view(3, 1, 1)
+    img = (img - mean) / std
+    G = boxes.shape[0]
+    c = (boxes[:, :2] + boxes[:, 2:]) / 2
+    wh = (boxes[:, 2:] - boxes[:, :2]).clamp(min=2.0)
+    a = torch.rand(G, generator=g) * math.pi - math.pi / 2
+    rb = torch.stack([c[:, 0], c[:, 1], torch.max(wh[:, 0], wh[:, 1]), torch.min(wh[:, 0], wh[:, 1]), a], 1)
+    labels = torch.randint(0, num_classes, (G,), generator=g)
+    return img.to(device), rb.to(device), labels.to(device), meta
+
+
 class SyntheticTiles:
     """A cycled dataset of `n` tiles resident on the device; `batch(i, B)` gives train_step's dict."""
 
-    def __init__(self, n=64, size=800, num_classes=8, mean_objects=300, seed=0, device='cpu', rank=0, world=1):
-        self.items = [make_tile(rank + world * k, size, num_classes, mean_objects, seed, device) for k in range(n)]
+    def __init__(self, n=64, size=800, num_classes=8, mean_objects=300, seed=0, device='cpu', rank=0, world=1,
+                 oriented=False):
+        make = make_tile_obb if oriented else make_tile
+        self.items = [make(rank + world * k, size, num_classes, mean_objects, seed, device) for k in range(n)]
 
     def __len__(self):
         return len(self.items)
@@ -55,7 +75,8 @@ def benchmark_init_(model, phase2=False):
     import torch
     with torch.no_grad():
         for m in (model.student, model.teacher):
-            m.backbone.conv1.weight.mul_(1.0 / 64.0)
+            if not hasattr(m.bbox_head, 'conv_angle'):       # the OBB config feeds mean/std-normalised pixels
+                m.backbone.conv1.weight.mul_(1.0 / 64.0)
             for fc in m.bbox_head.fc_reg:
                 fc.weight.mul_(0.01)
                 fc.bias.zero_()

@@ -155,6 +155,93 @@ def test_obb_proposals_and_augmentation_vs_oracle():
         assert float((out[0][i].cpu() != r[0]).float().mean()) < 2e-3
 
 
+def test_product_vs_reference_goldens():
+    """The product's own functions against the fixtures captured from the reference (tests/golden/obb_*.npz)."""
+    from conftest import load_golden
+    from point_teacher_amd import functional as F
+    from point_teacher_amd import obb as OB
+    from point_teacher_amd import obb_proposals as OP
+    g = load_golden('obb_transforms')
+    close(OP.obb2poly(g.t('in_rboxes').to(DEV)), g.t('out_poly'), atol=1e-4)
+    close(OP.poly2obb(g.t('in_quads').to(DEV)), g.t('out_quads_obb'), atol=1e-4)
+    close(OB.norm_angle(g.t('in_angles').to(DEV), 'le90'), g.t('out_norm_le90'))
+    g = load_golden('obb_coder')
+    cd = OB.DistanceAnglePointCoder(angle_version='le90')
+    close(cd.decode(g.t('in_points').to(DEV), g.t('in_distance').to(DEV)), g.t('out_decode'), atol=1e-4)
+    close(cd.encode(g.t('in_points').to(DEV), g.t('in_gt').to(DEV)), g.t('out_encode'), atol=1e-4)
+    close(cd.encode(g.t('in_points').to(DEV), g.t('in_gt').to(DEV), 16.0, 0.1), g.t('out_encode_clamped'), atol=1e-4)
+    g = load_golden('obb_proposals')
+    metas = [dict(img_shape=(256, 256, 3))] * 2
+    boxes = [g.t('in_boxes0').to(DEV), g.t('in_boxes1').to(DEV)]
+    real = [g.t('in_real0').to(DEV), g.t('in_real1').to(DEV)]
+    for tag, cfg in (('coarse', dict(gen_mode='refine', gen_proposal_mode='fix_gen', base_ratios=[1.0], shake_ratio=None, min_scale=0)),
+                     ('ext', dict(gen_mode='refine', gen_proposal_mode='fix_gen', base_ratios=[1.0, 1.2, 1.3, 0.8, 0.6],
+                                  shake_ratio=None, min_scale=4))):
+        pr, pv, pref, preal = OP.MIL_gen_proposals_from_cfg([b[:, :2] for b in boxes], boxes, cfg, real, metas)
+        for i in range(2):
+            close(pr[i], g.t(f'out_{tag}_props{i}'), atol=1e-4)
+            assert torch.equal(pv[i].cpu().reshape(-1), g.t(f'out_{tag}_valid{i}').reshape(-1))
+            close(pref[i], g.t(f'out_{tag}_ref{i}'))
+            close(preal[i], g.t(f'out_{tag}_real{i}'))
+    g = load_golden('obb_strong_aug')
+    H, W = [int(v) for v in g['hw']]
+    img = torch.zeros(4, 3, H, W, device=DEV)
+    params = ([str(f) for f in g['flips']], [int(a) for a in g['angles']], [float(s) for s in g['scales']])
+    out = OP.strong_augmentation(img, [g.t(f'in_gt_points{i}').to(DEV) for i in range(4)],
+                                 [g.t(f'in_labels{i}').to(DEV) for i in range(4)],
+                                 [g.t(f'in_pseudo_points{i}').to(DEV) for i in range(4)],
+                                 [g.t(f'in_labels{i}').to(DEV) for i in range(4)],
+                                 [g.t(f'in_pseudo_bboxes{i}').to(DEV) for i in range(4)], 'le90', params=params)
+    for i in range(4):
+        close(out[2][i], g.t(f'out_gt_points{i}'), atol=1e-3)
+        assert torch.equal(out[3][i].cpu(), g.t(f'out_gt_labels{i}'))
+        close(out[4][i], g.t(f'out_pseudo_points{i}'), atol=1e-3)
+        assert torch.equal(out[5][i].cpu(), g.t(f'out_pseudo_labels{i}'))
+        close(out[6][i][:, :4], g.t(f'out_pseudo_bboxes{i}')[:, :4], atol=2e-3)
+        da = (out[6][i][:, 4].cpu() - g.t(f'out_pseudo_bboxes{i}')[:, 4]).abs()
+        assert float(torch.min(da, math.pi - da).max()) < 1e-3
+    for name in ('small', 'mid'):
+        g = load_golden('obb_head_' + name)
+        pts, cls, reg = g.t('in_points').to(DEV), g.t('in_cls').to(DEV), g.t('in_reg').to(DEV)
+        gtb, lab = g.t('in_gt_bboxes').to(DEV), g.t('in_gt_labels').to(DEV)
+        G, P = gtb.shape[0], pts.shape[0]
+        off, _ = F.make_offsets([G], DEV)
+        dec = cd.decode(pts, reg)
+        gi, cand = F.fuse_assign_obb(pts, dec, cls, gtb[:, :2].contiguous(), lab, off, 1, 5, 3)
+        ps = F.pseudo_boxes_obb(P, dec, cls, gtb[:, :2].contiguous(), lab, off, 1, gi, cand)
+        close(ps['bboxes'], g.t('out_pseudo_bboxes'), atol=1e-3)
+        close(ps['points'], g.t('out_pseudo_points'), atol=1e-3)
+        gi = F.topk_assign(pts, gtb, off, 1, 3)
+        labels, tg, ang, ctr = F.fcos_targets_obb(pts, gi, gtb, None, off, 1, 9)
+        assert torch.equal(labels.cpu().long(), g.t('out_syn_labels'))
+        close(tg, g.t('out_syn_bbox_targets'), atol=1e-4)
+        close(ang, g.t('out_syn_angle_targets'))
+        pb2 = g.t('in_pseudo_bboxes2').to(DEV)
+        gi = F.topk_assign(pts, pb2, off, 1, 3)
+        labels, tg, ang, ctr = F.fcos_targets_obb(pts, gi, pb2, lab, off, 1, 9)
+        assert torch.equal(labels.cpu().long(), g.t('out_labels_reg'))
+        close(tg, g.t('out_bbox_targets'), atol=1e-4)
+        close(ang, g.t('out_angle_targets'))
+        close(ctr[labels < 9], g.t('out_centerness'), atol=1e-4)
+    g = load_golden('obb_mil')
+    merged = F.mil_bag_select(g.t('in_cls').to(DEV), g.t('in_ins').to(DEV), g.t('in_valid').reshape(-1).to(DEV),
+                              g.t('in_labels').to(DEV), g.t('in_bags').to(DEV), g.t('in_pseudo').to(DEV), 1, 25, 3, 0.25,
+                              (200, 240))
+    close(merged, g.t('out_merged'), atol=1e-3)
+    cls = g.t('in_cls').to(DEV).requires_grad_(True)
+    ins = g.t('in_ins').to(DEV).requires_grad_(True)
+    neg = g.t('in_neg_cls').to(DEV).requires_grad_(True)
+    total, nvalid = F.mil_bag_loss_sum(cls.reshape(-1, 25, 9), ins.reshape(-1, 25, 9), g.t('in_valid').reshape(-1).to(DEV),
+                                       g.t('in_labels').to(DEV))
+    ns = nvalid.clamp(min=1.0)
+    loss = 0.25 * total / ns + 0.75 * F.mil_neg_loss_sum(neg, g.t('in_neg_w').to(DEV)) / ns
+    close(loss, g.t('out_loss'), rtol=1e-4)
+    loss.backward()
+    close(cls.grad, g.t('out_grad_cls'), atol=1e-5)
+    close(ins.grad, g.t('out_grad_ins'), atol=1e-5)
+    close(neg.grad, g.t('out_grad_neg'), atol=1e-5)
+
+
 # ------------------------------------------------------------------- whole iteration --
 def _build(dev, phase2):
     import point_teacher_amd as pta
