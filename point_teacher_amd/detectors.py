@@ -13,7 +13,9 @@ import torch.nn as nn
 from . import functional as F
 from .core import bbox2result, bbox_overlaps, bbox_xyxy_to_cxcywh
 from .proposals import (MIL_gen_proposals_from_cfg, gen_negative_proposals, generate_black_paper_masked,
-                        load_basic_shape, random_point_in_quadrilateral, strong_augmentation_masked)
+                        load_basic_shape, random_point_in_quadrilateral, strong_augmentation_images,
+                        strong_augmentation_masked)
+from .nn_modules import refresh_bn_affines
 from .registry import DETECTORS, build_backbone, build_detector, build_head, build_neck
 
 
@@ -138,9 +140,12 @@ class TS_P2B_FCOS(BaseDetector):
     def _cxcywh(boxes):
         return bbox_xyxy_to_cxcywh(boxes)
 
-    def _strong_aug(self, img, gt_points, gt_labels, pseudo_points, pseudo_labels, pseudo_bboxes):
+    def _strong_aug_images(self, img):
+        return strong_augmentation_images(img, params=self._inject.get('aug'))
+
+    def _strong_aug(self, img, gt_points, gt_labels, pseudo_points, pseudo_labels, pseudo_bboxes, params=None, imgs=None):
         return strong_augmentation_masked(img, gt_points, gt_labels, pseudo_points, pseudo_labels, pseudo_bboxes,
-                                          params=self._inject.get('aug'))
+                                          params=params if params is not None else self._inject.get('aug'), imgs=imgs)
 
     def _black_paper(self, img, gt_bboxes, imgsize, draws):
         return generate_black_paper_masked(img, gt_bboxes, self.prior_size, range(int(len(self.pattern) / 2)), imgsize,
@@ -180,6 +185,9 @@ class TS_P2B_FCOS(BaseDetector):
         self._flat = None
         for p in self.teacher.parameters():
             p.requires_grad = False
+        for m in self.teacher.modules():      # the EMA moves the teacher's BN affines: their fused (scale, shift) cache
+            if isinstance(m, nn.BatchNorm2d):  # must follow (nn_modules._bn_key / refresh_bn_affines)
+                m._affine_dynamic = True
         # hooks for tests: inject the random draws of one iteration
         self._inject = {}
 
@@ -232,8 +240,10 @@ class TS_P2B_FCOS(BaseDetector):
             if self._flat is not None:
                 F.ema_update_(self._flat[0], self._flat[1], ema_decay)
             else:   # parameters not flattened yet (unit tests / CPU construction): per-tensor form
+                F.PARAM_EPOCH[0] += 1
                 for t, s in zip(teacher_model.parameters(), student_model.parameters()):
                     t.data.mul_(ema_decay).add_(s.data, alpha=1 - ema_decay)
+            refresh_bn_affines(teacher_model)     # the fused BN epilogue of the teacher follows the EMA
 
     def update_epoch(self, num_img, img_metas):
         """:259-264"""
@@ -280,11 +290,33 @@ class TS_P2B_FCOS(BaseDetector):
         real = self._cxcywh(torch.cat(gt_bboxes, dim=0))
         return (torch.sqrt((torch.cat(gt_points) - real[:, :2]) ** 2) / torch.sqrt((real[:, 2:4] / 2) ** 2)).mean()
 
+    def _student_passes(self, img, extra=None):
+        """ONE batched student pass over [extra (synthetic) images | clean images | strongly augmented images].
+        The reference runs them as separate passes (:146, :191 / :226, :243); every layer of the student is
+        per-sample (BatchNorm in eval mode, GroupNorm), so the batched pass computes the same features with a
+        third of the launches and one gradient accumulation per parameter.  The augmented PIXELS only depend on
+        the input image and the draws (the boxes/points are transformed later, after the MIL stage, with the
+        same draws).  Returns (aug_pre, [feature tuples per group])."""
+        B = img.shape[0]
+        params, aug_imgs = self._strong_aug_images(img)
+        img_aug = torch.stack(aug_imgs, dim=0)
+        parts = ([extra] if extra is not None else []) + [img, img_aug]
+        if img.is_contiguous(memory_format=torch.channels_last) and not img.is_contiguous():
+            parts = [p.contiguous(memory_format=torch.channels_last) for p in parts]
+        feat_all = self.extract_feat(torch.cat(parts, dim=0), self.student)
+        groups, o = [], 0
+        for p in parts:
+            groups.append(tuple(f[o:o + p.shape[0]] for f in feat_all))
+            o += p.shape[0]
+        return (params, aug_imgs), groups
+
     def _student_aug_loss(self, img, img_metas, gt_points, gt_labels, pseudo_points, pseudo_labels, pseudo_bboxes,
-                          gt_bboxes_ignore):
-        aug = self._strong_aug(img, gt_points, gt_labels, pseudo_points, pseudo_labels, pseudo_bboxes)
+                          gt_bboxes_ignore, aug_pre=None, feat_aug=None):
+        params, imgs = aug_pre if aug_pre is not None else (None, None)
+        aug = self._strong_aug(img, gt_points, gt_labels, pseudo_points, pseudo_labels, pseudo_bboxes, params=params,
+                               imgs=imgs)
         img_aug, img_aug_list, gp, gl, pp, pl, pb, gv, pv = aug
-        outs = self.student.bbox_head(self.extract_feat(img_aug, self.student))
+        outs = self.student.bbox_head(feat_aug if feat_aug is not None else self.extract_feat(img_aug, self.student))
         return self.student.bbox_head.loss_pseudo(*outs, gp, gl, pp, pl, pb, [None] * len(img_metas), img_metas,
                                                   img_aug_list, self.count <= self.burn_in_step, gt_bboxes_ignore,
                                                   gt_valid=gv, pseudo_valid=pv)
@@ -295,7 +327,7 @@ class TS_P2B_FCOS(BaseDetector):
         losses = {}
         pb_c, pp_c, pl_c, _, _ = self._teacher_pseudo(img, img_metas, img_list, gt_points, gt_labels, gt_bboxes,
                                                       gt_bboxes_ignore)
-        feat = self.extract_feat(img, self.student)
+        aug_pre, (feat, feat_aug) = self._student_passes(img)
         mil_feat = self.student.bbox_head.forward_mil(feat)
         pb_r, pp_r, mil_losses = self.forward_mil_head_burn_in_step2(num_img, pb_c, pp_c, pl_c, gt_bboxes, img_metas,
                                                                      mil_feat)
@@ -304,7 +336,8 @@ class TS_P2B_FCOS(BaseDetector):
         del feat, mil_feat
         gt_points = self.update_points(num_img, img_metas, pb_r)
         losses['refined_points_distance'] = self._refined_points_distance(gt_points, gt_bboxes)
-        lc, lb, lt = self._student_aug_loss(img, img_metas, gt_points, gt_labels, pp_r, pl_c, pb_r, gt_bboxes_ignore)
+        lc, lb, lt = self._student_aug_loss(img, img_metas, gt_points, gt_labels, pp_r, pl_c, pb_r, gt_bboxes_ignore,
+                                            aug_pre=aug_pre, feat_aug=feat_aug)
         losses['loss_cls'], losses['loss_bbox'], losses['loss_centerness'] = lc, lb, lt
         return losses
 
@@ -355,11 +388,8 @@ class TS_P2B_FCOS(BaseDetector):
         losses = {}
         img_syn, _, syn_boxes, syn_alive = self.genrate_syn(num_img, img_list, gt_bboxes, gt_labels)
         head = self.student.bbox_head
-        feat_all = self.extract_feat(torch.cat([img_syn, img], dim=0), self.student)
-        mil_all = head.forward_mil(feat_all)
-        feat_syn = [f[:num_img] for f in feat_all]
-        mil_syn = [m[:num_img] for m in mil_all]
-        mil_ori = [m[num_img:] for m in mil_all]
+        aug_pre, (feat_syn, feat_ori, feat_aug) = self._student_passes(img, extra=img_syn)
+        mil_syn, mil_ori = head.forward_mil(feat_syn), head.forward_mil(feat_ori)
         outs_syn = head(feat_syn)
         loss_syn = head.loss(*outs_syn, syn_boxes, img_metas, gt_bboxes_ignore, gt_valid=syn_alive)
         pb_c, pp_c, pl_c, _, _ = self._teacher_pseudo(img, img_metas, img_list, gt_points, gt_labels, gt_bboxes,
@@ -371,7 +401,8 @@ class TS_P2B_FCOS(BaseDetector):
             losses.update(mil_losses)
             gt_points = self.update_points(num_img, img_metas, pb_r)
             losses['refined_points_distance'] = self._refined_points_distance(gt_points, gt_bboxes)
-        lc, _, _ = self._student_aug_loss(img, img_metas, gt_points, gt_labels, pp_r, pl_c, pb_r, gt_bboxes_ignore)
+        lc, _, _ = self._student_aug_loss(img, img_metas, gt_points, gt_labels, pp_r, pl_c, pb_r, gt_bboxes_ignore,
+                                          aug_pre=aug_pre, feat_aug=feat_aug)
         losses['loss_cls'] = lc
         losses['loss_bbox'], losses['loss_centerness'] = loss_syn
         return losses

@@ -420,7 +420,13 @@ def mil_bag_select(cls, ins, valid, labels, bags, pseudo, U1, U2, topk, beta, im
 
 # ------------------------------------------------------- EMA / optimizer step --
 
+# Bumped by every kernel that rewrites parameters through raw pointers (autograd version counters do not
+# see those writes); caches derived from parameter values key on it (nn_modules._bn_affine).
+PARAM_EPOCH = [0]
+
+
 def ema_update_(teacher_flat, student_flat, alpha):
+    PARAM_EPOCH[0] += 1
     hip.call('pt_ema_update', teacher_flat, student_flat, teacher_flat.numel(), float(alpha), float(1 - alpha))
 
 
@@ -433,6 +439,7 @@ def grad_sqnorm(flat_grad):
 
 def sgd_step_(param, grad, mom, split, lr_t, momentum, weight_decay, bias_lr_mult, bias_decay_mult, sqnorm,
               max_norm, first_step):
+    PARAM_EPOCH[0] += 1
     hip.call('pt_sgd_step', param, grad, mom, param.numel(), int(split), lr_t, float(momentum), float(weight_decay),
              float(bias_lr_mult), float(bias_decay_mult), sqnorm, float(max_norm if max_norm else 0.0),
              int(bool(first_step)))

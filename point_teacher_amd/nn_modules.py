@@ -52,17 +52,54 @@ class Scale(nn.Module):
 
 
 # ------------------------------------------------------------------------ ResNet --
+def _bn_key(bn):
+    """Everything the (scale, shift) of an eval-mode BatchNorm depends on.  Modules flagged
+    `_affine_dynamic` (the teacher's: the flat EMA kernel rewrites their weight/bias through raw
+    pointers, which autograd's version counters do not see) also key on functional.PARAM_EPOCH."""
+    return (bn.weight._version, bn.bias._version, bn.running_var._version, bn.running_mean._version,
+            bn.weight.data_ptr(), bn.weight.device, F.PARAM_EPOCH[0] if getattr(bn, '_affine_dynamic', False) else 0)
+
+
 def _bn_affine(bn):
-    """(scale, shift) of a frozen eval-mode BatchNorm, cached until its tensors change."""
+    """(scale, shift) of an eval-mode BatchNorm with a non-trainable affine, cached until its tensors change."""
     cache = getattr(bn, '_affine', None)
-    ver = (bn.weight._version, bn.bias._version, bn.running_var._version, bn.running_mean._version,
-           bn.weight.data_ptr(), bn.weight.device)
+    ver = _bn_key(bn)
     if cache is None or cache[0] != ver:
         with torch.no_grad():
             sc = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).float().contiguous()
             cache = (ver, sc, (bn.bias - bn.running_mean * sc).float().contiguous())
         bn._affine = cache
     return cache[1], cache[2]
+
+
+def refresh_bn_affines(model):
+    """Recompute the cached (scale, shift) of EVERY eval-mode, non-trainable BatchNorm of `model` with a
+    handful of launches (4 concatenations + 4 element-wise ops into persistent buffers) instead of four tiny
+    kernels per layer.  Called after the teacher EMA; the per-layer pairs are views of two persistent
+    buffers, so HIP graphs that captured them keep reading current values."""
+    bns = [m for m in model.modules() if isinstance(m, nn.BatchNorm2d) and not m.training and not m.weight.requires_grad]
+    if not bns:
+        return
+    eps = bns[0].eps
+    assert all(b.eps == eps for b in bns)
+    n = sum(b.num_features for b in bns)
+    buf = getattr(model, '_bn_affine_buf', None)
+    if buf is None or buf[0].numel() != n or buf[0].device != bns[0].weight.device:
+        buf = (torch.empty(n, dtype=torch.float32, device=bns[0].weight.device),
+               torch.empty(n, dtype=torch.float32, device=bns[0].weight.device))
+        model._bn_affine_buf = buf
+    with torch.no_grad():
+        w = torch.cat([b.weight.float() for b in bns])
+        var = torch.cat([b.running_var.float() for b in bns])
+        torch.mul(w, torch.rsqrt(var + eps), out=buf[0])
+        mean = torch.cat([b.running_mean.float() for b in bns])
+        bias = torch.cat([b.bias.float() for b in bns])
+        torch.sub(bias, mean * buf[0], out=buf[1])
+    o = 0
+    for b in bns:
+        c = b.num_features
+        b._affine = (_bn_key(b), buf[0][o:o + c], buf[1][o:o + c])
+        o += c
 
 
 def conv_bn(x, conv, bn, relu, residual=None):

@@ -14,7 +14,7 @@ import torch
 from .detectors import Student_FCOS, TS_P2B_FCOS
 from .obb import rbbox_overlaps
 from .obb_proposals import (MIL_gen_proposals_from_cfg, gen_negative_proposals, generate_black_paper_obb_masked,
-                            obb2poly, strong_augmentation_masked)
+                            obb2poly, strong_augmentation_images, strong_augmentation_masked)
 from .registry import DETECTORS
 
 
@@ -82,9 +82,13 @@ class RotatedFCOS_TS(TS_P2B_FCOS):
     def _cxcywh(boxes):
         return boxes[:, :4]
 
-    def _strong_aug(self, img, gt_points, gt_labels, pseudo_points, pseudo_labels, pseudo_bboxes):
+    def _strong_aug_images(self, img):
+        return strong_augmentation_images(img, params=self._inject.get('aug'))
+
+    def _strong_aug(self, img, gt_points, gt_labels, pseudo_points, pseudo_labels, pseudo_bboxes, params=None, imgs=None):
         return strong_augmentation_masked(img, gt_points, gt_labels, pseudo_points, pseudo_labels, pseudo_bboxes,
-                                          self.angle_version, params=self._inject.get('aug'))
+                                          self.angle_version, params=params if params is not None else self._inject.get('aug'),
+                                          imgs=imgs)
 
     def _black_paper(self, img, gt_bboxes, imgsize, draws):
         return generate_black_paper_obb_masked(img, gt_bboxes, self.prior_size, range(int(len(self.pattern) / 2)),

@@ -181,16 +181,25 @@ def _inside_masks(rot, scaled, scale, H, W, bh, bw):
     return m
 
 
+def strong_augmentation_images(img, params=None):
+    """The pixel half of strong_augmentation (depends only on the image and the draws), see
+    proposals.strong_augmentation_images.  Returns (params, list of [C,H,W])."""
+    B = img.shape[0]
+    params = params if params is not None else draw_strong_aug_params(B)
+    return params, [_aug_image(img[i], params[0][i], params[1][i], params[2][i]) for i in range(B)]
+
+
 def strong_augmentation_masked(img, gt_points, gt_labels, pseudo_points, pseudo_labels, pseudo_bboxes, angle_version,
-                               params=None):
+                               params=None, imgs=None):
     """Sync-free strong_augmentation: nothing is filtered; `gt_valid` / `pseudo_valid` say which
-    entries the reference would have kept (order preserved)."""
+    entries the reference would have kept (order preserved).  `imgs`: precomputed augmented images."""
     B, C, H, W = img.shape
     flips, angles, scales = params if params is not None else draw_strong_aug_params(B)
+    pre = imgs
     imgs, gp_l, pp_l, pb_l, gv_l, pv_l = [], [], [], [], [], []
     for i in range(B):
         f, a, s = flips[i], angles[i], scales[i]
-        imgs.append(_aug_image(img[i], f, a, s))
+        imgs.append(pre[i] if pre is not None else _aug_image(img[i], f, a, s))
         rot, scaled, out, (bh, bw) = _aug_xy(gt_points[i], f, a, s, H, W)
         gp_l.append(out)
         gv_l.append(_inside_masks(rot, scaled, s, H, W, bh, bw))

@@ -175,15 +175,27 @@ def _refine_boxes(b):
     return bbox_cxcywh_to_xyxy(torch.cat([x + w / 2, y + h / 2, w, h], dim=1))
 
 
-def strong_augmentation_masked(img, gt_points, gt_labels, pseudo_points, pseudo_labels, pseudo_bboxes, params=None):
+def strong_augmentation_images(img, params=None):
+    """The pixel half of strong_augmentation (:41-63, :93-111): it depends only on the input image and the
+    (flip, scale) draws, so the detector can produce it BEFORE the MIL stage and push clean and augmented
+    images through the student in one batched pass.  Returns (params, list of [C,H,W])."""
+    B = img.shape[0]
+    params = params if params is not None else draw_strong_aug_params(B)
+    return params, [_aug_image(img[i], params[0][i], params[1][i]) for i in range(B)]
+
+
+def strong_augmentation_masked(img, gt_points, gt_labels, pseudo_points, pseudo_labels, pseudo_bboxes, params=None,
+                               imgs=None):
     """Sync-free strong_augmentation: nothing is filtered; instead `gt_valid` / `pseudo_valid`
     masks say which entries the reference would have kept (order is preserved, so assigning
-    with the masks equals assigning the filtered lists)."""
+    with the masks equals assigning the filtered lists).  `imgs`: the augmented images when they
+    were already produced by strong_augmentation_images with the same `params`."""
     B, C, H, W = img.shape
     flips, scales = params if params is not None else draw_strong_aug_params(B)
+    pre = imgs
     imgs, gp_l, pp_l, pb_l, gv_l, pv_l = [], [], [], [], [], []
     for i in range(B):
-        imgs.append(_aug_image(img[i], flips[i], scales[i]))
+        imgs.append(pre[i] if pre is not None else _aug_image(img[i], flips[i], scales[i]))
         gp, _, gv = _aug_geometry(gt_points[i], None, flips[i], scales[i], H, W)
         pp, pb, pv = _aug_geometry(pseudo_points[i], pseudo_bboxes[i], flips[i], scales[i], H, W)
         gp_l.append(gp); gv_l.append(gv)

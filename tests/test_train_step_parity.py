@@ -141,6 +141,34 @@ def test_step1_loss_dict():
     _check(lv, ref)
 
 
+def test_teacher_bn_affine_follows_ema():
+    """The flat EMA kernel rewrites the teacher's BatchNorm weight/bias through raw pointers; the cached
+    (scale, shift) of the fused BN epilogue must follow (nn_modules.refresh_bn_affines)."""
+    dev = torch.device('cuda:0')
+    pta, cfg, model = _build(dev, phase2=True)
+    trainer = pta.Trainer(model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config)
+    img = _data(dev)[0].to(dev)
+    with torch.no_grad():
+        before = model.extract_feat(img, model.teacher)[0].clone()               # fills the caches
+        for m in model.student.backbone.modules():                               # a student whose BN differs from the teacher's
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.fill_(1.04)
+                m.bias.fill_(0.01)
+        for _ in range(3):
+            model.update_teacher_model(model.teacher, model.student, 0.5)
+        bn = model.teacher.backbone.layer3[1].bn2
+        torch.testing.assert_close(bn.weight, torch.full_like(bn.weight, 1 + 0.04 * (1 - 0.5 ** 3)))
+        fused = model.extract_feat(img, model.teacher)[0]
+        for m in model.teacher.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.fuse_epilogue = False
+        plain = model.extract_feat(img, model.teacher)[0]
+    scale = float(plain.abs().max())
+    assert float((fused - plain).abs().max()) < 1e-3 * scale          # the fused epilogue saw the EMA-updated affine
+    assert float((before - plain).abs().max()) > 0.05 * scale         # ... which really changed the features
+    del trainer
+
+
 def test_eval_path_detections():
     """simple_test (fcos_p2b_teacher_student.py:276-298 -> get_bboxes :796-1005 -> multiclass_nms): the
     teacher's detections on the GPU equal a restatement from the oracle pieces (sigmoid scores x
