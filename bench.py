@@ -49,6 +49,8 @@ def algorithmic_bytes(name, shapes):
     if name in ('pt_roi_align_fwd', 'pt_roi_align_bwd', 'pt_roi_align_rotated_fwd', 'pt_roi_align_rotated_bwd'):
         K, C, o = shapes['K'], shapes['C'], shapes['out']
         return K * C * o * o * 4            # the [K,C,7,7] block written (fwd) / read (bwd); the map stays in L2/MALL
+    if name in ('pt_affine_relu_fwd', 'pt_affine_relu_bwd'):
+        return shapes['n'] * 4 * shapes['streams']   # fp32 streams read + written per element (x, y, residual / g, y, gx, gres)
     if name == 'pt_ema_update':
         return shapes['n'] * 12             # read teacher+student, write teacher
     if name == 'pt_sgd_step':
@@ -131,6 +133,10 @@ def main():
             shp = None
             if fn in ('pt_roi_align_fwd', 'pt_roi_align_bwd', 'pt_roi_align_rotated_fwd', 'pt_roi_align_rotated_bwd'):
                 shp = dict(K=a[6], C=a[3], out=a[7])
+            elif fn == 'pt_affine_relu_fwd':
+                shp = dict(n=a[4], streams=2 + (a[3] is not None))
+            elif fn == 'pt_affine_relu_bwd':
+                shp = dict(n=a[3], streams=1 + (a[1] is not None) + (a[7] is not None) + (a[8] is not None))
             elif fn in ('pt_ema_update', 'pt_sgd_step', 'pt_sqnorm_partial'):
                 shp = dict(n=a[2] if fn == 'pt_ema_update' else (a[3] if fn == 'pt_sgd_step' else a[1]))
             prof.setdefault(fn, []).append((e0, e1, shp))

@@ -119,6 +119,22 @@ extern "C" int pt_sgd_step(float* param, const float* grad, float* momentum_buf,
 // `inner` = H*W for NCHW tensors and 1 for channels_last ones (channel = (i / inner) % C).
 namespace pt {
 
+// Channel bookkeeping without per-element 64-bit division: a thread walks the tensor with a fixed stride, so
+// the channel of its float4 advances by a fixed step modulo C (channels_last, inner == 1), or is recomputed
+// with one division per float4 (NCHW - not on the benchmark path).
+struct ChanWalk {
+  int c, step, C;
+  __device__ __forceinline__ ChanWalk(long i0, long stride, int C_) : C(C_) {
+    c = (int)((i0 << 2) % C_);
+    step = (int)((stride << 2) % C_);
+  }
+  __device__ __forceinline__ void next() {
+    c += step;
+    c = c >= C ? c - C : c;
+  }
+};
+
+template <bool CL>
 __global__ void __launch_bounds__(256)
     affine_relu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                            const float* __restrict__ shift, const float* __restrict__ res, long n4, int C,
@@ -126,26 +142,30 @@ __global__ void __launch_bounds__(256)
   const float4* x4 = reinterpret_cast<const float4*>(x);
   const float4* r4 = reinterpret_cast<const float4*>(res);
   float4* y4 = reinterpret_cast<float4*>(y);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  ChanWalk w(i, stride, C);
+  for (; i < n4; i += stride) {
     float4 v = x4[i];
-    const long e = i << 2;
-    float s[4], b[4];
-    if (inner == 1) {              // channels_last: 4 consecutive channels (C % 4 == 0)
-      const int c = (int)(e % C);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { s[k] = scale[c + k]; b[k] = shift[c + k]; }
+    float4 s, b;
+    if (CL) {                      // 4 consecutive channels (C % 4 == 0): two aligned 16-byte loads
+      s = *reinterpret_cast<const float4*>(scale + w.c);
+      b = *reinterpret_cast<const float4*>(shift + w.c);
+      w.next();
     } else {                       // NCHW: inner % 4 == 0 -> one channel for the whole float4
-      const int c = (int)((e / inner) % C);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { s[k] = scale[c]; b[k] = shift[c]; }
+      const int c = (int)(((i << 2) / inner) % C);
+      const float sc = scale[c], sh = shift[c];
+      s = make_float4(sc, sc, sc, sc);
+      b = make_float4(sh, sh, sh, sh);
     }
-    v.x = v.x * s[0] + b[0]; v.y = v.y * s[1] + b[1]; v.z = v.z * s[2] + b[2]; v.w = v.w * s[3] + b[3];
+    v.x = v.x * s.x + b.x; v.y = v.y * s.y + b.y; v.z = v.z * s.z + b.z; v.w = v.w * s.w + b.w;
     if (res) { const float4 r = r4[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
     if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     y4[i] = v;
   }
 }
 
+template <bool CL>
 __global__ void __launch_bounds__(256)
     affine_relu_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ scale,
                            long n4, int C, long inner, int relu, float* __restrict__ gx, float* __restrict__ gres) {
@@ -153,7 +173,10 @@ __global__ void __launch_bounds__(256)
   const float4* y4 = reinterpret_cast<const float4*>(y);
   float4* gx4 = reinterpret_cast<float4*>(gx);
   float4* gr4 = reinterpret_cast<float4*>(gres);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  ChanWalk w(i, stride, C);
+  for (; i < n4; i += stride) {
     float4 v = g4[i];
     if (relu) {
       const float4 o = y4[i];
@@ -161,16 +184,16 @@ __global__ void __launch_bounds__(256)
     }
     if (gres) gr4[i] = v;
     if (gx) {
-      const long e = i << 2;
-      if (inner == 1) {
-        const int c = (int)(e % C);
-        v.x *= scale[c]; v.y *= scale[c + 1]; v.z *= scale[c + 2]; v.w *= scale[c + 3];
+      if (CL) {
+        const float4 s = *reinterpret_cast<const float4*>(scale + w.c);
+        v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
       } else {
-        const float s = scale[(int)((e / inner) % C)];
+        const float s = scale[(int)(((i << 2) / inner) % C)];
         v.x *= s; v.y *= s; v.z *= s; v.w *= s;
       }
       gx4[i] = v;
     }
+    if (CL) w.next();
   }
 }
 
@@ -189,8 +212,12 @@ extern "C" int pt_affine_relu_fwd(const float* x, const float* scale, const floa
   PT_REQUIRE(x && scale && shift && y, PT_EINVAL, "pt_affine_relu_fwd: NULL pointer");
   int rc = affine_check("pt_affine_relu_fwd", n, C, inner);
   if (rc) return rc;
-  hipLaunchKernelGGL(affine_relu_fwd_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, as_stream(stream), x, scale, shift,
-                     residual, (long)(n / 4), C, (long)inner, relu, y);
+  if (inner == 1)
+    hipLaunchKernelGGL(affine_relu_fwd_kernel<true>, dim3(stream_blocks(n / 4)), dim3(256), 0, as_stream(stream), x, scale,
+                       shift, residual, (long)(n / 4), C, (long)inner, relu, y);
+  else
+    hipLaunchKernelGGL(affine_relu_fwd_kernel<false>, dim3(stream_blocks(n / 4)), dim3(256), 0, as_stream(stream), x,
+                       scale, shift, residual, (long)(n / 4), C, (long)inner, relu, y);
   PT_LAUNCH_CHECK("pt_affine_relu_fwd");
   return PT_OK;
 }
@@ -201,8 +228,12 @@ extern "C" int pt_affine_relu_bwd(const float* grad_y, const float* y, const flo
   PT_REQUIRE(grad_y && scale && (grad_x || grad_res) && (!relu || y), PT_EINVAL, "pt_affine_relu_bwd: NULL pointer");
   int rc = affine_check("pt_affine_relu_bwd", n, C, inner);
   if (rc) return rc;
-  hipLaunchKernelGGL(affine_relu_bwd_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, as_stream(stream), grad_y, y,
-                     scale, (long)(n / 4), C, (long)inner, relu, grad_x, grad_res);
+  if (inner == 1)
+    hipLaunchKernelGGL(affine_relu_bwd_kernel<true>, dim3(stream_blocks(n / 4)), dim3(256), 0, as_stream(stream), grad_y,
+                       y, scale, (long)(n / 4), C, (long)inner, relu, grad_x, grad_res);
+  else
+    hipLaunchKernelGGL(affine_relu_bwd_kernel<false>, dim3(stream_blocks(n / 4)), dim3(256), 0, as_stream(stream), grad_y,
+                       y, scale, (long)(n / 4), C, (long)inner, relu, grad_x, grad_res);
   PT_LAUNCH_CHECK("pt_affine_relu_bwd");
   return PT_OK;
 }

@@ -153,6 +153,114 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// Both axes at once, zeroing only the columns the RoI touches (3 barriers, ~7*(nx+ny) LDS words cleared
+// instead of 2*7*256).  Same arithmetic as axis_weights().
+__device__ void axis_weights2(float sx, float bx, int gx, int Lx, float sy, float by, int gy, int Ly, int out_size,
+                              AxisW* AX, AxisW* AY) {
+  if (threadIdx.x < NB) { AX->lo[threadIdx.x] = 1 << 30; AX->hi[threadIdx.x] = -1; }
+  else if (threadIdx.x < 2 * NB) { AY->lo[threadIdx.x - NB] = 1 << 30; AY->hi[threadIdx.x - NB] = -1; }
+  if (threadIdx.x == 32) { AX->o = 1 << 30; AX->e = -1; AY->o = 1 << 30; AY->e = -1; }
+  __syncthreads();
+  const int nxs = out_size * gx, nys = out_size * gy;
+  for (int t = threadIdx.x; t < nxs + nys; t += blockDim.x) {   // pass 1: extents
+    const bool isx = t < nxs;
+    const int u = isx ? t : t - nxs, grid = isx ? gx : gy, L = isx ? Lx : Ly;
+    const float start = isx ? sx : sy, bin = isx ? bx : by;
+    AxisW* A = isx ? AX : AY;
+    const int p = u / grid, i = u - p * grid;
+    float v = start + p * bin + (i + .5f) * bin / (float)grid;
+    if (v < -1.0f || v > (float)L) continue;
+    if (v <= 0.f) v = 0.f;
+    int l = (int)v, h;
+    if (l >= L - 1) { h = l = L - 1; } else { h = l + 1; }
+    atomicMin(&A->o, l);
+    atomicMax(&A->e, h);
+  }
+  __syncthreads();
+  const int ox = AX->o, oy = AY->o;
+  const int nx = max(AX->e - ox + 1, 0), ny = max(AY->e - oy + 1, 0);
+  for (int t = threadIdx.x; t < NB * (nx + ny); t += blockDim.x) {   // clear only what is used
+    if (t < NB * nx) AX->w[t / nx][t % nx] = 0.f;
+    else { const int u = t - NB * nx; AY->w[u / ny][u % ny] = 0.f; }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < nxs + nys; t += blockDim.x) {   // pass 2: weights and bands
+    const bool isx = t < nxs;
+    const int u = isx ? t : t - nxs, grid = isx ? gx : gy, L = isx ? Lx : Ly, o = isx ? ox : oy;
+    const float start = isx ? sx : sy, bin = isx ? bx : by;
+    AxisW* A = isx ? AX : AY;
+    const int p = u / grid, i = u - p * grid;
+    float v = start + p * bin + (i + .5f) * bin / (float)grid;
+    if (v < -1.0f || v > (float)L) continue;
+    if (v <= 0.f) v = 0.f;
+    int l = (int)v, h;
+    if (l >= L - 1) { h = l = L - 1; v = (float)l; } else { h = l + 1; }
+    const float fl = v - (float)l, fh = 1.f - fl;
+    atomicAdd(&A->w[p][l - o], fh);
+    atomicAdd(&A->w[p][h - o], fl);
+    atomicMin(&A->lo[p], l - o);
+    atomicMax(&A->hi[p], h - o);
+  }
+  __syncthreads();
+}
+
+// Forward for out_size == 7 (every config): the 49 bin sums of channel c live in 49 REGISTERS of thread c.
+// Per footprint pixel: one coalesced global read + 7 FMAs against the dense per-bin column weights (LDS
+// broadcast), per footprint row: 49 FMAs against the row weights.  The LDS tile is written once, for the
+// transpose to the [C][49] output order.
+__global__ void __launch_bounds__(256)
+    roi_align_fwd_cl7(const float* __restrict__ feat, const float* __restrict__ rois, int B, int C, int H, int W,
+                      float scale, int sampling_ratio, int aligned, float* __restrict__ out,
+                      const int* __restrict__ fallback) {
+  extern __shared__ float tile[];  // [49][C+1]
+  __shared__ AxisW AX, AY;
+  const int k = blockIdx.x;
+  if (fallback && !fallback[k]) return;   // this RoI was done by the small-footprint kernel
+  const RoiGeom g = roi_geom(rois + (size_t)k * 5, 7, scale, sampling_ratio, aligned, B);
+  const int ld = C + 1;
+  axis_weights2(g.start_w, g.bin_w, g.grid_w, W, g.start_h, g.bin_h, g.grid_h, H, 7, &AX, &AY);
+  const float* fb = feat + (size_t)g.b * H * W * C;
+  const int ny = AY.e - AY.o + 1, nx = AX.e - AX.o + 1;
+  const float inv = 1.f / g.inv_count;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float acc[7][7];
+#pragma unroll
+    for (int a = 0; a < 7; ++a)
+#pragma unroll
+      for (int b = 0; b < 7; ++b) acc[a][b] = 0.f;
+    if (nx > 0 && ny > 0) {
+      for (int py = 0; py < ny; ++py) {
+        const float* row = fb + ((size_t)(AY.o + py) * W + AX.o) * C + c;
+        float t[7];
+#pragma unroll
+        for (int b = 0; b < 7; ++b) t[b] = 0.f;
+        for (int px = 0; px < nx; ++px) {
+          const float v = row[(size_t)px * C];
+#pragma unroll
+          for (int b = 0; b < 7; ++b) t[b] += AX.w[b][px] * v;
+        }
+#pragma unroll
+        for (int a = 0; a < 7; ++a) {
+          const float wy = AY.w[a][py];
+#pragma unroll
+          for (int b = 0; b < 7; ++b) acc[a][b] += wy * t[b];
+        }
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 7; ++a)
+#pragma unroll
+      for (int b = 0; b < 7; ++b) tile[(a * 7 + b) * ld + c] = acc[a][b] / g.inv_count;
+  }
+  (void)inv;
+  __syncthreads();
+  float* ob = out + (size_t)k * C * 49;
+  for (int o = threadIdx.x; o < C * 49; o += blockDim.x) {
+    const int c = o / 49, bin = o - c * 49;
+    ob[o] = tile[bin * ld + c];
+  }
+}
+
 // Backward, channels_last, generic: one workgroup per RoI; with the separable weights a RoI issues
 // ONE f32 atomic per footprint pixel and channel (256 contiguous bytes per wave instruction - the
 // full-rate shape) instead of 4 per bilinear tap.  RoIs whose bag was reduced on chip by the
@@ -489,8 +597,20 @@ extern "C" int pt_roi_align_fwd(const float* feat, const float* rois, int B, int
       PT_LAUNCH_CHECK("pt_roi_align_fwd(small)");
       fb = group_ws;
     }
-    hipLaunchKernelGGL(roi_align_fwd_cl, dim3(K), dim3(256), lds, s, feat, rois, B, C, H, W, out_size, spatial_scale,
-                       sampling_ratio, aligned, out, fb, group);
+    if (out_size == 7) {
+      static size_t attr7 = 0;
+      if (lds > attr7) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_cl7),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error("pt_roi_align_fwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr7 = lds;
+      }
+      hipLaunchKernelGGL(roi_align_fwd_cl7, dim3(K), dim3(256), lds, s, feat, rois, B, C, H, W, spatial_scale,
+                         sampling_ratio, aligned, out, fb);
+    } else {
+      hipLaunchKernelGGL(roi_align_fwd_cl, dim3(K), dim3(256), lds, s, feat, rois, B, C, H, W, out_size, spatial_scale,
+                         sampling_ratio, aligned, out, fb, group);
+    }
   } else {
     const long total = (long)K * C * out_size * out_size;
     int nb = cdiv(total, 256);

@@ -11,7 +11,7 @@ import torch.nn.functional as TF
 
 from . import functional as F
 from .core import (bbox2roi, bbox_cxcywh_to_xyxy, bbox_overlaps, bbox_xyxy_to_cxcywh, distance2bbox, multi_apply,
-                   multiclass_nms, reduce_mean)
+                   multiclass_nms, reduce_mean, reduce_mean_many)
 from .losses import diou_forward_masked
 from .nn_modules import ConvModule, Scale
 from .proposals import MIL_gen_proposals_from_cfg
@@ -199,14 +199,16 @@ class TS_P2BFCOSHead(nn.Module):
                 mean_iou, list(torch.split(valid, counts)))
 
     # --------------------------------------------------------------------- losses --
-    def _reg_branch(self, points, B, fr, ft, gi_reg, boxes, box_labels, off, loss_mod, dn):
+    def _reg_branch(self, points, B, fr, ft, gi_reg, boxes, box_labels, off, loss_mod, dn, cls_pos=None):
         """Shared tail of loss_pseudo (:436-463) and loss (:502-532): targets, centerness-weighted
-        (DN-)DIoU and centerness BCE, dense over all B*P points with the positive mask."""
+        (DN-)DIoU and centerness BCE, dense over all B*P points with the positive mask.  `cls_pos`
+        (optional device scalar): the positive count of the classification branch, reduced over the
+        ranks together with this branch's two normalisers; returned as a third value then."""
         P = points.shape[0]
         labels_reg, tg, ctr_t = F.fcos_targets(points, gi_reg, boxes, box_labels, off, B, self.num_classes)
         pos = labels_reg < self.num_classes
-        num_pos = reduce_mean(pos.sum().float()).clamp(min=1.0)
-        ctr_den = reduce_mean(ctr_t.sum().detach()).clamp(min=1e-6)
+        norms = reduce_mean_many(pos.sum(), ctr_t.sum().detach(), *([cls_pos] if cls_pos is not None else []))
+        num_pos, ctr_den = norms[0].clamp(min=1.0), norms[1].clamp(min=1e-6)
         pts = points.repeat(B, 1)
         pred = distance2bbox(pts, fr.reshape(-1, 4))
         tgt = distance2bbox(pts, tg)
@@ -216,6 +218,8 @@ class TS_P2BFCOSHead(nn.Module):
             loss_bbox = diou_forward_masked(loss_mod, pred, tgt, pos, ctr_t, ctr_den)
         bce = TF.binary_cross_entropy_with_logits(ft.reshape(-1), ctr_t, reduction='none')
         loss_ctr = self.loss_centerness.loss_weight * torch.where(pos, bce, torch.zeros_like(bce)).sum() / num_pos
+        if cls_pos is not None:
+            return loss_bbox, loss_ctr, norms[2].clamp(min=1.0)
         return loss_bbox, loss_ctr
 
     def loss_pseudo(self, cls_scores, bbox_preds, centernesses, all_level_points, gt_points, gt_labels, pseudo_points,
@@ -234,16 +238,16 @@ class TS_P2BFCOSHead(nn.Module):
         gi_cls = F.topk_assign(points, torch.cat(gt_points), goff, B, self.assigner.num_pre,
                                gt_valid=_cat(gt_valid) if gt_valid is not None else None)
         labels, _, _ = F.fcos_targets(points, gi_cls, None, torch.cat(gt_labels), goff, B, self.num_classes)
-        num_pos = reduce_mean((labels < self.num_classes).sum().float()).clamp(min=1.0)
-        loss_cls = self.loss_cls(fc.reshape(-1, self.cls_out_channels), labels, weight=None, avg_factor=num_pos)
         # regression: pseudo_assigner (3,3) on the pseudo-box centres (:683-706)
         pcounts = [int(b.shape[0]) for b in pseudo_bboxes]
         poff, _ = F.make_offsets(pcounts, dev)
         pb = torch.cat(pseudo_bboxes)
         gi_reg = F.topk_assign(points, bbox_xyxy_to_cxcywh(pb), poff, B, self.pseudo_assigner.num_pre,
                                gt_valid=_cat(pseudo_valid) if pseudo_valid is not None else None)
-        loss_bbox, loss_ctr = self._reg_branch(points, B, fr, ft, gi_reg, pb, torch.cat(pseudo_labels), poff,
-                                               self.loss_bbox_burn2, dn=True)
+        loss_bbox, loss_ctr, num_pos = self._reg_branch(points, B, fr, ft, gi_reg, pb, torch.cat(pseudo_labels), poff,
+                                                        self.loss_bbox_burn2, dn=True,
+                                                        cls_pos=(labels < self.num_classes).sum())
+        loss_cls = self.loss_cls(fc.reshape(-1, self.cls_out_channels), labels, weight=None, avg_factor=num_pos)
         return loss_cls, loss_bbox, loss_ctr
 
     def loss(self, cls_scores, bbox_preds, centernesses, all_level_points, gt_bboxes, img_metas, gt_bboxes_ignore=None,

@@ -14,7 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as TF
 
 from . import functional as F
-from .core import bbox_cxcywh_to_xyxy, bbox_xyxy_to_cxcywh, multi_apply, reduce_mean
+from .core import bbox_cxcywh_to_xyxy, bbox_xyxy_to_cxcywh, multi_apply, reduce_mean_many
 from .head import TS_P2BFCOSHead, _cat
 from .nn_modules import Scale
 from .obb import multiclass_nms_rotated, rbbox2roi, rbbox_overlaps
@@ -120,13 +120,14 @@ class TS_P2RBRotatedFCOSHead(TS_P2BFCOSHead):
                 mean_iou, list(torch.split(valid, counts)))
 
     # --------------------------------------------------------------------- losses --
-    def _reg_branch_obb(self, points, B, fr, ft, gi_reg, boxes5, box_labels, off):
+    def _reg_branch_obb(self, points, B, fr, ft, gi_reg, boxes5, box_labels, off, cls_pos=None):
         """Shared tail of loss_pseudo (:483-512) and loss (:583-624): oriented targets, centerness-weighted
-        RotatedIoULoss and centerness BCE, dense over all B*P points with the positive mask."""
+        RotatedIoULoss and centerness BCE, dense over all B*P points with the positive mask.  `cls_pos`: see
+        TS_P2BFCOSHead._reg_branch (one coalesced all-reduce for the normalisers of a loss call)."""
         labels_reg, tg, ang, ctr_t = F.fcos_targets_obb(points, gi_reg, boxes5, box_labels, off, B, self.num_classes)
         pos = labels_reg < self.num_classes
-        num_pos = reduce_mean(pos.sum().float()).clamp(min=1.0)
-        ctr_den = reduce_mean(ctr_t.sum().detach()).clamp(min=1e-6)
+        norms = reduce_mean_many(pos.sum(), ctr_t.sum().detach(), *([cls_pos] if cls_pos is not None else []))
+        num_pos, ctr_den = norms[0].clamp(min=1.0), norms[1].clamp(min=1e-6)
         pts = points.repeat(B, 1)
         pred = self.bbox_coder.decode(pts, fr.reshape(-1, 5))
         tgt = self.bbox_coder.decode(pts, torch.cat([tg, ang], dim=-1))
@@ -138,6 +139,8 @@ class TS_P2RBRotatedFCOSHead(TS_P2BFCOSHead):
         loss_bbox = self.loss_bbox.loss_weight * torch.where(pos, elem * ctr_t, torch.zeros_like(elem)).sum() / ctr_den
         bce = TF.binary_cross_entropy_with_logits(ft.reshape(-1), ctr_t, reduction='none')
         loss_ctr = self.loss_centerness.loss_weight * torch.where(pos, bce, torch.zeros_like(bce)).sum() / num_pos
+        if cls_pos is not None:
+            return loss_bbox, loss_ctr, norms[2].clamp(min=1.0)
         return loss_bbox, loss_ctr
 
     def loss_pseudo(self, cls_scores, bbox_preds, angle_preds, centernesses, all_level_points, gt_points, gt_labels,
@@ -154,14 +157,14 @@ class TS_P2RBRotatedFCOSHead(TS_P2BFCOSHead):
         gi_cls = F.topk_assign(points, torch.cat(gt_points), goff, B, self.assigner.num_pre,
                                gt_valid=_cat(gt_valid) if gt_valid is not None else None)
         labels, _, _ = F.fcos_targets(points, gi_cls, None, torch.cat(gt_labels), goff, B, self.num_classes)
-        num_pos = reduce_mean((labels < self.num_classes).sum().float()).clamp(min=1.0)
-        loss_cls = self.loss_cls(fc.reshape(-1, self.cls_out_channels), labels, weight=None, avg_factor=num_pos)
         pcounts = [int(b.shape[0]) for b in pseudo_bboxes]
         poff, _ = F.make_offsets(pcounts, dev)
         pb = torch.cat(pseudo_bboxes)
         gi_reg = F.topk_assign(points, pb, poff, B, self.pseudo_assigner.num_pre,
                                gt_valid=_cat(pseudo_valid) if pseudo_valid is not None else None)
-        loss_bbox, loss_ctr = self._reg_branch_obb(points, B, fr, ft, gi_reg, pb, torch.cat(pseudo_labels), poff)
+        loss_bbox, loss_ctr, num_pos = self._reg_branch_obb(points, B, fr, ft, gi_reg, pb, torch.cat(pseudo_labels), poff,
+                                                            cls_pos=(labels < self.num_classes).sum())
+        loss_cls = self.loss_cls(fc.reshape(-1, self.cls_out_channels), labels, weight=None, avg_factor=num_pos)
         return loss_cls, loss_bbox, loss_ctr
 
     def loss(self, cls_scores, bbox_preds, angle_preds, centernesses, all_level_points, gt_bboxes, img_metas,

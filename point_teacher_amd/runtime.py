@@ -57,6 +57,7 @@ class FlatParams:
         self.numel = sum(p.numel() for _, p in self.order)
         off = 0
         self.slices = {}
+        self.train_params, self.grad_views = [], []
         with torch.no_grad():
             for name, p in self.order:
                 n = p.numel()
@@ -77,12 +78,33 @@ class FlatParams:
                 t.data = view(self.teacher_flat)
                 if p.requires_grad:
                     p.grad = view(self.grad_flat)
+                    self.train_params.append(p)
+                    self.grad_views.append(p.grad)
                 self.slices[name] = (off, n)
                 off += (n + 3) // 4 * 4
         model._flat = (self.teacher_flat, self.student_flat)
 
     def zero_grad(self):
         self.grad_flat.zero_()
+
+    def detach_grads(self):
+        """Let autograd hand over freshly computed gradients instead of adding them, one small launch per
+        parameter, into the (zeroed) flat buffer: with `.grad = None` AccumulateGrad keeps the incoming tensor."""
+        for p in self.train_params:
+            p.grad = None
+
+    def gather_grads(self):
+        """Copy the gradients autograd left in `.grad` into the flat buffer with multi-tensor copies (segments of
+        parameters that received none stay zero), then drop them."""
+        dst, src = [], []
+        for p, v in zip(self.train_params, self.grad_views):
+            if p.grad is not None:
+                dst.append(v)
+                src.append(p.grad)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        for p, v in zip(self.train_params, self.grad_views):
+            p.grad = v
 
     def check_views(self):
         """Autograd must have accumulated in place: every .grad still aliases the flat buffer."""
@@ -124,6 +146,89 @@ class GradReducer:
                 dist.all_reduce(g[s:s + step])
         cur.wait_stream(self.stream)
         return g
+
+
+class BucketedGradExchange:
+    """Mean of the flat gradient over the data-parallel ranks, OVERLAPPED with backward.
+
+    The trainable segment of the flat gradient buffer is cut into `n_buckets` contiguous ranges on parameter
+    boundaries.  A post-accumulate hook on every parameter counts arrivals; when the last gradient of a bucket
+    has been produced the bucket is copied into the flat buffer with one multi-tensor copy and its all-reduce
+    (RCCL over xGMI; a few large messages, xGMI being point-to-point) is issued on a side stream while autograd
+    keeps computing the earlier layers.  `finish()` flushes buckets whose parameters received no gradient in
+    this iteration (their segment stays zero) and joins the side stream.  gloo / CPU: same logic, synchronous."""
+
+    def __init__(self, flat, n_buckets=6, device=None):
+        self.flat = flat
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.stream = torch.cuda.Stream(device=device) if (device is not None and device.type == 'cuda') else None
+        total = flat.n_train
+        target = max(total // max(int(n_buckets), 1), 1)
+        self.buckets = []                      # [start, end, [(param, view)]]
+        cur, start, acc = [], 0, 0
+        off = 0
+        for p, v in zip(flat.train_params, flat.grad_views):
+            n = (p.numel() + 3) // 4 * 4
+            cur.append((p, v))
+            off += n
+            acc += n
+            if acc >= target:
+                self.buckets.append([start, off, cur])
+                cur, start, acc = [], off, 0
+        if cur:
+            self.buckets.append([start, off, cur])
+        assert off == total, (off, total)
+        self.bucket_of = {id(p): b for b, (_, _, ps) in enumerate(self.buckets) for p, _ in ps}
+        self.left, self.done, self.active = [0] * len(self.buckets), [True] * len(self.buckets), False
+        for p in flat.train_params:
+            p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def begin(self):
+        self.left = [len(ps) for _, _, ps in self.buckets]
+        self.done = [False] * len(self.buckets)
+        self.active = True
+
+    def _on_grad(self, p):
+        if not self.active:
+            return
+        b = self.bucket_of[id(p)]
+        self.left[b] -= 1
+        if self.left[b] == 0:
+            self._flush(b)
+
+    def _flush(self, b):
+        start, end, ps = self.buckets[b]
+        dst, src = [], []
+        for p, v in ps:
+            if p.grad is not None:
+                dst.append(v)
+                src.append(p.grad)
+        if dst:
+            with torch.no_grad():
+                torch._foreach_copy_(dst, src)
+        for p, _ in ps:
+            p.grad = None                      # the copy in the flat buffer is the gradient from here on
+        g = self.flat.grad_flat[start:end]
+        if self.world > 1:
+            if self.stream is None:
+                g.div_(self.world)
+                dist.all_reduce(g)
+            else:
+                self.stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self.stream):
+                    g.div_(self.world)
+                    dist.all_reduce(g)
+        self.done[b] = True
+
+    def finish(self):
+        for b in range(len(self.buckets)):
+            if not self.done[b]:
+                self._flush(b)
+        self.active = False
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        for p, v in zip(self.flat.train_params, self.flat.grad_views):
+            p.grad = v
 
 
 class StepLR:
@@ -173,6 +278,8 @@ class Trainer:
         self.iter = 0
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         self.reducer = GradReducer(grad_chunks, dev)
+        # N > 1: bucketed exchange overlapped with backward; N == 1: nothing to exchange, one gather after backward
+        self.exchange = BucketedGradExchange(self.flat, max(grad_chunks, 1) + 2, dev) if self.world > 1 else None
         self.autocast_dtype = autocast_dtype
         self._broadcast_initial_state()
 
@@ -192,6 +299,7 @@ class Trainer:
         backward, gradient exchange, clip + SGD.  Returns train_step's dict."""
         self._set_lr()
         self.flat.zero_grad()
+        self.flat.detach_grads()
         if self.channels_last:
             data = dict(data, img=data['img'].contiguous(memory_format=torch.channels_last))
         if self.autocast_dtype is not None:
@@ -199,8 +307,13 @@ class Trainer:
                 out = self.model.train_step(data, None)
         else:
             out = self.model.train_step(data, None)
-        out['loss'].backward()
-        self.reducer.reduce_(self.flat.grad_flat)
+        if self.exchange is not None:
+            self.exchange.begin()
+            out['loss'].backward()
+            self.exchange.finish()
+        else:
+            out['loss'].backward()
+            self.flat.gather_grads()
         f = self.flat
         sq = F.grad_sqnorm(f.grad_flat) if self.max_norm > 0 else None
         F.sgd_step_(f.student_flat[:f.n_train], f.grad_flat, f.mom_flat, f.n_weights, self.lr_t, self.momentum,

@@ -33,6 +33,42 @@ def _worker(rank, world, port, q):
         assert red.world == world and red.stream is None
         out = red.reduce_(g.clone())
         torch.testing.assert_close(out, expect, rtol=1e-6, atol=1e-6)
+        # bucketed exchange overlapped with backward (runtime.BucketedGradExchange) on a toy teacher/student pair
+        from point_teacher_amd.runtime import BucketedGradExchange, FlatParams
+
+        class Pair(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                def net():
+                    return torch.nn.Sequential(torch.nn.Linear(37, 64), torch.nn.ReLU(), torch.nn.Linear(64, 50),
+                                               torch.nn.ReLU(), torch.nn.Linear(50, 3), torch.nn.Linear(3, 3))
+                self.student, self.teacher = net(), net()
+        torch.manual_seed(7)                                     # same weights on both ranks
+        pair = Pair()
+        for q_ in pair.student[5].parameters():                  # a layer that never receives a gradient
+            pass
+        flat = FlatParams(pair)
+        ex = BucketedGradExchange(flat, n_buckets=3, device=None)
+        assert len(ex.buckets) >= 2 and ex.buckets[-1][1] == flat.n_train
+        torch.manual_seed(200 + rank)
+        x = torch.randn(16, 37)
+        for it in range(2):                                      # twice: hooks and views survive an iteration
+            flat.zero_grad(); flat.detach_grads()
+            ex.begin()
+            pair.student[:5](x).pow(2).mean().backward()         # student[5] unused -> its segment must stay zero
+            ex.finish()
+            ref = Pair(); ref.load_state_dict(pair.state_dict())
+            ref.student[:5](x).pow(2).mean().backward()
+            mine = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in ref.student.parameters()])
+            gathered = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(gathered, mine)
+            expect_named = sum(gathered) / world
+            o = 0
+            for name, p in ref.student.named_parameters():
+                off, n = flat.slices[name]
+                torch.testing.assert_close(flat.grad_flat[off:off + n], expect_named[o:o + n], rtol=1e-5, atol=1e-6)
+                o += n
+            assert flat.check_views()
         # normalisers: every rank sees the mean of the per-rank counts
         npos = reduce_mean(torch.tensor(float(10 + 4 * rank)))
         assert float(npos) == pytest.approx(sum(10 + 4 * r for r in range(world)) / world)
