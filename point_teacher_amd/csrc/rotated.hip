@@ -232,6 +232,227 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---- channels_last fast path: one workgroup per RoI, one thread per channel --------------------
+// The <= 196 sample taps of a RoI (49 bins x <= 4 samples; config: sample_num = 2) are computed ONCE by the
+// first threads (one sin/cos per sample instead of one per output element) and shared through LDS.  The
+// samples of a tiny oriented object revisit the same few feature pixels (footprint 9-36 px for 784 neighbour
+// reads), so the footprint is staged on chip: [F][C] floats in LDS, thread c owning column c.
+//   forward : footprint rows are read once (1 KiB coalesced each), the 784 neighbour reads hit LDS;
+//   backward: gradients accumulate into the LDS footprint with plain read-modify-writes and are flushed with
+//             ONE global atomic per footprint pixel and channel instead of four per sample.
+// RoIs whose footprint exceeds RR_FMAX pixels read / scatter directly.
+constexpr int RR_MAXS = 196;       // samples per RoI on the fast path
+constexpr int RR_FMAX = 48;        // footprint pixels staged on chip
+
+struct RTaps {
+  int4 o[RR_MAXS];                 // neighbour index: y*W+x, rewritten to the footprint-local index when staged
+  float4 w[RR_MAXS];               // bilinear weights / count (0 for samples outside the map)
+  int y0, y1, x0, x1;              // bounding box of every neighbour
+};
+
+// Returns (block-uniform) the number of footprint pixels if the RoI is staged on chip, 0 if it is not, -1 if
+// every sample lies outside the map.
+__device__ __forceinline__ int rroi_taps(const RRoi& g, int out_size, int H, int W, RTaps* T) {
+  if (threadIdx.x == 0) { T->y0 = 1 << 30; T->x0 = 1 << 30; T->y1 = -1; T->x1 = -1; }
+  __syncthreads();
+  const int per = g.grid_h * g.grid_w, n = out_size * out_size * per;
+  int ly0 = 1 << 30, lx0 = 1 << 30, ly1 = -1, lx1 = -1;
+  for (int t = threadIdx.x; t < n; t += blockDim.x) {
+    const int bin = t / per, sidx = t - bin * per;
+    const int ph = bin / out_size, pw = bin - ph * out_size;
+    const int iy = sidx / g.grid_w, ix = sidx - iy * g.grid_w;
+    const float yy = g.start_h + ph * g.bin_h + (iy + .5f) * g.bin_h / (float)g.grid_h;
+    const float xx = g.start_w + pw * g.bin_w + (ix + .5f) * g.bin_w / (float)g.grid_w;
+    const float y = yy * g.cosv - xx * g.sinv + g.ch;
+    const float x = yy * g.sinv + xx * g.cosv + g.cw;
+    const Tap4 q = tap4(y, x, H, W);
+    const float m = q.valid ? 1.f / g.count : 0.f;
+    T->o[t] = make_int4((q.y0 << 16) | q.x0, (q.y0 << 16) | q.x1, (q.y1 << 16) | q.x0, (q.y1 << 16) | q.x1);
+    T->w[t] = make_float4(q.w1 * m, q.w2 * m, q.w3 * m, q.w4 * m);
+    if (q.valid) {
+      ly0 = min(ly0, q.y0); ly1 = max(ly1, q.y1);
+      lx0 = min(lx0, q.x0); lx1 = max(lx1, q.x1);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {                       // one LDS atomic per wave instead of one per sample
+    ly0 = min(ly0, __shfl_xor(ly0, o, 64)); ly1 = max(ly1, __shfl_xor(ly1, o, 64));
+    lx0 = min(lx0, __shfl_xor(lx0, o, 64)); lx1 = max(lx1, __shfl_xor(lx1, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0 && ly1 >= 0) {
+    atomicMin(&T->y0, ly0); atomicMax(&T->y1, ly1);
+    atomicMin(&T->x0, lx0); atomicMax(&T->x1, lx1);
+  }
+  __syncthreads();
+  if (T->y1 < T->y0) return -1;
+  const int nx = T->x1 - T->x0 + 1, ny = T->y1 - T->y0 + 1;
+  const bool staged = nx * ny <= RR_FMAX;
+  const int y0 = T->y0, x0 = T->x0;
+  for (int t = threadIdx.x; t < n * 4; t += blockDim.x) {          // packed (y,x) -> the index the main loop uses
+    int* p = reinterpret_cast<int*>(&T->o[0]) + t;
+    const int y = *p >> 16, x = *p & 0xffff;
+    const bool dead = reinterpret_cast<const float*>(&T->w[0])[t] == 0.f;   // invalid sample or zero weight
+    *p = dead ? 0 : (staged ? (y - y0) * nx + (x - x0) : y * W + x);
+  }
+  __syncthreads();
+  return staged ? nx * ny : 0;
+}
+
+// Both kernels are specialised for out_size == 7: the 49 bin values of channel c live in 49 registers of thread
+// c, and the [49][C+1] transpose tile (coalesced store of the output block / coalesced load of its gradient)
+// shares the LDS region of the staged footprint - the two are never live at the same time.
+constexpr int RR_BINS = 49;
+
+template <int PER>
+__global__ void __launch_bounds__(256)
+    roi_align_rotated_fwd_cl(const float* __restrict__ feat, const float* __restrict__ rois, int B, int C, int H, int W,
+                             float scale, int sample_num, int aligned, int clockwise, float* __restrict__ out) {
+  extern __shared__ float fp[];    // [RR_FMAX][C] staged footprint, later the [49][C+1] output tile
+  __shared__ RTaps T;
+  const int k = blockIdx.x;
+  const RRoi g = rroi_geom(rois + (size_t)k * 6, 7, scale, sample_num, aligned, clockwise, B);
+  const int F = rroi_taps(g, 7, H, W, &T);
+  const int ld = C + 1;
+  const float* fb = feat + (size_t)g.b * H * W * C;
+  for (int c0 = 0; c0 < C; c0 += blockDim.x) {
+    const int c = c0 + threadIdx.x;
+    float acc[RR_BINS];
+#pragma unroll
+    for (int bin = 0; bin < RR_BINS; ++bin) acc[bin] = 0.f;
+    if (c < C && F >= 0) {
+      if (F > 0) {
+        const int nx = T.x1 - T.x0 + 1;
+        for (int pix = 0; pix < F; ++pix)          // own column: no barrier between staging and use
+          fp[pix * C + c] = fb[((size_t)(T.y0 + pix / nx) * W + T.x0 + pix % nx) * C + c];
+      }
+      if (F > 0) {              // block-uniform: hoisted so that each variant is one straight-line block
+#pragma unroll
+        for (int bin = 0; bin < RR_BINS; ++bin) {
+          float a = 0.f;
+#pragma unroll
+          for (int sidx = 0; sidx < PER; ++sidx) {            // 16 independent LDS reads in flight per bin
+            const int4 o = T.o[bin * PER + sidx];
+            const float4 w = T.w[bin * PER + sidx];
+            a += w.x * fp[o.x * C + c] + w.y * fp[o.y * C + c] + w.z * fp[o.z * C + c] + w.w * fp[o.w * C + c];
+          }
+          acc[bin] = a;
+        }
+      } else {
+#pragma unroll
+        for (int bin = 0; bin < RR_BINS; ++bin) {
+          float a = 0.f;
+#pragma unroll
+          for (int sidx = 0; sidx < PER; ++sidx) {
+            const int4 o = T.o[bin * PER + sidx];
+            const float4 w = T.w[bin * PER + sidx];
+            a += w.x * fb[(size_t)o.x * C + c] + w.y * fb[(size_t)o.y * C + c] + w.z * fb[(size_t)o.z * C + c] +
+                 w.w * fb[(size_t)o.w * C + c];
+          }
+          acc[bin] = a;
+        }
+      }
+    }
+    __syncthreads();                               // every column has been consumed: the region becomes the tile
+    if (c < C) {
+#pragma unroll
+      for (int bin = 0; bin < RR_BINS; ++bin) fp[bin * ld + c] = acc[bin];
+    }
+    __syncthreads();
+    const int cn = min(C - c0, (int)blockDim.x);   // channels of this pass
+    float* ob = out + ((size_t)k * C + c0) * RR_BINS;
+    for (int o = threadIdx.x; o < cn * RR_BINS; o += blockDim.x) {
+      const int cc = o / RR_BINS, bin = o - cc * RR_BINS;
+      ob[o] = fp[bin * ld + c0 + cc];
+    }
+    __syncthreads();
+  }
+}
+
+// Backward as a GATHER over the footprint.  A scatter (sample -> 4 pixels) into an on-chip accumulator
+// serialises on LDS read-modify-write round trips because consecutive samples hit the same pixels, and LDS
+// float atomics execute one lane per clock on this part (measured: 8x slower).  Instead the taps are
+// bucketed by footprint pixel once per RoI (counting sort of <= 784 (bin, weight) entries, done by the first
+// threads); thread c then walks the entry list of each footprint pixel, reads the gradient tile (coalesced
+// load, transposed through LDS) with independent LDS reads, and issues ONE global atomic per footprint pixel
+// and channel (9-36 instead of 784).  RoIs with a footprint above RR_FMAX pixels scatter directly.
+struct RCsr {
+  int start[RR_FMAX + 1];
+  int cur[RR_FMAX];
+  int bin[RR_MAXS * 4];
+  float w[RR_MAXS * 4];
+};
+
+template <int PER>
+__global__ void __launch_bounds__(256)
+    roi_align_rotated_bwd_cl(const float* __restrict__ gout, const float* __restrict__ rois, int B, int C, int H, int W,
+                             float scale, int sample_num, int aligned, int clockwise, float* __restrict__ gfeat) {
+  extern __shared__ float fp[];    // the [49][C+1] gradient tile
+  __shared__ RTaps T;
+  __shared__ RCsr S;
+  const int k = blockIdx.x;
+  const RRoi g = rroi_geom(rois + (size_t)k * 6, 7, scale, sample_num, aligned, clockwise, B);
+  const int F = rroi_taps(g, 7, H, W, &T);
+  if (F < 0) return;                                        // every sample outside the map (block-uniform)
+  const int ld = C + 1, NE = RR_BINS * PER * 4;
+  float* fb = gfeat + (size_t)g.b * H * W * C;
+  const int* To = reinterpret_cast<const int*>(&T.o[0]);
+  const float* Tw = reinterpret_cast<const float*>(&T.w[0]);
+  if (F > 0) {                                              // bucket the taps by footprint pixel
+    for (int i = threadIdx.x; i <= F; i += blockDim.x) S.start[i] = 0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < NE; e += blockDim.x)
+      if (Tw[e] != 0.f) atomicAdd(&S.start[To[e] + 1], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int run = 0;
+      for (int i = 0; i < F; ++i) { run += S.start[i + 1]; S.start[i + 1] = run; S.cur[i] = S.start[i]; }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NE; e += blockDim.x) {
+      const float w = Tw[e];
+      if (w != 0.f) {
+        const int pos = atomicAdd(&S.cur[To[e]], 1);
+        S.bin[pos] = e / (PER * 4);
+        S.w[pos] = w;
+      }
+    }
+  }
+  const int nx = T.x1 - T.x0 + 1;
+  for (int c0 = 0; c0 < C; c0 += blockDim.x) {
+    const int c = c0 + threadIdx.x;
+    const int cn = min(C - c0, (int)blockDim.x);
+    const float* gb = gout + ((size_t)k * C + c0) * RR_BINS;
+    __syncthreads();
+    for (int o = threadIdx.x; o < cn * RR_BINS; o += blockDim.x) {      // coalesced read, transposed through LDS
+      const int cc = o / RR_BINS, bin = o - cc * RR_BINS;
+      fp[bin * ld + c0 + cc] = gb[o];
+    }
+    __syncthreads();
+    if (c >= C) continue;
+    if (F > 0) {
+      for (int pix = 0; pix < F; ++pix) {
+        float a = 0.f;
+        const int e1 = S.start[pix + 1];
+        int e = S.start[pix];
+        for (; e + 8 <= e1; e += 8) {                      // 8 independent (bin -> tile) read chains in flight
+          float v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = S.w[e + u] * fp[S.bin[e + u] * ld + c];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) a += v[u];
+        }
+        for (; e < e1; ++e) a += S.w[e] * fp[S.bin[e] * ld + c];
+        if (a != 0.f) atomicAdd(&fb[((size_t)(T.y0 + pix / nx) * W + T.x0 + pix % nx) * C + c], a);
+      }
+    } else {
+      for (int e = 0; e < NE; ++e) {
+        const float v = Tw[e] * fp[(e / (PER * 4)) * ld + c];
+        if (v != 0.f) atomicAdd(&fb[(size_t)To[e] * C + c], v);
+      }
+    }
+  }
+}
+
 }  // namespace pt
 
 using namespace pt;
@@ -266,7 +487,26 @@ static int rroi_launch(const char* fn, const float* src, const float* rois, int 
   int nb = cdiv(total, 256);
   if (nb > 65536) nb = 65536;
   hipStream_t s = as_stream(stream);
-  if (channels_last)
+  const size_t fpb = (size_t)RR_FMAX * C * sizeof(float), tlb = (size_t)RR_BINS * (C + 1) * sizeof(float);
+  const size_t lds = fpb > tlb ? fpb : tlb;
+  if (channels_last && out_size == 7 && sample_num == 2 &&
+      lds + sizeof(RTaps) <= 150 * 1024) {
+    // fast path: one workgroup per RoI, 49 bins x 4 samples (config 5: out_size 7, sample_num 2)
+    static size_t attr[2] = {0, 0};
+    const void* kf = BWD ? reinterpret_cast<const void*>(roi_align_rotated_bwd_cl<4>)
+                         : reinterpret_cast<const void*>(roi_align_rotated_fwd_cl<4>);
+    if (lds > attr[BWD]) {
+      hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { set_error("%s: LDS attribute: %s", fn, hipGetErrorString(e)); return (int)e; }
+      attr[BWD] = lds;
+    }
+    if (BWD)
+      hipLaunchKernelGGL(roi_align_rotated_bwd_cl<4>, dim3(K), dim3(256), lds, s, src, rois, B, C, H, W, scale, sample_num,
+                         aligned, clockwise, dst);
+    else
+      hipLaunchKernelGGL(roi_align_rotated_fwd_cl<4>, dim3(K), dim3(256), lds, s, src, rois, B, C, H, W, scale, sample_num,
+                         aligned, clockwise, dst);
+  } else if (channels_last)
     hipLaunchKernelGGL((roi_align_rotated_kernel<BWD, true>), dim3(nb), dim3(256), 0, s, src, rois, B, total, C, H, W,
                        out_size, scale, sample_num, aligned, clockwise, dst);
   else
