@@ -197,6 +197,68 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// Same epilogue for a BatchNorm in eval mode whose affine TRAINS (config 5: norm_cfg requires_grad=True,
+// norm_eval=True).  One pass over the activation does the element-wise backward AND the two per-channel
+// reductions the weight/bias gradients need:
+//     m = relu ? (y > 0) : 1;   grad_res = g*m;   grad_x = g*m*scale[c];
+//     sums[c] += g*m            (= dL/dshift)       sums[C + c] += g*m*x      (= dL/dscale)
+// channels_last only.  Each thread keeps the same 4 channels for its whole walk (the launch stride is a
+// multiple of C/4 float4 groups), accumulates 8 sums in registers, the block combines threads that share a
+// channel group through LDS and issues 8 atomics per group.
+constexpr int AFF_THREADS = 256;
+
+__global__ void __launch_bounds__(AFF_THREADS)
+    affine_relu_bwd_train_kernel(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ x,
+                                 const float* __restrict__ scale, long n4, int C, int relu, float* __restrict__ gx,
+                                 float* __restrict__ gres, float* __restrict__ sums) {
+  __shared__ float red[AFF_THREADS][9];                    // padded: 8 sums per thread
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  const float4* y4 = reinterpret_cast<const float4*>(y);
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  float4* gx4 = reinterpret_cast<float4*>(gx);
+  float4* gr4 = reinterpret_cast<float4*>(gres);
+  const int G = C >> 2;                                     // channel groups of 4
+  const long stride = (long)gridDim.x * blockDim.x;         // multiple of G by construction (host)
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cg = (int)(i % G);
+  const float4 sc = *reinterpret_cast<const float4*>(scale + 4 * cg);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+  for (; i < n4; i += stride) {
+    float4 v = g4[i];
+    if (relu) {
+      const float4 o = y4[i];
+      v.x = o.x > 0.f ? v.x : 0.f; v.y = o.y > 0.f ? v.y : 0.f; v.z = o.z > 0.f ? v.z : 0.f; v.w = o.w > 0.f ? v.w : 0.f;
+    }
+    const float4 xv = x4[i];
+    s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+    t0 += v.x * xv.x; t1 += v.y * xv.y; t2 += v.z * xv.z; t3 += v.w * xv.w;
+    if (gres) gr4[i] = v;
+    if (gx) gx4[i] = make_float4(v.x * sc.x, v.y * sc.y, v.z * sc.z, v.w * sc.w);
+  }
+  float* r = red[threadIdx.x];
+  r[0] = s0; r[1] = s1; r[2] = s2; r[3] = s3; r[4] = t0; r[5] = t1; r[6] = t2; r[7] = t3;
+  __syncthreads();
+  // threads tid, tid+G, tid+2G, ... of this block share a channel group when G <= blockDim; otherwise every
+  // thread of the block has its own group
+  const int per = G < AFF_THREADS ? AFF_THREADS / G : 1;
+  if (threadIdx.x < (G < AFF_THREADS ? G : AFF_THREADS)) {
+    float a[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] = 0.f;
+    for (int u = 0; u < per; ++u) {
+      const float* rr = red[threadIdx.x + u * G];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) a[q] += rr[q];
+    }
+    const int grp = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) % G);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      atomicAdd(&sums[4 * grp + q], a[q]);
+      atomicAdd(&sums[C + 4 * grp + q], a[4 + q]);
+    }
+  }
+}
+
 }  // namespace pt
 
 static int affine_check(const char* fn, int64_t n, int C, int64_t inner) {
@@ -235,5 +297,27 @@ extern "C" int pt_affine_relu_bwd(const float* grad_y, const float* y, const flo
     hipLaunchKernelGGL(affine_relu_bwd_kernel<false>, dim3(stream_blocks(n / 4)), dim3(256), 0, as_stream(stream), grad_y,
                        y, scale, (long)(n / 4), C, (long)inner, relu, grad_x, grad_res);
   PT_LAUNCH_CHECK("pt_affine_relu_bwd");
+  return PT_OK;
+}
+
+extern "C" int pt_affine_relu_bwd_train(const float* grad_y, const float* y, const float* x, const float* scale,
+                                        int64_t n, int C, int relu, float* grad_x, float* grad_res, float* sums,
+                                        void* stream) {
+  if (n == 0) return PT_OK;
+  PT_REQUIRE(grad_y && x && scale && sums && (!relu || y), PT_EINVAL, "pt_affine_relu_bwd_train: NULL pointer");
+  PT_REQUIRE(n > 0 && C > 0 && C % 4 == 0 && n % C == 0, PT_EINVAL, "pt_affine_relu_bwd_train: bad size");
+  const int G = C / 4;
+  PT_REQUIRE((G <= AFF_THREADS && AFF_THREADS % G == 0) || G % AFF_THREADS == 0, PT_ELIMIT,
+             "pt_affine_relu_bwd_train: C/4=%d must divide or be a multiple of %d", G, AFF_THREADS);
+  // the launch stride (blocks * 256 float4) must be a multiple of G so that a thread keeps its channel group
+  int nb = stream_blocks(n / 4);
+  if (G > AFF_THREADS) {
+    const int m = G / AFF_THREADS;
+    nb = nb / m * m;
+    if (nb < m) nb = m;
+  }
+  hipLaunchKernelGGL(affine_relu_bwd_train_kernel, dim3(nb), dim3(AFF_THREADS), 0, as_stream(stream), grad_y, y, x, scale,
+                     (long)(n / 4), C, relu, grad_x, grad_res, sums);
+  PT_LAUNCH_CHECK("pt_affine_relu_bwd_train");
   return PT_OK;
 }

@@ -486,6 +486,46 @@ class _AffineReLU(torch.autograd.Function):
         return gx, None, None, gres, None
 
 
+class _AffineReLUTrain(torch.autograd.Function):
+    """y = [relu](BN_eval(x) [+ residual]) for a BatchNorm whose weight/bias train while it normalises with its
+    running statistics (config 5).  x is kept (the weight gradient needs it), y is a new tensor."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, mean, var, eps, residual, relu):
+        C = x.shape[1]
+        with torch.no_grad():
+            rstd = torch.rsqrt(var.float() + eps)
+            scale = (weight.float() * rstd).contiguous()
+            shift = (bias.float() - mean.float() * scale).contiguous()
+        xb = x.permute(0, 2, 3, 1)
+        y = torch.empty_like(x)
+        rb = residual.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1) if residual is not None else None
+        hip.call('pt_affine_relu_fwd', xb, scale, shift, rb, x.numel(), C, 1, int(relu), y.permute(0, 2, 3, 1))
+        ctx.save_for_backward(x, y if relu else None, scale, rstd, mean)
+        ctx.cfg = (C, bool(relu), residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, scale, rstd, mean = ctx.saved_tensors
+        C, relu, has_res = ctx.cfg
+        g = g.contiguous(memory_format=torch.channels_last)
+        gx = torch.empty_like(g) if ctx.needs_input_grad[0] else None
+        gres = torch.empty_like(g) if (has_res and ctx.needs_input_grad[6]) else None
+        sums = torch.zeros((2, C), dtype=f32, device=g.device)
+        hip.call('pt_affine_relu_bwd_train', g.permute(0, 2, 3, 1), y.permute(0, 2, 3, 1) if y is not None else None,
+                 x.permute(0, 2, 3, 1), scale, g.numel(), C, int(relu),
+                 gx.permute(0, 2, 3, 1) if gx is not None else None, gres.permute(0, 2, 3, 1) if gres is not None else None,
+                 sums)
+        gw = (sums[1] - mean.float() * sums[0]) * rstd          # d/dw of w*rstd*(x - mean) + b
+        return gx, gw, sums[0], None, None, None, gres, None
+
+
+def bn_eval_relu(x, bn, residual=None, relu=True):
+    """Fused eval-mode BatchNorm with a TRAINABLE affine (+ residual) (+ ReLU); x: fp32, channels_last."""
+    return _AffineReLUTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, residual, relu)
+
+
 def affine_relu_(x, scale, shift, residual=None, relu=True):
     """Frozen-BN epilogue (pt_affine_relu_*): x must be fp32, 4-D, dense NCHW or channels_last."""
     return _AffineReLU.apply(x, scale, shift, residual, relu)

@@ -115,6 +115,13 @@ def conv_bn(x, conv, bn, relu, residual=None):
     if fused:
         sc, sh = _bn_affine(bn)
         return F.affine_relu_(y, sc, sh, residual, relu)
+    C = y.shape[1]
+    if (not bn.training and bn.weight.requires_grad and y.dtype == torch.float32 and y.is_cuda and y.dim() == 4
+            and getattr(bn, 'fuse_epilogue', True) and C % 4 == 0 and (256 % (C // 4) == 0 or (C // 4) % 256 == 0)
+            and y.is_contiguous(memory_format=torch.channels_last) and not y.is_contiguous()):
+        # eval-mode BatchNorm whose affine trains (config 5): fused forward, one-pass backward with the
+        # per-channel reductions of the weight / bias gradients (pt_affine_relu_bwd_train)
+        return F.bn_eval_relu(y, bn, residual, relu)
     y = bn(y)
     if residual is not None:
         y = y + residual

@@ -421,6 +421,43 @@ def test_frozen_bn_epilogue(channels_last, relu, with_res):
         close(rg.grad, rr.grad, atol=1e-6)
 
 
+@pytest.mark.parametrize('C,HW', [(64, (40, 52)), (256, (20, 30)), (1024, (9, 11)), (2048, (5, 7))])
+@pytest.mark.parametrize('relu,with_res', [(True, False), (True, True), (False, False)])
+def test_trainable_bn_epilogue(C, HW, relu, with_res):
+    """pt_affine_relu_fwd + pt_affine_relu_bwd_train == eval-mode BatchNorm with a TRAINING affine (+ identity)
+    (+ ReLU) of torch: values, input / residual gradients and the weight / bias gradients (config 5)."""
+    from point_teacher_amd import nn_modules
+    gen = torch.Generator().manual_seed(33)
+    N, (H, W) = 3, HW
+    x = torch.randn(N, C, H, W, generator=gen)
+    res = torch.randn(N, C, H, W, generator=gen)
+    bn = torch.nn.BatchNorm2d(C).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=gen) + 0.5); bn.bias.copy_(torch.randn(C, generator=gen))
+        bn.running_mean.copy_(torch.randn(C, generator=gen)); bn.running_var.copy_(torch.rand(C, generator=gen) + 0.2)
+    xr, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    y = bn(xr) + (rr if with_res else 0)
+    y = torch.relu(y) if relu else y
+    wgt = torch.randn(y.shape, generator=gen)
+    (y * wgt).sum().backward()
+    import copy
+    bng = copy.deepcopy(bn).to(DEV)
+    bng.weight.grad = bng.bias.grad = None
+    xg = cu(x).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    rg = cu(res).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    ident = torch.nn.Identity()
+    out = nn_modules.conv_bn(xg, ident, bng, relu, residual=rg if with_res else None)
+    assert out.data_ptr() != xg.data_ptr()                       # x is kept for the weight gradient
+    close(out, y, atol=1e-5)
+    (out * cu(wgt)).sum().backward()
+    close(xg.grad, xr.grad, atol=1e-5)
+    if with_res:
+        close(rg.grad, rr.grad, atol=1e-6)
+    scale = float(bn.weight.grad.abs().max())
+    close(bng.weight.grad, bn.weight.grad, rtol=1e-3, atol=1e-4 * scale)
+    close(bng.bias.grad, bn.bias.grad, rtol=1e-3, atol=1e-4 * float(bn.bias.grad.abs().max()))
+
+
 def test_diff_iou_rotated():
     f = F()
     gen = torch.Generator().manual_seed(41)
