@@ -49,7 +49,7 @@ def algorithmic_bytes(name, shapes):
     if name in ('pt_roi_align_fwd', 'pt_roi_align_bwd', 'pt_roi_align_rotated_fwd', 'pt_roi_align_rotated_bwd'):
         K, C, o = shapes['K'], shapes['C'], shapes['out']
         return K * C * o * o * 4            # the [K,C,7,7] block written (fwd) / read (bwd); the map stays in L2/MALL
-    if name in ('pt_affine_relu_fwd', 'pt_affine_relu_bwd'):
+    if name in ('pt_affine_relu_fwd', 'pt_affine_relu_bwd', 'pt_affine_relu_bwd_train'):
         return shapes['n'] * 4 * shapes['streams']   # fp32 streams read + written per element (x, y, residual / g, y, gx, gres)
     if name == 'pt_ema_update':
         return shapes['n'] * 12             # read teacher+student, write teacher
@@ -125,7 +125,7 @@ def main():
     orig_call = hip.call
 
     def timed_call(fn, *a):
-        if fn.startswith('pt_') and fn not in ('pt_focal_nblocks', 'pt_sqnorm_nblocks', 'pt_abi_version'):
+        if fn.startswith('pt_') and fn not in ('pt_focal_nblocks', 'pt_sqnorm_nblocks', 'pt_abi_version', 'pt_affine_train_rows'):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             r = orig_call(fn, *a)
@@ -137,6 +137,8 @@ def main():
                 shp = dict(n=a[4], streams=2 + (a[3] is not None))
             elif fn == 'pt_affine_relu_bwd':
                 shp = dict(n=a[3], streams=1 + (a[1] is not None) + (a[7] is not None) + (a[8] is not None))
+            elif fn == 'pt_affine_relu_bwd_train':
+                shp = dict(n=a[4], streams=2 + (a[1] is not None) + (a[7] is not None) + (a[8] is not None))
             elif fn in ('pt_ema_update', 'pt_sgd_step', 'pt_sqnorm_partial'):
                 shp = dict(n=a[2] if fn == 'pt_ema_update' else (a[3] if fn == 'pt_sgd_step' else a[1]))
             prof.setdefault(fn, []).append((e0, e1, shp))

@@ -214,11 +214,14 @@ int pt_affine_relu_bwd(const float* grad_y, const float* y, const float* scale, 
  * norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, OBB_TOD/configs/point teacher/
  * sodaa_fcos_pointteacher_1x.py:36-38): one pass produces grad_x / grad_res as pt_affine_relu_bwd and
  * accumulates sums[c] += g*m (dL/dshift) and sums[C+c] += g*m*x (dL/dscale), x = the convolution
- * output the forward read.  channels_last only ([N,H,W,C] flattened, n = N*H*W*C); sums[2*C] must be
- * zeroed by the caller; C/4 must divide 256 or be a multiple of it. */
+ * output the forward read.  channels_last only ([N,H,W,C] flattened, n = N*H*W*C); C/4 must divide 256
+ * or be a multiple of it.  No atomics: every workgroup writes a private row of
+ * partial_ws[pt_affine_train_rows(n, C)][2*C] and a second launch adds the rows into sums[2*C]
+ * (deterministic). */
+int pt_affine_train_rows(int64_t n, int C);
 int pt_affine_relu_bwd_train(const float* grad_y, const float* y, const float* x, const float* scale,
                              int64_t n, int C, int relu, float* grad_x, float* grad_res, float* sums,
-                             void* stream);
+                             float* partial_ws, void* stream);
 
 /* ------------------------------------------------------------------------ NMS --
  * mmcv.ops.nms (offset 0), call site core/post_processing/bbox_nms.py:76 through

@@ -204,13 +204,14 @@ __global__ void __launch_bounds__(256)
 //     sums[c] += g*m            (= dL/dshift)       sums[C + c] += g*m*x      (= dL/dscale)
 // channels_last only.  Each thread keeps the same 4 channels for its whole walk (the launch stride is a
 // multiple of C/4 float4 groups), accumulates 8 sums in registers, the block combines threads that share a
-// channel group through LDS and issues 8 atomics per group.
+// channel group through LDS and writes one private row of partial sums; a second tiny kernel adds the rows
+// (2 048 blocks x 8 float atomics per group on 2*C addresses cost more than the whole streaming pass).
 constexpr int AFF_THREADS = 256;
 
 __global__ void __launch_bounds__(AFF_THREADS)
     affine_relu_bwd_train_kernel(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ x,
                                  const float* __restrict__ scale, long n4, int C, int relu, float* __restrict__ gx,
-                                 float* __restrict__ gres, float* __restrict__ sums) {
+                                 float* __restrict__ gres, float* __restrict__ partial) {
   __shared__ float red[AFF_THREADS][9];                    // padded: 8 sums per thread
   const float4* g4 = reinterpret_cast<const float4*>(g);
   const float4* y4 = reinterpret_cast<const float4*>(y);
@@ -250,12 +251,36 @@ __global__ void __launch_bounds__(AFF_THREADS)
 #pragma unroll
       for (int q = 0; q < 8; ++q) a[q] += rr[q];
     }
+    // no atomics: block-private row of the workspace (blocks that cover complementary channel groups, C/4 > 256,
+    // share a row), reduced by affine_train_finish -> deterministic sums
     const int grp = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) % G);
+    const int m = G > AFF_THREADS ? G / AFF_THREADS : 1;
+    float* row = partial + (size_t)(blockIdx.x / m) * 2 * C;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      atomicAdd(&sums[4 * grp + q], a[q]);
-      atomicAdd(&sums[C + 4 * grp + q], a[4 + q]);
+      row[4 * grp + q] = a[q];
+      row[C + 4 * grp + q] = a[4 + q];
     }
+  }
+}
+
+// sums[j] = sum over rows of partial[row][j]: 16 columns x 16 row lanes per workgroup (a column's rows are
+// split over 16 threads, combined through LDS).
+__global__ void __launch_bounds__(256) affine_train_finish(const float* __restrict__ partial, int rows, int C2,
+                                                            float* __restrict__ sums) {
+  __shared__ float red[16][17];
+  const int col = threadIdx.x & 15, lane = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + col;
+  float a = 0.f;
+  if (j < C2)
+    for (int r = lane; r < rows; r += 16) a += partial[(size_t)r * C2 + j];
+  red[lane][col] = a;
+  __syncthreads();
+  if (lane == 0 && j < C2) {
+    float t = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t += red[u][col];
+    sums[j] = t;
   }
 }
 
@@ -300,24 +325,40 @@ extern "C" int pt_affine_relu_bwd(const float* grad_y, const float* y, const flo
   return PT_OK;
 }
 
-extern "C" int pt_affine_relu_bwd_train(const float* grad_y, const float* y, const float* x, const float* scale,
-                                        int64_t n, int C, int relu, float* grad_x, float* grad_res, float* sums,
-                                        void* stream) {
-  if (n == 0) return PT_OK;
-  PT_REQUIRE(grad_y && x && scale && sums && (!relu || y), PT_EINVAL, "pt_affine_relu_bwd_train: NULL pointer");
-  PT_REQUIRE(n > 0 && C > 0 && C % 4 == 0 && n % C == 0, PT_EINVAL, "pt_affine_relu_bwd_train: bad size");
+static int affine_train_blocks(int64_t n, int C) {
   const int G = C / 4;
-  PT_REQUIRE((G <= AFF_THREADS && AFF_THREADS % G == 0) || G % AFF_THREADS == 0, PT_ELIMIT,
-             "pt_affine_relu_bwd_train: C/4=%d must divide or be a multiple of %d", G, AFF_THREADS);
-  // the launch stride (blocks * 256 float4) must be a multiple of G so that a thread keeps its channel group
   int nb = stream_blocks(n / 4);
-  if (G > AFF_THREADS) {
+  if (G > AFF_THREADS) {               // the launch stride (blocks * 256 float4) must be a multiple of G
     const int m = G / AFF_THREADS;
     nb = nb / m * m;
     if (nb < m) nb = m;
   }
-  hipLaunchKernelGGL(affine_relu_bwd_train_kernel, dim3(nb), dim3(AFF_THREADS), 0, as_stream(stream), grad_y, y, x, scale,
-                     (long)(n / 4), C, relu, grad_x, grad_res, sums);
+  return nb;
+}
+
+extern "C" int pt_affine_train_rows(int64_t n, int C) {
+  if (n <= 0 || C <= 0 || C % 4) return 0;
+  const int G = C / 4;
+  return affine_train_blocks(n, C) / (G > AFF_THREADS ? G / AFF_THREADS : 1);
+}
+
+extern "C" int pt_affine_relu_bwd_train(const float* grad_y, const float* y, const float* x, const float* scale,
+                                        int64_t n, int C, int relu, float* grad_x, float* grad_res, float* sums,
+                                        float* partial_ws, void* stream) {
+  if (n == 0) return PT_OK;
+  PT_REQUIRE(grad_y && x && scale && sums && partial_ws && (!relu || y), PT_EINVAL,
+             "pt_affine_relu_bwd_train: NULL pointer");
+  PT_REQUIRE(n > 0 && C > 0 && C % 4 == 0 && n % C == 0, PT_EINVAL, "pt_affine_relu_bwd_train: bad size");
+  const int G = C / 4;
+  PT_REQUIRE((G <= AFF_THREADS && AFF_THREADS % G == 0) || G % AFF_THREADS == 0, PT_ELIMIT,
+             "pt_affine_relu_bwd_train: C/4=%d must divide or be a multiple of %d", G, AFF_THREADS);
+  const int nb = affine_train_blocks(n, C);
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(affine_relu_bwd_train_kernel, dim3(nb), dim3(AFF_THREADS), 0, s, grad_y, y, x, scale,
+                     (long)(n / 4), C, relu, grad_x, grad_res, partial_ws);
   PT_LAUNCH_CHECK("pt_affine_relu_bwd_train");
+  hipLaunchKernelGGL(affine_train_finish, dim3(cdiv(2 * C, 16)), dim3(256), 0, s, partial_ws,
+                     pt_affine_train_rows(n, C), 2 * C, sums);
+  PT_LAUNCH_CHECK("pt_affine_relu_bwd_train(finish)");
   return PT_OK;
 }

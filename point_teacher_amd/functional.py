@@ -512,11 +512,12 @@ class _AffineReLUTrain(torch.autograd.Function):
         g = g.contiguous(memory_format=torch.channels_last)
         gx = torch.empty_like(g) if ctx.needs_input_grad[0] else None
         gres = torch.empty_like(g) if (has_res and ctx.needs_input_grad[6]) else None
-        sums = torch.zeros((2, C), dtype=f32, device=g.device)
+        sums = torch.empty((2, C), dtype=f32, device=g.device)
+        ws = torch.empty((hip.call('pt_affine_train_rows', g.numel(), C), 2 * C), dtype=f32, device=g.device)
         hip.call('pt_affine_relu_bwd_train', g.permute(0, 2, 3, 1), y.permute(0, 2, 3, 1) if y is not None else None,
                  x.permute(0, 2, 3, 1), scale, g.numel(), C, int(relu),
                  gx.permute(0, 2, 3, 1) if gx is not None else None, gres.permute(0, 2, 3, 1) if gres is not None else None,
-                 sums)
+                 sums, ws)
         gw = (sums[1] - mean.float() * sums[0]) * rstd          # d/dw of w*rstd*(x - mean) + b
         return gx, gw, sums[0], None, None, None, gres, None
 

@@ -100,7 +100,7 @@ def call(fn, *args):
     if auto_stream:
         conv.append(torch.cuda.current_stream().cuda_stream)
     rc = getattr(_lib, fn)(*conv)
-    if restype is ctypes.c_int and fn not in ('pt_abi_version', 'pt_focal_nblocks', 'pt_sqnorm_nblocks') and rc != 0:
+    if restype is ctypes.c_int and fn not in ('pt_abi_version', 'pt_focal_nblocks', 'pt_sqnorm_nblocks', 'pt_affine_train_rows') and rc != 0:
         raise RuntimeError(f'{fn} failed (code {rc}): {last_error()}')
     return rc
 
