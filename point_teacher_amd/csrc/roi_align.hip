@@ -281,8 +281,7 @@ __global__ void __launch_bounds__(256)
     const int c = o / bins, bin = o - c * bins;
     tile[bin * ld + c] = gb[o];
   }
-  axis_weights(g.start_w, g.bin_w, g.grid_w, W, out_size, &AX);   // ends with a barrier
-  axis_weights(g.start_h, g.bin_h, g.grid_h, H, out_size, &AY);
+  axis_weights2(g.start_w, g.bin_w, g.grid_w, W, g.start_h, g.bin_h, g.grid_h, H, out_size, &AX, &AY);   // ends with a barrier
   const int ny = AY.e - AY.o + 1, nx = AX.e - AX.o + 1;
   if (ny <= 0 || nx <= 0) return;
   float* fb = gfeat + (size_t)g.b * H * W * C;
