@@ -32,6 +32,12 @@ def reduce_mean(tensor):
     return tensor
 
 
+def mean0(t):
+    """t.mean() that is 0 (not NaN) for an empty tensor: a batch without any object logs zeros (the reference
+    never sees one: its datasets filter empty images)."""
+    return t.sum() / max(t.numel(), 1)
+
+
 def reduce_mean_many(*scalars):
     """The normalisers of one loss call (num_pos of the classification branch, num_pos and the centerness
     sum of the regression branch) in ONE coalesced all-reduce instead of one tiny collective each

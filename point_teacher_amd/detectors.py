@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from . import functional as F
-from .core import bbox2result, bbox_overlaps, bbox_xyxy_to_cxcywh
+from .core import bbox2result, bbox_overlaps, bbox_xyxy_to_cxcywh, mean0
 from .proposals import (MIL_gen_proposals_from_cfg, gen_negative_proposals, generate_black_paper_masked,
                         load_basic_shape, random_point_in_quadrilateral, strong_augmentation_images,
                         strong_augmentation_masked)
@@ -288,7 +288,7 @@ class TS_P2B_FCOS(BaseDetector):
 
     def _refined_points_distance(self, gt_points, gt_bboxes):
         real = self._cxcywh(torch.cat(gt_bboxes, dim=0))
-        return (torch.sqrt((torch.cat(gt_points) - real[:, :2]) ** 2) / torch.sqrt((real[:, 2:4] / 2) ** 2)).mean()
+        return mean0(torch.sqrt((torch.cat(gt_points) - real[:, :2]) ** 2) / torch.sqrt((real[:, 2:4] / 2) ** 2))
 
     def _student_passes(self, img, extra=None):
         """ONE batched student pass over [extra (synthetic) images | clean images | strongly augmented images].
@@ -353,7 +353,7 @@ class TS_P2B_FCOS(BaseDetector):
         refined_b = [b.clone() for b in pseudo_bboxes]
         refined_p = [p.clone() for p in pseudo_points]
         gb_cat = torch.cat(gb_t, dim=0)
-        losses['coarse_bboxes_iou'] = self._aligned_iou(torch.cat(pb_t, dim=0), gb_cat).mean()
+        losses['coarse_bboxes_iou'] = mean0(self._aligned_iou(torch.cat(pb_t, dim=0), gb_cat))
         head = self.student.bbox_head
         for stage in range(self.num_stages):
             cfg = self.fine_proposal_cfg[stage]
@@ -361,7 +361,7 @@ class TS_P2B_FCOS(BaseDetector):
             neg, negw = self._neg_gen(pp_t, cfg, pr, img_meta=img_metas, uniforms=self._inject.get(f'neg{stage}'))
             mil_loss, pb_t = head.MIL_head_burn_in_step2(x_ori, img_metas, pr, pv, pref, preal, neg, negw, pb_t, pl_t,
                                                          self.fine_proposal_extensive_cfg[stage], stage)
-            losses[f'stage{stage}_refine_bboxes_iou'] = self._aligned_iou(torch.cat(pb_t, dim=0), gb_cat).mean()
+            losses[f'stage{stage}_refine_bboxes_iou'] = mean0(self._aligned_iou(torch.cat(pb_t, dim=0), gb_cat))
             mil_loss[f'stage{stage}_loss_mil_bbox'] = mil_loss[f'stage{stage}_loss_mil_bbox'] * self.alpha[0]
             mil_loss[f'stage{stage}_loss_mil_bags'] = mil_loss[f'stage{stage}_loss_mil_bags'] * self.alpha[1]
             losses.update(mil_loss)
@@ -438,7 +438,7 @@ class TS_P2B_FCOS(BaseDetector):
         refined_b = [b.clone() for b in pseudo_bboxes]
         refined_p = [p.clone() for p in pseudo_points]
         gb_cat = torch.cat(gb_t, dim=0)
-        losses['coarse_bboxes_iou'] = self._aligned_iou(torch.cat(pb_t, dim=0), gb_cat).mean()
+        losses['coarse_bboxes_iou'] = mean0(self._aligned_iou(torch.cat(pb_t, dim=0), gb_cat))
         head = self.student.bbox_head
         for stage in range(self.num_stages):
             cfg = self.fine_proposal_cfg[stage]
@@ -452,7 +452,7 @@ class TS_P2B_FCOS(BaseDetector):
             mil_loss, pb_t = head.MIL_head_burn_in_step1(x_ori, x_synthetic, img_metas, pr, pv, pref, preal, spr, spv,
                                                          spref, spreal, neg, negw, syn_t, pb_t, pl_t, ext, stage,
                                                          syn_bag_weight=bag_w)
-            losses[f'stage{stage}_refine_bboxes_iou'] = self._aligned_iou(torch.cat(pb_t, dim=0), gb_cat).mean()
+            losses[f'stage{stage}_refine_bboxes_iou'] = mean0(self._aligned_iou(torch.cat(pb_t, dim=0), gb_cat))
             mil_loss[f'stage{stage}_loss_mil_bbox'] = mil_loss[f'stage{stage}_loss_mil_bbox'] * self.alpha[0]
             mil_loss[f'stage{stage}_loss_mil_bags'] = mil_loss[f'stage{stage}_loss_mil_bags'] * self.alpha[1]
             losses.update(mil_loss)

@@ -10,7 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as TF
 
 from . import functional as F
-from .core import (bbox2roi, bbox_cxcywh_to_xyxy, bbox_overlaps, bbox_xyxy_to_cxcywh, distance2bbox, multi_apply,
+from .core import (bbox2roi, bbox_cxcywh_to_xyxy, bbox_overlaps, bbox_xyxy_to_cxcywh, distance2bbox, mean0, multi_apply,
                    multiclass_nms, reduce_mean, reduce_mean_many)
 from .losses import diou_forward_masked
 from .nn_modules import ConvModule, Scale
@@ -291,7 +291,7 @@ class TS_P2BFCOSHead(nn.Module):
                           bag_weight=None):
         """:1182-1236.  bag_weight (optional, per image [n_i*U1*U2] float) multiplies the validity
         weights - used by step 1 where padded synthetic boxes must not count."""
-        U1 = sum(p.shape[0] for p in proposals_list) // max(num_gt, 1)      # :1185 (same U1 for every image)
+        U1 = max(sum(p.shape[0] for p in proposals_list) // max(num_gt, 1), 1)   # :1185 (same U1 for every image)
         bbox_results['base_shaking_num'] = U1
         points_list = [bbox_xyxy_to_cxcywh(p)[:, :2] for p in proposals_list]
         ext, ext_valid, _, ext_ref = MIL_gen_proposals_from_cfg(points_list, proposals_list, fine_proposal_cfg,
@@ -303,7 +303,7 @@ class TS_P2BFCOSHead(nn.Module):
         valid = torch.cat(ext_valid).reshape(-1)
         K = bags.shape[0]
         if bag_weight is None:
-            bbox_results['coarse_bags_iou'] = bbox_overlaps(bags, real, is_aligned=True).mean()
+            bbox_results['coarse_bags_iou'] = mean0(bbox_overlaps(bags, real, is_aligned=True))
             wgt, avg = valid.float(), float(max(K, 1))
             wsum = None
         else:
@@ -324,7 +324,7 @@ class TS_P2BFCOSHead(nn.Module):
             bbox_results['loss_mil_bbox'] = self.loss_bbox_denosing.forward_masked(
                 bbox_pred, ref, torch.cat(bag_weight) > 0, valid.float(), avg)
         ri = bbox_overlaps(pred_d, real, is_aligned=True)
-        bbox_results['refine_bags_iou'] = ri.mean() if wsum is None else (ri * torch.cat(bag_weight)).sum() / wsum
+        bbox_results['refine_bags_iou'] = mean0(ri) if wsum is None else (ri * torch.cat(bag_weight)).sum() / wsum
         sizes = [e.shape[0] for e in ext]
         bbox_results['extensive_bags'] = list(torch.split(pred_d, sizes))
         bbox_results['extensive_bags_valid'] = ext_valid
@@ -338,8 +338,8 @@ class TS_P2BFCOSHead(nn.Module):
         feats = self._fc_stack(self.shared_fcs_bag[stage],
                                self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois,
                                                        group=self._bag_group(U1, U2)).flatten(1))
-        bbox_results['cls_score'] = self.fc_cls[stage](feats).view(num_gt, U1, U2, -1)
-        bbox_results['ins_score'] = self.fc_ins[stage](feats).view(num_gt, U1, U2, -1)
+        bbox_results['cls_score'] = self.fc_cls[stage](feats).view(num_gt, U1, U2, self.num_classes)
+        bbox_results['ins_score'] = self.fc_ins[stage](feats).view(num_gt, U1, U2, self.num_classes)
 
     def forward_mil_head(self, num_gt, num_gt_pre_image, x, proposals_list, proposals_valid_list,
                          proposals_reference_list, proposals_real_list, img_metas, fine_proposal_cfg, stage,

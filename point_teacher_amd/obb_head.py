@@ -14,7 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as TF
 
 from . import functional as F
-from .core import bbox_cxcywh_to_xyxy, bbox_xyxy_to_cxcywh, multi_apply, reduce_mean_many
+from .core import bbox_cxcywh_to_xyxy, bbox_xyxy_to_cxcywh, mean0, multi_apply, reduce_mean_many
 from .head import TS_P2BFCOSHead, _cat
 from .nn_modules import Scale
 from .obb import multiclass_nms_rotated, rbbox2roi, rbbox_overlaps
@@ -186,7 +186,7 @@ class TS_P2RBRotatedFCOSHead(TS_P2BFCOSHead):
                           bag_weight=None):
         """:1285-1343.  The refinement regresses the axis-aligned (cx,cy,w,h) part of each bag with the
         HBB delta coder and DN-DIoU; the angle of the bag is carried through unchanged."""
-        U1 = sum(p.shape[0] for p in proposals_list) // max(num_gt, 1)
+        U1 = max(sum(p.shape[0] for p in proposals_list) // max(num_gt, 1), 1)
         bbox_results['base_shaking_num'] = U1
         points_list = [p[:, :2] for p in proposals_list]
         ext, ext_valid, _, ext_ref = MIL_gen_proposals_from_cfg(points_list, proposals_list, fine_proposal_cfg,
@@ -199,7 +199,7 @@ class TS_P2RBRotatedFCOSHead(TS_P2BFCOSHead):
         K = bags.shape[0]
         ci = rbbox_overlaps(bags, real, is_aligned=True)
         if bag_weight is None:
-            bbox_results['coarse_bags_iou'] = ci.mean()
+            bbox_results['coarse_bags_iou'] = mean0(ci)
             wgt, avg, wsum = valid.float(), float(max(K, 1)), None
         else:
             bw = torch.cat(bag_weight)
@@ -221,7 +221,7 @@ class TS_P2RBRotatedFCOSHead(TS_P2BFCOSHead):
                 bbox_pred, target, torch.cat(bag_weight) > 0, valid.float(), avg)
         refined = torch.cat([bbox_xyxy_to_cxcywh(pred_d), bags[:, 4:5]], dim=1)
         ri = rbbox_overlaps(refined, real, is_aligned=True)
-        bbox_results['refine_bags_iou'] = ri.mean() if wsum is None else (ri * torch.cat(bag_weight)).sum() / wsum
+        bbox_results['refine_bags_iou'] = mean0(ri) if wsum is None else (ri * torch.cat(bag_weight)).sum() / wsum
         sizes = [e.shape[0] for e in ext]
         bbox_results['extensive_bags'] = list(torch.split(refined, sizes))
         bbox_results['extensive_bags_valid'] = ext_valid
@@ -234,8 +234,8 @@ class TS_P2RBRotatedFCOSHead(TS_P2BFCOSHead):
         U1, U2 = bbox_results['base_shaking_num'], bbox_results['extensive_shaking_num']
         feats = self._fc_stack(self.shared_fcs_bag[stage],
                                self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois).flatten(1))
-        bbox_results['cls_score'] = self.fc_cls[stage](feats).view(num_gt, U1, U2, -1)
-        bbox_results['ins_score'] = self.fc_ins[stage](feats).view(num_gt, U1, U2, -1)
+        bbox_results['cls_score'] = self.fc_cls[stage](feats).view(num_gt, U1, U2, self.num_classes)
+        bbox_results['ins_score'] = self.fc_ins[stage](feats).view(num_gt, U1, U2, self.num_classes)
 
     def forward_mil_head(self, num_gt, num_gt_pre_image, x, proposals_list, proposals_valid_list,
                          proposals_reference_list, proposals_real_list, img_metas, fine_proposal_cfg, stage,

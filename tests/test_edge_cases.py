@@ -1,0 +1,35 @@
+"""Ragged / empty inputs through the whole iteration on the GPU (the reference filters empty images in the dataset,
+`filter_empty_gt=True`, and divides by the first image's object count in mil_bag_extensive; here an image without
+objects - or a whole batch without any - must simply contribute nothing): every configuration runs two iterations,
+emits the full key set and only finite values."""
+import pytest
+import torch
+
+import test_obb_parity as TO
+import test_train_step_parity as T
+
+pytestmark = pytest.mark.gpu
+
+KEYS = {'coarse_bboxes_iou', 'stage0_refine_bboxes_iou', 'stage0_loss_mil_bbox', 'stage0_loss_mil_bags',
+        'stage0_coarse_bags_iou', 'stage0_refine_bags_iou', 'refined_points_distance', 'loss_cls', 'loss_bbox',
+        'loss_centerness', 'loss'}
+
+
+@pytest.mark.parametrize('variant', ['hbb', 'obb'])
+@pytest.mark.parametrize('phase2', [True, False])
+@pytest.mark.parametrize('counts', [(1, 0), (0, 0)])
+def test_images_without_objects(variant, phase2, counts):
+    dev = torch.device('cuda:0')
+    mod = T if variant == 'hbb' else TO
+    pta, cfg, model = mod._build(dev, phase2=phase2)
+    trainer = pta.Trainer(model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config)
+    img, boxes, labels, metas = mod._data(dev) if variant == 'hbb' else mod._data()
+    boxes = [b[:n] for b, n in zip(boxes, counts)]
+    labels = [l[:n] for l, n in zip(labels, counts)]
+    data = dict(img=img.to(dev), img_metas=metas, gt_bboxes=[b.to(dev) for b in boxes], gt_labels=[l.to(dev) for l in labels])
+    for _ in range(2):
+        lv = trainer.step(data)['log_vars'].materialize()
+    assert set(lv) == KEYS, set(lv) ^ KEYS
+    bad = [k for k, v in lv.items() if v != v or abs(v) == float('inf')]
+    assert not bad, (bad, lv)
+    assert torch.isfinite(trainer.flat.student_flat).all() and torch.isfinite(trainer.flat.teacher_flat).all()
