@@ -169,6 +169,36 @@ def test_teacher_bn_affine_follows_ema():
     del trainer
 
 
+def test_runner_checkpoint_resume(tmp_path):
+    """runner.Runner: log lines, checkpoint and a resume that continues in the same phase with the same counters,
+    point dictionaries, momentum and weights (the reference loses `count` and the dictionaries)."""
+    import json
+    from point_teacher_amd.runner import Runner
+    from point_teacher_amd.synthetic import SyntheticTiles
+    dev = torch.device('cuda:0')
+    pta, cfg, model = _build(dev, phase2=True)
+    model.burn_in_step = 2                                   # iterations 0-2 are phase 1, then phase 2
+    trainer = pta.Trainer(model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config, iters_per_epoch=3)
+    data = SyntheticTiles(n=4, size=256, mean_objects=20, seed=3, device=dev)
+    runner = Runner(trainer, data.batch, str(tmp_path), max_epochs=2, iters_per_epoch=3, log_interval=1)
+    assert runner.run(max_iters=3) == 3
+    assert runner.epoch == 1 and os.path.exists(tmp_path / 'epoch_1.pth') and os.path.islink(tmp_path / 'latest.pth')
+    lines = [json.loads(l) for l in open(tmp_path / 'log.json')]
+    assert len(lines) == 3 and lines[0]['epoch'] == 1 and 'loss_cls' in lines[0] and lines[0]['lr'] > 0
+    # a fresh process: new model, resume, and the state is the saved one
+    pta2, cfg2, model2 = _build(dev, phase2=True)
+    trainer2 = pta2.Trainer(model2, cfg2.optimizer, cfg2.optimizer_config, cfg2.lr_config, iters_per_epoch=3)
+    runner2 = Runner(trainer2, data.batch, str(tmp_path), max_epochs=2, iters_per_epoch=3, log_interval=1)
+    meta = runner2.resume(str(tmp_path / 'latest.pth'))
+    assert meta['epoch'] == 1 and trainer2.iter == 3 and model2.count == 3 and runner2.epoch == 1
+    assert set(model2.gt_bboxes_point) == set(model.gt_bboxes_point) and len(model2.gt_bboxes_point) == 4
+    torch.testing.assert_close(trainer2.flat.student_flat, trainer.flat.student_flat, rtol=0, atol=0)
+    torch.testing.assert_close(trainer2.flat.teacher_flat, trainer.flat.teacher_flat, rtol=0, atol=0)
+    torch.testing.assert_close(trainer2.flat.mom_flat, trainer.flat.mom_flat, rtol=0, atol=0)
+    assert trainer2.flat.check_views()
+    assert runner2.run(max_iters=1) == 1 and model2.count == 4              # first phase-2 iteration after the resume
+
+
 def test_eval_path_detections():
     """simple_test (fcos_p2b_teacher_student.py:276-298 -> get_bboxes :796-1005 -> multiclass_nms): the
     teacher's detections on the GPU equal a restatement from the oracle pieces (sigmoid scores x

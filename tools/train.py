@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Train a Point-Teacher config on MI355X (the counterpart of the reference's tools/train.py for this path).
+
+    python tools/train.py <config.py> [--work-dir DIR] [--resume-from CKPT] [--synthetic N] [--max-iters K]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/train.py <config.py> ...
+
+The dataset readers of the reference (COCO-json / DOTA-txt) are not part of this build: the loop
+runs on `--synthetic N` seeded tiles of the config's image size (default 64) resident on the GPU."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('config')
+    ap.add_argument('--work-dir', default=None)
+    ap.add_argument('--resume-from', default=None)
+    ap.add_argument('--synthetic', type=int, default=64)
+    ap.add_argument('--max-iters', type=int, default=None)
+    ap.add_argument('--iters-per-epoch', type=int, default=None)
+    ap.add_argument('--objects', type=int, default=300)
+    args = ap.parse_args()
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)          # RCCL
+    import point_teacher_amd as pta
+    from point_teacher_amd.runner import Runner
+    from point_teacher_amd.synthetic import SyntheticTiles, benchmark_init_
+    cfg = pta.Config.fromfile(args.config)
+    torch.manual_seed(0)
+    model = pta.build_detector(cfg.model).to(dev)
+    benchmark_init_(model)                 # no network for the pretrained backbones: see its docstring
+    model.train()
+    oriented = cfg.model.type == 'RotatedFCOS_TS'
+    size = 1200 if oriented else 800
+    ipe = args.iters_per_epoch or max(args.synthetic // (cfg.data.samples_per_gpu * world), 1)
+    trainer = pta.Trainer(model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config, iters_per_epoch=ipe, channels_last=True)
+    torch.backends.cudnn.benchmark = True
+    data = SyntheticTiles(n=max(args.synthetic // world, 2), size=size, mean_objects=args.objects, seed=0, device=dev,
+                          rank=rank, world=world, oriented=oriented, num_classes=cfg.model._model_.bbox_head.num_classes)
+    work_dir = args.work_dir or os.path.join(ROOT, 'work_dirs', os.path.splitext(os.path.basename(args.config))[0])
+    runner = Runner(trainer, data.batch, work_dir, cfg.runner.max_epochs, ipe, cfg.log_config.interval,
+                    cfg.checkpoint_config.interval, cfg.data.samples_per_gpu)
+    if args.resume_from:
+        meta = runner.resume(args.resume_from)
+        if rank == 0:
+            print(f'resumed from {args.resume_from}: {meta}')
+    runner.run(max_iters=args.max_iters)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
