@@ -147,9 +147,15 @@ class TS_P2B_FCOS(BaseDetector):
         return strong_augmentation_masked(img, gt_points, gt_labels, pseudo_points, pseudo_labels, pseudo_bboxes,
                                           params=params if params is not None else self._inject.get('aug'), imgs=imgs)
 
+    def _prior_on(self, dev):
+        """The shape priors on the device (uploaded once; a per-iteration `.to(device)` is a blocking copy)."""
+        if getattr(self, '_prior_dev', None) is None or self._prior_dev.device != dev:
+            self._prior_dev = self.prior_size.to(dev)
+        return self._prior_dev
+
     def _black_paper(self, img, gt_bboxes, imgsize, draws):
-        return generate_black_paper_masked(img, gt_bboxes, self.prior_size, range(int(len(self.pattern) / 2)), imgsize,
-                                           draws=draws)
+        return generate_black_paper_masked(img, gt_bboxes, self._prior_on(img.device), range(int(len(self.pattern) / 2)),
+                                           imgsize, draws=draws)
 
     def _initial_points(self, gt_bboxes, u):
         return random_point_in_quadrilateral(gt_bboxes, self._point_, *(u if u is not None else (None, None)))

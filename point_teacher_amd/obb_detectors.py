@@ -91,7 +91,7 @@ class RotatedFCOS_TS(TS_P2B_FCOS):
                                           imgs=imgs)
 
     def _black_paper(self, img, gt_bboxes, imgsize, draws):
-        return generate_black_paper_obb_masked(img, gt_bboxes, self.prior_size, range(int(len(self.pattern) / 2)),
+        return generate_black_paper_obb_masked(img, gt_bboxes, self._prior_on(img.device), range(int(len(self.pattern) / 2)),
                                                imgsize, draws=draws)
 
     def _initial_points(self, gt_bboxes, u):

@@ -132,7 +132,8 @@ class TS_P2RBRotatedFCOSHead(TS_P2BFCOSHead):
         pred = self.bbox_coder.decode(pts, fr.reshape(-1, 5))
         tgt = self.bbox_coder.decode(pts, torch.cat([tg, ang], dim=-1))
         # rows outside `pos` do not exist in the reference: give them a harmless unit box on both sides
-        dummy = pred.new_tensor([0.0, 0.0, 1.0, 1.0, 0.0])
+        dummy = pred.new_zeros(5)                 # (0, 0, 1, 1, 0) built on the device: new_tensor(list) is a blocking upload
+        dummy[2:4] = 1.0
         pred = torch.where(pos[:, None], pred, dummy)
         tgt = torch.where(pos[:, None], tgt, dummy)
         elem = self.loss_bbox._elem(pred, tgt)

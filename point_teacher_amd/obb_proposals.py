@@ -112,15 +112,15 @@ def rotate_image_nearest(img, angle):
     _gen_affine_grid, _apply_grid_transform)."""
     C, H, W = img.shape
     rot = math.radians(angle)
-    # _get_inverse_affine_matrix(center=0, angle=-angle, translate=0, scale=1, shear=0)
-    theta = torch.tensor([[math.cos(rot), -math.sin(rot), 0.0], [math.sin(rot), math.cos(rot), 0.0]],
-                         dtype=img.dtype, device=img.device).reshape(1, 2, 3)
-    base = torch.empty(1, H, W, 3, dtype=img.dtype, device=img.device)
-    base[..., 0].copy_(torch.linspace(-W * 0.5 + 0.5, W * 0.5 + 0.5 - 1, steps=W, device=img.device))
-    base[..., 1].copy_(torch.linspace(-H * 0.5 + 0.5, H * 0.5 + 0.5 - 1, steps=H, device=img.device).unsqueeze_(-1))
-    base[..., 2].fill_(1)
-    rescaled = theta.transpose(1, 2) / torch.tensor([0.5 * W, 0.5 * H], dtype=img.dtype, device=img.device)
-    grid = base.view(1, H * W, 3).bmm(rescaled).view(1, H, W, 2)
+    # _get_inverse_affine_matrix(center=0, angle=-angle, translate=0, scale=1, shear=0) = [[cos, -sin, 0], [sin, cos, 0]];
+    # theta is folded into scalar multipliers (a device tensor built from host numbers would be a blocking upload):
+    # grid = base @ (theta^T / [W/2, H/2]) with base = (x, y, 1) on torchvision's half-pixel-centred lattice
+    xs = torch.linspace(-W * 0.5 + 0.5, W * 0.5 + 0.5 - 1, steps=W, dtype=img.dtype, device=img.device)[None, :]
+    ys = torch.linspace(-H * 0.5 + 0.5, H * 0.5 + 0.5 - 1, steps=H, dtype=img.dtype, device=img.device)[:, None]
+    c, s_ = math.cos(rot), math.sin(rot)
+    gx = xs * (c / (0.5 * W)) + ys * (-s_ / (0.5 * W))
+    gy = xs * (s_ / (0.5 * H)) + ys * (c / (0.5 * H))
+    grid = torch.stack([gx, gy], dim=-1).unsqueeze(0)
     return TF.grid_sample(img.unsqueeze(0), grid, mode='nearest', padding_mode='zeros', align_corners=False).squeeze(0)
 
 

@@ -170,8 +170,8 @@ def _refine_boxes(b):
         return b
     w = (b[:, 0] - b[:, 2]).abs().reshape(-1, 1)
     h = (b[:, 1] - b[:, 3]).abs().reshape(-1, 1)
-    x = torch.min(b[:, [0, 2]], dim=1)[0].reshape(-1, 1)
-    y = torch.min(b[:, [1, 3]], dim=1)[0].reshape(-1, 1)
+    x = torch.minimum(b[:, 0], b[:, 2]).reshape(-1, 1)     # (a python-list index would be uploaded with a blocking copy)
+    y = torch.minimum(b[:, 1], b[:, 3]).reshape(-1, 1)
     return bbox_cxcywh_to_xyxy(torch.cat([x + w / 2, y + h / 2, w, h], dim=1))
 
 
@@ -241,7 +241,7 @@ def generate_black_paper_masked(img, gt_bboxes, prior_size, dense_cls, imgsize, 
     dev = img.device
     G = gt_bboxes.shape[0]
     L = prior_size.shape[0]
-    prior = prior_size.to(dev)
+    prior = prior_size if prior_size.device == dev else prior_size.to(dev)   # callers on the training path pass a device copy
     d = draws or {}
 
     def draw(name, shape, kind='rand'):
@@ -282,9 +282,9 @@ def generate_black_paper_masked(img, gt_bboxes, prior_size, dense_cls, imgsize, 
         hit = fire & (rank == r)
         idx = torch.argmax(hit.int()) if G else None          # first hit (0 when there is none)
         has = hit.any() if G else None
-        if G:
-            extras.append(ex[idx])
-            extras_ok.append(eok[idx] & has)
+        if G:                                  # index_select: `ex[idx]` with a 0-dim device index reads it back to the host
+            extras.append(ex.index_select(0, idx.reshape(1))[0])
+            extras_ok.append(eok.index_select(0, idx.reshape(1))[0] & has)
         else:
             extras.append(torch.zeros(5, 6, device=dev))
             extras_ok.append(torch.zeros(5, dtype=torch.bool, device=dev))
@@ -300,8 +300,10 @@ def generate_black_paper_masked(img, gt_bboxes, prior_size, dense_cls, imgsize, 
     sc = torch.where(exist, allb[:, 5], torch.full_like(allb[:, 5], -1.0))
     order = torch.sort(sc, descending=True, stable=True)[1]
     sb = allb[order]
-    keep = F.nms_rotated_mask(torch.where(exist[order][:, None], sb, sb.new_tensor([-1e4, -1e4, 1e-3, 1e-3, 0, 0])),
-                              0.05).bool()
+    far = sb.new_zeros(6)                      # a box nowhere near the image for the rows that do not exist
+    far[:2] = -1e4
+    far[2:4] = 1e-3
+    keep = F.nms_rotated_mask(torch.where(exist[order][:, None], sb, far), 0.05).bool()
     xyxy = obb2xyxy(sb)
     inside = (xyxy.min(-1)[0] >= 0) & (xyxy.max(-1)[0] <= imgsize - 1)
     alive = keep & exist[order] & (sb[:, 5] < 1) & inside

@@ -169,6 +169,72 @@ def test_teacher_bn_affine_follows_ema():
     del trainer
 
 
+def test_full_size_iteration_properties():
+    """BASELINE size (bs 2, 800x800, ~300 points/image, 88 M parameters): properties that do not need the oracle.
+    (1) the teacher after the flat EMA kernel is exactly alpha*t + (1-alpha)*s of the previous state (fp32, same
+    rounding as torch's mul_/add_); (2) the flat gradient the optimizer consumes equals the per-parameter autograd
+    gradients of the same iteration (gather path) and unused parameters stay zero; (3) clip + SGD moves every
+    trainable parameter by -lr*(clip*g + wd*w) on the first step and never touches frozen ones; (4) nothing in the
+    iteration synchronises the host (checked with torch.cuda.set_sync_debug_mode)."""
+    from point_teacher_amd.synthetic import SyntheticTiles, benchmark_init_
+    dev = torch.device('cuda:0')
+    import point_teacher_amd as pta
+    torch.manual_seed(5)
+    cfg = pta.Config.fromfile(os.path.join(ROOT, 'point_teacher_amd', 'configs', 'point_teacher', 'aitodv2_point_teacher_0.py'))
+    cfg.model['burn_in_step'] = -1
+    model = pta.build_detector(cfg.model).to(dev)
+    benchmark_init_(model, phase2=True)
+    model.train()
+    trainer = pta.Trainer(model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config, channels_last=True)
+    data = SyntheticTiles(n=2, size=800, mean_objects=300, seed=1, device=dev)
+    f = trainer.flat
+    t0, s0 = f.teacher_flat.clone(), f.student_flat.clone()
+    batch = data.batch(0, 2)
+    trainer.step(batch)                                              # warm-up iteration (allocator, MIOpen)
+    t1, s1 = f.teacher_flat.clone(), f.student_flat.clone()
+    torch.testing.assert_close(t1, t0 * 0.999 + s0 * (1 - 0.999), rtol=1e-6, atol=1e-8)        # (1) EMA ran BEFORE the update
+    g = f.grad_flat.clone()
+    assert torch.isfinite(g).all() and float(g.abs().max()) > 0
+    # (3) first SGD step: p1 = p0 - lr_g * (coef*g + wd_g*p0), bias group lr x2 / wd x0 (configs :212-215)
+    lr = trainer.sched.lr_at(0)
+    coef = min(1.0, 35.0 / (float(g.double().norm()) + 1e-6))
+    nw = f.n_weights
+    exp_w = s0[:nw] - lr * (coef * g[:nw] + 1e-4 * s0[:nw])
+    exp_b = s0[nw:f.n_train] - 2 * lr * (coef * g[nw:f.n_train])
+    torch.testing.assert_close(s1[:nw], exp_w, rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(s1[nw:f.n_train], exp_b, rtol=1e-4, atol=1e-7)
+    assert torch.equal(s1[f.n_train:], s0[f.n_train:])                                         # frozen segment untouched
+    # (2) gather path == autograd: rerun the same iteration by hand on the updated weights
+    model._inject = dict(neg0=torch.rand(2, 4, 200, device=dev), aug=(['None', 'horizontal'], [1.0, 0.9]))
+    f.zero_grad(); f.detach_grads()
+    model.ema_alpha = 1.0
+    out = model.train_step(dict(batch, img=batch['img'].contiguous(memory_format=torch.channels_last)), None)
+    out['loss'].backward()
+    per_param = {n: (p.grad.clone() if p.grad is not None else None) for n, p in f.order if p.requires_grad}
+    f.gather_grads()
+    unused = 0
+    for n, p in f.order:
+        if not p.requires_grad:
+            continue
+        off, k = f.slices[n]
+        seg = f.grad_flat[off:off + k]
+        if per_param[n] is None:
+            unused += 1
+            assert float(seg.abs().max()) == 0, n
+        else:
+            ref = per_param[n].permute(0, 2, 3, 1).reshape(-1) if per_param[n].dim() == 4 else per_param[n].reshape(-1)
+            assert torch.equal(seg, ref), n
+    assert unused >= 4 and f.check_views()            # shared_fcs / shared_fcs_refine / fc_iou never receive gradients
+    # (4) no host synchronisation inside a steady-state iteration
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode('error')
+    try:
+        model._inject = {}
+        trainer.step(data.batch(1, 2))
+    finally:
+        torch.cuda.set_sync_debug_mode('default')
+
+
 def test_runner_checkpoint_resume(tmp_path):
     """runner.Runner: log lines, checkpoint and a resume that continues in the same phase with the same counters,
     point dictionaries, momentum and weights (the reference loses `count` and the dictionaries)."""
