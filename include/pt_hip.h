@@ -295,6 +295,26 @@ int pt_mil_bag_select_obb(const float* cls, const float* ins, const uint8_t* val
                           int U1, int U2, int C, int topk, float beta, float img_h, float img_w,
                           float* merged, void* stream);
 
+/* ------------------------------------------------ (modulated) deformable convolution --
+ * mmcv.ops.DeformConv2d / ModulatedDeformConv2d(Pack) (`conv_cfg=dict(type='DCN'|'DCNv2')`), reachable on the path
+ * through `dcn_on_last_conv=True` (HBB_TOD/mmdet/models/dense_heads/anchor_free_head.py:101-102,121-122,
+ * fcos_head_p2b_ts.py:197-198; no shipped Point-Teacher config turns it on).  The contraction is a plain GEMM on
+ * col (caller: hipBLASLt); these entries are the data-dependent halves.  x[B,C,H,W] (NCHW),
+ * offset[B, 2*dg*kh*kw, Ho, Wo] = (dy, dx) per tap per deformable group, mask[B, dg*kh*kw, Ho, Wo] or NULL
+ * (DCNv1), col / grad_col[B, C*kh*kw, Ho*Wo].  Samples outside (-1,H)x(-1,W) are 0, neighbours outside the
+ * map contribute 0 (mmcv modulated_deform_conv_cuda_kernel.cuh).  col2im ACCUMULATES into grad_x;
+ * col2im_coord writes grad_offset (and grad_mask when mask != NULL). */
+int pt_deform_im2col(const float* x, const float* offset, const float* mask, int B, int C, int H, int W,
+                     int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h,
+                     int dil_w, int deform_groups, float* col, void* stream);
+int pt_deform_col2im(const float* grad_col, const float* offset, const float* mask, int B, int C, int H,
+                     int W, int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h,
+                     int dil_w, int deform_groups, float* grad_x, void* stream);
+int pt_deform_col2im_coord(const float* grad_col, const float* x, const float* offset, const float* mask,
+                           int B, int C, int H, int W, int kh, int kw, int pad_h, int pad_w,
+                           int stride_h, int stride_w, int dil_h, int dil_w, int deform_groups,
+                           float* grad_offset, float* grad_mask, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -937,3 +937,44 @@ def dn_iou_loss_values(pred, target, hyper=0.2, eps=1e-6, mode='log'):
             t[:, 3] = t[:, 3] - anx * h * j
             bank.append(loss_of(t))
     return (base + torch.stack(bank, 1).min(1)[0]) / 2
+
+
+def modulated_deform_conv2d(x, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1, deform_groups=1):
+    """mmcv.ops.(modulated_)deform_conv2d restated from the published algorithm
+    (modulated_deform_conv_cuda_kernel.cuh: dmcn_im2col_bilinear + GEMM), PARITY UNPINNED (mmcv-full absent).
+    Pure torch gathers, so autograd supplies the reference gradients for x, offset, mask, weight and bias.
+    offset[B, 2*dg*K, Ho, Wo] = (dy, dx) per tap; mask[B, dg*K, Ho, Wo] or None; groups = 1."""
+    B, C, H, W = x.shape
+    O, _, kh, kw = weight.shape
+    s, p, d = (stride, stride) if isinstance(stride, int) else stride, (padding, padding) if isinstance(padding, int) else padding, \
+        (dilation, dilation) if isinstance(dilation, int) else dilation
+    Ho = (H + 2 * p[0] - (d[0] * (kh - 1) + 1)) // s[0] + 1
+    Wo = (W + 2 * p[1] - (d[1] * (kw - 1) + 1)) // s[1] + 1
+    K, cpg = kh * kw, C // deform_groups
+    ho = torch.arange(Ho, dtype=x.dtype)[:, None] * s[0] - p[0]
+    wo = torch.arange(Wo, dtype=x.dtype)[None, :] * s[1] - p[1]
+    cols = []
+    flat = x.reshape(B, C, H * W)
+    for t in range(K):
+        ki, kj = t // kw, t % kw
+        per_group = []
+        for g in range(deform_groups):
+            h = ho + ki * d[0] + offset[:, (g * K + t) * 2]                  # [B, Ho, Wo]
+            w = wo + kj * d[1] + offset[:, (g * K + t) * 2 + 1]
+            inside = (h > -1) & (w > -1) & (h < H) & (w < W)
+            hl, wl = torch.floor(h), torch.floor(w)
+            lh, lw = h - hl, w - wl
+            val = 0
+            for dy, dx, wt in ((0, 0, (1 - lh) * (1 - lw)), (0, 1, (1 - lh) * lw), (1, 0, lh * (1 - lw)), (1, 1, lh * lw)):
+                yy, xx = hl.long() + dy, wl.long() + dx
+                ok = inside & (yy >= 0) & (yy <= H - 1) & (xx >= 0) & (xx <= W - 1)
+                idx = (yy.clamp(0, H - 1) * W + xx.clamp(0, W - 1)).reshape(B, 1, -1).expand(B, cpg, -1)
+                v = torch.gather(flat[:, g * cpg:(g + 1) * cpg], 2, idx).reshape(B, cpg, Ho, Wo)
+                val = val + v * (wt * ok.to(x.dtype))[:, None]
+            if mask is not None:
+                val = val * mask[:, g * K + t][:, None]
+            per_group.append(val)
+        cols.append(torch.cat(per_group, 1))                                   # [B, C, Ho, Wo]
+    col = torch.stack(cols, 2).reshape(B, C * K, Ho * Wo)                      # channel-major, tap-minor
+    out = torch.matmul(weight.reshape(O, -1), col).reshape(B, O, Ho, Wo)
+    return out if bias is None else out + bias.view(1, -1, 1, 1)

@@ -650,3 +650,65 @@ class _RoIAlignRotated(torch.autograd.Function):
 def roi_align_rotated(feat, rois, out_size, spatial_scale, sample_num=0, aligned=True, clockwise=False):
     """mmcv.ops.roi_align_rotated: rois [K,6] = (batch, cx, cy, w, h, theta)."""
     return _RoIAlignRotated.apply(feat, rois, int(out_size), spatial_scale, int(sample_num), bool(aligned), bool(clockwise))
+
+
+# ------------------------------------------------------ (modulated) deformable conv --
+class _DeformConv(torch.autograd.Function):
+    """mmcv.ops.(modulated_)deform_conv2d, groups = 1: gather (HIP) -> GEMM (hipBLASLt) and the mirrored backward."""
+
+    @staticmethod
+    def forward(ctx, x, offset, mask, weight, bias, stride, padding, dilation, deform_groups):
+        x, offset = _f(x), _f(offset)
+        mask = _f(mask) if mask is not None else None
+        B, C, H, W = x.shape
+        O, _, kh, kw = weight.shape
+        Ho = (H + 2 * padding[0] - (dilation[0] * (kh - 1) + 1)) // stride[0] + 1
+        Wo = (W + 2 * padding[1] - (dilation[1] * (kw - 1) + 1)) // stride[1] + 1
+        assert offset.shape == (B, 2 * deform_groups * kh * kw, Ho, Wo), (offset.shape, (B, 2 * deform_groups * kh * kw, Ho, Wo))
+        col = torch.empty((B, C * kh * kw, Ho * Wo), dtype=f32, device=x.device)
+        geo = (B, C, H, W, kh, kw, padding[0], padding[1], stride[0], stride[1], dilation[0], dilation[1], deform_groups)
+        hip.call('pt_deform_im2col', x, offset, mask, *geo, col)
+        out = torch.matmul(weight.float().reshape(O, -1), col).reshape(B, O, Ho, Wo)
+        if bias is not None:
+            out = out + bias.float().view(1, -1, 1, 1)
+        ctx.save_for_backward(x, offset, mask, weight, col)
+        ctx.geo, ctx.has_bias = geo, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, offset, mask, weight, col = ctx.saved_tensors
+        geo = ctx.geo
+        B, C, H, W, kh, kw = geo[:6]
+        O = weight.shape[0]
+        g2 = _f(g).reshape(B, O, -1)
+        gx = goff = gmask = gw = gb = None
+        if ctx.needs_input_grad[3]:
+            gw = torch.matmul(g2, col.transpose(1, 2)).sum(0).reshape(weight.shape)
+        if ctx.has_bias and ctx.needs_input_grad[4]:
+            gb = g2.sum((0, 2))
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or (mask is not None and ctx.needs_input_grad[2]):
+            gcol = torch.matmul(weight.float().reshape(O, -1).t(), g2).contiguous()          # [B, C*K, L]
+            if ctx.needs_input_grad[0]:
+                gx = torch.zeros_like(x)
+                hip.call('pt_deform_col2im', gcol, offset, mask, *geo, gx)
+            goff = torch.empty_like(offset)
+            gmask = torch.empty_like(mask) if mask is not None else None
+            hip.call('pt_deform_col2im_coord', gcol, x, offset, mask, *geo, goff, gmask)
+        return gx, goff, gmask, gw, gb, None, None, None, None
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+def deform_conv2d(x, offset, weight, stride=1, padding=0, dilation=1, groups=1, deform_groups=1):
+    """mmcv.ops.deform_conv2d (DCNv1, no bias)."""
+    assert groups == 1, 'groups=1 is what the path can reach'
+    return _DeformConv.apply(x, offset, None, weight, None, _pair(stride), _pair(padding), _pair(dilation), deform_groups)
+
+
+def modulated_deform_conv2d(x, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, deform_groups=1):
+    """mmcv.ops.modulated_deform_conv2d (DCNv2)."""
+    assert groups == 1, 'groups=1 is what the path can reach'
+    return _DeformConv.apply(x, offset, mask, weight, bias, _pair(stride), _pair(padding), _pair(dilation), deform_groups)

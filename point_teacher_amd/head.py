@@ -42,7 +42,6 @@ class TS_P2BFCOSHead(nn.Module):
         super().__init__()
         assert norm_cfg is None or norm_cfg['type'] == 'GN', 'head norm is None (HBB configs) or GroupNorm (OBB config)'
         self.norm_cfg = norm_cfg
-        assert not dcn_on_last_conv, 'dcn_on_last_conv=False in every Point-Teacher config (DCN is a later row)'
         self.num_classes = self.cls_out_channels = num_classes
         self.in_channels, self.feat_channels, self.stacked_convs = in_channels, feat_channels, stacked_convs
         self.strides = list(strides)
@@ -79,9 +78,11 @@ class TS_P2BFCOSHead(nn.Module):
     # ------------------------------------------------------------------ layers --
     def _init_layers(self):
         """anchor_free_head.py:86-135 + fcos_head_p2b_ts.py:189-263 (same parameter names)."""
-        def stack(n, cin):
+        def stack(n, cin):      # `dcn_on_last_conv`: the last conv of a tower is a DCNv2 (anchor_free_head.py:101-102,121-122)
             return nn.ModuleList([ConvModule(cin if i == 0 else self.feat_channels, self.feat_channels, 3, padding=1,
-                                             bias=self.conv_bias, norm_cfg=self.norm_cfg) for i in range(n)])
+                                             bias=self.conv_bias, norm_cfg=self.norm_cfg,
+                                             conv_cfg=dict(type='DCNv2') if (self.dcn_on_last_conv and i == self.stacked_convs - 1)
+                                             else None) for i in range(n)])
         self.cls_convs = stack(self.stacked_convs, self.in_channels)
         self.reg_convs = stack(self.stacked_convs, self.in_channels)
         self.conv_cls = nn.Conv2d(self.feat_channels, self.cls_out_channels, 3, padding=1)
@@ -110,8 +111,8 @@ class TS_P2BFCOSHead(nn.Module):
 
     def init_weights(self):
         """init_cfg of fcos_head_p2b_ts.py:137-145: Normal(std .01) on convs, conv_cls bias_prob .01."""
-        for m in self.modules():
-            if isinstance(m, nn.Conv2d):
+        for name, m in self.named_modules():
+            if isinstance(m, nn.Conv2d) and not name.endswith('conv_offset'):   # DCN offset predictors stay zero (mmcv)
                 nn.init.normal_(m.weight, 0, 0.01)
                 if m.bias is not None:
                     nn.init.constant_(m.bias, 0)

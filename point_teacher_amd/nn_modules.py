@@ -15,16 +15,70 @@ from . import functional as F
 from .registry import BACKBONES, NECKS, ROI_EXTRACTORS
 
 
+class ModulatedDeformConv2dPack(nn.Module):
+    """mmcv.ops.ModulatedDeformConv2dPack (`conv_cfg=dict(type='DCNv2')`): a zero-initialised `conv_offset` predicts
+    (dy, dx) offsets and a sigmoid mask per kernel tap, `pt_deform_*` does the sampling.  Parameter names as mmcv
+    (`weight`, `bias`, `conv_offset.weight`, `conv_offset.bias`)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, deform_groups=1,
+                 bias=True):
+        super().__init__()
+        assert groups == 1
+        k = kernel_size if isinstance(kernel_size, tuple) else (kernel_size, kernel_size)
+        self.stride, self.padding, self.dilation, self.deform_groups, self.kernel_size = stride, padding, dilation, deform_groups, k
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, *k))
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        n = in_channels * k[0] * k[1]
+        nn.init.uniform_(self.weight, -1.0 / n ** 0.5, 1.0 / n ** 0.5)                 # mmcv ModulatedDeformConv2d.init_weights
+        self.conv_offset = nn.Conv2d(in_channels, deform_groups * 3 * k[0] * k[1], k, stride=stride, padding=padding,
+                                     dilation=dilation, bias=True)
+        nn.init.zeros_(self.conv_offset.weight)
+        nn.init.zeros_(self.conv_offset.bias)
+
+    def forward(self, x):
+        out = self.conv_offset(x)
+        o1, o2, mask = torch.chunk(out, 3, dim=1)
+        offset = torch.cat((o1, o2), dim=1)
+        return F.modulated_deform_conv2d(x, offset, torch.sigmoid(mask), self.weight, self.bias, self.stride, self.padding,
+                                         self.dilation, 1, self.deform_groups)
+
+
+class DeformConv2dPack(nn.Module):
+    """mmcv.ops.DeformConv2dPack (`conv_cfg=dict(type='DCN')`, no bias, no mask)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, deform_groups=1,
+                 bias=False):
+        super().__init__()
+        assert groups == 1 and not bias
+        k = kernel_size if isinstance(kernel_size, tuple) else (kernel_size, kernel_size)
+        self.stride, self.padding, self.dilation, self.deform_groups = stride, padding, dilation, deform_groups
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, *k))
+        nn.init.kaiming_uniform_(self.weight, nonlinearity='relu')
+        self.conv_offset = nn.Conv2d(in_channels, deform_groups * 2 * k[0] * k[1], k, stride=stride, padding=padding,
+                                     dilation=dilation, bias=True)
+        nn.init.zeros_(self.conv_offset.weight)
+        nn.init.zeros_(self.conv_offset.bias)
+
+    def forward(self, x):
+        return F.deform_conv2d(x, self.conv_offset(x), self.weight, self.stride, self.padding, self.dilation, 1,
+                               self.deform_groups)
+
+
+_CONV_LAYERS = {'Conv2d': nn.Conv2d, 'DCN': DeformConv2dPack, 'DCNv2': ModulatedDeformConv2dPack}
+
+
 class ConvModule(nn.Module):
     """The subset of mmcv.cnn.ConvModule on this path: conv (+GroupNorm) (+ReLU).  Parameter paths
     `.conv` and `.gn` (mmcv names the norm layer after its type); bias='auto' means "no bias when a
     norm layer follows" (mmcv/cnn/bricks/conv_module.py:113-116)."""
 
-    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, act=True, norm_cfg=None):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, act=True, norm_cfg=None,
+                 conv_cfg=None):
         super().__init__()
         if bias == 'auto':
             bias = norm_cfg is None
-        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=bias)
+        conv_cls = _CONV_LAYERS[(conv_cfg or dict(type='Conv2d'))['type']]           # mmcv build_conv_layer
+        self.conv = conv_cls(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=bias)
         self.with_activation = act
         self.with_norm = norm_cfg is not None
         if self.with_norm:

@@ -33,3 +33,31 @@ def test_images_without_objects(variant, phase2, counts):
     bad = [k for k, v in lv.items() if v != v or abs(v) == float('inf')]
     assert not bad, (bad, lv)
     assert torch.isfinite(trainer.flat.student_flat).all() and torch.isfinite(trainer.flat.teacher_flat).all()
+
+
+def test_iteration_with_dcn_on_last_conv():
+    """The latent `dcn_on_last_conv=True` option (anchor_free_head.py:101-102; no shipped config sets it): both phases
+    train through the DCNv2 tower convs (pt_deform_*), offsets receive gradients, everything stays finite."""
+    import os
+    dev = torch.device('cuda:0')
+    import point_teacher_amd as pta
+    from point_teacher_amd.nn_modules import ModulatedDeformConv2dPack
+    from point_teacher_amd.synthetic import benchmark_init_
+    torch.manual_seed(3)
+    cfg = pta.Config.fromfile(os.path.join(T.ROOT, 'point_teacher_amd', 'configs', 'point_teacher', 'aitodv2_point_teacher_0.py'))
+    cfg.model['_model_']['bbox_head']['dcn_on_last_conv'] = True
+    cfg.model['burn_in_step'] = 0                      # iteration 0: phase 1, iteration 1: phase 2
+    model = pta.build_detector(cfg.model).to(dev)
+    benchmark_init_(model, phase2=True)
+    model.train()
+    assert isinstance(model.student.bbox_head.reg_convs[3].conv, ModulatedDeformConv2dPack)
+    trainer = pta.Trainer(model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config)
+    img, boxes, labels, metas = T._data(dev)
+    data = dict(img=img.to(dev), img_metas=metas, gt_bboxes=[b.to(dev) for b in boxes], gt_labels=[l.to(dev) for l in labels])
+    w0 = model.student.bbox_head.reg_convs[3].conv.conv_offset.weight.detach().clone()
+    for _ in range(2):
+        lv = trainer.step(data)['log_vars'].materialize()
+        assert all(v == v and abs(v) != float('inf') for v in lv.values()), lv
+    w1 = model.student.bbox_head.reg_convs[3].conv.conv_offset.weight.detach()
+    assert float((w1 - w0).abs().max()) > 0            # the offset predictor trains
+    assert torch.isfinite(trainer.flat.student_flat).all()

@@ -2,6 +2,8 @@
 (oracle/ref_ops.py) on seeded inputs and against the golden fixtures captured from the
 reference.  Index outputs bit-exact; fp32 outputs within 1e-3 relative (north_star's
 tolerance; most are ~1e-6).  All calls go through the C ABI (point_teacher_amd.hip)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -10,6 +12,7 @@ from conftest import load_golden
 from oracle import ref_ops as R
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEV = 'cuda'
 RT = 1e-3     # north_star: within 1e-3 relative on fp32
 
@@ -456,6 +459,79 @@ def test_trainable_bn_epilogue(C, HW, relu, with_res):
     scale = float(bn.weight.grad.abs().max())
     close(bng.weight.grad, bn.weight.grad, rtol=1e-3, atol=1e-4 * scale)
     close(bng.bias.grad, bn.bias.grad, rtol=1e-3, atol=1e-4 * float(bn.bias.grad.abs().max()))
+
+
+@pytest.mark.parametrize('modulated,dg,stride,dil', [(True, 1, 1, 1), (True, 2, 2, 1), (False, 1, 1, 2), (True, 4, 1, 1)])
+def test_deform_conv(modulated, dg, stride, dil):
+    """pt_deform_* + GEMM == the published (modulated) deformable convolution: values and every gradient against the
+    torch-gather oracle; zero offsets and unit mask reduce to a plain convolution; samples far outside contribute 0."""
+    f = F()
+    gen = torch.Generator().manual_seed(51)
+    B, C, H, W, O, k = 2, 8, 13, 17, 6, 3
+    pad = dil
+    x = torch.randn(B, C, H, W, generator=gen)
+    wgt = torch.randn(O, C, k, k, generator=gen) * 0.2
+    bias = torch.randn(O, generator=gen) if modulated else None
+    Ho = (H + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+    Wo = (W + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+    off = torch.randn(B, 2 * dg * k * k, Ho, Wo, generator=gen) * 2.0
+    off[0, 0, 0, 0] = -50.0                                        # a sample far outside the map
+    off = off + 0.013                                               # keep samples off the integer lattice (floor kinks)
+    mask = torch.rand(B, dg * k * k, Ho, Wo, generator=gen) if modulated else None
+    xr, offr, wr = x.clone().requires_grad_(True), off.clone().requires_grad_(True), wgt.clone().requires_grad_(True)
+    mr = mask.clone().requires_grad_(True) if modulated else None
+    br = bias.clone().requires_grad_(True) if bias is not None else None
+    ref = R.modulated_deform_conv2d(xr, offr, mr, wr, br, stride, pad, dil, dg)
+    gout = torch.randn(ref.shape, generator=gen)
+    (ref * gout).sum().backward()
+    xg, offg, wg = cu(x).requires_grad_(True), cu(off).requires_grad_(True), cu(wgt).requires_grad_(True)
+    mg = cu(mask).requires_grad_(True) if modulated else None
+    bg = cu(bias).requires_grad_(True) if bias is not None else None
+    if modulated:
+        out = f.modulated_deform_conv2d(xg, offg, mg, wg, bg, stride, pad, dil, 1, dg)
+    else:
+        out = f.deform_conv2d(xg, offg, wg, stride, pad, dil, 1, dg)
+    close(out, ref, atol=1e-4)
+    (out * cu(gout)).sum().backward()
+    close(xg.grad, xr.grad, atol=1e-4)
+    close(offg.grad, offr.grad, atol=2e-4)
+    close(wg.grad, wr.grad, atol=2e-4)
+    if modulated:
+        close(mg.grad, mr.grad, atol=1e-4)
+        close(bg.grad, br.grad, atol=1e-4)
+    # zero offsets (+ unit mask) == plain convolution
+    z = torch.zeros_like(off)
+    if modulated:
+        y0 = f.modulated_deform_conv2d(cu(x), cu(z), cu(torch.ones_like(mask)), cu(wgt), cu(bias), stride, pad, dil, 1, dg)
+    else:
+        y0 = f.deform_conv2d(cu(x), cu(z), cu(wgt), stride, pad, dil, 1, dg)
+    close(y0, torch.nn.functional.conv2d(x, wgt, bias, stride, pad, dil), atol=1e-4)
+
+
+def test_dcn_on_last_conv_head():
+    """`dcn_on_last_conv=True` (anchor_free_head.py:101-102): the last conv of both towers is a DCNv2 pack; with its
+    zero-initialised offset predictor (mask = sigmoid(0) = 0.5) the tower equals the plain one at half amplitude, and
+    gradients reach the offset predictor."""
+    import point_teacher_amd as pta
+    from point_teacher_amd.nn_modules import ModulatedDeformConv2dPack
+    cfg = pta.Config.fromfile(os.path.join(ROOT, 'point_teacher_amd', 'configs', 'point_teacher', 'aitodv2_point_teacher_0.py'))
+    hc = dict(cfg.model['_model_']['bbox_head'])
+    hc.update(dcn_on_last_conv=True, train_cfg=cfg.model['train_cfg'], test_cfg=cfg.model['test_cfg'])
+    head = pta.build_from_cfg(hc, pta.HEADS).to(DEV)
+    assert isinstance(head.cls_convs[3].conv, ModulatedDeformConv2dPack) and isinstance(head.reg_convs[3].conv, ModulatedDeformConv2dPack)
+    assert isinstance(head.cls_convs[2].conv, torch.nn.Conv2d)
+    assert float(head.cls_convs[3].conv.conv_offset.weight.abs().max()) == 0
+    x = torch.randn(2, 256, 16, 16, device=DEV, requires_grad=True)
+    cls, reg, ctr, pts = head([x])
+    d = head.cls_convs[3].conv
+    t = x
+    for l in list(head.cls_convs)[:3]:
+        t = l(t)
+    plain = torch.relu(torch.nn.functional.conv2d(t, d.weight, d.bias, 1, 1) * 0.5 + d.bias.view(1, -1, 1, 1) * 0.5)
+    close(head.conv_cls(plain), cls[0], atol=1e-4)
+    (cls[0].square().mean() + reg[0].mean()).backward()
+    assert d.conv_offset.weight.grad is not None and float(d.conv_offset.weight.grad.abs().max()) > 0
+    assert x.grad is not None and torch.isfinite(x.grad).all()
 
 
 def test_diff_iou_rotated():
