@@ -315,6 +315,20 @@ int pt_deform_col2im_coord(const float* grad_col, const float* x, const float* o
                            int stride_h, int stride_w, int dil_h, int dil_w, int deform_groups,
                            float* grad_offset, float* grad_mask, void* stream);
 
+/* -------------------------------------------------------- evaluator (next row N1) --
+ * evaluateImg of the COCO / AI-TOD protocol (aitodpycocotools.cocoeval.COCOeval, called at
+ * HBB_TOD/mmdet/datasets/aitod.py:109-146): greedy matching of the detections of every (image,
+ * category) segment, in descending score order, against that segment's ground truths, for A area
+ * ranges x T IoU thresholds at once (A*T <= 64).  det_box[Nd,4] xyxy sorted by (segment, -score);
+ * det_off[S+1], gt_off[S+1] segment offsets; gt_flags bit 0 = ignore, bit 1 = iscrowd; only the first
+ * max_det detections of a segment are matched.  gt_matched[Ng*64] is zeroed scratch.  Outputs, per
+ * detection and lane (a*T + t): dtm = matched gt row or -1, dt_ig = ignored flag (matched to an ignored
+ * gt, or unmatched with an area outside the range). */
+int pt_coco_match(const float* det_box, const int32_t* det_off, const float* gt_box,
+                  const float* gt_area, const uint8_t* gt_flags, const int32_t* gt_off, int S,
+                  const float* area_lo, const float* area_hi, int A, const float* iou_thr, int T,
+                  int max_det, uint8_t* gt_matched, int32_t* dtm, uint8_t* dt_ig, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,187 @@
+"""AI-TOD / COCO-style box evaluator on the GPU: the counterpart of
+`AITODDataset.evaluate(metric='bbox')` (/root/reference/HBB_TOD/mmdet/datasets/aitod.py:23-246), which hands the
+detections to `aitodpycocotools.cocoeval.COCOeval` (un-vendored).  Same inputs as the reference's method (the
+per-image, per-class arrays `simple_test` returns), same metric names (`bbox_mAP`, `bbox_mAP_50`, `bbox_mAP_vt`, ...).
+
+Matching (`evaluateImg`) is one HIP launch for the whole dataset (`pt_coco_match`: a wavefront per (image, category),
+a lane per (area range, IoU threshold)); accumulation (`accumulate`: global score sort, cumulative TP/FP, precision
+envelope, 101-point recall sampling) and `summarize` are a few dozen batched torch ops on the device.
+
+Protocol: area ranges all / verytiny [0,8^2] / tiny [8^2,16^2] / small [16^2,32^2] / medium [32^2,inf), maxDets
+(100, 300, 1500) (aitod.py:30), IoU thresholds 0.50:0.05:0.95 unless given.  The fork's `evaluate` overwrites its
+`iou_thrs` argument with [0.25] (aitod.py:64, a debugging leftover): pass `iou_thrs=[0.25]` to reproduce that.
+The fork's oLRP statistics are not computed.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import hip
+
+AREAS = (('all', 0.0, 1e5 ** 2), ('verytiny', 0.0, 8.0 ** 2), ('tiny', 8.0 ** 2, 16.0 ** 2), ('small', 16.0 ** 2, 32.0 ** 2),
+         ('medium', 32.0 ** 2, 1e5 ** 2))
+MAX_DETS = (100, 300, 1500)
+
+
+def _default_iou_thrs():
+    return np.linspace(.5, 0.95, int(np.round((0.95 - .5) / .05)) + 1, endpoint=True)
+
+
+class AITODEvaluator:
+    def __init__(self, gts, num_classes, device='cuda', areas=AREAS, max_dets=MAX_DETS, iou_thrs=None):
+        """gts[i] = dict(bboxes [G,4] xyxy, labels [G], optional area [G], iscrowd [G], ignore [G]) for image i."""
+        self.K, self.areas, self.max_dets = num_classes, areas, tuple(max_dets)
+        self.iou_thrs = np.asarray(_default_iou_thrs() if iou_thrs is None else iou_thrs, dtype=np.float64)
+        self.device = torch.device(device)
+        assert len(areas) * len(self.iou_thrs) <= 64, 'area ranges x IoU thresholds must fit one wavefront'
+        box, img, lab, area, flags = [], [], [], [], []
+        for i, g in enumerate(gts):
+            b = np.asarray(g['bboxes'], np.float32).reshape(-1, 4)
+            n = b.shape[0]
+            box.append(b)
+            img.append(np.full(n, i, np.int64))
+            lab.append(np.asarray(g['labels'], np.int64).reshape(-1))
+            area.append(np.asarray(g['area'], np.float32).reshape(-1) if 'area' in g
+                        else (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]))
+            crowd = np.asarray(g['iscrowd']).reshape(-1).astype(bool) if 'iscrowd' in g else np.zeros(n, bool)
+            ign = np.asarray(g['ignore']).reshape(-1).astype(bool) if 'ignore' in g else np.zeros(n, bool)
+            flags.append((ign | crowd).astype(np.uint8) | (crowd.astype(np.uint8) << 1))
+        self.n_img = len(gts)
+        cat = np.concatenate(lab) if lab else np.zeros(0, np.int64)
+        key = (np.concatenate(img) if img else np.zeros(0, np.int64)) * self.K + cat
+        order = np.argsort(key, kind='stable')                              # segment-major, original order inside
+        dev = self.device
+        self.gt_key = torch.from_numpy(key[order]).to(dev)
+        self.gt_box = torch.from_numpy(np.concatenate(box)[order] if box else np.zeros((0, 4), np.float32)).to(dev)
+        self.gt_area = torch.from_numpy(np.concatenate(area)[order] if area else np.zeros(0, np.float32)).to(dev)
+        self.gt_flags = torch.from_numpy(np.concatenate(flags)[order] if flags else np.zeros(0, np.uint8)).to(dev)
+        self.gt_cat = torch.from_numpy(cat[order]).to(dev)
+
+    # ------------------------------------------------------------------------------
+    def _flatten(self, results):
+        """mmdet bbox2result layout -> (boxes, scores, segment key) sorted by (key, -score), stable."""
+        box, score, key = [], [], []
+        assert len(results) == self.n_img, (len(results), self.n_img)
+        for i, per_cls in enumerate(results):
+            assert len(per_cls) == self.K
+            for k, arr in enumerate(per_cls):
+                arr = np.asarray(arr, np.float32).reshape(-1, 5)
+                if arr.shape[0]:
+                    o = np.argsort(-arr[:, 4], kind='mergesort')
+                    box.append(arr[o, :4]); score.append(arr[o, 4]); key.append(np.full(arr.shape[0], i * self.K + k, np.int64))
+        if not box:
+            return (torch.zeros((0, 4), device=self.device), torch.zeros(0, device=self.device),
+                    torch.zeros(0, dtype=torch.long, device=self.device))
+        dev = self.device
+        return (torch.from_numpy(np.concatenate(box)).to(dev), torch.from_numpy(np.concatenate(score)).to(dev),
+                torch.from_numpy(np.concatenate(key)).to(dev))
+
+    def evaluate(self, results):
+        """-> OrderedDict of the reference's `bbox_*` metrics (+ `precision` [T,R,K,A,M] and `recall` [T,K,A,M] tensors)."""
+        dev = self.device
+        A, T, K, M = len(self.areas), len(self.iou_thrs), self.K, len(self.max_dets)
+        R = 101
+        dbox, dscore, dkey = self._flatten(results)
+        Nd, Ng = dbox.shape[0], self.gt_box.shape[0]
+        # segments = every (image, category) that has detections or ground truths
+        keys = torch.unique(torch.cat([dkey, self.gt_key]))
+        S = int(keys.numel())
+        det_off = torch.searchsorted(dkey, torch.cat([keys, keys[-1:] + 1]) if S else keys).to(torch.int32)
+        gt_off = torch.searchsorted(self.gt_key, torch.cat([keys, keys[-1:] + 1]) if S else keys).to(torch.int32)
+        L = A * T
+        dtm = torch.full((Nd, L), -1, dtype=torch.int32, device=dev)
+        dt_ig = torch.zeros((Nd, L), dtype=torch.uint8, device=dev)
+        if S and Nd:
+            lo = torch.tensor([a[1] for a in self.areas], dtype=torch.float32, device=dev)
+            hi = torch.tensor([a[2] for a in self.areas], dtype=torch.float32, device=dev)
+            thr = torch.tensor(self.iou_thrs, dtype=torch.float32, device=dev)
+            scratch = torch.zeros((max(Ng, 1) * 64,), dtype=torch.uint8, device=dev)
+            hip.call('pt_coco_match', dbox.contiguous(), det_off, self.gt_box, self.gt_area, self.gt_flags, gt_off, S, lo, hi, A,
+                     thr, T, int(self.max_dets[-1]), scratch, dtm, dt_ig)
+        # rank of every detection inside its segment (for the maxDets prefixes) and its category
+        seg_of = torch.searchsorted(keys, dkey) if Nd else dkey
+        rank = torch.arange(Nd, device=dev) - det_off[:-1].long()[seg_of] if Nd else dkey
+        dcat = dkey % K
+        precision = -torch.ones((T, R, K, A, M), dtype=torch.float64, device=dev)
+        recall = -torch.ones((T, K, A, M), dtype=torch.float64, device=dev)
+        # numpy's linspace, bit for bit: recall values such as 7/10 tie with the thresholds (cocoeval.py Params.recThrs)
+        rec_thrs = torch.from_numpy(np.linspace(.0, 1.00, int(np.round((1.00 - .0) / .01)) + 1, endpoint=True)).to(dev)
+        lo_t = torch.tensor([a[1] for a in self.areas], dtype=torch.float32, device=dev)
+        hi_t = torch.tensor([a[2] for a in self.areas], dtype=torch.float32, device=dev)
+        g_ign = ((self.gt_flags & 1).bool()[:, None] | (self.gt_area[:, None] < lo_t[None]) | (self.gt_area[:, None] > hi_t[None]))
+        eps = float(np.spacing(1))
+        for k in range(K):
+            gsel = self.gt_cat == k
+            npig_a = (~g_ign[gsel]).sum(0)                                    # [A] non-ignored gts of this category
+            dsel_k = dcat == k
+            if not bool(gsel.any()) and not bool(dsel_k.any()):
+                continue
+            for m, md in enumerate(self.max_dets):
+                sel = (dsel_k & (rank < md)).nonzero().reshape(-1)
+                sc = dscore[sel]
+                order = torch.sort(sc, descending=True, stable=True)[1]
+                sel = sel[order]
+                nd = int(sel.numel())
+                mt = dtm[sel].reshape(nd, A, T) >= 0                          # [nd, A, T]
+                ig = dt_ig[sel].reshape(nd, A, T).bool()
+                tp = torch.cumsum((mt & ~ig).double(), 0)
+                fp = torch.cumsum((~mt & ~ig).double(), 0)
+                for a in range(A):
+                    npig = int(npig_a[a])
+                    if npig == 0:
+                        continue
+                    if nd == 0:
+                        recall[:, k, a, m] = 0
+                        precision[:, :, k, a, m] = 0
+                        continue
+                    # divide by a TENSOR: torch turns `x / python_scalar` into `x * (1 / scalar)`, and 7 * (1/10) is one ulp
+                    # above 7/10 - enough to move a recall value across the 0.70 threshold of the 101-point sampling
+                    rc = (tp[:, a, :] / npig_a[a].double()).t().contiguous()  # [T, nd] non-decreasing
+                    pr = (tp[:, a, :] / (fp[:, a, :] + tp[:, a, :] + eps)).t().contiguous()
+                    recall[:, k, a, m] = rc[:, -1]
+                    pr = torch.flip(torch.cummax(torch.flip(pr, [1]), 1)[0], [1])      # precision envelope
+                    idx = torch.searchsorted(rc, rec_thrs[None, :].expand(T, R).contiguous(), right=False)
+                    q = torch.where(idx < nd, torch.gather(pr, 1, idx.clamp(max=nd - 1)), torch.zeros((), dtype=torch.float64, device=dev))
+                    precision[:, :, k, a, m] = q
+        return self._summarize(precision, recall)
+
+    def _summarize(self, precision, recall):
+        M = len(self.max_dets)
+
+        def mean_valid(s):
+            s = s[s > -1]
+            return float(s.mean()) if s.numel() else -1.0
+
+        def ap(thr=None, area=0, md=M - 1):
+            s = precision[:, :, :, area, md]
+            if thr is not None:
+                w = np.where(np.isclose(self.iou_thrs, thr))[0]
+                if len(w) == 0:
+                    return -1.0
+                s = s[torch.as_tensor(w, device=s.device)]
+            return mean_valid(s)
+
+        def ar(area=0, md=M - 1):
+            return mean_valid(recall[:, :, area, md])
+        md = self.max_dets
+        out = OrderedDict()
+        for name, v in (('mAP', ap()), ('mAP_25', ap(.25)), ('mAP_50', ap(.5)), ('mAP_75', ap(.75)), ('mAP_vt', ap(area=1)),
+                        ('mAP_t', ap(area=2)), ('mAP_s', ap(area=3)), ('mAP_m', ap(area=4)), (f'AR@{md[0]}', ar(md=0)),
+                        (f'AR@{md[1]}', ar(md=1)), (f'AR@{md[2]}', ar(md=2)), (f'AR_vt@{md[2]}', ar(1)), (f'AR_t@{md[2]}', ar(2)),
+                        (f'AR_s@{md[2]}', ar(3)), (f'AR_m@{md[2]}', ar(4))):
+            out['bbox_' + name] = v
+        out['precision'], out['recall'] = precision, recall
+        return out
+
+
+def single_gpu_test(model, batches, n_batches):
+    """apis/test.py:16-66 for this path: `model(return_loss=False, rescale=True, **data)` over the data, results
+    collected in dataset order (one list of per-class arrays per image)."""
+    model.eval()
+    results = []
+    with torch.no_grad():
+        for it in range(n_batches):
+            data = batches(it)
+            results.extend(model(return_loss=False, rescale=True, img=data['img'], img_metas=data['img_metas']))
+    return results

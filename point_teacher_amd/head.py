@@ -454,7 +454,8 @@ class TS_P2BFCOSHead(nn.Module):
             mc.append(ctr)
         bb, sc, ct = torch.cat(mb, 1), torch.cat(ms, 1), torch.cat(mc, 1)
         if rescale:
-            bb = bb / bb.new_tensor([m['scale_factor'] for m in img_metas]).unsqueeze(1)
+            import numpy as np
+            bb = bb / bb.new_tensor(np.stack([np.asarray(m['scale_factor'], np.float32) for m in img_metas])).unsqueeze(1)
         sc = torch.cat([sc, sc.new_zeros(B, sc.shape[1], 1)], dim=-1)
         if not with_nms:
             return [tuple(t) for t in zip(bb, sc, ct)]
