@@ -290,6 +290,36 @@ def install_obb():
     imp('mmrotate.models.dense_heads.rotated_fcos_head_p2rb_ts')
 
 
+def install_obb_eval(iou_fn):
+    """Load OBB_TOD/mmrotate/core/evaluation/eval_map.py with mmcv's box_iou_rotated replaced by `iou_fn`
+    (the rotated IoU itself is parity-unpinned; everything else in the file is the reference's own numpy) and a
+    serial stand-in for the multiprocessing pool (spawned workers would not see the shims)."""
+    install_obb()
+    import numpy as np
+    if 'terminaltables' not in sys.modules:
+        _pkg('terminaltables', stub=True)
+    _pkg('mmdet.core.evaluation', os.path.join(HBB, 'mmdet', 'core', 'evaluation'))
+    for n in ('mmdet.core.evaluation.bbox_overlaps', 'mmdet.core.evaluation.class_names'):
+        _pkg(n, stub=True)
+    sys.modules['mmcv.utils'].print_log = lambda *a, **k: None
+    mean_ap = importlib.import_module('mmdet.core.evaluation.mean_ap')
+    sys.modules['mmdet.core'].average_precision = mean_ap.average_precision
+    sys.modules['mmcv.ops'].box_iou_rotated = iou_fn
+    _pkg('mmrotate.core.evaluation', os.path.join(OBB, 'mmrotate', 'core', 'evaluation'))
+    em = importlib.import_module('mmrotate.core.evaluation.eval_map')
+    em.box_iou_rotated = iou_fn
+
+    class _SerialPool:
+        def starmap(self, f, it):
+            return [f(*a) for a in it]
+
+        def close(self):
+            pass
+    em.get_context = lambda kind: type('Ctx', (), {'Pool': staticmethod(lambda n: _SerialPool())})()
+    em.print_map_summary = lambda *a, **k: None
+    return em
+
+
 def ref_obb(name):
     """Return a loaded OBB reference module, e.g. ref_obb('core.bbox.transforms')."""
     install_obb()

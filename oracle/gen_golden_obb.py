@@ -227,10 +227,62 @@ def gen_head():
            out_grad_neg=gr[2])
 
 
+def gen_eval_map():
+    """core/evaluation/eval_map.py eval_rbbox_map (:126-246) + tpfp_default (:12-94) + mmdet average_precision, run on a
+    seeded scene.  mmcv's box_iou_rotated is replaced by the fp64 polygon-clip IoU of oracle/ref_ops.py (unpinned)."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from oracle import ref_ops as R
+    # tpfp_default hands the (m, 6) detection rows (score included) to the op; the stand-in reads the five box columns
+    em = L.install_obb_eval(lambda a, b: R.box_iou_rotated(a[:, :5], b[:, :5]))
+    rng = np.random.RandomState(7)
+    K, n_img = 3, 7
+    dets, anns, flat = [], [], {}
+    for i in range(n_img):
+        NG = rng.randint(0, 10)
+        c = rng.rand(NG, 2) * 300 + 30
+        wh = np.exp(rng.randn(NG, 2) * 0.5 + np.log(20.0)).clip(4, 90)
+        a = rng.rand(NG, 1) * np.pi - np.pi / 2
+        gb = np.concatenate([c, wh, a], 1).astype(np.float32)
+        lab = rng.randint(0, K, NG)
+        ign = rng.rand(NG) < 0.15
+        ann = dict(bboxes=gb[~ign], labels=lab[~ign], bboxes_ignore=gb[ign], labels_ignore=lab[ign])
+        anns.append(ann)
+        per = []
+        for k in range(K):
+            g = gb[lab == k]
+            keep = rng.rand(len(g)) < 0.8
+            d = g[keep] + rng.randn(int(keep.sum()), 5).astype(np.float32) * np.array([1.5, 1.5, 1.5, 1.5, 0.05], np.float32)
+            d = np.concatenate([d, d[: len(d) // 2] + 0.5], 0)
+            nf = rng.randint(0, 4)
+            f = np.concatenate([rng.rand(nf, 2) * 300 + 30, np.exp(rng.randn(nf, 2) * 0.5 + np.log(20.0)).clip(4, 90),
+                                rng.rand(nf, 1) * np.pi - np.pi / 2], 1)
+            d = np.concatenate([d, f], 0).astype(np.float32)
+            sc = (rng.rand(len(d), 1) * 0.9 + 0.05).astype(np.float32)      # distinct scores (ties would be ordered by numpy's quicksort)
+            per.append(np.concatenate([d, sc], 1).astype(np.float32))
+        dets.append(per)
+    out = {}
+    for thr in (0.5, 0.25):
+        mean_ap, res = em.eval_rbbox_map(dets, anns, iou_thr=thr, nproc=1)
+        out[f'out_map_{int(thr * 100)}'] = np.float64(mean_ap)
+        for k in range(K):
+            out[f'out_ap_{int(thr * 100)}_{k}'] = np.float64(res[k]['ap'])
+            out[f'out_recall_{int(thr * 100)}_{k}'] = np.asarray(res[k]['recall'], np.float64)
+            out[f'out_precision_{int(thr * 100)}_{k}'] = np.asarray(res[k]['precision'], np.float64)
+            out[f'out_num_gts_{int(thr * 100)}_{k}'] = np.int64(res[k]['num_gts'])
+    for i in range(n_img):
+        for key in ('bboxes', 'labels', 'bboxes_ignore', 'labels_ignore'):
+            out[f'in_ann{i}_{key}'] = anns[i][key]
+        for k in range(K):
+            out[f'in_det{i}_{k}'] = dets[i][k]
+    allsc = np.concatenate([d[:, -1] for per in dets for d in per])
+    assert len(np.unique(allsc)) == len(allsc), 'score ties: the reference would order them with an unstable sort'
+    G.save('obb_eval_map', n_img=np.int64(n_img), num_classes=np.int64(K), **out)
+
+
 if __name__ == '__main__':
     L.install_obb()
     torch.manual_seed(0); np.random.seed(0); random.seed(0)
-    for fn in [gen_transforms, gen_coder, gen_proposals, gen_strong_aug, gen_head]:
+    for fn in [gen_transforms, gen_coder, gen_proposals, gen_strong_aug, gen_head, gen_eval_map]:
         print(fn.__name__)
         fn()
     print('done')

@@ -156,3 +156,80 @@ def evaluate(results, gts, num_classes, iou_thrs=None, max_dets=MAX_DETS, areas=
              f'AR@{max_dets[2]}': ar(md=2), f'AR_vt@{max_dets[2]}': ar(1), f'AR_t@{max_dets[2]}': ar(2),
              f'AR_s@{max_dets[2]}': ar(3), f'AR_m@{max_dets[2]}': ar(4)}
     return stats, precision, recall
+
+
+# ------------------------------------------------------------------------------------------------
+# DOTA-style mAP of the oriented tree (config 5: `evaluation = dict(metric='mAP')`):
+# OBB_TOD/mmrotate/core/evaluation/eval_map.py eval_rbbox_map (:126-246) + tpfp_default (:12-94) +
+# HBB_TOD/mmdet/core/evaluation/mean_ap.py average_precision (mode '11points' by default, 'area' on request).  Pinned by
+# tests/golden/obb_eval_map.npz, captured from the reference's own file (only mmcv's rotated IoU replaced).
+# ------------------------------------------------------------------------------------------------
+def average_precision_area(recalls, precisions):
+    mrec = np.hstack(([0.0], recalls, [1.0]))
+    mpre = np.hstack(([0.0], precisions, [0.0]))
+    for i in range(len(mpre) - 1, 0, -1):
+        mpre[i - 1] = max(mpre[i - 1], mpre[i])
+    ind = np.where(mrec[1:] != mrec[:-1])[0]
+    return float(np.sum((mrec[ind + 1] - mrec[ind]) * mpre[ind + 1]))
+
+
+def average_precision_11points(recalls, precisions):
+    """mean_ap.py average_precision mode '11points' (VOC07) - the default of eval_rbbox_map (use_07_metric=True)."""
+    ap = 0.0
+    for thr in np.arange(0, 1 + 1e-3, 0.1):
+        precs = precisions[recalls >= thr]
+        ap += precs.max() if precs.size > 0 else 0
+    return float(ap / 11)
+
+
+def eval_rbbox_map(det_results, annotations, iou_thr=0.5, iou_fn=None, use_07_metric=True):
+    """det_results[i][k] = [n,6] (cx,cy,w,h,a,score); annotations[i] = dict(bboxes [G,5], labels [G],
+    bboxes_ignore, labels_ignore).  Returns (mAP, per-class list of dict(ap, recall, precision, num_gts))."""
+    from . import ref_ops as R
+    iou_fn = iou_fn or (lambda a, b: R.box_iou_rotated(a, b).numpy())
+    import torch
+    K = len(det_results[0])
+    out = []
+    for k in range(K):
+        tps, fps, scores, num_gts = [], [], [], 0
+        for dets, ann in zip(det_results, annotations):
+            d = np.asarray(dets[k], np.float32).reshape(-1, 6)
+            g = np.asarray(ann['bboxes'], np.float32).reshape(-1, 5)[np.asarray(ann['labels']) == k]
+            gi = np.zeros((0, 5), np.float32)
+            if ann.get('labels_ignore', None) is not None:
+                gi = np.asarray(ann['bboxes_ignore'], np.float32).reshape(-1, 5)[np.asarray(ann['labels_ignore']) == k]
+            num_gts += g.shape[0]
+            ignore = np.concatenate([np.zeros(len(g), bool), np.ones(len(gi), bool)])
+            allg = np.vstack([g, gi])
+            tp, fp = np.zeros(len(d), np.float32), np.zeros(len(d), np.float32)
+            if allg.shape[0] == 0:
+                fp[:] = 1
+            elif len(d):
+                ious = np.asarray(iou_fn(torch.from_numpy(d[:, :5]).float(), torch.from_numpy(allg).float()))
+                imax, iarg = ious.max(1), ious.argmax(1)
+                covered = np.zeros(len(allg), bool)
+                for i in np.argsort(-d[:, -1]):
+                    if imax[i] >= iou_thr:
+                        m = iarg[i]
+                        if not ignore[m]:
+                            if not covered[m]:
+                                covered[m] = True
+                                tp[i] = 1
+                            else:
+                                fp[i] = 1
+                    else:
+                        fp[i] = 1
+            tps.append(tp); fps.append(fp); scores.append(d[:, -1])
+        sc = np.concatenate(scores)
+        order = np.argsort(-sc)
+        tp = np.cumsum(np.concatenate(tps)[order])
+        fp = np.cumsum(np.concatenate(fps)[order])
+        eps = np.finfo(np.float32).eps
+        # dtypes as in the reference: tp/fp are float32, num_gts an int64 array -> recalls float64, precisions float32
+        # (recall values such as 3/10 sit exactly on the 11-point thresholds, so the dtype decides `>=`)
+        rec = (tp / np.maximum(np.array([num_gts], dtype=int)[:, np.newaxis], eps))[0]
+        prec = tp / np.maximum(tp + fp, eps)
+        ap = average_precision_11points(rec, prec) if use_07_metric else average_precision_area(rec, prec)
+        out.append(dict(ap=ap, recall=rec, precision=prec, num_gts=num_gts))
+    aps = [r['ap'] for r in out if r['num_gts'] > 0]
+    return (float(np.mean(aps)) if aps else 0.0), out

@@ -185,3 +185,83 @@ def single_gpu_test(model, batches, n_batches):
             data = batches(it)
             results.extend(model(return_loss=False, rescale=True, img=data['img'], img_metas=data['img_metas']))
     return results
+
+
+# ------------------------------------------------------------------------------------------------
+# Oriented tree (config 5, `evaluation = dict(metric='mAP')`): DOTA-style mAP with rotated IoU
+# ------------------------------------------------------------------------------------------------
+def eval_rbbox_map(det_results, annotations, iou_thr=0.5, use_07_metric=True, device='cuda'):
+    """/root/reference/OBB_TOD/mmrotate/core/evaluation/eval_map.py:126-246 (eval_rbbox_map, tpfp_default, VOC07
+    11-point average precision by default as in the reference, `area` with use_07_metric=False) on the GPU.  det_results[i][k] = ndarray [n,6] (cx,cy,w,h,a,score) as `rbbox2result` returns
+    them; annotations[i] = dict(bboxes [G,5], labels [G], optional bboxes_ignore / labels_ignore).
+    Returns (mAP, per-class list of dict(ap, recall, precision, num_gts, num_dets)).
+
+    A detection is a true positive iff its best-IoU ground truth (IoU >= iou_thr, `pt_box_iou_rotated`) is not an
+    ignored one and no higher-scored detection of the image claimed that ground truth first; detections whose best
+    match is an ignored box are neither TP nor FP.  The "first claimant" rule needs no sequential loop: it is the
+    first occurrence of each (image, gt) key in score order.  The reference's dataset wrapper overwrites `iou_thr`
+    with 0.25 (sodaa_rewrite.py:206, a debugging leftover); pass iou_thr=0.25 to reproduce it."""
+    from . import functional as F
+    dev = torch.device(device)
+    K = len(det_results[0])
+    eps = float(np.finfo(np.float32).eps)
+    out = []
+    for k in range(K):
+        tp_l, fp_l, sc_l, num_gts = [], [], [], 0
+        gt_base = 0
+        for dets, ann in zip(det_results, annotations):
+            d = torch.as_tensor(np.asarray(dets[k], np.float32).reshape(-1, 6), device=dev)
+            lab = np.asarray(ann['labels'])
+            g = np.asarray(ann['bboxes'], np.float32).reshape(-1, 5)[lab == k]
+            gi = np.zeros((0, 5), np.float32)
+            if ann.get('labels_ignore', None) is not None:
+                gi = np.asarray(ann['bboxes_ignore'], np.float32).reshape(-1, 5)[np.asarray(ann['labels_ignore']) == k]
+            num_gts += g.shape[0]
+            n, G = d.shape[0], g.shape[0] + gi.shape[0]
+            tp = torch.zeros(n, device=dev)
+            fp = torch.zeros(n, device=dev)
+            if n and G == 0:
+                fp[:] = 1
+            elif n:
+                allg = torch.as_tensor(np.vstack([g, gi]), device=dev)
+                ious = F.box_iou_rotated(d[:, :5].contiguous(), allg)
+                imax, iarg = ious.max(1)
+                hit = imax >= iou_thr
+                ign = iarg >= g.shape[0]
+                order = torch.sort(d[:, 5], descending=True, stable=True)[1]
+                # first detection (in score order) of every matched, non-ignored gt
+                key = torch.where(hit & ~ign, iarg, torch.full_like(iarg, G))[order]
+                first = torch.zeros(G + 1, dtype=torch.long, device=dev).scatter_reduce(
+                    0, key, torch.arange(n, device=dev), reduce='amin', include_self=False)
+                is_first = torch.zeros(n, dtype=torch.bool, device=dev)
+                is_first[order] = (first[key] == torch.arange(n, device=dev)) & (key < G)
+                tp = is_first.float()
+                fp = ((hit & ~ign & ~is_first) | ~hit).float()
+            tp_l.append(tp); fp_l.append(fp); sc_l.append(d[:, 5])
+            gt_base += G
+        sc = torch.cat(sc_l)
+        order = torch.sort(sc, descending=True, stable=True)[1]
+        # the per-class curves are short: finish on the host with the reference's dtypes (tp/fp float32, recalls
+        # float64 because num_gts is an int64 array, precisions float32) - recall values such as 3/10 sit exactly on
+        # the 11-point thresholds, so the rounding of this division decides `>=`
+        tp = torch.cumsum(torch.cat(tp_l)[order], 0).cpu().numpy().astype(np.float32)
+        fp = torch.cumsum(torch.cat(fp_l)[order], 0).cpu().numpy().astype(np.float32)
+        feps = np.finfo(np.float32).eps
+        rec = (tp / np.maximum(np.array([num_gts], dtype=int)[:, np.newaxis], feps))[0]
+        prec = tp / np.maximum(tp + fp, feps)
+        if use_07_metric:   # average_precision(mode='11points'): max precision at recall >= 0, .1, ..., 1
+            ap = np.float32(0)
+            for thr in np.arange(0, 1 + 1e-3, 0.1):
+                precs = prec[rec >= thr]
+                ap += precs.max() if precs.size > 0 else 0
+            ap = float(ap / 11)
+        else:               # mode='area': envelope from the right, sum over recall steps
+            mrec = np.hstack(([0.0], rec, [1.0]))
+            mpre = np.hstack(([0.0], prec, [0.0]))
+            for i in range(len(mpre) - 1, 0, -1):
+                mpre[i - 1] = max(mpre[i - 1], mpre[i])
+            ind = np.where(mrec[1:] != mrec[:-1])[0]
+            ap = float(np.sum((mrec[ind + 1] - mrec[ind]) * mpre[ind + 1]))
+        out.append(dict(ap=ap, recall=rec, precision=prec, num_gts=num_gts, num_dets=int(sc.numel())))
+    aps = [r['ap'] for r in out if r['num_gts'] > 0]
+    return (float(np.mean(aps)) if aps else 0.0), out

@@ -139,3 +139,43 @@ def test_eval_loop_end_to_end():
     oracle_det = [[np.concatenate([g['bboxes'][g['labels'] == k], np.full((int((g['labels'] == k).sum()), 1), 0.9, np.float32)], 1)
                    for k in range(8)] for g in gts]
     assert ev.evaluate(oracle_det)['bbox_mAP'] == pytest.approx(1.0)
+
+
+# ------------------------------------------------------------------ oriented tree: DOTA-style mAP --
+def _load_obb_eval():
+    from conftest import load_golden
+    g = load_golden('obb_eval_map')
+    n_img, K = int(g['n_img']), int(g['num_classes'])
+    anns = [{key: g[f'in_ann{i}_{key}'] for key in ('bboxes', 'labels', 'bboxes_ignore', 'labels_ignore')} for i in range(n_img)]
+    dets = [[g[f'in_det{i}_{k}'] for k in range(K)] for i in range(n_img)]
+    return g, dets, anns, K
+
+
+@pytest.mark.parametrize('thr', [0.5, 0.25])
+def test_oracle_eval_rbbox_map_vs_reference_golden(thr):
+    """oracle restatement == the reference's own eval_rbbox_map run (tests/golden/obb_eval_map.npz)."""
+    g, dets, anns, K = _load_obb_eval()
+    mean_ap, res = RC.eval_rbbox_map(dets, anns, iou_thr=thr)
+    t = int(thr * 100)
+    assert mean_ap == pytest.approx(float(g[f'out_map_{t}']), abs=1e-6)
+    for k in range(K):
+        assert res[k]['num_gts'] == int(g[f'out_num_gts_{t}_{k}'])
+        assert res[k]['ap'] == pytest.approx(float(g[f'out_ap_{t}_{k}']), abs=1e-6)
+        np.testing.assert_allclose(res[k]['recall'], g[f'out_recall_{t}_{k}'], atol=1e-6)
+        np.testing.assert_allclose(res[k]['precision'], g[f'out_precision_{t}_{k}'], atol=1e-6)
+    assert 0.2 < mean_ap < 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('thr', [0.5, 0.25])
+def test_gpu_eval_rbbox_map_vs_reference_golden(thr):
+    from point_teacher_amd.evaluation import eval_rbbox_map
+    g, dets, anns, K = _load_obb_eval()
+    mean_ap, res = eval_rbbox_map(dets, anns, iou_thr=thr)
+    t = int(thr * 100)
+    assert mean_ap == pytest.approx(float(g[f'out_map_{t}']), abs=1e-5)
+    for k in range(K):
+        assert res[k]['num_gts'] == int(g[f'out_num_gts_{t}_{k}'])
+        assert res[k]['ap'] == pytest.approx(float(g[f'out_ap_{t}_{k}']), abs=1e-5)
+        np.testing.assert_allclose(res[k]['recall'], g[f'out_recall_{t}_{k}'], atol=1e-6)
+        np.testing.assert_allclose(res[k]['precision'], g[f'out_precision_{t}_{k}'], atol=1e-6)
