@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Evaluate a checkpoint (the counterpart of the reference's tools/test.py for this path).
+
+    python tools/test.py <config.py> <checkpoint.pth> [--synthetic N] [--iou-thr 0.5]
+
+Runs `simple_test` of the TEACHER over the data (apis/test.py:16-66) and reports the reference's metrics: AI-TOD
+COCO-style `bbox_mAP*` / `AR*` for the horizontal configs (datasets/aitod.py), DOTA-style `mAP` for the oriented one
+(core/evaluation/eval_map.py).  The dataset readers are not part of this build: `--synthetic N`
+seeded tiles stand in for the validation set."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('config')
+    ap.add_argument('checkpoint', nargs='?', default=None)
+    ap.add_argument('--synthetic', type=int, default=16)
+    ap.add_argument('--objects', type=int, default=100)
+    ap.add_argument('--iou-thr', type=float, default=0.5)
+    args = ap.parse_args()
+    dev = torch.device('cuda', 0)
+    import point_teacher_amd as pta
+    from point_teacher_amd.evaluation import AITODEvaluator, eval_rbbox_map, single_gpu_test
+    from point_teacher_amd.synthetic import SyntheticTiles
+    cfg = pta.Config.fromfile(args.config)
+    model = pta.build_detector(cfg.model).to(dev)
+    if args.checkpoint:
+        state = torch.load(args.checkpoint, map_location=dev, weights_only=False)
+        model.load_state_dict(state['model'] if 'model' in state else state.get('state_dict', state))
+    oriented = cfg.model.type == 'RotatedFCOS_TS'
+    K = cfg.model._model_.bbox_head.num_classes
+    B = cfg.data.samples_per_gpu
+    data = SyntheticTiles(n=args.synthetic, size=1200 if oriented else 800, mean_objects=args.objects, seed=1, device=dev,
+                          oriented=oriented, num_classes=K)
+    results = single_gpu_test(model, lambda it: data.batch(it, B), args.synthetic // B)
+    n = len(results)
+    if oriented:
+        anns = [dict(bboxes=data.items[i][1].cpu().numpy(), labels=data.items[i][2].cpu().numpy()) for i in range(n)]
+        mean_ap, per_cls = eval_rbbox_map(results, anns, iou_thr=args.iou_thr)
+        print({'mAP': round(mean_ap, 4), 'per_class_AP': [round(r['ap'], 4) for r in per_cls]})
+    else:
+        gts = [dict(bboxes=data.items[i][1].cpu().numpy(), labels=data.items[i][2].cpu().numpy()) for i in range(n)]
+        out = AITODEvaluator(gts, K).evaluate(results)
+        print({k: round(v, 4) for k, v in out.items() if isinstance(v, float)})
+
+
+if __name__ == '__main__':
+    main()
