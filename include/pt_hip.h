@@ -223,6 +223,14 @@ int pt_affine_relu_bwd_train(const float* grad_y, const float* y, const float* x
                              int64_t n, int C, int relu, float* grad_x, float* grad_res, float* sums,
                              float* partial_ws, void* stream);
 
+/* bf16 activations (BASELINE configs[2]: bf16 autocast backbone): the frozen-BN epilogue on channels_last bf16
+ * tensors (stored as uint16_t), arithmetic in fp32, fp32 scale/shift, C % 8 == 0. */
+int pt_affine_relu_fwd_bf16(const uint16_t* x, const float* scale, const float* shift,
+                            const uint16_t* residual, int64_t n, int C, int relu, uint16_t* y,
+                            void* stream);
+int pt_affine_relu_bwd_bf16(const uint16_t* grad_y, const uint16_t* y, const float* scale, int64_t n,
+                            int C, int relu, uint16_t* grad_x, uint16_t* grad_res, void* stream);
+
 /* ------------------------------------------------------------------------ NMS --
  * mmcv.ops.nms (offset 0), call site core/post_processing/bbox_nms.py:76 through
  * batched_nms: boxes[N,4] must be sorted by descending score; class-aware when

@@ -284,6 +284,72 @@ __global__ void __launch_bounds__(256) affine_train_finish(const float* __restri
   }
 }
 
+// ---- bf16 activations (configs[2]: bf16 autocast backbone): same epilogue on [N,H,W,C] bf16 tensors, 8 elements
+// (16 bytes) per thread and iteration, arithmetic in fp32, scale/shift stay fp32, round-to-nearest-even on store.
+__device__ __forceinline__ float bf2f(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+struct alignas(16) BF8 { unsigned short v[8]; };
+
+__global__ void __launch_bounds__(256)
+    affine_relu_fwd_bf16_kernel(const BF8* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                const BF8* __restrict__ res, long n8, int C, int relu, BF8* __restrict__ y) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int c = (int)((i << 3) % C);
+  const int step = (int)((stride << 3) % C);
+  for (; i < n8; i += stride) {
+    const BF8 xv = x[i];
+    BF8 rv, o;
+    if (res) rv = res[i];
+    const float4 s0 = *reinterpret_cast<const float4*>(scale + c), s1 = *reinterpret_cast<const float4*>(scale + c + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(shift + c), b1 = *reinterpret_cast<const float4*>(shift + c + 4);
+    const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    const float sh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float v = bf2f(xv.v[k]) * sc[k] + sh[k];
+      if (res) v += bf2f(rv.v[k]);
+      if (relu) v = fmaxf(v, 0.f);
+      o.v[k] = f2bf(v);
+    }
+    y[i] = o;
+    c += step;
+    c = c >= C ? c - C : c;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    affine_relu_bwd_bf16_kernel(const BF8* __restrict__ g, const BF8* __restrict__ y, const float* __restrict__ scale,
+                                long n8, int C, int relu, BF8* __restrict__ gx, BF8* __restrict__ gres) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int c = (int)((i << 3) % C);
+  const int step = (int)((stride << 3) % C);
+  for (; i < n8; i += stride) {
+    BF8 gv = g[i];
+    if (relu) {
+      const BF8 yv = y[i];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) gv.v[k] = (yv.v[k] & 0x7fffu) != 0 && !(yv.v[k] & 0x8000u) ? gv.v[k] : (unsigned short)0;
+    }
+    if (gres) gres[i] = gv;
+    if (gx) {
+      const float4 s0 = *reinterpret_cast<const float4*>(scale + c), s1 = *reinterpret_cast<const float4*>(scale + c + 4);
+      const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+      BF8 o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o.v[k] = f2bf(bf2f(gv.v[k]) * sc[k]);
+      gx[i] = o;
+    }
+    c += step;
+    c = c >= C ? c - C : c;
+  }
+}
+
 }  // namespace pt
 
 static int affine_check(const char* fn, int64_t n, int C, int64_t inner) {
@@ -360,5 +426,29 @@ extern "C" int pt_affine_relu_bwd_train(const float* grad_y, const float* y, con
   hipLaunchKernelGGL(affine_train_finish, dim3(cdiv(2 * C, 16)), dim3(256), 0, s, partial_ws,
                      pt_affine_train_rows(n, C), 2 * C, sums);
   PT_LAUNCH_CHECK("pt_affine_relu_bwd_train(finish)");
+  return PT_OK;
+}
+
+extern "C" int pt_affine_relu_fwd_bf16(const uint16_t* x, const float* scale, const float* shift, const uint16_t* residual,
+                                       int64_t n, int C, int relu, uint16_t* y, void* stream) {
+  if (n == 0) return PT_OK;
+  PT_REQUIRE(x && scale && shift && y, PT_EINVAL, "pt_affine_relu_fwd_bf16: NULL pointer");
+  PT_REQUIRE(n > 0 && C > 0 && C % 8 == 0 && n % C == 0, PT_EINVAL, "pt_affine_relu_fwd_bf16: need channels_last with C %% 8 == 0");
+  hipLaunchKernelGGL(affine_relu_fwd_bf16_kernel, dim3(stream_blocks(n / 8)), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const BF8*>(x), scale, shift, reinterpret_cast<const BF8*>(residual), (long)(n / 8), C,
+                     relu, reinterpret_cast<BF8*>(y));
+  PT_LAUNCH_CHECK("pt_affine_relu_fwd_bf16");
+  return PT_OK;
+}
+
+extern "C" int pt_affine_relu_bwd_bf16(const uint16_t* grad_y, const uint16_t* y, const float* scale, int64_t n, int C,
+                                       int relu, uint16_t* grad_x, uint16_t* grad_res, void* stream) {
+  if (n == 0) return PT_OK;
+  PT_REQUIRE(grad_y && scale && (grad_x || grad_res) && (!relu || y), PT_EINVAL, "pt_affine_relu_bwd_bf16: NULL pointer");
+  PT_REQUIRE(n > 0 && C > 0 && C % 8 == 0 && n % C == 0, PT_EINVAL, "pt_affine_relu_bwd_bf16: need channels_last with C %% 8 == 0");
+  hipLaunchKernelGGL(affine_relu_bwd_bf16_kernel, dim3(stream_blocks(n / 8)), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const BF8*>(grad_y), reinterpret_cast<const BF8*>(y), scale, (long)(n / 8), C, relu,
+                     reinterpret_cast<BF8*>(grad_x), reinterpret_cast<BF8*>(grad_res));
+  PT_LAUNCH_CHECK("pt_affine_relu_bwd_bf16");
   return PT_OK;
 }

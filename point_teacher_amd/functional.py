@@ -527,6 +527,39 @@ def bn_eval_relu(x, bn, residual=None, relu=True):
     return _AffineReLUTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, residual, relu)
 
 
+class _AffineReLUBf16(torch.autograd.Function):
+    """The frozen-BN epilogue on a channels_last bf16 activation (bf16 autocast backbone), in place on x."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, residual, relu):
+        C = x.shape[1]
+        xb = x.permute(0, 2, 3, 1)
+        rb = residual.to(torch.bfloat16).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1) if residual is not None else None
+        hip.call('pt_affine_relu_fwd_bf16', xb, scale, shift, rb, x.numel(), C, int(relu), xb)
+        ctx.mark_dirty(x)
+        ctx.save_for_backward(x if relu else None, scale)
+        ctx.cfg = (C, bool(relu), residual is not None)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        y, scale = ctx.saved_tensors
+        C, relu, has_res = ctx.cfg
+        g = g.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        gx = torch.empty_like(g) if ctx.needs_input_grad[0] else None
+        gres = torch.empty_like(g) if (has_res and ctx.needs_input_grad[3]) else None
+        if gx is None and gres is None:
+            return None, None, None, None, None
+        hip.call('pt_affine_relu_bwd_bf16', g.permute(0, 2, 3, 1), y.permute(0, 2, 3, 1) if y is not None else None, scale,
+                 g.numel(), C, int(relu), gx.permute(0, 2, 3, 1) if gx is not None else None,
+                 gres.permute(0, 2, 3, 1) if gres is not None else None)
+        return gx, None, None, gres, None
+
+
+def affine_relu_bf16_(x, scale, shift, residual=None, relu=True):
+    return _AffineReLUBf16.apply(x, scale, shift, residual, relu)
+
+
 def affine_relu_(x, scale, shift, residual=None, relu=True):
     """Frozen-BN epilogue (pt_affine_relu_*): x must be fp32, 4-D, dense NCHW or channels_last."""
     return _AffineReLU.apply(x, scale, shift, residual, relu)

@@ -170,6 +170,11 @@ def conv_bn(x, conv, bn, relu, residual=None):
         sc, sh = _bn_affine(bn)
         return F.affine_relu_(y, sc, sh, residual, relu)
     C = y.shape[1]
+    if (not bn.training and not bn.weight.requires_grad and y.dtype == torch.bfloat16 and y.is_cuda and y.dim() == 4
+            and getattr(bn, 'fuse_epilogue', True) and C % 8 == 0
+            and y.is_contiguous(memory_format=torch.channels_last) and not y.is_contiguous()):
+        sc, sh = _bn_affine(bn)                       # bf16 autocast backbone (configs[2]): same epilogue, bf16 in / out
+        return F.affine_relu_bf16_(y, sc, sh, residual, relu)
     if (not bn.training and bn.weight.requires_grad and y.dtype == torch.float32 and y.is_cuda and y.dim() == 4
             and getattr(bn, 'fuse_epilogue', True) and C % 4 == 0 and (256 % (C // 4) == 0 or (C // 4) % 256 == 0)
             and y.is_contiguous(memory_format=torch.channels_last) and not y.is_contiguous()):

@@ -424,6 +424,39 @@ def test_frozen_bn_epilogue(channels_last, relu, with_res):
         close(rg.grad, rr.grad, atol=1e-6)
 
 
+@pytest.mark.parametrize('relu,with_res', [(True, False), (True, True), (False, False)])
+def test_frozen_bn_epilogue_bf16(relu, with_res):
+    """pt_affine_relu_*_bf16 == eval-mode BatchNorm (+ identity) (+ ReLU) on bf16 channels_last activations (arithmetic
+    in fp32, one rounding on store): within bf16 resolution of the fp32 result, gradients likewise."""
+    from point_teacher_amd import nn_modules
+    gen = torch.Generator().manual_seed(35)
+    N, C, H, W = 2, 64, 12, 20
+    x = torch.randn(N, C, H, W, generator=gen)
+    res = torch.randn(N, C, H, W, generator=gen)
+    bn = torch.nn.BatchNorm2d(C).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=gen) + 0.5); bn.bias.copy_(torch.randn(C, generator=gen))
+        bn.running_mean.copy_(torch.randn(C, generator=gen)); bn.running_var.copy_(torch.rand(C, generator=gen) + 0.2)
+    for p in bn.parameters():
+        p.requires_grad = False
+    xb, rb = x.bfloat16().float(), res.bfloat16().float()              # the values the kernel sees
+    xr, rr = xb.clone().requires_grad_(True), rb.clone().requires_grad_(True)
+    y = bn(xr) + (rr if with_res else 0)
+    y = torch.relu(y) if relu else y
+    wgt = torch.randn(y.shape, generator=gen).bfloat16().float()
+    (y * wgt).sum().backward()
+    bng = bn.to(DEV)
+    xg = cu(x).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    rg = cu(res).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    out = nn_modules.conv_bn(xg * 1.0, torch.nn.Identity(), bng, relu, residual=rg if with_res else None)
+    assert out.dtype == torch.bfloat16
+    close(out.float(), y, rtol=1e-2, atol=2e-2)
+    (out.float() * cu(wgt)).sum().backward()
+    close(xg.grad.float(), xr.grad, rtol=1e-2, atol=2e-2)
+    if with_res:
+        close(rg.grad.float(), rr.grad, rtol=1e-2, atol=2e-2)
+
+
 @pytest.mark.parametrize('C,HW', [(64, (40, 52)), (256, (20, 30)), (1024, (9, 11)), (2048, (5, 7))])
 @pytest.mark.parametrize('relu,with_res', [(True, False), (True, True), (False, False)])
 def test_trainable_bn_epilogue(C, HW, relu, with_res):
