@@ -147,6 +147,16 @@ def main():
     hip.call = timed_call
     import point_teacher_amd.functional as PF
     PF.hip.call = timed_call
+    # what an (event, event) pair measures with NOTHING in between: the per-launch bias of the HIP-event timings below
+    # (rocprofv3 reports the bare kernel time, which therefore lies between `avg_launch_us - overhead` and `avg_launch_us`)
+    cal = []
+    for _ in range(200):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); e1.record()
+        cal.append((e0, e1))
+    torch.cuda.synchronize()
+    cal = sorted(a.elapsed_time(b) for a, b in cal)
+    event_overhead_us = cal[len(cal) // 2] * 1e3
 
     barrier()
     t0 = time.perf_counter()
@@ -181,6 +191,7 @@ def main():
         pass
     roofline = dict(bound='hbm', kernel=dom, achieved=round(achieved, 1), peak=8000.0, unit='GB/s',
                     frac=round(achieved / 8000.0, 4), traffic=traffic, avg_launch_us=round(d['avg_ms'] * 1e3, 2),
+                    event_pair_overhead_us=round(event_overhead_us, 2),
                     launches=d['calls'], bytes_per_launch=int(d['bytes']))
 
     if rank == 0:
