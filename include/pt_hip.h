@@ -337,6 +337,22 @@ int pt_coco_match(const float* det_box, const int32_t* det_off, const float* gt_
                   const float* area_lo, const float* area_hi, int A, const float* iou_thr, int T,
                   int max_det, uint8_t* gt_matched, int32_t* dtm, uint8_t* dt_ig, void* stream);
 
+/* ----------------------------------------------------- data pipeline (next row N2) --
+ * Fused Resize -> RandomFlip -> Normalize -> Pad -> DefaultFormatBundle (+ collate zero padding) of the
+ * reference's pipelines (HBB_TOD/mmdet/datasets/pipelines/transforms.py:212-237, :437-440, :652-655,
+ * :587-599; formating.py:196-203; configs `train_pipeline`, e.g. aitodv2_point_teacher_0%.py:180-189),
+ * whose pixel work is mmcv 1.x over OpenCV (cv2.resize INTER_LINEAR 8-bit fixed point, cv2.flip,
+ * cv2.subtract / cv2.multiply, cv2.copyMakeBorder).
+ * src: DEVICE uint8 [src_h, src_w, 3] (BGR as decoded), rows src_row_stride bytes apart.
+ * (rs_h, rs_w): size after Resize; flip: 0 none, 1 horizontal, 2 vertical, 3 diagonal (applied after the resize);
+ * mean_host / stdinv_host: HOST arrays of 3 (indexed by OUTPUT channel) or both NULL = no Normalize;
+ * to_rgb swaps channels 0 and 2 before the mean; [rs, pad) is filled with pad_val, [pad, out) with 0.
+ * dst: DEVICE float, element strides (c, h, w) - NCHW planes or the channels-last slice of a batch. */
+int pt_image_prep(const uint8_t* src, int src_h, int src_w, int64_t src_row_stride, int channels,
+                  int rs_h, int rs_w, int flip, const float* mean_host, const double* stdinv_host,
+                  int to_rgb, int pad_h, int pad_w, float pad_val, int out_h, int out_w, float* dst,
+                  int64_t dst_stride_c, int64_t dst_stride_h, int64_t dst_stride_w, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -324,3 +324,50 @@ def ref_obb(name):
     """Return a loaded OBB reference module, e.g. ref_obb('core.bbox.transforms')."""
     install_obb()
     return importlib.import_module('mmrotate.' + name)
+
+
+def install_pipeline():
+    """Load the HOST LOGIC of the data pipeline by path: the HBB transforms / samplers / COCO
+    reader and the OBB RResize / RRandomFlip.  mmcv's image functions (imrescale, imflip, imnormalize, impad - cv2
+    underneath, neither installed) are NOT provided: only the methods that never touch pixels are called by
+    oracle/gen_golden_pipeline.py (box scaling / flipping, scale sampling, annotation parsing, index sampling)."""
+    install_obb()
+    if getattr(sys.modules['mmdet'], '_pt_pipeline', False):
+        return
+    sys.modules['mmdet']._pt_pipeline = True
+    mmcv = sys.modules['mmcv']
+    mmcv.is_list_of = lambda seq, typ: isinstance(seq, list) and all(isinstance(x, typ) for x in seq)   # type check only
+    mmcv.is_str = lambda x: isinstance(x, str)
+    sys.modules['mmcv.runner'].get_dist_info = lambda: (0, 1)
+    sys.modules['mmcv.utils'].print_log = lambda *a, **k: None
+    for n in ('terminaltables', 'aitodpycocotools', 'aitodpycocotools.mask', 'aitodpycocotools.coco',
+              'aitodpycocotools.cocoeval', 'mmcv.parallel'):
+        if n not in sys.modules:
+            _pkg(n, stub=True)
+    md = os.path.join(HBB, 'mmdet')
+    if 'mmdet.core.evaluation' not in sys.modules:
+        _pkg('mmdet.core.evaluation', os.path.join(md, 'core', 'evaluation'))
+    sys.modules.pop('mmdet.core.evaluation.bbox_overlaps', None)
+    importlib.import_module('mmdet.core.evaluation.bbox_overlaps')            # pure numpy
+    _pkg('mmdet.datasets', os.path.join(md, 'datasets'))
+    bld = _pkg('mmdet.datasets.builder')
+    bld.PIPELINES, bld.DATASETS = _Registry('pipeline'), _Registry('dataset')
+    _pkg('mmdet.datasets.pipelines', os.path.join(md, 'datasets', 'pipelines'))
+    _pkg('mmdet.datasets.samplers', os.path.join(md, 'datasets', 'samplers'))
+    _pkg('mmdet.datasets.api_wrappers', stub=True)
+    tr = importlib.import_module('mmdet.datasets.pipelines.transforms')
+    # mmrotate's transforms were written against a newer mmdet: class placeholders for the two names this tree lacks
+    for n in ('Mosaic', 'RandomCrop'):
+        if not hasattr(tr, n):
+            setattr(tr, n, type(n, (), {}))
+    importlib.import_module('mmdet.datasets.samplers.group_sampler')
+    sys.modules['mmdet.datasets.pipelines'].Compose = importlib.import_module('mmdet.datasets.pipelines.compose').Compose
+    mr = os.path.join(OBB, 'mmrotate')
+    _pkg('mmrotate.datasets', os.path.join(mr, 'datasets'))
+    rb = _pkg('mmrotate.datasets.builder')
+    rb.ROTATED_PIPELINES, rb.ROTATED_DATASETS = bld.PIPELINES, bld.DATASETS
+    _pkg('mmrotate.datasets.pipelines', os.path.join(mr, 'datasets', 'pipelines'))
+    core = sys.modules['mmrotate.core']
+    rtr = importlib.import_module('mmrotate.core.bbox.transforms')
+    core.norm_angle, core.obb2poly_np, core.poly2obb_np = rtr.norm_angle, rtr.obb2poly_np, rtr.poly2obb_np
+    importlib.import_module('mmrotate.datasets.pipelines.transforms')

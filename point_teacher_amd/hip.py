@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, 'libpt_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'pt_hip.h')
 
 _CT = {
-    'int': ctypes.c_int, 'float': ctypes.c_float, 'int64_t': ctypes.c_int64,
+    'int': ctypes.c_int, 'float': ctypes.c_float, 'int64_t': ctypes.c_int64, 'double': ctypes.c_double,
     'void': None,
 }
 
@@ -104,6 +104,13 @@ def call(fn, *args):
     if restype is ctypes.c_int and fn not in ('pt_abi_version', 'pt_focal_nblocks', 'pt_sqnorm_nblocks', 'pt_affine_train_rows') and rc != 0:
         raise RuntimeError(f'{fn} failed (code {rc}): {last_error()}')
     return rc
+
+
+def host_doubles(vals):
+    arr = (ctypes.c_double * max(len(vals), 1))()
+    for i, v in enumerate(vals):
+        arr[i] = float(v)
+    return arr
 
 
 def host_floats(vals):
