@@ -276,3 +276,22 @@ def build_dataloader(dataset, samples_per_gpu, workers_per_gpu, num_gpus=1, dist
     if device is None:
         device = torch.device('cuda', torch.cuda.current_device())
     return DeviceLoader(dataset, sampler, samples_per_gpu, workers_per_gpu, device, channels_last=channels_last, **kwargs)
+
+
+class EpochBatches:
+    """Adapter for runner.Runner / Trainer loops, which ask for `batches(iteration, batch_size)`: walks the loader epoch
+    after epoch (EpochBasedRunner.train: `data_loader.sampler.set_epoch(epoch)` then one pass)."""
+
+    def __init__(self, loader, start_epoch=0):
+        self.loader, self.epoch, self._it = loader, int(start_epoch), None
+
+    def __call__(self, iteration=None, batch_size=None):
+        while True:
+            if self._it is None:
+                self.loader.set_epoch(self.epoch)
+                self._it = iter(self.loader)
+            try:
+                return next(self._it)
+            except StopIteration:
+                self._it = None
+                self.epoch += 1

@@ -421,7 +421,7 @@ def test_loader_batches_match_oracle_and_feed_a_training_step(tmp_path):
     ds = D.build_dataset(dict(type='AITODDataset', ann_file=ann_file, img_prefix=prefix, pipeline=TRAIN_PIPELINE))
     np.random.seed(1)
     loader = D.build_dataloader(ds, samples_per_gpu=2, workers_per_gpu=2, dist=False, shuffle=True, device=dev)
-    assert len(loader) == 4                                                  # 2 groups of 3 -> padded to 4 each
+    assert len(loader) == 3 and ds.flag.tolist() == [0, 1, 0, 0, 0, 1]       # groups of 4 and 2 -> batches never mix groups
     n_seen = 0
     by_name = {info['filename']: i for i, info in enumerate(ds.data_infos)}
     batches = list(loader)
@@ -436,11 +436,16 @@ def test_loader_batches_match_oracle_and_feed_a_training_step(tmp_path):
             assert batch['gt_bboxes'][b].is_cuda and batch['gt_labels'][b].dtype == torch.int64
             n_seen += 1
         np.testing.assert_array_equal(img.cpu().numpy(), R.collate_images(exp))
-    assert n_seen == 8
-    # one Point-Teacher iteration fed by the loader (phase 1), finite losses
+    assert n_seen == 6
+    # one Point-Teacher iteration fed by the loader (phase 1), finite losses.  AI-TOD tiles share one size (800x800) and the
+    # hot path keeps the reference's one-size-per-batch assumption, so this loader reads a uniform folder
+    uni = os.path.join(str(tmp_path), 'uniform')
+    ann_u, prefix_u, _ = _make_aitod(uni, n=4, sizes=((160, 160),), seed=9)
+    du = D.build_dataset(dict(type='AITODDataset', ann_file=ann_u, img_prefix=prefix_u, pipeline=TRAIN_PIPELINE))
+    first = next(iter(D.build_dataloader(du, samples_per_gpu=2, workers_per_gpu=2, dist=False, shuffle=True, device=dev)))
     _, cfg, model = T._build(dev, phase2=False)
     trainer = pta.Trainer(model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config)
-    lv = trainer.step(batches[0])['log_vars'].materialize()
+    lv = trainer.step(first)['log_vars'].materialize()
     assert all(v == v and abs(v) != float('inf') for v in lv.values()), lv
     # test mode: list per augmentation, sequential order, teacher inference + the AI-TOD evaluator on the results
     dt = D.build_dataset(dict(type='AITODDataset', ann_file=ann_file, img_prefix=prefix, pipeline=TEST_PIPELINE, test_mode=True))

@@ -5,8 +5,9 @@
 
 Runs `simple_test` of the TEACHER over the data (apis/test.py:16-66) and reports the reference's metrics: AI-TOD
 COCO-style `bbox_mAP*` / `AR*` for the horizontal configs (datasets/aitod.py), DOTA-style `mAP` for the oriented one
-(core/evaluation/eval_map.py).  The dataset readers are not part of this build: `--synthetic N`
-seeded tiles stand in for the validation set."""
+(core/evaluation/eval_map.py).  When the config's `data.test` paths exist (or `--ann-file/--img-prefix` are given) the
+validation set is read through `point_teacher_amd.datasets` and scored by the dataset's own `evaluate`; otherwise
+`--synthetic N` seeded tiles stand in for it."""
 import argparse
 import os
 import sys
@@ -23,6 +24,9 @@ def main():
     ap.add_argument('--synthetic', type=int, default=16)
     ap.add_argument('--objects', type=int, default=100)
     ap.add_argument('--iou-thr', type=float, default=0.5)
+    ap.add_argument('--ann-file', default=None)
+    ap.add_argument('--img-prefix', default=None)
+    ap.add_argument('--ori-ann-file', default=None)
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
     import point_teacher_amd as pta
@@ -36,6 +40,23 @@ def main():
     oriented = cfg.model.type == 'RotatedFCOS_TS'
     K = cfg.model._model_.bbox_head.num_classes
     B = cfg.data.samples_per_gpu
+    tcfg = dict(cfg.data.test)
+    for k, v in (('ann_file', args.ann_file), ('img_prefix', args.img_prefix), ('ori_ann_file', args.ori_ann_file)):
+        if v is not None:
+            tcfg[k] = v
+    if os.path.exists(str(tcfg.get('ann_file', ''))):
+        from point_teacher_amd.datasets import build_dataloader, build_dataset
+        tcfg['test_mode'] = True
+        dataset = build_dataset(tcfg)
+        loader = build_dataloader(dataset, 1, cfg.data.workers_per_gpu, dist=False, shuffle=False, device=dev)
+        it = iter(loader)
+        results = single_gpu_test(model, lambda _: next(it), len(loader))
+        if oriented and hasattr(dataset, 'evaluate_map'):
+            print(dataset.evaluate_map(results, iou_thr=args.iou_thr))
+        else:
+            out = dataset.evaluate(results)
+            print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in out.items()})
+        return
     data = SyntheticTiles(n=args.synthetic, size=1200 if oriented else 800, mean_objects=args.objects, seed=1, device=dev,
                           oriented=oriented, num_classes=K)
     results = single_gpu_test(model, lambda it: data.batch(it, B), args.synthetic // B)

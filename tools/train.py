@@ -4,8 +4,9 @@
     python tools/train.py <config.py> [--work-dir DIR] [--resume-from CKPT] [--synthetic N] [--max-iters K]
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/train.py <config.py> ...
 
-The dataset readers of the reference (COCO-json / DOTA-txt) are not part of this build: the loop
-runs on `--synthetic N` seeded tiles of the config's image size (default 64) resident on the GPU."""
+When the config's `data.train` paths exist (or `--ann-file/--img-prefix` point at a dataset) the loop reads it through
+`point_teacher_amd.datasets` (readers + pipelines + the fused GPU image preparation); otherwise it runs
+on `--synthetic N` seeded tiles of the config's image size resident on the GPU."""
 import argparse
 import os
 import sys
@@ -25,6 +26,10 @@ def main():
     ap.add_argument('--max-iters', type=int, default=None)
     ap.add_argument('--iters-per-epoch', type=int, default=None)
     ap.add_argument('--objects', type=int, default=300)
+    ap.add_argument('--ann-file', default=None, help="override data.train.ann_file")
+    ap.add_argument('--img-prefix', default=None, help="override data.train.img_prefix")
+    ap.add_argument('--ori-ann-file', default=None, help="override data.train.ori_ann_file (SODA-A)")
+    ap.add_argument('--seed', type=int, default=0)
     args = ap.parse_args()
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
@@ -42,13 +47,29 @@ def main():
     model.train()
     oriented = cfg.model.type == 'RotatedFCOS_TS'
     size = 1200 if oriented else 800
-    ipe = args.iters_per_epoch or max(args.synthetic // (cfg.data.samples_per_gpu * world), 1)
+    tcfg = dict(cfg.data.train)
+    for k, v in (('ann_file', args.ann_file), ('img_prefix', args.img_prefix), ('ori_ann_file', args.ori_ann_file)):
+        if v is not None:
+            tcfg[k] = v
+    real = os.path.exists(str(tcfg.get('ann_file', '')))
+    if real:
+        from point_teacher_amd.datasets import EpochBatches, build_dataloader, build_dataset
+        dataset = build_dataset(tcfg)
+        loader = build_dataloader(dataset, cfg.data.samples_per_gpu, cfg.data.workers_per_gpu, dist=world > 1, shuffle=True,
+                                  seed=args.seed, device=dev)
+        ipe = args.iters_per_epoch or len(loader)
+        batches = EpochBatches(loader)
+        if rank == 0:
+            print(f'{type(dataset).__name__}: {len(dataset)} images, {len(loader)} iterations per epoch per rank')
+    else:
+        ipe = args.iters_per_epoch or max(args.synthetic // (cfg.data.samples_per_gpu * world), 1)
+        data = SyntheticTiles(n=max(args.synthetic // world, 2), size=size, mean_objects=args.objects, seed=0, device=dev,
+                              rank=rank, world=world, oriented=oriented, num_classes=cfg.model._model_.bbox_head.num_classes)
+        batches = data.batch
     trainer = pta.Trainer(model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config, iters_per_epoch=ipe, channels_last=True)
     torch.backends.cudnn.benchmark = True
-    data = SyntheticTiles(n=max(args.synthetic // world, 2), size=size, mean_objects=args.objects, seed=0, device=dev,
-                          rank=rank, world=world, oriented=oriented, num_classes=cfg.model._model_.bbox_head.num_classes)
     work_dir = args.work_dir or os.path.join(ROOT, 'work_dirs', os.path.splitext(os.path.basename(args.config))[0])
-    runner = Runner(trainer, data.batch, work_dir, cfg.runner.max_epochs, ipe, cfg.log_config.interval,
+    runner = Runner(trainer, batches, work_dir, cfg.runner.max_epochs, ipe, cfg.log_config.interval,
                     cfg.checkpoint_config.interval, cfg.data.samples_per_gpu)
     if args.resume_from:
         meta = runner.resume(args.resume_from)
