@@ -337,6 +337,23 @@ int pt_coco_match(const float* det_box, const int32_t* det_off, const float* gt_
                   const float* area_lo, const float* area_hi, int A, const float* iou_thr, int T,
                   int max_det, uint8_t* gt_matched, int32_t* dtm, uint8_t* dt_ig, void* stream);
 
+/* SODA-A protocol (OBB_TOD/mmrotate/datasets/sodaa_eval/sodaa_eval.py:158-179 computeIoU over mmcv's
+ * box_iou_rotated, :181-262 evaluateImg): the same greedy matching with the IoU between ORIENTED boxes.
+ * pt_segment_iou_rotated fills, per (image, category) segment, the row-major [min(D_s, max_det), G_s] IoU matrix
+ * at iou[iou_off[s]] (boxes (cx, cy, w, h, a); max_pairs = the largest segment's pair count, sizes the grid;
+ * at most 65535 segments per call).  pt_coco_match_iou is pt_coco_match reading those matrices; det_area[Nd] is
+ * w*h of each detection (the area test of unmatched detections).  gt_zero / det_zero (row index or -1): SODAAeval
+ * numbers ground truths and detections from 0 (:108, :121) and reads 0 as "no match" (:392, :415, :509) - a
+ * detection matched to row gt_zero is reported unmatched and detection det_zero does not block its ground truth. */
+int pt_segment_iou_rotated(const float* det_box, const int32_t* det_off, const float* gt_box,
+                           const int32_t* gt_off, int S, int max_det, const int64_t* iou_off,
+                           int64_t max_pairs, float* iou, void* stream);
+int pt_coco_match_iou(const float* det_area, const int32_t* det_off, const float* iou,
+                      const int64_t* iou_off, const float* gt_area, const uint8_t* gt_flags,
+                      const int32_t* gt_off, int S, const float* area_lo, const float* area_hi, int A,
+                      const float* iou_thr, int T, int max_det, int gt_zero, int det_zero,
+                      uint8_t* gt_matched, int32_t* dtm, uint8_t* dt_ig, void* stream);
+
 /* ----------------------------------------------------- data pipeline (next row N2) --
  * Fused Resize -> RandomFlip -> Normalize -> Pad -> DefaultFormatBundle (+ collate zero padding) of the
  * reference's pipelines (HBB_TOD/mmdet/datasets/pipelines/transforms.py:212-237, :437-440, :652-655,

@@ -279,10 +279,84 @@ def gen_eval_map():
     G.save('obb_eval_map', n_img=np.int64(n_img), num_classes=np.int64(K), **out)
 
 
+def gen_sodaa_eval():
+    """datasets/sodaa_eval/sodaa_eval.py SODAAeval (evaluate -> accumulate -> summarize, the class behind
+    SODAADataset.evaluate, sodaa.py:377-470) run on a seeded scene of whole images.  mmcv's box_iou_rotated is replaced by the
+    fp64 polygon-clip IoU of oracle/ref_ops.py rounded to float32 (what the fp32 op returns); `np.float`, removed from
+    numpy, is aliased to float for the two `astype(dtype=np.float)` calls.  Scene: object sizes spread over the four
+    SODA area bins, jittered / duplicated / spurious detections with distinct scores, one image without objects and one
+    category that never occurs; image 0's first annotation and the first detection exercise the id-0 quirk."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from oracle import ref_ops as R
+    L.install_obb()
+    import importlib
+    import types
+    if not hasattr(np, 'float'):
+        np.float = float
+    sys.modules['mmcv.ops'].box_iou_rotated = lambda a, b: torch.from_numpy(
+        np.asarray(R.box_iou_rotated(a.numpy().astype(np.float64), b.numpy().astype(np.float64)), np.float64).astype(np.float32).reshape(len(a), len(b)))
+    pkg = types.ModuleType('mmrotate.datasets.sodaa_eval')
+    pkg.__path__ = [os.path.join(L.OBB, 'mmrotate', 'datasets', 'sodaa_eval')]
+    sys.modules['mmrotate.datasets.sodaa_eval'] = pkg
+    if 'mmrotate.datasets' not in sys.modules:
+        L._pkg('mmrotate.datasets', os.path.join(L.OBB, 'mmrotate', 'datasets'))
+    se = importlib.import_module('mmrotate.datasets.sodaa_eval.sodaa_eval')
+    rng = np.random.RandomState(11)
+    K, n_img = 4, 6
+    anns, dets = [], []
+    for i in range(n_img):
+        NG = 0 if i == 3 else rng.randint(6, 16)
+        c = rng.rand(NG, 2) * 500 + 40
+        side = np.exp(rng.uniform(np.log(5.0), np.log(46.0), (NG, 1)))
+        wh = side * np.exp(rng.randn(NG, 2) * 0.2)
+        a = rng.rand(NG, 1) * np.pi - np.pi / 2
+        gb = np.concatenate([c, wh, a], 1).astype(np.float32)
+        lab = rng.randint(0, K - 1, NG)                                      # category K-1 never occurs
+        anns.append(dict(bboxes=gb, labels=lab.astype(np.int64)))
+        per = []
+        for k in range(K):
+            g = gb[lab == k]
+            keep = rng.rand(len(g)) < 0.85
+            d = g[keep] + rng.randn(int(keep.sum()), 5).astype(np.float32) * np.array([0.8, 0.8, 0.8, 0.8, 0.04], np.float32)
+            d = np.concatenate([d, d[: len(d) // 2] + 0.4], 0)
+            nf = rng.randint(0, 4)
+            f = np.concatenate([rng.rand(nf, 2) * 500 + 40, np.exp(rng.uniform(np.log(5.0), np.log(46.0), (nf, 2))),
+                                rng.rand(nf, 1) * np.pi - np.pi / 2], 1)
+            d = np.concatenate([d, f], 0).astype(np.float32)
+            sc = (rng.rand(len(d), 1) * 0.9 + 0.05).astype(np.float32)
+            per.append(np.concatenate([d, sc], 1).astype(np.float32))
+        dets.append(per)
+    allsc = np.concatenate([d[:, -1] for per in dets for d in per])
+    assert len(np.unique(allsc)) == len(allsc)
+    assert len(dets[0][0]) > 0 and len(anns[0]['labels']) > 0
+    out = {}
+    for tag, thrs in (('default', None), ('t25', np.array([0.25]))):
+        ev = se.SODAAeval(anns, dets, numCats=K, nproc=0)
+        if thrs is not None:
+            ev.params.iouThrs = thrs
+        ev.evaluate()
+        ev.accumulate()
+        ev.summarize()
+        out[f'out_{tag}_stats'] = np.asarray(ev.stats, np.float64)
+        out[f'out_{tag}_precision'] = ev.eval['precision']
+        out[f'out_{tag}_recall'] = ev.eval['recall']
+    for i in range(n_img):
+        out[f'in_ann{i}_bboxes'], out[f'in_ann{i}_labels'] = anns[i]['bboxes'], anns[i]['labels']
+        for k in range(K):
+            out[f'in_det{i}_{k}'] = dets[i][k]
+    G.save('obb_sodaa_eval', n_img=np.int64(n_img), num_classes=np.int64(K), **out)
+
+
 if __name__ == '__main__':
     L.install_obb()
     torch.manual_seed(0); np.random.seed(0); random.seed(0)
-    for fn in [gen_transforms, gen_coder, gen_proposals, gen_strong_aug, gen_head, gen_eval_map]:
+    if len(sys.argv) > 1:                       # regenerate selected fixtures only, e.g. `gen_golden_obb.py gen_sodaa_eval`
+        for name in sys.argv[1:]:
+            print(name)
+            globals()[name]()
+        print('done')
+        sys.exit(0)
+    for fn in [gen_transforms, gen_coder, gen_proposals, gen_strong_aug, gen_head, gen_eval_map, gen_sodaa_eval]:
         print(fn.__name__)
         fn()
     print('done')

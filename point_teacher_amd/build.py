@@ -33,7 +33,7 @@ def build(force=False, verbose=True):
     cc = hipcc()
     objdir = os.path.join(HERE, 'build')
     os.makedirs(objdir, exist_ok=True)
-    hdrs = [os.path.join(CSRC, 'pt_common.h'), os.path.join(HERE, '..', 'include', 'pt_hip.h')]
+    hdrs = [os.path.join(CSRC, 'pt_common.h'), os.path.join(CSRC, 'pt_rotated_iou.h'), os.path.join(HERE, '..', 'include', 'pt_hip.h')]
     jobs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)

@@ -430,12 +430,40 @@ class SODAADataset(CustomDataset):
             return [(info.get('id'), r) for info, r in zip(self.data_infos, results)]
         return merge_patch_detections([i['filename'] for i in self.data_infos], results, len(self.CLASSES), nms_iou_thr, device)
 
-    def evaluate(self, results, metric='mAP', **kwargs):
-        """sodaa.py:377-470 scores the merged detections with the vendored `SODAAeval` (a COCOeval over rotated IoUs
-        with SODA's area bins); that protocol is not part of this build.  `evaluate_map` gives the DOTA-style mAP of
-        SODAADOTADataset on the same merged detections."""
-        raise NotImplementedError('SODAAeval (sodaa_eval/sodaa_eval.py) is not restated; use SODAADataset.evaluate_map '
-                                  '(DOTA-style mAP over the merged whole-image detections) or SODAADOTADataset')
+    def evaluate(self, results, metric='mAP', logger=None, proposal_nums=(100, 300, 1000), iou_thr=None, scale_ranges=None,
+                 metric_items=None, nproc=4, device='cuda', reference_ids=True):
+        """sodaa.py:377-470: merge the patch detections into whole images (rotated NMS at 0.5), then the SODA-A protocol
+        (`evaluation.SODAAEvaluator` = SODAAeval on the GPU) against the whole-image annotations."""
+        from ..evaluation import SODAAEvaluator
+        merged = self.merge_det(results, device=device)
+        merge_idx = [self.ori_img_ids.index(name) for name, _ in merged]
+        dets = [r for _, r in merged]
+        if not isinstance(metric, str):
+            assert len(metric) == 1
+            metric = metric[0]
+        if metric not in ['mAP']:
+            raise KeyError(f'metric {metric} is not supported')
+        annotations = [self.get_ori_ann_info(i) for i in merge_idx]
+        # sodaa.py:401-403 only defines `iou_thrs` when iou_thr is None (a float argument raises NameError there)
+        if iou_thr is not None:
+            raise NotImplementedError('SODAADataset.evaluate: the reference only works with iou_thr=None (0.50:0.05:0.95)')
+        ev = SODAAEvaluator(annotations, len(self.CLASSES), device=device, reference_ids=reference_ids)
+        out = ev.evaluate(dets)
+        prec = out['precision']                                              # [T, R, K, A, M]
+        per = []
+        for k, name in self.cat_ids.items():
+            p = prec[:, :, k, 0, -1]
+            p = p[p > -1]
+            per.append((f'{name}', f'{float(p.mean()) if p.numel() else float("nan"):0.3f}'))
+        if metric_items is None:
+            metric_items = ['AP', 'AP_50', 'AP_75', 'AP_eS', 'AP_rS', 'AP_gS', 'AP_Normal']
+        eval_results = {}
+        for item in metric_items:
+            eval_results[f'{metric}_{item}'] = float(f'{out[item]:.3f}')
+        ap = out['stats'][:7]
+        eval_results[f'{metric}_mAP_copypaste'] = ' '.join(f'{v:.3f}' for v in ap) + ' '
+        eval_results['classwise'] = per
+        return eval_results
 
     def evaluate_map(self, results, iou_thr=0.5, nms_iou_thr=0.5, device='cuda'):
         from ..evaluation import eval_rbbox_map

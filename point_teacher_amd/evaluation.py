@@ -29,6 +29,12 @@ def _default_iou_thrs():
 
 
 class AITODEvaluator:
+    box_dim = 4                      # xyxy; the SODA-A subclass evaluates (cx, cy, w, h, a)
+
+    @staticmethod
+    def _box_area(b):
+        return (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+
     def __init__(self, gts, num_classes, device='cuda', areas=AREAS, max_dets=MAX_DETS, iou_thrs=None):
         """gts[i] = dict(bboxes [G,4] xyxy, labels [G], optional area [G], iscrowd [G], ignore [G]) for image i."""
         self.K, self.areas, self.max_dets = num_classes, areas, tuple(max_dets)
@@ -37,13 +43,12 @@ class AITODEvaluator:
         assert len(areas) * len(self.iou_thrs) <= 64, 'area ranges x IoU thresholds must fit one wavefront'
         box, img, lab, area, flags = [], [], [], [], []
         for i, g in enumerate(gts):
-            b = np.asarray(g['bboxes'], np.float32).reshape(-1, 4)
+            b = np.asarray(g['bboxes'], np.float32).reshape(-1, self.box_dim)
             n = b.shape[0]
             box.append(b)
             img.append(np.full(n, i, np.int64))
             lab.append(np.asarray(g['labels'], np.int64).reshape(-1))
-            area.append(np.asarray(g['area'], np.float32).reshape(-1) if 'area' in g
-                        else (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]))
+            area.append(np.asarray(g['area'], np.float32).reshape(-1) if 'area' in g else self._box_area(b))
             crowd = np.asarray(g['iscrowd']).reshape(-1).astype(bool) if 'iscrowd' in g else np.zeros(n, bool)
             ign = np.asarray(g['ignore']).reshape(-1).astype(bool) if 'ignore' in g else np.zeros(n, bool)
             flags.append((ign | crowd).astype(np.uint8) | (crowd.astype(np.uint8) << 1))
@@ -53,7 +58,7 @@ class AITODEvaluator:
         order = np.argsort(key, kind='stable')                              # segment-major, original order inside
         dev = self.device
         self.gt_key = torch.from_numpy(key[order]).to(dev)
-        self.gt_box = torch.from_numpy(np.concatenate(box)[order] if box else np.zeros((0, 4), np.float32)).to(dev)
+        self.gt_box = torch.from_numpy(np.concatenate(box)[order] if box else np.zeros((0, self.box_dim), np.float32)).to(dev)
         self.gt_area = torch.from_numpy(np.concatenate(area)[order] if area else np.zeros(0, np.float32)).to(dev)
         self.gt_flags = torch.from_numpy(np.concatenate(flags)[order] if flags else np.zeros(0, np.uint8)).to(dev)
         self.gt_cat = torch.from_numpy(cat[order]).to(dev)
@@ -66,12 +71,13 @@ class AITODEvaluator:
         for i, per_cls in enumerate(results):
             assert len(per_cls) == self.K
             for k, arr in enumerate(per_cls):
-                arr = np.asarray(arr, np.float32).reshape(-1, 5)
+                D = self.box_dim
+                arr = np.asarray(arr, np.float32).reshape(-1, D + 1)
                 if arr.shape[0]:
-                    o = np.argsort(-arr[:, 4], kind='mergesort')
-                    box.append(arr[o, :4]); score.append(arr[o, 4]); key.append(np.full(arr.shape[0], i * self.K + k, np.int64))
+                    o = np.argsort(-arr[:, D], kind='mergesort')
+                    box.append(arr[o, :D]); score.append(arr[o, D]); key.append(np.full(arr.shape[0], i * self.K + k, np.int64))
         if not box:
-            return (torch.zeros((0, 4), device=self.device), torch.zeros(0, device=self.device),
+            return (torch.zeros((0, self.box_dim), device=self.device), torch.zeros(0, device=self.device),
                     torch.zeros(0, dtype=torch.long, device=self.device))
         dev = self.device
         return (torch.from_numpy(np.concatenate(box)).to(dev), torch.from_numpy(np.concatenate(score)).to(dev),
@@ -97,8 +103,7 @@ class AITODEvaluator:
             hi = torch.tensor([a[2] for a in self.areas], dtype=torch.float32, device=dev)
             thr = torch.tensor(self.iou_thrs, dtype=torch.float32, device=dev)
             scratch = torch.zeros((max(Ng, 1) * 64,), dtype=torch.uint8, device=dev)
-            hip.call('pt_coco_match', dbox.contiguous(), det_off, self.gt_box, self.gt_area, self.gt_flags, gt_off, S, lo, hi, A,
-                     thr, T, int(self.max_dets[-1]), scratch, dtm, dt_ig)
+            self._match(dbox.contiguous(), det_off, gt_off, S, lo, hi, A, thr, T, int(self.max_dets[-1]), scratch, dtm, dt_ig)
         # rank of every detection inside its segment (for the maxDets prefixes) and its category
         seg_of = torch.searchsorted(keys, dkey) if Nd else dkey
         rank = torch.arange(Nd, device=dev) - det_off[:-1].long()[seg_of] if Nd else dkey
@@ -146,6 +151,10 @@ class AITODEvaluator:
                     precision[:, :, k, a, m] = q
         return self._summarize(precision, recall)
 
+    def _match(self, dbox, det_off, gt_off, S, lo, hi, A, thr, T, max_det, scratch, dtm, dt_ig):
+        hip.call('pt_coco_match', dbox, det_off, self.gt_box, self.gt_area, self.gt_flags, gt_off, S, lo, hi, A, thr, T, max_det,
+                 scratch, dtm, dt_ig)
+
     def _summarize(self, precision, recall):
         M = len(self.max_dets)
 
@@ -171,6 +180,102 @@ class AITODEvaluator:
                         (f'AR@{md[1]}', ar(md=1)), (f'AR@{md[2]}', ar(md=2)), (f'AR_vt@{md[2]}', ar(1)), (f'AR_t@{md[2]}', ar(2)),
                         (f'AR_s@{md[2]}', ar(3)), (f'AR_m@{md[2]}', ar(4))):
             out['bbox_' + name] = v
+        out['precision'], out['recall'] = precision, recall
+        return out
+
+
+SODA_AREAS = (('Small', 0.0 ** 2, 32.0 ** 2), ('eS', 0.0 ** 2, 12.0 ** 2), ('rS', 12.0 ** 2, 20.0 ** 2), ('gS', 20.0 ** 2, 32.0 ** 2),
+              ('Normal', 32.0 ** 2, 40.0 * 50.0))
+
+
+class SODAAEvaluator(AITODEvaluator):
+    """The SODA-A protocol of config 5 (`evaluation = dict(metric='mAP')` on SODAADataset):
+    /root/reference/OBB_TOD/mmrotate/datasets/sodaa_eval/sodaa_eval.py - COCOeval with the IoU between oriented boxes
+    (`box_iou_rotated`), area = w*h, the five SODA area bins (Small / eS / rS / gS / Normal), maxDets = [20000], no crowd
+    and no ignore flags.  `annotations[i] = dict(bboxes [G,5], labels [G])` per whole image, `results[i][k] = ndarray
+    [n,6]` (cx, cy, w, h, a, score) after the patch merge.  The IoU matrices of all (image, category) segments are
+    filled by `pt_segment_iou_rotated` (chunks of <= 2^28 pairs), the greedy matching is `pt_coco_match_iou`: one
+    wavefront per segment, one lane per (area bin, IoU threshold) - 5 x 10 = 50 lanes."""
+    box_dim = 5
+    PAIR_CHUNK = 1 << 28
+
+    @staticmethod
+    def _box_area(b):
+        return b[:, 2] * b[:, 3]
+
+    def __init__(self, annotations, num_classes=9, device='cuda', iou_thrs=None, max_dets=(20000,), areas=SODA_AREAS,
+                 reference_ids=True):
+        """reference_ids: keep SODAAeval's instance numbering from 0, which its matching code reads as "none"
+        (sodaa_eval.py:108,121 vs :392,415,509): a detection matched to the dataset's first annotation counts as unmatched
+        and the dataset's first detection does not block the ground truth it takes.  False = the intended COCO protocol."""
+        super().__init__(annotations, num_classes, device=device, areas=areas, max_dets=max_dets, iou_thrs=iou_thrs)
+        self.reference_ids = reference_ids
+        self._gt_zero = self._det_zero = -1
+        if reference_ids:                      # row of annotation 0 of the first image that has one, after the (image, category) sort
+            for i, g in enumerate(annotations):
+                lab = np.asarray(g['labels']).reshape(-1)
+                if lab.size:
+                    self._gt_zero = int((self.gt_key < i * self.K + int(lab[0])).sum())
+                    break
+
+    def _flatten(self, results):
+        out = super()._flatten(results)
+        self._det_zero = -1
+        if self.reference_ids:                 # row of the first detection in (image, category) order, after the score sort
+            seen = 0
+            for per_cls in results:
+                for arr in per_cls:
+                    arr = np.asarray(arr, np.float32).reshape(-1, 6)
+                    if arr.shape[0]:
+                        self._det_zero = seen + int(np.where(np.argsort(-arr[:, 5], kind='mergesort') == 0)[0][0])
+                        return out
+                    seen += arr.shape[0]
+        return out
+
+    def _match(self, dbox, det_off, gt_off, S, lo, hi, A, thr, T, max_det, scratch, dtm, dt_ig):
+        dev = dbox.device
+        darea = (dbox[:, 2] * dbox[:, 3]).contiguous()
+        nd = (det_off[1:] - det_off[:-1]).clamp(max=max_det).long()
+        pairs = nd * (gt_off[1:] - gt_off[:-1]).long()
+        cum = torch.cumsum(pairs, 0).cpu()
+        pairs_c = pairs.cpu()
+        s0 = 0
+        while s0 < S:                                   # segment ranges whose IoU matrices fit the chunk budget
+            base = int(cum[s0 - 1]) if s0 else 0
+            s1 = s0 + 1
+            while s1 < min(S, s0 + 65535) and int(cum[s1]) - base <= self.PAIR_CHUNK:
+                s1 += 1
+            n = int(cum[s1 - 1]) - base
+            off = torch.zeros(s1 - s0 + 1, dtype=torch.int64, device=dev)
+            off[1:] = torch.cumsum(pairs[s0:s1], 0)
+            iou = torch.empty((max(n, 1),), dtype=torch.float32, device=dev)
+            do, go = det_off[s0:s1 + 1].contiguous(), gt_off[s0:s1 + 1].contiguous()
+            hip.call('pt_segment_iou_rotated', dbox, do, self.gt_box, go, s1 - s0, max_det, off, int(pairs_c[s0:s1].max()), iou)
+            hip.call('pt_coco_match_iou', darea, do, iou, off, self.gt_area, self.gt_flags, go, s1 - s0, lo, hi, A, thr, T, max_det,
+                     self._gt_zero, self._det_zero, scratch, dtm, dt_ig)
+            s0 = s1
+
+    NAMES = ('AP', 'AP_50', 'AP_75', 'AP_eS', 'AP_rS', 'AP_gS', 'AP_Normal', 'AR@20000', 'AR_eS@20000', 'AR_rS@20000', 'AR_gS@20000',
+             'AR_Normal@20000')
+
+    def _summarize(self, precision, recall):
+        """sodaa_eval.py:560-650 `_summarizeDets`: 12 statistics at maxDets[0]; an IoU threshold is selected by exact equality
+        with the linspace values, as the reference does."""
+        def mean_valid(s):
+            s = s[s > -1]
+            return float(s.mean()) if s.numel() else -1.0
+
+        def pick(s, thr):
+            if thr is None:
+                return s
+            w = np.where(thr == self.iou_thrs)[0]
+            return s[torch.as_tensor(w, device=s.device, dtype=torch.long)]
+        stats = [mean_valid(pick(precision, None)[:, :, :, 0, 0]), mean_valid(pick(precision, .50)[:, :, :, 0, 0]),
+                 mean_valid(pick(precision, .75)[:, :, :, 0, 0])]
+        stats += [mean_valid(precision[:, :, :, a, 0]) for a in (1, 2, 3, 4)]
+        stats += [mean_valid(recall[:, :, a, 0]) for a in (0, 1, 2, 3, 4)]
+        out = OrderedDict((n, v) for n, v in zip(self.NAMES, stats))
+        out['stats'] = np.array(stats)
         out['precision'], out['recall'] = precision, recall
         return out
 

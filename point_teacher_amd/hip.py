@@ -64,7 +64,7 @@ def last_error():
     return _lib.pt_last_error().decode()
 
 
-_DT = {'float': torch.float32, 'int32_t': torch.int32, 'uint8_t': torch.uint8, 'uint64_t': torch.int64,
+_DT = {'float': torch.float32, 'int32_t': torch.int32, 'uint8_t': torch.uint8, 'uint64_t': torch.int64, 'int64_t': torch.int64, 'double': torch.float64,
        'uint16_t': torch.bfloat16}      # uint16_t* in the header = bf16 storage
 
 

@@ -334,8 +334,6 @@ def test_min_area_rect_and_sodaa_reader(tmp_path):
     np.testing.assert_allclose(ann['bboxes'], [[100, 120, 40, 10, 0], [300, 310, 36, 12, -np.pi / 2]], atol=1e-5)
     assert ann['labels'].tolist() == [2, 8] and ann['polygons'].shape == (2, 8) and ann['bboxes_ignore'].shape == (0, 5)
     assert ds.ori_img_ids == ['00001'] and ds.get_ori_ann_info(0)['bboxes'].shape == (1, 5)
-    with pytest.raises(NotImplementedError, match='SODAAeval'):
-        ds.evaluate([])
 
 
 def test_obb_config_pipeline_builds():
