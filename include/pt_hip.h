@@ -370,6 +370,20 @@ int pt_image_prep(const uint8_t* src, int src_h, int src_w, int64_t src_row_stri
                   int to_rgb, int pad_h, int pad_w, float pad_val, int out_h, int out_w, float* dst,
                   int64_t dst_stride_c, int64_t dst_stride_h, int64_t dst_stride_w, void* stream);
 
+/* ------------------------------------------- supervised FCOS baseline (next row N4) --
+ * FCOSHead.get_targets / _get_target_single (HBB_TOD/mmdet/models/dense_heads/fcos_head.py:806-1007) of
+ * configs/baselines/aitodv2_fcos_r50_1x.py: per image and point, the smallest-area ground truth whose box
+ * (centre-sampled with sample_radius[p] = stride * center_sample_radius when center_sampling != 0) contains the
+ * point and whose largest side distance lies in regress_ranges[p] = (lo, hi); none -> label num_classes.
+ * points[P,2], regress_ranges[P,2], sample_radius[P], target_norm[P] (stride when norm_on_bbox, else 1);
+ * boxes[sumG,4] xyxy, box_labels[sumG], off[B+1].  Outputs image-major: labels[B*P], bbox_targets[B*P,4]
+ * = (l,t,r,b) / target_norm (of box 0 for background points, as the reference leaves them; zeros when the
+ * image has no box), ctr_target[B*P] = centerness of the positive points, 0 elsewhere (either may be NULL). */
+int pt_fcos_dense_targets(const float* points, const float* regress_ranges, const float* sample_radius,
+                          const float* target_norm, int P, const float* boxes, const int32_t* box_labels,
+                          const int32_t* off, int B, int num_classes, int center_sampling,
+                          int32_t* labels, float* bbox_targets, float* ctr_target, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -373,6 +373,84 @@ __global__ void fcos_targets_obb_kernel(const float* __restrict__ points, int P,
   ctr[i] = c;
 }
 
+
+// ------------------------------------------------------------ dense FCOS targets (row N4) --
+// FCOSHead._get_target_single (HBB_TOD/mmdet/models/dense_heads/fcos_head.py:877-1007) for the supervised FCOS baseline
+// (configs/baselines/aitodv2_fcos_r50_1x.py): every point takes the SMALLEST-AREA ground truth whose (centre-sampled)
+// box contains it and whose largest side distance lies in the level's regress range; none -> background.  The reference
+// materialises five [P, G] float tensors per image; here one thread owns a point and streams the image's boxes through
+// LDS (256 per tile), keeping the running minimum in registers.  Ties keep the first box, an all-INF row keeps box 0
+// (what `areas.min(dim=1)` returns), so the unused targets of background points match as well.
+struct DenseGt {
+  float x1, y1, x2, y2, area;
+  int label;
+};
+
+__global__ void __launch_bounds__(256)
+    fcos_dense_targets_kernel(const float* __restrict__ points, const float* __restrict__ ranges,
+                              const float* __restrict__ radius, const float* __restrict__ norm, int P,
+                              const float* __restrict__ boxes, const int32_t* __restrict__ box_labels,
+                              const int32_t* __restrict__ off, int num_classes, int center_sampling,
+                              int32_t* __restrict__ labels, float* __restrict__ bbox_targets, float* __restrict__ ctr_target) {
+  __shared__ DenseGt tile[256];
+  const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int g0 = off[b], G = off[b + 1] - g0;
+  const bool live = p < P;
+  const float x = live ? points[2 * p] : 0.f, y = live ? points[2 * p + 1] : 0.f;
+  const float lo = live ? ranges[2 * p] : 0.f, hi = live ? ranges[2 * p + 1] : 0.f;
+  const float rad = live ? radius[p] : 0.f;
+  constexpr float INF = 1e8f;
+  float best = INF, bl = 0.f, bt = 0.f, br = 0.f, bb = 0.f;
+  int bidx = -1;
+  for (int base = 0; base < G; base += 256) {
+    const int n = min(256, G - base);
+    __syncthreads();
+    if ((int)threadIdx.x < n) {
+      const float* q = boxes + (size_t)(g0 + base + threadIdx.x) * 4;
+      DenseGt t;
+      t.x1 = q[0]; t.y1 = q[1]; t.x2 = q[2]; t.y2 = q[3];
+      t.area = (q[2] - q[0]) * (q[3] - q[1]);
+      t.label = box_labels[g0 + base + threadIdx.x];
+      tile[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (!live) continue;
+    for (int k = 0; k < n; ++k) {
+      const DenseGt t = tile[k];
+      const float l = x - t.x1, r = t.x2 - x, tp = y - t.y1, bo = t.y2 - y;
+      bool inside;
+      if (center_sampling) {
+        const float cx = (t.x1 + t.x2) / 2.f, cy = (t.y1 + t.y2) / 2.f;
+        const float xmin = cx - rad, ymin = cy - rad, xmax = cx + rad, ymax = cy + rad;
+        const float c0 = xmin > t.x1 ? xmin : t.x1, c1 = ymin > t.y1 ? ymin : t.y1;
+        const float c2 = xmax > t.x2 ? t.x2 : xmax, c3 = ymax > t.y2 ? t.y2 : ymax;
+        inside = fminf(fminf(x - c0, y - c1), fminf(c2 - x, c3 - y)) > 0.f;
+      } else {
+        inside = fminf(fminf(l, tp), fminf(r, bo)) > 0.f;
+      }
+      const float maxd = fmaxf(fmaxf(l, tp), fmaxf(r, bo));
+      const float area = (inside && maxd >= lo && maxd <= hi) ? t.area : INF;
+      if (bidx < 0 || area < best) {               // the first box initialises (all-INF rows keep index 0)
+        bl = l; bt = tp; br = r; bb = bo;
+        best = area;
+        bidx = base + k;
+      }
+    }
+  }
+  if (!live) return;
+  const size_t o = (size_t)b * P + p;
+  const bool pos = bidx >= 0 && best < INF;
+  labels[o] = pos ? box_labels[g0 + bidx] : num_classes;
+  const float nm = norm[p];
+  const float tl = bl / nm, tt = bt / nm, tr = br / nm, tb = bb / nm;      // norm_on_bbox: / stride (1 otherwise)
+  if (bbox_targets) {
+    float* q = bbox_targets + o * 4;
+    q[0] = tl; q[1] = tt; q[2] = tr; q[3] = tb;
+  }
+  if (ctr_target)   // fcos_head.py:1009-1031 on the (normalised) targets of positive points; 0 elsewhere
+    ctr_target[o] = pos ? sqrtf((fminf(tl, tr) / fmaxf(tl, tr)) * (fminf(tt, tb) / fmaxf(tt, tb))) : 0.f;
+}
+
 }  // namespace pt
 
 using namespace pt;
@@ -494,5 +572,19 @@ extern "C" int pt_fcos_targets(const float* points, int P, const int32_t* gt_ind
   hipLaunchKernelGGL(fcos_targets_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), points, P, gt_inds,
                      boxes, box_labels, off, B, num_classes, labels, bbox_targets, ctr_target);
   PT_LAUNCH_CHECK("pt_fcos_targets");
+  return PT_OK;
+}
+
+extern "C" int pt_fcos_dense_targets(const float* points, const float* regress_ranges, const float* sample_radius,
+                                     const float* target_norm, int P, const float* boxes, const int32_t* box_labels,
+                                     const int32_t* off, int B, int num_classes, int center_sampling, int32_t* labels,
+                                     float* bbox_targets, float* ctr_target, void* stream) {
+  PT_REQUIRE(points && regress_ranges && sample_radius && target_norm && off && labels && P > 0 && B > 0, PT_EINVAL,
+             "pt_fcos_dense_targets: bad argument");
+  PT_REQUIRE(B <= 65535, PT_ELIMIT, "pt_fcos_dense_targets: B=%d above 65535", B);
+  hipLaunchKernelGGL(fcos_dense_targets_kernel, dim3(cdiv(P, 256), B), dim3(256), 0, as_stream(stream), points, regress_ranges,
+                     sample_radius, target_norm, P, boxes, box_labels, off, num_classes, center_sampling, labels, bbox_targets,
+                     ctr_target);
+  PT_LAUNCH_CHECK("pt_fcos_dense_targets");
   return PT_OK;
 }

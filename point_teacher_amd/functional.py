@@ -123,6 +123,22 @@ def fcos_targets(points, gt_inds, boxes, box_labels, off, B, num_classes, want_c
     return labels, tg, ctr
 
 
+def fcos_dense_targets(points, regress_ranges, sample_radius, target_norm, boxes, box_labels, off, B, num_classes,
+                       center_sampling=True):
+    """pt_fcos_dense_targets (FCOSHead.get_targets of the supervised baseline) -> labels int32 [B*P],
+    bbox_targets [B*P,4] (already / target_norm), ctr_target [B*P]."""
+    P = points.shape[0]
+    dev = points.device
+    labels = torch.empty((B * P,), dtype=i32, device=dev)
+    tg = torch.zeros((B * P, 4), dtype=f32, device=dev)
+    ctr = torch.zeros((B * P,), dtype=f32, device=dev)
+    nb = boxes.shape[0]
+    hip.call('pt_fcos_dense_targets', _f(points), _f(regress_ranges), _f(sample_radius), _f(target_norm), P,
+             _f(boxes) if nb else None, box_labels.to(i32).contiguous() if nb else None, off, B, num_classes,
+             int(bool(center_sampling)), labels, tg, ctr)
+    return labels, tg, ctr
+
+
 def fuse_assign_obb(points, dec, cls, gt_xy, gt_labels, off, B, num_pre=5, topk=3, cls_w=1.0, reg_w=1.0, loc_w=1.0):
     """pt_fuse_assign_obb.  dec [B*P,5] decoded (cx,cy,w,h,a), cls [B*P,C] logits."""
     P = points.shape[0]

@@ -33,9 +33,11 @@ class FlatParams:
         without per-call layout transposes; the flat-buffer kernels are order-agnostic."""
         self.model = model
         self.channels_last = channels_last
-        student = list(model.student.named_parameters())
-        teacher = dict(model.teacher.named_parameters())
-        assert [n for n, _ in student] == list(teacher.keys()), 'teacher/student parameter lists differ'
+        # a plain detector (the supervised FCOS baseline, row N4) has no teacher: its own parameters are the "student"
+        self.has_teacher = hasattr(model, 'student') and hasattr(model, 'teacher')
+        student = list((model.student if self.has_teacher else model).named_parameters())
+        teacher = dict(model.teacher.named_parameters()) if self.has_teacher else None
+        assert teacher is None or [n for n, _ in student] == list(teacher.keys()), 'teacher/student parameter lists differ'
 
         def is_bias(name, p):           # mmcv DefaultOptimizerConstructor: key name == 'bias' (norm layers are frozen here)
             return name.endswith('.bias') or name == 'bias'
@@ -51,7 +53,7 @@ class FlatParams:
         total = self.n_train + self.n_frozen
         dev = student[0][1].device
         self.student_flat = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.teacher_flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.teacher_flat = torch.zeros(total, dtype=torch.float32, device=dev) if self.has_teacher else None
         self.grad_flat = torch.zeros(self.n_train, dtype=torch.float32, device=dev)
         self.mom_flat = torch.zeros(self.n_train, dtype=torch.float32, device=dev)
         self.numel = sum(p.numel() for _, p in self.order)
@@ -61,28 +63,32 @@ class FlatParams:
         with torch.no_grad():
             for name, p in self.order:
                 n = p.numel()
-                t = teacher[name]
+                t = teacher[name] if teacher is not None else None
                 if channels_last and p.dim() == 4:
                     O, I, KH, KW = p.shape
 
                     def view(buf):
                         return buf[off:off + n].view(O, KH, KW, I).permute(0, 3, 1, 2)
                     view(self.student_flat).copy_(p.data)
-                    view(self.teacher_flat).copy_(t.data)
+                    if t is not None:
+                        view(self.teacher_flat).copy_(t.data)
                 else:
                     def view(buf):
                         return buf[off:off + n].view(p.shape)
                     self.student_flat[off:off + n].copy_(p.data.reshape(-1))
-                    self.teacher_flat[off:off + n].copy_(t.data.reshape(-1))
+                    if t is not None:
+                        self.teacher_flat[off:off + n].copy_(t.data.reshape(-1))
                 p.data = view(self.student_flat)
-                t.data = view(self.teacher_flat)
+                if t is not None:
+                    t.data = view(self.teacher_flat)
                 if p.requires_grad:
                     p.grad = view(self.grad_flat)
                     self.train_params.append(p)
                     self.grad_views.append(p.grad)
                 self.slices[name] = (off, n)
                 off += (n + 3) // 4 * 4
-        model._flat = (self.teacher_flat, self.student_flat)
+        if self.has_teacher:
+            model._flat = (self.teacher_flat, self.student_flat)
 
     def zero_grad(self):
         self.grad_flat.zero_()
@@ -286,7 +292,8 @@ class Trainer:
     def _broadcast_initial_state(self):
         if self.world > 1:                     # identical initial weights on every rank, as DDP does
             dist.broadcast(self.flat.student_flat, src=0)
-            dist.broadcast(self.flat.teacher_flat, src=0)
+            if self.flat.teacher_flat is not None:
+                dist.broadcast(self.flat.teacher_flat, src=0)
 
     def _set_lr(self):
         lr = self.sched.lr_at(self.iter)
