@@ -5,6 +5,6 @@ from .datasets import (DATASETS, ROTATED_DATASETS, AITODDataset, CocoDataset, Cu
                        SODAADOTADataset, build_dataset, merge_patch_detections, min_area_rect, poly2obb_np)
 from .loader import (DeviceLoader, DistributedGroupSampler, DistributedSampler, EpochBatches, GroupSampler,  # noqa: F401
                      build_dataloader, collate_to_device)
-from .pipelines import (PIPELINES, ROTATED_PIPELINES, Collect, Compose, DataContainer, DefaultFormatBundle,  # noqa: F401
+from .pipelines import (PIPELINES, ROTATED_PIPELINES, Collect, Compose, DataContainer, DefaultFormatBundle, DeviceImageCache,  # noqa: F401
                         ImageToTensor, LazyImage, LoadAnnotations, LoadImageFromFile, MultiScaleFlipAug, Normalize, Pad,
                         RandomFlip, Resize, RRandomFlip, RResize, decode_image, rescale_size)

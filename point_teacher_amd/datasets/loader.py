@@ -155,23 +155,28 @@ def _unwrap(x):
     return x.data if isinstance(x, DataContainer) else x
 
 
-def _render_batch(images, device, channels_last, stream):
-    """[LazyImage] -> float32 [B, 3, Hmax, Wmax] on `device`: one pinned uint8 upload + one pt_image_prep per image."""
+def _render_batch(images, device, channels_last, stream, cache=None):
+    """[LazyImage] -> float32 [B, 3, Hmax, Wmax] on `device`: one pinned uint8 upload (none for an image that comes out of
+    the HBM cache) + one pt_image_prep per image."""
     H = max(im.shape[0] for im in images)
     W = max(im.shape[1] for im in images)
     fmt = torch.channels_last if channels_last else torch.contiguous_format
     out = torch.empty((len(images), 3, H, W), dtype=torch.float32, device=device, memory_format=fmt)
     for b, im in enumerate(images):
-        host = torch.from_numpy(im.src)
-        pinned = torch.empty(host.shape, dtype=torch.uint8, pin_memory=True)
-        pinned.copy_(host)
-        dsrc = pinned.to(device, non_blocking=True)
-        dsrc.record_stream(stream)
+        if isinstance(im.src, torch.Tensor):
+            dsrc = im.src
+        else:
+            host = torch.from_numpy(im.src)
+            pinned = torch.empty(host.shape, dtype=torch.uint8, pin_memory=True)
+            pinned.copy_(host)
+            dsrc = pinned.to(device, non_blocking=True)
+            if cache is not None and im.cache_key is not None:
+                cache.put(im.cache_key, dsrc)
         im.render(out[b], device_src=dsrc, stream=stream.cuda_stream)
     return out
 
 
-def collate_to_device(samples, device, channels_last=True, stream=None):
+def collate_to_device(samples, device, channels_last=True, stream=None, cache=None):
     """mmcv.parallel.collate + MMDataParallel.scatter for one GPU: a list of pipeline outputs -> the keyword
     arguments of `forward_train` / `forward_test`, already resident on `device`.
     train sample: {'img_metas': DC(meta), 'img': DC(LazyImage), 'gt_bboxes': DC(tensor), ...}
@@ -188,12 +193,12 @@ def collate_to_device(samples, device, channels_last=True, stream=None):
                 cols = []
                 for a in range(len(vals[0])):
                     col = [_unwrap(v[a]) for v in vals]
-                    cols.append(_render_batch(col, device, channels_last, stream) if isinstance(col[0], LazyImage) else col)
+                    cols.append(_render_batch(col, device, channels_last, stream, cache) if isinstance(col[0], LazyImage) else col)
                 out[key] = cols
                 continue
             data = [_unwrap(v) for v in vals]
             if isinstance(data[0], LazyImage):
-                out[key] = _render_batch(data, device, channels_last, stream)
+                out[key] = _render_batch(data, device, channels_last, stream, cache)
             elif isinstance(data[0], torch.Tensor):
                 out[key] = [d.to(device, non_blocking=True) for d in data]
             else:
@@ -204,8 +209,22 @@ def collate_to_device(samples, device, channels_last=True, stream=None):
 class DeviceLoader:
     """Iterable over device-resident batches.  `len()` = batches per epoch; `set_epoch` reseeds a distributed sampler."""
 
-    def __init__(self, dataset, sampler, batch_size, num_workers, device, channels_last=True, drop_last=False, prefetch=2):
+    def __init__(self, dataset, sampler, batch_size, num_workers, device, channels_last=True, drop_last=False, prefetch=2,
+                 cache_bytes=0):
+        """cache_bytes > 0: keep the decoded uint8 tiles in HBM (pipelines.DeviceImageCache) up to that many bytes."""
         self.dataset, self.sampler, self.batch_size, self.device = dataset, sampler, int(batch_size), torch.device(device)
+        self.cache = None
+        if cache_bytes:
+            from .pipelines import DeviceImageCache, LoadImageFromFile, MultiScaleFlipAug
+            self.cache = DeviceImageCache(cache_bytes)
+
+            def install(compose):
+                for t in compose.transforms:
+                    if isinstance(t, LoadImageFromFile):
+                        t.cache = self.cache
+                    elif isinstance(t, MultiScaleFlipAug):
+                        install(t.transforms)
+            install(dataset.pipeline)
         self.channels_last, self.drop_last, self.prefetch = channels_last, drop_last, max(int(prefetch), 1)
         self.num_workers = max(int(num_workers), 1)
         self._pool = ThreadPoolExecutor(max_workers=self.num_workers, thread_name_prefix='pt-data')
@@ -231,7 +250,7 @@ class DeviceLoader:
 
     def _finish(self, futures):
         samples = [f.result() for f in futures]
-        batch = collate_to_device(samples, self.device, self.channels_last, self._stream)
+        batch = collate_to_device(samples, self.device, self.channels_last, self._stream, self.cache)
         ready = torch.cuda.Event()
         ready.record(self._stream)
         return batch, ready

@@ -458,3 +458,29 @@ def test_loader_batches_match_oracle_and_feed_a_training_step(tmp_path):
     assert len(results) == len(dt) == 7 and len(results[0]) == 8
     ev = dt.evaluate(results, device=dev)
     assert 'bbox_mAP' in ev and 'bbox_mAP_vt' in ev and len(ev['bbox_classwise']) == 8
+
+
+@pytest.mark.gpu
+def test_hbm_image_cache(tmp_path):
+    """DeviceLoader(cache_bytes=...): the second epoch is served from HBM - the files can be gone - and renders the same
+    pixels; a cache that is too small simply stops growing."""
+    import shutil
+    dev = torch.device('cuda:0')
+    ann_file, prefix, pix = _make_aitod(str(tmp_path), n=6, sizes=((160, 160),), seed=5)
+    pipe = [t for t in TRAIN_PIPELINE if t['type'] != 'RandomFlip']
+    pipe.insert(3, dict(type='RandomFlip', flip_ratio=0.0))
+    ds = D.build_dataset(dict(type='AITODDataset', ann_file=ann_file, img_prefix=prefix, pipeline=pipe))
+    loader = D.build_dataloader(ds, samples_per_gpu=2, workers_per_gpu=2, dist=False, shuffle=False, device=dev, cache_bytes=1 << 30)
+    first = {m['ori_filename']: b['img'][i].clone() for b in loader for i, m in enumerate(b['img_metas'])}
+    assert len(first) == 5 and len(loader.cache) == 5 and loader.cache.hits == 0 and loader.cache.bytes == 5 * 160 * 160 * 3
+    shutil.rmtree(prefix)                                                   # nothing left to decode
+    second = {m['ori_filename']: b['img'][i].clone() for b in loader for i, m in enumerate(b['img_metas'])}
+    assert loader.cache.hits == 5 and set(second) == set(first)
+    for k in first:
+        assert torch.equal(first[k], second[k])
+    ann2, prefix2, _ = _make_aitod(os.path.join(str(tmp_path), 'b'), n=6, sizes=((160, 160),), seed=6)
+    ds2 = D.build_dataset(dict(type='AITODDataset', ann_file=ann2, img_prefix=prefix2, pipeline=pipe))
+    small = D.build_dataloader(ds2, samples_per_gpu=2, workers_per_gpu=1, dist=False, shuffle=False, device=dev, cache_bytes=2 * 160 * 160 * 3)
+    for _ in small:
+        pass
+    assert len(small.cache) == 2

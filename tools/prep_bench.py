@@ -40,7 +40,7 @@ def kernel(dev, src_hw, dst_hw, norm, reps=200):
                 GBps=round(byts / us / 1e3, 1))
 
 
-def loader(dev, n=64, size=800, workers=8):
+def loader(dev, n=64, size=800, workers=8, cache_bytes=0):
     from PIL import Image
     tmp = tempfile.mkdtemp()
     os.makedirs(os.path.join(tmp, 'img'))
@@ -60,7 +60,7 @@ def loader(dev, n=64, size=800, workers=8):
             dict(type='Normalize', mean=[0.0, 0.0, 0.0], std=[1.0, 1.0, 1.0], to_rgb=False), dict(type='Pad', size_divisor=32),
             dict(type='DefaultFormatBundle'), dict(type='Collect', keys=['img', 'gt_bboxes', 'gt_labels'])]
     ds = D.build_dataset(dict(type='AITODDataset', ann_file=os.path.join(tmp, 'a.json'), img_prefix=os.path.join(tmp, 'img'), pipeline=pipe))
-    ld = D.build_dataloader(ds, samples_per_gpu=2, workers_per_gpu=workers, dist=False, shuffle=True, device=dev)
+    ld = D.build_dataloader(ds, samples_per_gpu=2, workers_per_gpu=workers, dist=False, shuffle=True, device=dev, cache_bytes=cache_bytes)
     for _ in ld:                                   # warm the page cache / pinned pool
         pass
     torch.cuda.synchronize()
@@ -70,14 +70,14 @@ def loader(dev, n=64, size=800, workers=8):
         k += b['img'].shape[0]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return dict(images=k, workers=workers, seconds=round(dt, 3), images_per_s=round(k / dt, 1))
+    return dict(images=k, workers=workers, hbm_cache=bool(cache_bytes), seconds=round(dt, 3), images_per_s=round(k / dt, 1))
 
 
 def main():
     dev = torch.device('cuda:0')
     out = dict(kernel=[kernel(dev, (800, 800), (800, 800), False), kernel(dev, (800, 800), (800, 800), True),
                        kernel(dev, (800, 800), (1200, 1200), True)],
-               loader=[loader(dev, workers=w) for w in (2, 8)])
+               loader=[loader(dev, workers=w) for w in (2, 8)] + [loader(dev, workers=2, cache_bytes=8 << 30)])
     print(json.dumps(out))
 
 

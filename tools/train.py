@@ -30,6 +30,7 @@ def main():
     ap.add_argument('--img-prefix', default=None, help="override data.train.img_prefix")
     ap.add_argument('--ori-ann-file', default=None, help="override data.train.ori_ann_file (SODA-A)")
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--cache-gb', type=float, default=48.0, help='decoded uint8 tiles kept in HBM between epochs (0 = off)')
     args = ap.parse_args()
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
@@ -56,7 +57,7 @@ def main():
         from point_teacher_amd.datasets import EpochBatches, build_dataloader, build_dataset
         dataset = build_dataset(tcfg)
         loader = build_dataloader(dataset, cfg.data.samples_per_gpu, cfg.data.workers_per_gpu, dist=world > 1, shuffle=True,
-                                  seed=args.seed, device=dev)
+                                  seed=args.seed, device=dev, cache_bytes=int(args.cache_gb * (1 << 30)))
         ipe = args.iters_per_epoch or len(loader)
         batches = EpochBatches(loader)
         if rank == 0:
