@@ -28,6 +28,30 @@ class Runner:
         if self.rank == 0:
             os.makedirs(work_dir, exist_ok=True)
         self._json = os.path.join(work_dir, 'log.json')
+        self._eval = None
+
+    # ------------------------------------------------------------------------ evaluation --
+    def register_eval(self, dataset, loader, interval=1, **eval_kwargs):
+        """mmdet's EvalHook (apis/train.py:140-155, `evaluation = dict(interval=12, metric='bbox')` in the configs): every
+        `interval` epochs rank 0 runs the test loop over `loader` (a test-mode DeviceLoader) and `dataset.evaluate`."""
+        self._eval = (dataset, loader, int(interval), eval_kwargs)
+
+    def evaluate(self):
+        from .evaluation import single_gpu_test
+        dataset, loader, _, kw = self._eval
+        model = self.trainer.model
+        was_training = model.training
+        it = iter(loader)
+        results = single_gpu_test(model, lambda _: next(it), len(loader))
+        model.train(was_training)
+        metrics = dataset.evaluate(results, **kw)
+        rec = dict(mode='val', epoch=self.epoch, iter=len(results))
+        rec.update({k: v for k, v in metrics.items() if isinstance(v, (int, float, str))})
+        with open(self._json, 'a') as f:
+            f.write(json.dumps(rec) + '\n')
+        print(f'Epoch(val) [{self.epoch}][{len(results)}]\t' + ', '.join(f'{k}: {v:.4f}' for k, v in rec.items() if isinstance(v, float)),
+              flush=True)
+        return metrics
 
     # ---------------------------------------------------------------------- checkpoints --
     def save_checkpoint(self, name=None):
@@ -87,6 +111,8 @@ class Runner:
                 self.epoch += 1
                 if self.epoch % self.checkpoint_interval == 0:
                     self.save_checkpoint()
+                if self._eval is not None and self.epoch % self._eval[2] == 0 and self.rank == 0:
+                    self.evaluate()
             if stop:
                 break
         return done

@@ -484,3 +484,29 @@ def test_hbm_image_cache(tmp_path):
     for _ in small:
         pass
     assert len(small.cache) == 2
+
+
+@pytest.mark.gpu
+def test_runner_trains_from_loader_and_evaluates(tmp_path):
+    """The whole outer loop on a generated AI-TOD folder: EpochBatches feeds the Runner from the device loader, the epoch
+    ends with a checkpoint and an evaluation pass (mmdet's EvalHook) whose metrics land in log.json."""
+    import test_train_step_parity as T
+    from point_teacher_amd.runner import Runner
+    dev = torch.device('cuda:0')
+    ann_file, prefix, _ = _make_aitod(str(tmp_path), n=4, sizes=((160, 160),), seed=12)
+    pipe = [dict(t) for t in TRAIN_PIPELINE]
+    ds = D.build_dataset(dict(type='AITODDataset', ann_file=ann_file, img_prefix=prefix, pipeline=pipe))
+    loader = D.build_dataloader(ds, samples_per_gpu=2, workers_per_gpu=2, dist=False, shuffle=True, device=dev, cache_bytes=1 << 28)
+    dv = D.build_dataset(dict(type='AITODDataset', ann_file=ann_file, img_prefix=prefix, pipeline=TEST_PIPELINE, test_mode=True))
+    vl = D.build_dataloader(dv, samples_per_gpu=1, workers_per_gpu=1, dist=False, shuffle=False, device=dev)
+    _, cfg, model = T._build(dev, phase2=False)
+    trainer = pta.Trainer(model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config, iters_per_epoch=len(loader))
+    work = os.path.join(str(tmp_path), 'work')
+    runner = Runner(trainer, D.EpochBatches(loader), work, max_epochs=2, iters_per_epoch=len(loader), log_interval=1)
+    runner.register_eval(dv, vl, interval=1, device=dev)
+    assert runner.run() == 2 * len(loader) and runner.epoch == 2
+    assert loader.cache.hits >= len(ds) and len(loader.cache) == len(ds)    # the second epoch came out of HBM (3 images padded to 2 batches)
+    recs = [json.loads(l) for l in open(os.path.join(work, 'log.json'))]
+    train, val = [r for r in recs if r['mode'] == 'train'], [r for r in recs if r['mode'] == 'val']
+    assert len(train) == 2 * len(loader) and len(val) == 2 and 'bbox_mAP' in val[0] and val[1]['epoch'] == 2
+    assert os.path.exists(os.path.join(work, 'epoch_2.pth')) and model.training

@@ -72,6 +72,12 @@ def main():
     work_dir = args.work_dir or os.path.join(ROOT, 'work_dirs', os.path.splitext(os.path.basename(args.config))[0])
     runner = Runner(trainer, batches, work_dir, cfg.runner.max_epochs, ipe, cfg.log_config.interval,
                     cfg.checkpoint_config.interval, cfg.data.samples_per_gpu)
+    vcfg = dict(cfg.data.get('val', {}))
+    if real and os.path.exists(str(vcfg.get('ann_file', ''))) and cfg.get('evaluation'):
+        vcfg['test_mode'] = True
+        vds = build_dataset(vcfg)
+        vld = build_dataloader(vds, 1, cfg.data.workers_per_gpu, dist=False, shuffle=False, device=dev)
+        runner.register_eval(vds, vld, cfg.evaluation.get('interval', 1))
     if args.resume_from:
         meta = runner.resume(args.resume_from)
         if rank == 0:
