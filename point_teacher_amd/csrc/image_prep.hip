@@ -13,8 +13,8 @@
 //   * imnormalize: float32 pixel, BGR->RGB swap, float32 subtract of the mean, multiply by 1/std in double
 //     rounded once to float32;
 //   * Pad writes pad_val to the right/bottom up to (pad_h, pad_w); the batch collate pads further with 0.
-// HBM-bound byte work: 3 B read + 12 B written per output pixel, one thread per output pixel, the three
-// channel stores of a pixel are adjacent in the channels-last layout the backbone consumes.
+// HBM-bound byte work: 3 B read + 12 B written per output pixel; a thread owns four pixels of a row = 48 contiguous
+// bytes of the channels-last layout the backbone consumes, written as three 16-byte stores.
 #include "pt_common.h"
 
 namespace pt {
@@ -41,10 +41,8 @@ __device__ __forceinline__ void linear_tap(int d, double scale, int n, bool clam
   w1 = __float2int_rn(f * 2048.f);
 }
 
-__global__ void __launch_bounds__(256) image_prep_kernel(const uint8_t* __restrict__ src, PrepGeom g, float* __restrict__ dst) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x >= g.out_w) return;
-  float v[3];
+// one prepared pixel (3 channels) of the padded output at (x, y)
+__device__ __forceinline__ void prep_pixel(const uint8_t* __restrict__ src, const PrepGeom& g, int x, int y, float v[3]) {
   if (y < g.rs_h && x < g.rs_w) {
     const int xr = (g.flip & 1) ? g.rs_w - 1 - x : x, yr = (g.flip & 2) ? g.rs_h - 1 - y : y;
     int p[3];
@@ -81,10 +79,37 @@ __global__ void __launch_bounds__(256) image_prep_kernel(const uint8_t* __restri
     const float f = (y < g.pad_h && x < g.pad_w) ? g.pad_val : 0.f;
     v[0] = v[1] = v[2] = f;
   }
-  float* o = dst + (size_t)y * g.sh + (size_t)x * g.sw;
-  o[0] = v[0];
-  o[g.sc] = v[1];
-  o[2 * g.sc] = v[2];
+}
+
+// A thread owns FOUR consecutive output pixels of a row.  In the channels-last layout the backbone consumes (element
+// strides c = 1, w = 3) these are 12 consecutive floats: three 16-byte stores per lane, full lines per wavefront, instead
+// of twelve 4-byte stores 12 bytes apart (VEC = true; the host checks width % 4 and 16-byte alignment of every row).
+template <bool VEC>
+__global__ void __launch_bounds__(256) image_prep_kernel(const uint8_t* __restrict__ src, PrepGeom g, float* __restrict__ dst) {
+  const int nq = (g.out_w + 3) >> 2;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)nq * g.out_h) return;
+  const int y = (int)(i / nq), x0 = (int)(i - (long)y * nq) * 4;
+  float v[4][3];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (VEC || x0 + k < g.out_w) prep_pixel(src, g, x0 + k, y, v[k]);
+  float* o = dst + (size_t)y * g.sh + (size_t)x0 * g.sw;
+  if (VEC) {
+    float4* o4 = reinterpret_cast<float4*>(o);
+    o4[0] = make_float4(v[0][0], v[0][1], v[0][2], v[1][0]);
+    o4[1] = make_float4(v[1][1], v[1][2], v[2][0], v[2][1]);
+    o4[2] = make_float4(v[2][2], v[3][0], v[3][1], v[3][2]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (x0 + k < g.out_w) {
+        float* q = o + (size_t)k * g.sw;
+        q[0] = v[k][0];
+        q[g.sc] = v[k][1];
+        q[2 * g.sc] = v[k][2];
+      }
+  }
 }
 
 }  // namespace pt
@@ -105,7 +130,6 @@ extern "C" int pt_image_prep(const uint8_t* src, int src_h, int src_w, int64_t s
              out_w);
   PT_REQUIRE(flip >= 0 && flip <= 3, PT_EINVAL, "pt_image_prep: flip=%d (0 none, 1 horizontal, 2 vertical, 3 diagonal)", flip);
   PT_REQUIRE((mean_host == nullptr) == (stdinv_host == nullptr), PT_EINVAL, "pt_image_prep: mean and 1/std come together");
-  PT_REQUIRE(out_h <= 65535, PT_ELIMIT, "pt_image_prep: out_h=%d above 65535", out_h);
   PrepGeom g;
   g.src_h = src_h; g.src_w = src_w; g.rs_h = rs_h; g.rs_w = rs_w; g.pad_h = pad_h; g.pad_w = pad_w;
   g.out_h = out_h; g.out_w = out_w; g.flip = flip; g.to_rgb = to_rgb != 0; g.normalize = mean_host != nullptr;
@@ -117,7 +141,13 @@ extern "C" int pt_image_prep(const uint8_t* src, int src_h, int src_w, int64_t s
     g.stdinv[c] = stdinv_host ? stdinv_host[c] : 1.0;
   }
   g.pad_val = pad_val;
-  hipLaunchKernelGGL(image_prep_kernel, dim3(cdiv(out_w, 256), out_h), dim3(256), 0, as_stream(stream), src, g, dst);
+  const bool vec = dst_stride_c == 1 && dst_stride_w == 3 && out_w % 4 == 0 && dst_stride_h % 4 == 0 &&
+                   (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+  const long threads = (long)((out_w + 3) / 4) * out_h;
+  if (vec)
+    hipLaunchKernelGGL(image_prep_kernel<true>, dim3(cdiv(threads, 256)), dim3(256), 0, as_stream(stream), src, g, dst);
+  else
+    hipLaunchKernelGGL(image_prep_kernel<false>, dim3(cdiv(threads, 256)), dim3(256), 0, as_stream(stream), src, g, dst);
   PT_LAUNCH_CHECK("pt_image_prep");
   return PT_OK;
 }

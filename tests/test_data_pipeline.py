@@ -386,6 +386,10 @@ def test_image_prep_bit_exact(case):
     got = out[0].cpu().numpy()
     np.testing.assert_array_equal(got[:, :want.shape[1], :want.shape[2]], want.astype(np.float32))
     assert (got[:, want.shape[1]:, :] == 0).all() and (got[:, :, want.shape[2]:] == 0).all()
+    if im.shape[1] % 4 == 0:           # exact-size channels-last target: the kernel's 16-byte store path
+        out2 = torch.full((1, 3, im.shape[0], im.shape[1]), 7.0, device=dev).contiguous(memory_format=torch.channels_last)
+        im.render(out2[0])
+        np.testing.assert_array_equal(out2[0].cpu().numpy(), want.astype(np.float32))
 
 
 @pytest.mark.gpu
@@ -510,3 +514,40 @@ def test_runner_trains_from_loader_and_evaluates(tmp_path):
     train, val = [r for r in recs if r['mode'] == 'train'], [r for r in recs if r['mode'] == 'val']
     assert len(train) == 2 * len(loader) and len(val) == 2 and 'bbox_mAP' in val[0] and val[1]['epoch'] == 2
     assert os.path.exists(os.path.join(work, 'epoch_2.pth')) and model.training
+
+
+@pytest.mark.gpu
+def test_image_prep_full_size_properties():
+    """A 2160x3840 frame resized by a non-trivial factor (sizes the numpy oracle is not run at): flips commute with the
+    rendering, normalisation is the affine map of the un-normalised rendering (same roundings), the resize of a constant
+    is that constant and the pad / margin regions hold pad_val / 0."""
+    dev = torch.device('cuda:0')
+    r = np.random.RandomState(8)
+    bgr = r.randint(0, 256, (2160, 3840, 3)).astype(np.uint8)
+    size = D.rescale_size((3840, 2160), (2666, 1600))
+    mean, std = np.array([123.675, 116.28, 103.53], np.float32), np.array([58.395, 57.12, 57.375], np.float32)
+
+    def render(flip=None, norm=False, src=bgr):
+        im = D.LazyImage(src)
+        im.resize(size)
+        if flip:
+            im.flip_(flip)
+        if norm:
+            im.normalize(mean, std, True)
+        im.pad_to(-(-size[1] // 32) * 32, -(-size[0] // 32) * 32, 3.0)
+        out = torch.empty((1, 3, im.shape[0] + 32, im.shape[1]), device=dev).contiguous(memory_format=torch.channels_last)
+        im.render(out[0])
+        return out[0]
+    base = render()
+    h, w = size[1], size[0]
+    assert float(base[:, :h, :w].min()) >= 0 and float(base[:, :h, :w].max()) <= 255 and bool((base[:, :h, :w] == base[:, :h, :w].round()).all())
+    assert bool((base[:, h:-32, :] == 3.0).all()) and bool((base[:, :-32, w:] == 3.0).all()) and bool((base[:, -32:] == 0).all())
+    for flip, dims in (('horizontal', [2]), ('vertical', [1]), ('diagonal', [1, 2])):
+        assert torch.equal(render(flip)[:, :h, :w], torch.flip(base[:, :h, :w], dims))
+    want = ((base[:, :h, :w].flip(0) - torch.from_numpy(mean).to(dev)[:, None, None]).double()
+            * torch.from_numpy(1 / np.float64(std)).to(dev)[:, None, None]).float()
+    assert torch.equal(render(norm=True)[:, :h, :w], want)
+    const = render(src=np.full_like(bgr, 77))
+    assert bool((const[:, :h, :w] == 77).all())
+    # bilinear interpolation preserves the mean up to rounding
+    assert abs(float(base[:, :h, :w].mean()) - float(bgr.mean())) < 0.5

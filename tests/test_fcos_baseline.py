@@ -153,3 +153,48 @@ def test_baseline_trains_and_infers():
     with torch.no_grad():
         res = model(return_loss=False, rescale=True, img=[data['img']], img_metas=[metas])
     assert len(res) == 2 and len(res[0]) == 8 and all(r.shape[1] == 5 for r in res[0])
+
+
+@pytest.mark.gpu
+def test_dense_targets_full_size_properties():
+    """BASELINE size (800x800 -> 13 343 points x 5 levels, 600 boxes per image): size-independent properties of the assignment,
+    and the smallest-area rule re-derived with torch on a random subset of points."""
+    dev = torch.device('cuda:0')
+    from point_teacher_amd.fcos_baseline import FCOSHead
+    from point_teacher_amd.synthetic import make_tile
+    h = FCOSHead(8, 4, feat_channels=4, stacked_convs=1, strides=[8, 16, 32, 64, 128], center_sampling=True, norm_on_bbox=True,
+                 centerness_on_reg=True, norm_cfg=None, conv_bias=True, loss_bbox=dict(type='DIoULoss', loss_weight=1.0)).to(dev)
+    sizes = [(100, 100), (50, 50), (25, 25), (13, 13), (7, 7)]
+    pts = h.get_points(sizes, torch.float32, dev)
+    P = sum(p.shape[0] for p in pts)
+    assert P == 13343
+    tiles = [make_tile(i, 800, 8, 600, seed=4, device=dev, max_objects=600) for i in range(2)]
+    boxes, labels = [t[1] for t in tiles], [t[2] for t in tiles]
+    lab_cs, tg_cs, ctr_cs = h.get_targets(pts, boxes, labels)
+    h.center_sampling = False
+    lab_pl, tg_pl, _ = h.get_targets(pts, boxes, labels)
+    rr, rad, nm = h._point_tables(pts)
+    allp = torch.cat(pts)
+    for lab, tg, cs in ((lab_cs, tg_cs, True), (lab_pl, tg_pl, False)):
+        lab, tg = lab.view(2, P), tg.view(2, P, 4)
+        assert int(lab.min()) >= 0 and int(lab.max()) == 8
+        pos = lab < 8
+        assert 200 < int(pos.sum()) < 2 * P
+        raw = tg * nm[None, :, None]
+        assert bool((raw[pos] > 0).all())                                   # a positive point lies inside its box
+        mx = raw.max(-1)[0]
+        assert bool((mx[pos] >= rr[:, 0].expand(2, P)[pos]).all()) and bool((mx[pos] <= rr[:, 1].expand(2, P)[pos]).all())
+    assert bool(((lab_cs < 8) <= (lab_pl < 8)).all())                       # centre sampling only removes positives
+    assert bool((ctr_cs[lab_cs < 8] > 0).all()) and bool((ctr_cs[lab_cs < 8] <= 1).all()) and bool((ctr_cs[lab_cs == 8] == 0).all())
+    # smallest-area rule on 400 random points of image 0 (plain assignment), straight from the definition
+    g = torch.Generator().manual_seed(0)
+    idx = torch.randperm(P, generator=g)[:400].to(dev)
+    b = boxes[0]
+    x, y = allp[idx, 0:1], allp[idx, 1:2]
+    d = torch.stack([x - b[None, :, 0], y - b[None, :, 1], b[None, :, 2] - x, b[None, :, 3] - y], -1)
+    ok = (d.min(-1)[0] > 0) & (d.max(-1)[0] >= rr[idx, 0:1]) & (d.max(-1)[0] <= rr[idx, 1:2])
+    area = ((b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]))[None].expand(400, -1).clone()
+    area[~ok] = 1e8
+    best, bi = area.min(1)
+    want = torch.where(best < 1e8, labels[0][bi], torch.full_like(bi, 8))
+    assert torch.equal(lab_pl.view(2, P)[0, idx].long(), want.long())
