@@ -106,13 +106,23 @@ class Student_FCOS(BaseDetector):
     def with_neck_agg(self):
         return hasattr(self, 'neck_agg') and self.neck_agg is not None
 
+    backbone_autocast = None      # torch.bfloat16 = BASELINE configs[2]: bf16 backbone / necks, fp32 head (set by the Trainer)
+
     def extract_feat(self, img):
-        x = self.backbone(img)
-        if self.with_neck:
-            x = self.neck(x)
-        if self.with_neck_agg:
-            x = self.neck_agg(x)
-        return x
+        if self.backbone_autocast is None:
+            x = self.backbone(img)
+            if self.with_neck:
+                x = self.neck(x)
+            if self.with_neck_agg:
+                x = self.neck_agg(x)
+            return x
+        with torch.autocast('cuda', dtype=self.backbone_autocast):
+            x = self.backbone(img)
+            if self.with_neck:
+                x = self.neck(x)
+            if self.with_neck_agg:
+                x = self.neck_agg(x)
+        return tuple(f.float() for f in x)          # the dense head, the MIL head and every loss run in fp32
 
     def forward_dummy(self, img):
         return self.bbox_head(self.extract_feat(img))

@@ -286,7 +286,11 @@ class Trainer:
         self.reducer = GradReducer(grad_chunks, dev)
         # N > 1: bucketed exchange overlapped with backward; N == 1: nothing to exchange, one gather after backward
         self.exchange = BucketedGradExchange(self.flat, max(grad_chunks, 1) + 2, dev) if self.world > 1 else None
+        # BASELINE configs[2] "bf16 backbone + fp32 head": autocast covers backbone / FPN / PSAGG only (Student_FCOS.extract_feat)
         self.autocast_dtype = autocast_dtype
+        for m in model.modules():
+            if hasattr(m, 'backbone') and hasattr(m, 'extract_feat'):
+                m.backbone_autocast = autocast_dtype
         self._broadcast_initial_state()
 
     def _broadcast_initial_state(self):
@@ -309,11 +313,7 @@ class Trainer:
         self.flat.detach_grads()
         if self.channels_last:
             data = dict(data, img=data['img'].contiguous(memory_format=torch.channels_last))
-        if self.autocast_dtype is not None:
-            with torch.autocast('cuda', dtype=self.autocast_dtype):
-                out = self.model.train_step(data, None)
-        else:
-            out = self.model.train_step(data, None)
+        out = self.model.train_step(data, None)     # reduced precision, if any, is scoped inside extract_feat
         if self.exchange is not None:
             self.exchange.begin()
             out['loss'].backward()

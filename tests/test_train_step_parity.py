@@ -308,3 +308,34 @@ def test_eval_path_detections():
                 kg = torch.argsort((got[:, 0] + got[:, 2]) * 4096 + (got[:, 1] + got[:, 3]))
                 kr = torch.argsort((rb[:, 0] + rb[:, 2]) * 4096 + (rb[:, 1] + rb[:, 3]))
                 torch.testing.assert_close(got[kg, :4], rb[kr], rtol=1e-3, atol=5e-2)
+
+
+def test_bf16_backbone_fp32_head():
+    """BASELINE configs[2] ("bf16 backbone + fp32 head"): with Trainer(autocast_dtype=bfloat16) the backbone / FPN / PSAGG
+    convolutions run in bf16, while the dense head, the MIL head and the losses see and produce fp32; both phases stay finite
+    and on the scale of the fp32 iteration."""
+    dev = torch.device('cuda:0')
+    seen = {}
+    for phase2 in (False, True):
+        pta, cfg, model = _build(dev, phase2=phase2)
+        ref_pta, _, ref_model = _build(dev, phase2=phase2)
+        tr = pta.Trainer(model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config, autocast_dtype=torch.bfloat16)
+        tr32 = ref_pta.Trainer(ref_model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config)
+        hooks = [model.student.backbone.layer2[0].conv1.register_forward_hook(lambda m, i, o: seen.__setitem__('backbone', o.dtype)),
+                 model.student.neck.fpn_convs[0].register_forward_hook(lambda m, i, o: seen.__setitem__('neck', o.dtype)),
+                 model.student.bbox_head.cls_convs[0].register_forward_hook(lambda m, i, o: seen.__setitem__('head', (i[0].dtype, o.dtype))),
+                 model.student.bbox_head.conv_reg.register_forward_hook(lambda m, i, o: seen.__setitem__('reg', o.dtype))]
+        img, boxes, labels, metas = _data(dev)
+        data = dict(img=img.to(dev), img_metas=metas, gt_bboxes=[b.to(dev) for b in boxes], gt_labels=[l.to(dev) for l in labels])
+        lv = tr.step(data)['log_vars'].materialize()
+        lv32 = tr32.step(data)['log_vars'].materialize()
+        for h in hooks:
+            h.remove()
+        assert seen['backbone'] == torch.bfloat16 and seen['neck'] == torch.bfloat16
+        assert seen['head'] == (torch.float32, torch.float32) and seen['reg'] == torch.float32
+        assert all(v == v and abs(v) != float('inf') for v in lv.values()), lv
+        # a randomly initialised net turns bf16 feature noise into different point->box decisions: same scale, not same value
+        assert lv['loss_cls'] == pytest.approx(lv32['loss_cls'], rel=0.1), (lv['loss_cls'], lv32['loss_cls'])
+        for k in ('loss_bbox', 'loss_centerness'):
+            assert 0.5 * lv32[k] < lv[k] < 2.0 * lv32[k], (k, lv[k], lv32[k])
+        assert torch.isfinite(tr.flat.student_flat).all()
