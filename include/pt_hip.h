@@ -384,6 +384,19 @@ int pt_fcos_dense_targets(const float* points, const float* regress_ranges, cons
                           const int32_t* off, int B, int num_classes, int center_sampling,
                           int32_t* labels, float* bbox_targets, float* ctr_target, void* stream);
 
+/* MaxIoUAssigner.assign / assign_wrt_overlaps (HBB_TOD/mmdet/core/bbox/assigners/max_iou_assigner.py:98-212) of the
+ * anchor-based baselines (configs/baselines/aitodv2_retinanet_r50_1x.py), for a whole batch without the [G, A] overlap
+ * matrix.  anchors[A,4] xyxy shared by the images; gt_boxes[sumG,4], off[B+1].  Per image: max_overlaps[B*A] and its
+ * argmax, assigned_gt_inds[B*A] = -1 ignore / 0 background / i+1 (box i of the image): background where
+ * neg_iou_lo <= max < neg_iou_hi (a float neg_iou_thr t is (0, t)), positive where max >= pos_iou_thr; with
+ * match_low_quality every box whose best IoU >= min_pos_iou claims all anchors that tie that best (gt_max_assign_all)
+ * or its first best anchor, later boxes overriding earlier ones.  An image without boxes is all background.
+ * argmax_ws[B*A] int32 and gt_best_ws[sumG] uint64 (ZEROED by the caller) are scratch. */
+int pt_max_iou_assign(const float* anchors, int A, const float* gt_boxes, const int32_t* off, int B,
+                      float pos_iou_thr, float neg_iou_lo, float neg_iou_hi, float min_pos_iou,
+                      int match_low_quality, int gt_max_assign_all, float* max_overlaps,
+                      int32_t* argmax_ws, uint64_t* gt_best_ws, int32_t* assigned_gt_inds, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -205,6 +205,92 @@ __global__ void overlaps_pairwise_kernel(const float4* __restrict__ a, const flo
   out[i] = overlap_one(a[m], b[n], mode, eps);
 }
 
+// ------------------------------------------------------------ MaxIoUAssigner (row N4) --
+// core/bbox/assigners/max_iou_assigner.py:98-212 (assign + assign_wrt_overlaps) for the anchor-based baselines
+// (configs/baselines/aitodv2_retinanet_r50_1x.py).  The reference materialises overlaps[G, A] (A ~ 120 000 anchors, G ~ 300:
+// 144 MB per image) and walks it four times; here the matrix is never stored: pass 1 computes each anchor's best box and,
+// with one packed 64-bit atomicMax per (box, workgroup), each box's best anchor; pass 2 re-evaluates the same IoU (same
+// instruction sequence -> same bits) for the "every anchor that ties a box's maximum" rule.  Boxes go through LDS in tiles.
+constexpr int MI_TILE = 256;
+
+__global__ void __launch_bounds__(256)
+    max_iou_pass1_kernel(const float4* __restrict__ anchors, int A, const float4* __restrict__ gts, const int32_t* __restrict__ off,
+                         float eps, float* __restrict__ max_ov, int32_t* __restrict__ argmax,
+                         unsigned long long* __restrict__ gt_best) {
+  __shared__ float4 tile[MI_TILE];
+  __shared__ unsigned long long tile_best[MI_TILE];
+  const int b = blockIdx.y, a = blockIdx.x * blockDim.x + threadIdx.x;
+  const int g0 = off[b], G = off[b + 1] - g0;
+  const bool live = a < A;
+  const float4 an = live ? anchors[a] : make_float4(0.f, 0.f, 0.f, 0.f);
+  float best = -1.f;
+  int bi = 0;
+  for (int base = 0; base < G; base += MI_TILE) {
+    const int n = min(MI_TILE, G - base);
+    __syncthreads();
+    if ((int)threadIdx.x < n) {
+      tile[threadIdx.x] = gts[g0 + base + threadIdx.x];
+      tile_best[threadIdx.x] = 0ull;
+    }
+    __syncthreads();
+    if (live)
+      for (int k = 0; k < n; ++k) {
+        const float iou = overlap_one(tile[k], an, 0, eps);
+        if (iou > best) { best = iou; bi = base + k; }               // first box on ties (overlaps.max(dim=0))
+        // key: IoU bits (>= 0, so monotonic as an integer) above the complemented anchor index -> max = highest IoU, lowest index
+        const unsigned long long key = ((unsigned long long)__float_as_uint(iou) << 32) | (0xFFFFFFFFu - (unsigned)a);
+        if (key > tile_best[k]) atomicMax(&tile_best[k], key);
+      }
+    __syncthreads();
+    if ((int)threadIdx.x < n && tile_best[threadIdx.x]) atomicMax(&gt_best[g0 + base + threadIdx.x], tile_best[threadIdx.x]);
+  }
+  if (live) {
+    max_ov[(size_t)b * A + a] = G ? best : 0.f;
+    argmax[(size_t)b * A + a] = bi;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    max_iou_pass2_kernel(const float4* __restrict__ anchors, int A, const float4* __restrict__ gts, const int32_t* __restrict__ off,
+                         float eps, const float* __restrict__ max_ov, const int32_t* __restrict__ argmax,
+                         const unsigned long long* __restrict__ gt_best, float pos_thr, float neg_lo, float neg_hi, float min_pos,
+                         int match_low_quality, int assign_all, int32_t* __restrict__ assigned) {
+  __shared__ float4 tile[MI_TILE];
+  __shared__ unsigned long long tile_best[MI_TILE];
+  const int b = blockIdx.y, a = blockIdx.x * blockDim.x + threadIdx.x;
+  const int g0 = off[b], G = off[b + 1] - g0;
+  const bool live = a < A;
+  const float4 an = live ? anchors[a] : make_float4(0.f, 0.f, 0.f, 0.f);
+  int res = G ? -1 : 0;                                               // no box in the image: everything is background
+  if (live && G) {
+    const float mo = max_ov[(size_t)b * A + a];
+    if (mo >= neg_lo && mo < neg_hi) res = 0;
+    if (mo >= pos_thr) res = argmax[(size_t)b * A + a] + 1;
+  }
+  if (match_low_quality)
+    for (int base = 0; base < G; base += MI_TILE) {
+      const int n = min(MI_TILE, G - base);
+      __syncthreads();
+      if ((int)threadIdx.x < n) {
+        tile[threadIdx.x] = gts[g0 + base + threadIdx.x];
+        tile_best[threadIdx.x] = gt_best[g0 + base + threadIdx.x];
+      }
+      __syncthreads();
+      if (live)
+        for (int k = 0; k < n; ++k) {                                 // ascending box index: a later box overrides (the python loop)
+          const unsigned long long kb = tile_best[k];
+          const float gmax = __uint_as_float((unsigned)(kb >> 32));
+          if (!(gmax >= min_pos)) continue;
+          if (assign_all) {
+            if (overlap_one(tile[k], an, 0, eps) == gmax) res = base + k + 1;
+          } else if ((unsigned)a == 0xFFFFFFFFu - (unsigned)(kb & 0xFFFFFFFFull)) {
+            res = base + k + 1;
+          }
+        }
+    }
+  if (live) assigned[(size_t)b * A + a] = res;
+}
+
 // --------------------------------------------------------------- delta2bbox --
 __global__ void delta2bbox_kernel(const float4* __restrict__ rois, const float4* __restrict__ deltas,
                                   const float4* __restrict__ gout, int N, float max_h, float max_w,
@@ -337,5 +423,27 @@ extern "C" int pt_delta2bbox_bwd(const float* rois, const float* deltas, const f
                      reinterpret_cast<const float4*>(grad_out), N, max_h, max_w, fabsf(logf(wh_ratio_clip)),
                      (float4*)nullptr, reinterpret_cast<float4*>(grad_deltas));
   PT_LAUNCH_CHECK("pt_delta2bbox_bwd");
+  return PT_OK;
+}
+
+extern "C" int pt_max_iou_assign(const float* anchors, int A, const float* gt_boxes, const int32_t* off, int B, float pos_iou_thr,
+                                 float neg_iou_lo, float neg_iou_hi, float min_pos_iou, int match_low_quality,
+                                 int gt_max_assign_all, float* max_overlaps, int32_t* argmax_ws, uint64_t* gt_best_ws,
+                                 int32_t* assigned_gt_inds, void* stream) {
+  PT_REQUIRE(anchors && off && max_overlaps && argmax_ws && assigned_gt_inds && A > 0 && B > 0, PT_EINVAL,
+             "pt_max_iou_assign: bad argument");
+  PT_REQUIRE(B <= 65535, PT_ELIMIT, "pt_max_iou_assign: B=%d above 65535", B);
+  PT_REQUIRE((reinterpret_cast<uintptr_t>(anchors) & 15) == 0 && (!gt_boxes || (reinterpret_cast<uintptr_t>(gt_boxes) & 15) == 0),
+             PT_EINVAL, "pt_max_iou_assign: boxes must be 16-byte aligned");
+  const dim3 grid(cdiv(A, 256), B);
+  hipLaunchKernelGGL(max_iou_pass1_kernel, grid, dim3(256), 0, as_stream(stream), reinterpret_cast<const float4*>(anchors), A,
+                     reinterpret_cast<const float4*>(gt_boxes), off, 1e-6f, max_overlaps, argmax_ws,
+                     reinterpret_cast<unsigned long long*>(gt_best_ws));
+  PT_LAUNCH_CHECK("pt_max_iou_assign (pass 1)");
+  hipLaunchKernelGGL(max_iou_pass2_kernel, grid, dim3(256), 0, as_stream(stream), reinterpret_cast<const float4*>(anchors), A,
+                     reinterpret_cast<const float4*>(gt_boxes), off, 1e-6f, max_overlaps, argmax_ws,
+                     reinterpret_cast<const unsigned long long*>(gt_best_ws), pos_iou_thr, neg_iou_lo, neg_iou_hi, min_pos_iou,
+                     match_low_quality, gt_max_assign_all, assigned_gt_inds);
+  PT_LAUNCH_CHECK("pt_max_iou_assign (pass 2)");
   return PT_OK;
 }

@@ -139,6 +139,22 @@ def fcos_dense_targets(points, regress_ranges, sample_radius, target_norm, boxes
     return labels, tg, ctr
 
 
+def max_iou_assign(anchors, gt_boxes, off, B, pos_iou_thr, neg_iou_thr, min_pos_iou=0.0, match_low_quality=True,
+                   gt_max_assign_all=True):
+    """pt_max_iou_assign -> (assigned_gt_inds int32 [B, A] (-1 ignore, 0 background, i+1 = box i of the image), max_overlaps [B, A])."""
+    A = anchors.shape[0]
+    dev = anchors.device
+    lo, hi = (0.0, float(neg_iou_thr)) if isinstance(neg_iou_thr, float) else (float(neg_iou_thr[0]), float(neg_iou_thr[1]))
+    mo = torch.empty((B, A), dtype=f32, device=dev)
+    am = torch.empty((B, A), dtype=i32, device=dev)
+    out = torch.empty((B, A), dtype=i32, device=dev)
+    nb = gt_boxes.shape[0]
+    best = torch.zeros((max(nb, 1),), dtype=torch.int64, device=dev)
+    hip.call('pt_max_iou_assign', _f(anchors), A, _f(gt_boxes) if nb else None, off, B, float(pos_iou_thr), lo, hi,
+             float(min_pos_iou), int(bool(match_low_quality)), int(bool(gt_max_assign_all)), mo, am, best, out)
+    return out, mo
+
+
 def fuse_assign_obb(points, dec, cls, gt_xy, gt_labels, off, B, num_pre=5, topk=3, cls_w=1.0, reg_w=1.0, loc_w=1.0):
     """pt_fuse_assign_obb.  dec [B*P,5] decoded (cx,cy,w,h,a), cls [B*P,C] logits."""
     P = points.shape[0]
