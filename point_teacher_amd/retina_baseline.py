@@ -91,8 +91,9 @@ class AnchorGenerator:
                 sx = torch.arange(0, fw, device=device) * stride[0]
                 sy = torch.arange(0, fh, device=device) * stride[1]
                 xx, yy = sx.repeat(len(sy)), sy.view(-1, 1).repeat(1, len(sx)).view(-1)
-                shifts = torch.stack([xx, yy, xx, yy], dim=-1).type_as(base)
-                out.append((base.to(device)[None, :, :] + shifts[:, None, :]).view(-1, 4))
+                base = base.to(device)
+                shifts = torch.stack([xx, yy, xx, yy], dim=-1).to(base.dtype)
+                out.append((base[None, :, :] + shifts[:, None, :]).view(-1, 4))
             self._cache[key] = out
         return self._cache[key]
 

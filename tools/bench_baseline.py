@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Iterations/s of the supervised FCOS baseline (configs/baselines/aitodv2_fcos_r50_1x.py, row N4) on one MI355X: the same
-synthetic 800x800 tiles, batch 2, fp32, flat-parameter Trainer as bench.py uses for the Point-Teacher iteration."""
+"""Iterations/s of the supervised baselines of row N4 on one MI355X - `--model fcos` (configs/baselines/aitodv2_fcos_r50_1x.py)
+or `--model retinanet` (aitodv2_retinanet_r50_1x.py): the same synthetic 800x800 tiles, batch 2, fp32 and flat-parameter
+Trainer as bench.py uses for the Point-Teacher iteration."""
 import json
 import os
 import sys
@@ -12,16 +13,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main(steps=20, warmup=5, batch=2):
+def main(model_name='fcos', steps=20, warmup=5, batch=2):
     import point_teacher_amd as pta
     from point_teacher_amd.synthetic import SyntheticTiles
     dev = torch.device('cuda:0')
     torch.backends.cudnn.benchmark = True
     torch.manual_seed(1234)
-    cfg = pta.Config.fromfile(os.path.join(ROOT, 'point_teacher_amd', 'configs', 'baselines', 'aitodv2_fcos_r50_1x.py'))
+    cfg = pta.Config.fromfile(os.path.join(ROOT, 'point_teacher_amd', 'configs', 'baselines', f'aitodv2_{model_name}_r50_1x.py'))
     model = pta.build_detector(cfg.model).to(dev)
     with torch.no_grad():
-        model.backbone.conv1.weight.mul_(1.0 / 64.0)
+        model.backbone.conv1.weight.mul_(1.0 / 64.0)       # raw 0-255 tiles into a random stem (synthetic.benchmark_init_)
     model.train()
     trainer = pta.Trainer(model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config, iters_per_epoch=5000, channels_last=True)
     data = SyntheticTiles(n=8, size=800, mean_objects=300, seed=7, device=dev)
@@ -34,9 +35,9 @@ def main(steps=20, warmup=5, batch=2):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     lv = out['log_vars'].materialize()
-    print(json.dumps(dict(metric='train iters/sec (supervised FCOS baseline, 800x800, ~300 boxes/img)', value=round(steps / dt, 3),
+    print(json.dumps(dict(metric=f'train iters/sec (supervised {model_name} baseline, 800x800, ~300 boxes/img)', value=round(steps / dt, 3),
                           ms_per_step=round(dt / steps * 1e3, 2), batch=batch, dtype='f32', data='synthetic', loss=round(lv['loss'], 4))))
 
 
 if __name__ == '__main__':
-    main()
+    main(sys.argv[sys.argv.index('--model') + 1] if '--model' in sys.argv else 'fcos')

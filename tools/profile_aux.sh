@@ -1,7 +1,8 @@
 # usage (GPU box, repo root): bash tools/profile_aux.sh   -> rocprofv3 per-kernel stats of the N2 image preparation
-# (tools/prep_bench.py) and of the supervised FCOS baseline iteration (tools/bench_fcos_baseline.py)
+# (tools/prep_bench.py); whole-run statistics include MIOpen's find pass, so the training benches are profiled with
+# tools/profile_step.sh (steady-state window) instead
 export TMPDIR=/tmp
-for job in prep_bench bench_fcos_baseline; do
+for job in prep_bench; do
   out=gpurun_out/prof_$job
   rm -rf $out && mkdir -p $out
   rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python tools/$job.py > $out/run.json 2> $out/run.err || { tail -5 $out/run.err; exit 1; }
