@@ -169,3 +169,36 @@ def test_retinanet_trains_and_infers():
     with torch.no_grad():
         res = model(return_loss=False, rescale=True, img=[data['img']], img_metas=[metas])
     assert len(res) == 2 and len(res[0]) == 8 and all(r.shape[1] == 5 for r in res[0])
+
+
+@pytest.mark.gpu
+def test_max_iou_assign_full_size():
+    """BASELINE size: 120 087 anchors (800x800, five levels, nine per location) x 600 boxes per image, two images - against
+    the reference algorithm written with torch ops on the device (the explicit [G, A] matrix the kernel never stores)."""
+    from point_teacher_amd import functional as PF
+    from point_teacher_amd.retina_baseline import AnchorGenerator
+    from point_teacher_amd.synthetic import make_tile
+    dev = torch.device('cuda:0')
+    gen = AnchorGenerator(octave_base_scale=4, scales_per_octave=3, ratios=[0.5, 1.0, 2.0], strides=[8, 16, 32, 64, 128])
+    anchors = torch.cat(gen.grid_anchors([(100, 100), (50, 50), (25, 25), (13, 13), (7, 7)], dev))
+    assert anchors.shape[0] == 120087
+    boxes = [make_tile(i, 800, 8, 600, seed=9, device=dev, max_objects=600)[1] for i in range(2)]
+    off, _ = PF.make_offsets([int(b.shape[0]) for b in boxes], dev)
+    inds, mo = PF.max_iou_assign(anchors, torch.cat(boxes), off, 2, 0.5, 0.4, 0.0, True, True)
+    for b in range(2):
+        g = boxes[b]
+        a1 = (g[:, 2] - g[:, 0]) * (g[:, 3] - g[:, 1])
+        a2 = (anchors[:, 2] - anchors[:, 0]) * (anchors[:, 3] - anchors[:, 1])
+        wh = (torch.min(g[:, None, 2:], anchors[None, :, 2:]) - torch.max(g[:, None, :2], anchors[None, :, :2])).clamp(min=0)
+        ov = wh[..., 0] * wh[..., 1]
+        ov = ov / torch.max(a1[:, None] + a2[None, :] - ov, ov.new_tensor([1e-6]))
+        m, am = ov.max(0)
+        gm = ov.max(1)[0]
+        want = torch.full((anchors.shape[0],), -1, dtype=torch.long, device=dev)
+        want[(m >= 0) & (m < 0.4)] = 0
+        want[m >= 0.5] = am[m >= 0.5] + 1
+        for i in range(g.shape[0]):
+            want[ov[i] == gm[i]] = i + 1
+        assert torch.equal(mo[b], m)
+        assert torch.equal(inds[b].long(), want)
+        assert int((inds[b] > 0).sum()) >= g.shape[0] * 0.5
