@@ -551,3 +551,62 @@ def test_image_prep_full_size_properties():
     assert bool((const[:, :h, :w] == 77).all())
     # bilinear interpolation preserves the mean up to rounding
     assert abs(float(base[:, :h, :w].mean()) - float(bgr.mean())) < 0.5
+
+
+@pytest.mark.gpu
+def test_sodaa_folder_feeds_the_oriented_config(tmp_path):
+    """Config 5 end to end on a generated SODA-A style folder (JPEG patches + one json per patch): SODAADOTADataset ->
+    the config's own train pipeline at a reduced scale (RResize, RRandomFlip, Normalize, Pad) -> device loader -> one
+    RotatedFCOS_TS iteration; then the test pipeline (DefaultFormatBundle inside MultiScaleFlipAug) -> teacher inference ->
+    the dataset's DOTA-style evaluation."""
+    from PIL import Image
+    import test_obb_parity as TO
+    dev = torch.device('cuda:0')
+    r = np.random.RandomState(21)
+    ann_dir, img_dir = os.path.join(str(tmp_path), 'ann'), os.path.join(str(tmp_path), 'img')
+    os.makedirs(ann_dir), os.makedirs(img_dir)
+    for k in range(4):
+        name = f'{k:05d}__800__{k * 600}___0'
+        Image.fromarray(r.randint(0, 256, (160, 160, 3)).astype(np.uint8)).save(os.path.join(img_dir, name + '.jpg'), quality=95)
+        anns = []
+        for _ in range(7):
+            cx, cy, w, h, a = r.uniform(30, 130), r.uniform(30, 130), r.uniform(8, 30), r.uniform(4, 12), r.uniform(-1.4, 1.4)
+            c, s = np.cos(a), np.sin(a)
+            pts = np.array([[-w / 2, -h / 2], [w / 2, -h / 2], [w / 2, h / 2], [-w / 2, h / 2]]) @ np.array([[c, s], [-s, c]]) + [cx, cy]
+            anns.append(dict(poly=[float(v) for v in pts.reshape(-1)], cat_id=int(r.randint(0, 9)), trunc=0))
+        json.dump(dict(annotations=anns), open(os.path.join(ann_dir, name + '.json'), 'w'))
+    cfg = pta.Config.fromfile(os.path.join(ROOT, 'point_teacher_amd', 'configs', 'obb', 'point_teacher', 'sodaa_fcos_pointteacher_1x.py'))
+    tp = [dict(t) for t in cfg.data.train['pipeline']]
+    for t in tp:
+        if t['type'] == 'RResize':
+            t['img_scale'] = (240, 240)                                    # the config's 1200 at test size
+    ds = D.build_dataset(dict(type=cfg.data.train['type'], ann_file=ann_dir, img_prefix=img_dir, pipeline=tp))
+    assert type(ds).__name__ == 'SODAADOTADataset' and len(ds) == 4 and ds[0]['gt_bboxes'].data.shape[1] == 5
+    loader = D.build_dataloader(ds, samples_per_gpu=2, workers_per_gpu=2, dist=False, shuffle=True, device=dev)
+    batch = next(iter(loader))
+    assert batch['img'].shape == (2, 3, 256, 256) and batch['gt_bboxes'][0].shape[1] == 5 and 'filename' in batch['img_metas'][0]
+    sf = batch['img_metas'][0]['scale_factor']
+    np.testing.assert_allclose(sf, [1.5, 1.5, 1.5, 1.5])
+    # the rendered pixels = the oracle's pipeline on the decoded JPEG
+    from PIL import Image as _I
+    m0 = batch['img_metas'][0]
+    bgr = np.asarray(_I.open(m0['filename']).convert('RGB'))[:, :, ::-1].copy()
+    want, _ = R.prepare_image(bgr, scale=(240, 240), keep_ratio=True, flip=None,
+                              norm=dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True), size_divisor=32)
+    np.testing.assert_array_equal(batch['img'][0].cpu().numpy(), want)
+    _, mcfg, model = TO._build(dev, phase2=False)
+    trainer = pta.Trainer(model, mcfg.optimizer, mcfg.optimizer_config, mcfg.lr_config)
+    lv = trainer.step(batch)['log_vars'].materialize()
+    assert all(v == v and abs(v) != float('inf') for v in lv.values()), lv
+    vp = [dict(t) for t in cfg.data.test['pipeline']]
+    vp[1] = dict(vp[1], img_scale=(240, 240))
+    dv = D.build_dataset(dict(type=cfg.data.test['type'], ann_file=ann_dir, img_prefix=img_dir, pipeline=vp, test_mode=True))
+    vl = D.build_dataloader(dv, samples_per_gpu=1, workers_per_gpu=1, dist=False, shuffle=False, device=dev)
+    model.eval()
+    results = []
+    with torch.no_grad():
+        for b in vl:
+            results.extend(model(return_loss=False, rescale=True, img=b['img'], img_metas=b['img_metas']))
+    assert len(results) == 4 and len(results[0]) == 9 and all(r.shape[1] == 6 for r in results[0])
+    ev = dv.evaluate(results, device=dev)
+    assert set(ev) == {'mAP'} and 0.0 <= ev['mAP'] <= 1.0
