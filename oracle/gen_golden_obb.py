@@ -347,6 +347,92 @@ def gen_sodaa_eval():
     G.save('obb_sodaa_eval', n_img=np.int64(n_img), num_classes=np.int64(K), **out)
 
 
+def gen_aitod_eval_cocofork():
+    """Pins the AI-TOD evaluator configuration of row N1 (5 AI-TOD area ranges, maxDets 100/300/1500, IoU 0.50:0.95) through the
+    COCOeval fork that IS vendored in the reference: datasets/sodaa_eval/sodaa_eval.py run with those parameters on
+    axis-aligned boxes written as (cx, cy, w, h, 0) - the IoU of two oriented boxes with angle 0 is the axis-aligned IoU
+    (the stand-in for mmcv's op computes exactly that, in float32).  The scene keeps the fork's id-0 quirk silent (annotation
+    0 is a far-away box no detection touches, detection 0 is a false positive), so its arrays are what pycocotools' COCOeval
+    (the algorithm `aitodpycocotools` forks, absent here) gives for non-crowd data.  Coordinates are multiples of 1/4 so that
+    the (cx, cy, w, h) <-> (x1, y1, x2, y2) conversion is exact in float32."""
+    L.install_obb()
+    import importlib
+    import types
+    if not hasattr(np, 'float'):
+        np.float = float
+
+    def hbb_iou(a, b):
+        a, b = a.numpy().astype(np.float32), b.numpy().astype(np.float32)
+        ax1, ay1, ax2, ay2 = a[:, 0] - a[:, 2] / 2, a[:, 1] - a[:, 3] / 2, a[:, 0] + a[:, 2] / 2, a[:, 1] + a[:, 3] / 2
+        bx1, by1, bx2, by2 = b[:, 0] - b[:, 2] / 2, b[:, 1] - b[:, 3] / 2, b[:, 0] + b[:, 2] / 2, b[:, 1] + b[:, 3] / 2
+        w = np.minimum(ax2[:, None], bx2[None]) - np.maximum(ax1[:, None], bx1[None])
+        h = np.minimum(ay2[:, None], by2[None]) - np.maximum(ay1[:, None], by1[None])
+        inter = np.where((w <= 0) | (h <= 0), np.float32(0), w * h).astype(np.float32)
+        ua = ((ax2 - ax1) * (ay2 - ay1))[:, None] + ((bx2 - bx1) * (by2 - by1))[None] - inter
+        return torch.from_numpy(np.where(inter > 0, inter / ua, np.float32(0)).astype(np.float32))
+    sys.modules['mmcv.ops'].box_iou_rotated = hbb_iou
+    if 'mmrotate.datasets' not in sys.modules:
+        L._pkg('mmrotate.datasets', os.path.join(L.OBB, 'mmrotate', 'datasets'))
+    pkg = types.ModuleType('mmrotate.datasets.sodaa_eval')
+    pkg.__path__ = [os.path.join(L.OBB, 'mmrotate', 'datasets', 'sodaa_eval')]
+    sys.modules['mmrotate.datasets.sodaa_eval'] = pkg
+    sys.modules.pop('mmrotate.datasets.sodaa_eval.sodaa_eval', None)
+    se = importlib.import_module('mmrotate.datasets.sodaa_eval.sodaa_eval')
+    rng = np.random.RandomState(23)
+    K, n_img = 3, 5
+    q = lambda v: np.round(np.asarray(v) * 4) / 4                           # noqa: E731
+    anns, dets = [], []
+    for i in range(n_img):
+        NG = rng.randint(8, 30)
+        c = q(rng.rand(NG, 2) * 600 + 60)
+        wh = np.round(np.exp(rng.uniform(np.log(3.0), np.log(60.0), (NG, 2))))          # verytiny .. medium
+        lab = rng.randint(0, K, NG)
+        if i == 0:
+            c[0], wh[0], lab[0] = [5000.0, 5000.0], [10.0, 10.0], 0                      # annotation id 0: out of reach
+        gb = np.concatenate([c, wh, np.zeros((NG, 1))], 1).astype(np.float32)
+        anns.append(dict(bboxes=gb, labels=lab.astype(np.int64)))
+        per = []
+        for k in range(K):
+            g = gb[lab == k]
+            g = g[g[:, 0] < 4000]
+            keep = rng.rand(len(g)) < 0.85
+            d = g[keep].copy()
+            d[:, :2] += q(rng.randn(len(d), 2) * 1.0)
+            d[:, 2:4] = np.maximum(d[:, 2:4] + np.round(rng.randn(len(d), 2) * 0.8), 1)
+            nf = 170 if (i == 1 and k == 0) else rng.randint(0, 6)                      # > 100 detections in one segment
+            f = np.concatenate([q(rng.rand(nf, 2) * 600 + 60), np.round(np.exp(rng.uniform(np.log(3.0), np.log(60.0), (nf, 2)))),
+                                np.zeros((nf, 1))], 1)
+            d = np.concatenate([d, d[: len(d) // 2] + np.array([0.5, 0.25, 0, 0, 0]), f], 0).astype(np.float32)
+            if i == 0 and k == 0:
+                d = np.concatenate([np.array([[3000.0, 3000.0, 9.0, 9.0, 0.0]], np.float32), d], 0)   # detection id 0: a false positive
+            per.append(d)
+        dets.append(per)
+    n_tot = sum(len(d) for per in dets for d in per)
+    sc = (rng.permutation(n_tot).astype(np.float32) + 1) / np.float32(n_tot + 1)        # distinct scores
+    o = 0
+    for per in dets:
+        for k in range(K):
+            n = len(per[k])
+            per[k] = np.concatenate([per[k], sc[o:o + n, None]], 1).astype(np.float32)
+            o += n
+    ev = se.SODAAeval(anns, dets, numCats=K, nproc=0)
+    ev.params.areaRng = [[0 ** 2, 1e5 ** 2], [0 ** 2, 8 ** 2], [8 ** 2, 16 ** 2], [16 ** 2, 32 ** 2], [32 ** 2, 1e5 ** 2]]
+    ev.params.areaRngLbl = ['all', 'verytiny', 'tiny', 'small', 'medium']
+    ev.params.maxDets = [100, 300, 1500]
+    ev.evaluate()
+    ev.accumulate()
+    out = dict(out_precision=ev.eval['precision'], out_recall=ev.eval['recall'])
+    for i in range(n_img):
+        b = anns[i]['bboxes']
+        out[f'in_gt{i}_xyxy'] = np.stack([b[:, 0] - b[:, 2] / 2, b[:, 1] - b[:, 3] / 2, b[:, 0] + b[:, 2] / 2, b[:, 1] + b[:, 3] / 2], 1)
+        out[f'in_gt{i}_labels'] = anns[i]['labels']
+        for k in range(K):
+            d = dets[i][k]
+            out[f'in_det{i}_{k}'] = np.concatenate([np.stack([d[:, 0] - d[:, 2] / 2, d[:, 1] - d[:, 3] / 2, d[:, 0] + d[:, 2] / 2,
+                                                               d[:, 1] + d[:, 3] / 2], 1), d[:, 5:6]], 1).astype(np.float32)
+    G.save('aitod_eval_cocofork', n_img=np.int64(n_img), num_classes=np.int64(K), **out)
+
+
 if __name__ == '__main__':
     L.install_obb()
     torch.manual_seed(0); np.random.seed(0); random.seed(0)

@@ -2,7 +2,10 @@
 
 The reference evaluates through `aitodpycocotools.cocoeval.COCOeval`
 (/root/reference/HBB_TOD/mmdet/datasets/aitod.py:10, :100-135), an un-vendored fork of pycocotools that is
-not installed here (neither is pycocotools): PARITY UNPINNED.  This file restates the published COCOeval
+not installed here (neither is pycocotools).  PINNED for non-crowd data through the COCOeval fork that IS vendored in the
+reference (OBB_TOD/mmrotate/datasets/sodaa_eval/sodaa_eval.py): run with the AI-TOD parameters on axis-aligned boxes at
+angle 0 it produced tests/golden/aitod_eval_cocofork.npz (oracle/gen_golden_obb.py gen_aitod_eval_cocofork), which
+`evaluate` below reproduces to 1e-12; the crowd / ignore handling and the fork's oLRP extras stay PARITY UNPINNED.  This file restates the published COCOeval
 algorithm for boxes (pycocotools/cocoeval.py: evaluateImg, accumulate, summarize) with the AI-TOD
 parameterisation the reference's metric table names (aitod.py:117-135):
 

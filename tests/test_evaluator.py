@@ -322,3 +322,37 @@ def test_sodaa_dataset_evaluate_merges_patches(tmp_path):
     assert ev['mAP_AP'] == 1.0 and ev['mAP_AP_50'] == 1.0 and ev['mAP_AP_eS'] == 1.0 and ev['mAP_mAP_copypaste'].startswith('1.000 1.000')
     ref = ds.evaluate(results, device='cuda:0')                          # reference numbering: annotation 0 can never be a TP
     assert ref['mAP_AP'] < 1.0
+
+
+# ------------------------------------------------------------------------------------------------
+# AI-TOD configuration pinned through the COCOeval fork that IS vendored in the reference (sodaa_eval.py at angle 0)
+# ------------------------------------------------------------------------------------------------
+def _cocofork_golden():
+    from conftest import load_golden
+    g = load_golden('aitod_eval_cocofork')
+    n, K = int(g['n_img']), int(g['num_classes'])
+    gts = [dict(bboxes=g[f'in_gt{i}_xyxy'], labels=g[f'in_gt{i}_labels']) for i in range(n)]
+    res = [[g[f'in_det{i}_{k}'] for k in range(K)] for i in range(n)]
+    return g, gts, res, K
+
+
+def test_oracle_cocoeval_vs_vendored_fork_golden():
+    """oracle/ref_cocoeval.py (AI-TOD areas, maxDets 100/300/1500, IoU .50:.95) == the arrays the reference's own COCOeval
+    fork produced with those parameters (oracle/gen_golden_obb.py gen_aitod_eval_cocofork): evaluateImg + accumulate of row
+    N1 are pinned for non-crowd data; what stays unpinned is the fork's crowd handling and its oLRP extras."""
+    g, gts, res, K = _cocofork_golden()
+    _, pr, rc = RC.evaluate(res, gts, K)
+    assert pr.shape == g['out_precision'].shape == (10, 101, K, 5, 3)
+    np.testing.assert_allclose(pr, g['out_precision'], atol=1e-12)
+    np.testing.assert_allclose(rc, g['out_recall'], atol=1e-12)
+    assert (g['out_precision'][:, :, :, 1:, :] > -1).any(axis=(0, 1, 2, 4)).all()      # every AI-TOD area range is populated
+    assert np.abs(g['out_recall'][:, 0, 0, 0] - g['out_recall'][:, 0, 0, 2]).max() > 0     # maxDets 100 vs 1500 differ
+
+
+@pytest.mark.gpu
+def test_gpu_aitod_evaluator_vs_vendored_fork_golden():
+    from point_teacher_amd.evaluation import AITODEvaluator
+    g, gts, res, K = _cocofork_golden()
+    out = AITODEvaluator(gts, K, device='cuda:0').evaluate(res)
+    np.testing.assert_allclose(out['precision'].cpu().numpy(), g['out_precision'], atol=1e-9)
+    np.testing.assert_allclose(out['recall'].cpu().numpy(), g['out_recall'], atol=1e-9)
