@@ -272,13 +272,23 @@ class DeviceLoader:
         return batch
 
     def __iter__(self):
-        pending = []                              # batches being decoded by the threads, oldest first
+        pending, ready = [], []                   # batches being decoded by the threads / batches already rendered, oldest first
         for idx in self._index_batches():
             pending.append([self._pool.submit(self.dataset.__getitem__, i) for i in idx])
             if len(pending) > self.prefetch:
-                yield self._hand_over(*self._finish(pending.pop(0)))
+                ready.append(self._finish(pending.pop(0)))
+            # render one batch ahead: while the consumer trains on batch k, batch k+1 is already uploaded and prepared on the
+            # loader's stream (only when its decode is finished - otherwise hand batch k over first)
+            if pending and not ready and all(f.done() for f in pending[0]):
+                ready.append(self._finish(pending.pop(0)))
+            while len(ready) > 1:
+                yield self._hand_over(*ready.pop(0))
         while pending:
-            yield self._hand_over(*self._finish(pending.pop(0)))
+            ready.append(self._finish(pending.pop(0)))
+            while len(ready) > 1:
+                yield self._hand_over(*ready.pop(0))
+        while ready:
+            yield self._hand_over(*ready.pop(0))
 
 
 def build_dataloader(dataset, samples_per_gpu, workers_per_gpu, num_gpus=1, dist=True, shuffle=True, seed=None, device=None,
