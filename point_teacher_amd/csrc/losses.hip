@@ -213,6 +213,15 @@ __global__ void overlaps_pairwise_kernel(const float4* __restrict__ a, const flo
 // instruction sequence -> same bits) for the "every anchor that ties a box's maximum" rule.  Boxes go through LDS in tiles.
 constexpr int MI_TILE = 256;
 
+// overlap_one(g, a, iou) with the division skipped for disjoint boxes: 0 / union is exactly 0, so the value is the same
+__device__ __forceinline__ float iou_or_zero(const float4 g, const float4 a, float eps) {
+  const float w = fminf(g.z, a.z) - fmaxf(g.x, a.x), h = fminf(g.w, a.w) - fmaxf(g.y, a.y);
+  if (!(w > 0.f && h > 0.f)) return 0.f;
+  const float ov = w * h;
+  const float uni = fmaxf((g.z - g.x) * (g.w - g.y) + (a.z - a.x) * (a.w - a.y) - ov, eps);
+  return ov / uni;
+}
+
 __global__ void __launch_bounds__(256)
     max_iou_pass1_kernel(const float4* __restrict__ anchors, int A, const float4* __restrict__ gts, const int32_t* __restrict__ off,
                          float eps, float* __restrict__ max_ov, int32_t* __restrict__ argmax,
@@ -235,11 +244,14 @@ __global__ void __launch_bounds__(256)
     __syncthreads();
     if (live)
       for (int k = 0; k < n; ++k) {
-        const float iou = overlap_one(tile[k], an, 0, eps);
+        const float iou = iou_or_zero(tile[k], an, eps);
         if (iou > best) { best = iou; bi = base + k; }               // first box on ties (overlaps.max(dim=0))
-        // key: IoU bits (>= 0, so monotonic as an integer) above the complemented anchor index -> max = highest IoU, lowest index
-        const unsigned long long key = ((unsigned long long)__float_as_uint(iou) << 32) | (0xFFFFFFFFu - (unsigned)a);
-        if (key > tile_best[k]) atomicMax(&tile_best[k], key);
+        if (iou > 0.f) {                                             // disjoint pairs (almost all) never touch the per-box maximum:
+          // key: IoU bits (> 0, monotonic as an integer) above the complemented anchor index -> max = highest IoU, lowest index.
+          // A box no anchor overlaps keeps key 0 = "maximum 0 at anchor 0", which is what overlaps.max(dim=1) returns for it.
+          const unsigned long long key = ((unsigned long long)__float_as_uint(iou) << 32) | (0xFFFFFFFFu - (unsigned)a);
+          if (key > tile_best[k]) atomicMax(&tile_best[k], key);
+        }
       }
     __syncthreads();
     if ((int)threadIdx.x < n && tile_best[threadIdx.x]) atomicMax(&gt_best[g0 + base + threadIdx.x], tile_best[threadIdx.x]);
@@ -282,8 +294,8 @@ __global__ void __launch_bounds__(256)
           const float gmax = __uint_as_float((unsigned)(kb >> 32));
           if (!(gmax >= min_pos)) continue;
           if (assign_all) {
-            if (overlap_one(tile[k], an, 0, eps) == gmax) res = base + k + 1;
-          } else if ((unsigned)a == 0xFFFFFFFFu - (unsigned)(kb & 0xFFFFFFFFull)) {
+            if (iou_or_zero(tile[k], an, eps) == gmax) res = base + k + 1;
+          } else if ((unsigned)a == (kb ? 0xFFFFFFFFu - (unsigned)(kb & 0xFFFFFFFFull) : 0u)) {
             res = base + k + 1;
           }
         }
