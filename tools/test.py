@@ -51,11 +51,8 @@ def main():
         loader = build_dataloader(dataset, 1, cfg.data.workers_per_gpu, dist=False, shuffle=False, device=dev)
         it = iter(loader)
         results = single_gpu_test(model, lambda _: next(it), len(loader))
-        if oriented and hasattr(dataset, 'evaluate_map'):
-            print(dataset.evaluate_map(results, iou_thr=args.iou_thr))
-        else:
-            out = dataset.evaluate(results)
-            print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in out.items()})
+        out = dataset.evaluate(results)              # the dataset's own protocol: AI-TOD COCO-style / SODA-A / DOTA-style mAP
+        print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in out.items()})
         return
     data = SyntheticTiles(n=args.synthetic, size=1200 if oriented else 800, mean_objects=args.objects, seed=1, device=dev,
                           oriented=oriented, num_classes=K)
