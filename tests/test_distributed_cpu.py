@@ -69,6 +69,40 @@ def _worker(rank, world, port, q):
                 torch.testing.assert_close(flat.grad_flat[off:off + n], expect_named[o:o + n], rtol=1e-5, atol=1e-6)
                 o += n
             assert flat.check_views()
+        # a detector without a teacher (the supervised baselines of row N4): same flat layout, same exchange
+        torch.manual_seed(9)
+        solo = torch.nn.Sequential(torch.nn.Linear(11, 20), torch.nn.ReLU(), torch.nn.Linear(20, 4))
+        sflat = FlatParams(solo)
+        assert not sflat.has_teacher and sflat.teacher_flat is None and not hasattr(solo, '_flat')
+        sex = BucketedGradExchange(sflat, n_buckets=2, device=None)
+        torch.manual_seed(300 + rank)
+        xs = torch.randn(8, 11)
+        sflat.zero_grad(); sflat.detach_grads()
+        sex.begin()
+        solo(xs).pow(2).mean().backward()
+        sex.finish()
+        gsum = sflat.grad_flat.clone()
+        dist.all_reduce(gsum)                                    # every rank already holds the mean: the sum is world x it
+        torch.testing.assert_close(gsum, sflat.grad_flat * world, rtol=1e-5, atol=1e-7)
+        assert float(sflat.grad_flat.abs().sum()) > 0
+        # data side: under an initialised group build_dataloader picks the distributed samplers with this rank, the ranks
+        # split every epoch between them and agree on the permutation (samplers/group_sampler.py:106-140)
+        import types
+        import numpy as np
+        from point_teacher_amd.datasets import DistributedGroupSampler, DistributedSampler, build_dataloader
+        ds = types.SimpleNamespace(flag=(np.arange(21) % 3 == 0).astype(np.uint8), pipeline=None, __len__=lambda: 21)
+        ds = type('DS', (), dict(flag=ds.flag, __len__=lambda self: 21, __getitem__=lambda self, i: i))()
+        ld = build_dataloader(ds, samples_per_gpu=2, workers_per_gpu=1, dist=True, shuffle=True, seed=5, device='cpu')
+        assert isinstance(ld.sampler, DistributedGroupSampler) and ld.sampler.rank == rank and ld.sampler.num_replicas == world
+        ld.set_epoch(4)
+        mine_idx = torch.tensor(list(iter(ld.sampler)))
+        both = [torch.empty_like(mine_idx) for _ in range(world)]
+        dist.all_gather(both, mine_idx)
+        assert set(torch.cat(both).tolist()) == set(range(21)) and len(mine_idx) == len(ld.sampler) == 12
+        for pair_ in torch.cat(both).view(-1, 2).tolist():          # a batch never mixes aspect-ratio groups
+            assert ds.flag[pair_[0]] == ds.flag[pair_[1]]
+        lt = build_dataloader(ds, samples_per_gpu=1, workers_per_gpu=1, dist=True, shuffle=False, device='cpu')
+        assert isinstance(lt.sampler, DistributedSampler) and list(iter(lt.sampler)) == [i % 21 for i in range(rank, 22, world)]
         # normalisers: every rank sees the mean of the per-rank counts
         npos = reduce_mean(torch.tensor(float(10 + 4 * rank)))
         assert float(npos) == pytest.approx(sum(10 + 4 * r for r in range(world)) / world)
