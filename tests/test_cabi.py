@@ -42,3 +42,7 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
                 assert 'ref_ops' not in src, f
+    for f in os.listdir(os.path.join(ROOT, 'tools')):            # tools are product-side too: only tests, smoke() and bench's cpu_baseline may
+        if f.endswith('.py'):
+            src = open(os.path.join(ROOT, 'tools', f)).read()
+            assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
