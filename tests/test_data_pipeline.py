@@ -610,3 +610,43 @@ def test_sodaa_folder_feeds_the_oriented_config(tmp_path):
     assert len(results) == 4 and len(results[0]) == 9 and all(r.shape[1] == 6 for r in results[0])
     ev = dv.evaluate(results, device=dev)
     assert set(ev) == {'mAP'} and 0.0 <= ev['mAP'] <= 1.0
+
+
+def test_host_side_helpers():
+    """CPU-only pieces of the loader: the HBM cache bookkeeping (with CPU tensors standing in), the epoch adapter and the
+    lazy image's shape / dtype answers along the pipeline."""
+    cache = D.DeviceImageCache(max_bytes=100)
+    a, b = torch.zeros(60, dtype=torch.uint8), torch.zeros(60, dtype=torch.uint8)
+    assert cache.get('a') is None and cache.misses == 1
+    assert cache.put('a', a) and not cache.put('a', a) and not cache.put('b', b)         # duplicate key / over budget
+    assert cache.get('a') is a and cache.hits == 1 and len(cache) == 1 and cache.bytes == 60
+
+    class FakeLoader:
+        def __init__(self):
+            self.epochs = []
+
+        def set_epoch(self, e):
+            self.epochs.append(e)
+
+        def __iter__(self):
+            return iter([f'e{self.epochs[-1]}b0', f'e{self.epochs[-1]}b1'])
+    fl = FakeLoader()
+    nxt = D.EpochBatches(fl, start_epoch=3)
+    assert [nxt(i, 2) for i in range(5)] == ['e3b0', 'e3b1', 'e4b0', 'e4b1', 'e5b0'] and fl.epochs == [3, 4, 5]
+
+    im = D.LazyImage(np.zeros((30, 50, 3), np.uint8))
+    assert im.shape == (30, 50, 3) and im.dtype == np.uint8
+    im.resize((75, 45))
+    assert im.shape == (45, 75, 3)
+    im.flip_('horizontal')
+    im.normalize([1, 2, 3], [4, 5, 6], True)
+    assert im.dtype == np.float32 and im.shape == (45, 75, 3)
+    im.pad_to(64, 96, dict(img=7))
+    assert im.shape == (64, 96, 3) and im.pad == (64, 96, 7.0)
+    c = im.copy()
+    c.flip = 0
+    assert im.flip == 1 and c.src is im.src                                  # augmentations share the pixels, not the state
+    with pytest.raises(TypeError):
+        D.LazyImage(np.zeros((4, 4), np.uint8))
+    with pytest.raises(TypeError):
+        D.LazyImage(torch.zeros(4, 4, 3, dtype=torch.uint8))                 # a cached image must live on the GPU
