@@ -97,5 +97,53 @@ def main():
     G.save('fcos_baseline', **out)
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and len(sys.argv) == 1:
     main()
+
+
+def gen_eval_decode():
+    """fcos_head_p2b_ts.py get_bboxes / _get_bboxes (:797-1005) with `with_nms=False` (NMS is an mmcv op): per-level top
+    `nms_pre` by score x centerness, distance2bbox with clipping to the image, rescale by 1/scale_factor, the background
+    score column -> tests/golden/eval_decode.npz.  The decode half of the Point-Teacher eval path (row a21)."""
+    L.install()
+    import importlib
+    import types
+    hd = L.ref('models.dense_heads.fcos_head_p2b_ts')
+    md = os.path.join(L.HBB, 'mmdet')
+    if 'mmdet.core.export' not in sys.modules:
+        ex = L._pkg('mmdet.core.export')
+        ex.get_k_for_topk = lambda k, size: int(k) if 0 < int(k) < size else -1      # core/export/onnx_helper.py outside ONNX export
+        ex.add_dummy_nms_for_onnx = None
+    h = object.__new__(hd.TS_P2BFCOSHead)
+    torch.nn.Module.__init__(h)
+    h.num_classes = h.cls_out_channels = 8
+    h.strides = [8, 16, 32]
+    for n in ['get_bboxes']:
+        f = getattr(hd.TS_P2BFCOSHead, n)
+        if hasattr(f, '__wrapped__'):
+            setattr(hd.TS_P2BFCOSHead, n, f.__wrapped__)
+    g = torch.Generator().manual_seed(5)
+    B, sizes, strides = 2, [(20, 24), (10, 12), (5, 6)], [8, 16, 32]
+    cls = [torch.randn(B, 8, hh, ww, generator=g) * 2 - 1 for hh, ww in sizes]
+    reg = [(torch.randn(B, 4, hh, ww, generator=g).abs() * 3 + 0.5) * s for (hh, ww), s in zip(sizes, strides)]
+    ctr = [torch.randn(B, 1, hh, ww, generator=g) for hh, ww in sizes]
+    pts = []
+    for (hh, ww), s in zip(sizes, strides):
+        ys, xs = torch.meshgrid(torch.arange(hh, dtype=torch.float32), torch.arange(ww, dtype=torch.float32), indexing='ij')
+        pts.append(torch.stack((xs.reshape(-1) * s, ys.reshape(-1) * s), dim=-1) + s // 2)
+    metas = [dict(img_shape=(150, 180, 3), scale_factor=np.array([1.5, 1.25, 1.5, 1.25], np.float32)),
+             dict(img_shape=(160, 192, 3), scale_factor=np.array([1.0, 1.0, 1.0, 1.0], np.float32))]
+    cfg = types.SimpleNamespace(score_thr=0.05, nms=dict(type='nms', iou_threshold=0.5), max_per_img=100)
+    cfg.get = lambda k, d=None: dict(nms_pre=60).get(k, d)
+    out = {}
+    for tag, rescale in (('plain', False), ('rescale', True)):
+        res = h.get_bboxes(cls, reg, ctr, pts, metas, cfg=cfg, rescale=rescale, with_nms=False)
+        for b in range(B):
+            out[f'out_{tag}_bboxes{b}'], out[f'out_{tag}_scores{b}'], out[f'out_{tag}_ctr{b}'] = res[b]
+    for i in range(len(sizes)):
+        out[f'in_cls{i}'], out[f'in_reg{i}'], out[f'in_ctr{i}'], out[f'in_points{i}'] = cls[i], reg[i], ctr[i], pts[i]
+    G.save('eval_decode', **out)
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'eval_decode':
+    gen_eval_decode()

@@ -198,3 +198,29 @@ def test_dense_targets_full_size_properties():
     best, bi = area.min(1)
     want = torch.where(best < 1e8, labels[0][bi], torch.full_like(bi, 8))
     assert torch.equal(lab_pl.view(2, P)[0, idx].long(), want.long())
+
+
+def test_eval_decode_matches_reference():
+    """The decode half of the eval path (`get_bboxes(with_nms=False)`: per-level top-k by score x centerness, distance2bbox
+    with clipping, rescale, background column) of the Point-Teacher head - shared by FCOSHead - against the reference's own
+    `TS_P2BFCOSHead.get_bboxes` (tests/golden/eval_decode.npz, oracle/gen_golden_fcos.py eval_decode).  Pure torch in the
+    product as in the reference, so it runs on the CPU; the NMS that follows is parity-tested on the GPU."""
+    from point_teacher_amd.fcos_baseline import FCOSHead
+    E = load_golden('eval_decode')
+    h = FCOSHead(8, 4, feat_channels=4, stacked_convs=1, strides=[8, 16, 32], regress_ranges=RANGES, norm_cfg=None, conv_bias=True,
+                 loss_bbox=dict(type='DIoULoss', loss_weight=1.0))
+    cls, reg, ctr = ([E.t(f'in_{n}{i}') for i in range(3)] for n in ('cls', 'reg', 'ctr'))
+    pts = h.get_points([c.shape[-2:] for c in cls], torch.float32, 'cpu')
+    for i in range(3):
+        np.testing.assert_array_equal(pts[i].numpy(), E[f'in_points{i}'])
+    metas = [dict(img_shape=(150, 180, 3), scale_factor=np.array([1.5, 1.25, 1.5, 1.25], np.float32)),
+             dict(img_shape=(160, 192, 3), scale_factor=np.array([1.0, 1.0, 1.0, 1.0], np.float32))]
+    cfg = dict(nms_pre=60, score_thr=0.05, nms=dict(type='nms', iou_threshold=0.5), max_per_img=100)
+    for tag, rescale in (('plain', False), ('rescale', True)):
+        res = h.get_bboxes(cls, reg, ctr, pts, metas, cfg=cfg, rescale=rescale, with_nms=False)
+        for b in range(2):
+            bb, sc, ct = res[b]
+            assert bb.shape == (60 + 60 + 30, 4) and sc.shape == (150, 9)
+            np.testing.assert_allclose(bb.numpy(), E[f'out_{tag}_bboxes{b}'], rtol=1e-6, atol=1e-6)
+            np.testing.assert_array_equal(sc.numpy(), E[f'out_{tag}_scores{b}'])
+            np.testing.assert_array_equal(ct.numpy(), E[f'out_{tag}_ctr{b}'])
