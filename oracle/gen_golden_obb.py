@@ -433,6 +433,51 @@ def gen_aitod_eval_cocofork():
     G.save('aitod_eval_cocofork', n_img=np.int64(n_img), num_classes=np.int64(K), **out)
 
 
+def gen_eval_decode():
+    """rotated_fcos_head_p2rb_ts.py get_bboxes / _get_bboxes_single (:931-1083) up to the rotated NMS (an mmcv op): per level
+    top `nms_pre` by the maximum class score, DistanceAnglePointCoder.decode with clipping, rescale of the first four
+    columns, background column.  `multiclass_nms_rotated` is replaced by a recorder that stores its arguments (its result
+    is not used); `prior_generator.grid_priors` - the tree expects a newer mmdet's signature - hands back the level points
+    (x * s + s // 2), the same points the training path uses.  -> tests/golden/obb_eval_decode.npz"""
+    import types
+    L.install_obb()
+    hd = L.ref_obb('models.dense_heads.rotated_fcos_head_p2rb_ts')
+    cd = L.ref_obb('core.bbox.coder.distance_angle_point_coder')
+    rec = []
+    hd.multiclass_nms_rotated = lambda b, s, thr, nms, mx, score_factors=None: (rec.append((b.clone(), s.clone(), score_factors.clone())), (b, s))[1]
+    f = hd.TS_P2RBRotatedFCOSHead.get_bboxes
+    if hasattr(f, '__wrapped__'):
+        hd.TS_P2RBRotatedFCOSHead.get_bboxes = f.__wrapped__
+    h = object.__new__(hd.TS_P2RBRotatedFCOSHead)
+    torch.nn.Module.__init__(h)
+    h.num_classes = h.cls_out_channels = 9
+    h.bbox_coder = cd.DistanceAnglePointCoder(angle_version='le90')
+    g = torch.Generator().manual_seed(6)
+    B, sizes, strides = 2, [(20, 24), (10, 12), (5, 6)], [8, 16, 32]
+    pts = []
+    for (hh, ww), s in zip(sizes, strides):
+        ys, xs = torch.meshgrid(torch.arange(hh, dtype=torch.float32), torch.arange(ww, dtype=torch.float32), indexing='ij')
+        pts.append(torch.stack((xs.reshape(-1) * s, ys.reshape(-1) * s), dim=-1) + s // 2)
+    h.prior_generator = types.SimpleNamespace(grid_priors=lambda sizes_, dtype, device: pts)
+    cls = [torch.randn(B, 9, hh, ww, generator=g) * 2 - 1 for hh, ww in sizes]
+    reg = [(torch.randn(B, 4, hh, ww, generator=g).abs() * 3 + 0.5) * s for (hh, ww), s in zip(sizes, strides)]
+    ang = [torch.randn(B, 1, hh, ww, generator=g) * 0.6 for hh, ww in sizes]
+    ctr = [torch.randn(B, 1, hh, ww, generator=g) for hh, ww in sizes]
+    metas = [dict(img_shape=(150, 180, 3), scale_factor=np.array([1.5, 1.25, 1.5, 1.25], np.float32)),
+             dict(img_shape=(160, 192, 3), scale_factor=np.array([1.0, 1.0, 1.0, 1.0], np.float32))]
+    cfg = types.SimpleNamespace(score_thr=0.05, nms=dict(iou_thr=0.1), max_per_img=100)
+    cfg.get = lambda k, d=None: dict(nms_pre=60).get(k, d)
+    out = {}
+    for tag, rescale in (('plain', False), ('rescale', True)):
+        rec.clear()
+        h.get_bboxes(cls, reg, ang, ctr, pts, metas, cfg=cfg, rescale=rescale)
+        for b in range(B):
+            out[f'out_{tag}_bboxes{b}'], out[f'out_{tag}_scores{b}'], out[f'out_{tag}_factors{b}'] = rec[b]
+    for i in range(len(sizes)):
+        out[f'in_cls{i}'], out[f'in_reg{i}'], out[f'in_ang{i}'], out[f'in_ctr{i}'], out[f'in_points{i}'] = cls[i], reg[i], ang[i], ctr[i], pts[i]
+    G.save('obb_eval_decode', **out)
+
+
 if __name__ == '__main__':
     L.install_obb()
     torch.manual_seed(0); np.random.seed(0); random.seed(0)

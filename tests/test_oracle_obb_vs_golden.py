@@ -114,3 +114,31 @@ def test_mil_selection_and_bag_loss():
     close(gr[1], g.t('out_grad_ins'), atol=1e-6)
     close(gr[2], g.t('out_grad_neg'), atol=1e-6)
     close(O.mil_bag_loss_obb(cls, ins, valid, labels, None, None), g.t('out_loss_pos_only'), rtol=1e-5)
+
+
+def test_product_eval_decode_matches_reference():
+    """The decode half of the oriented eval path (`TS_P2RBRotatedFCOSHead.get_bboxes(with_nms=False)`: per-level top-k by
+    the best class score, DistanceAnglePointCoder.decode with clipping, rescale, background column) against what the
+    reference's own get_bboxes hands to the rotated NMS (tests/golden/obb_eval_decode.npz, gen_golden_obb.py gen_eval_decode).
+    Pure torch in the product, so it runs on the CPU; centerness is NOT applied (the reference passes ones as score factors)."""
+    import os
+    import point_teacher_amd as pta
+    E = load_golden('obb_eval_decode')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = pta.Config.fromfile(os.path.join(root, 'point_teacher_amd', 'configs', 'obb', 'point_teacher', 'sodaa_fcos_pointteacher_1x.py'))
+    hcfg = dict(cfg.model['_model_']['bbox_head'])
+    hcfg.update(strides=[8, 16, 32], train_cfg=cfg.model['_model_'].get('train_cfg'), test_cfg=cfg.model['_model_'].get('test_cfg'))
+    h = pta.registry.HEADS.build(hcfg)
+    cls, reg, ang, ctr = ([E.t(f'in_{n}{i}') for i in range(3)] for n in ('cls', 'reg', 'ang', 'ctr'))
+    pts = [E.t(f'in_points{i}') for i in range(3)]
+    metas = [dict(img_shape=(150, 180, 3), scale_factor=np.array([1.5, 1.25, 1.5, 1.25], np.float32)),
+             dict(img_shape=(160, 192, 3), scale_factor=np.array([1.0, 1.0, 1.0, 1.0], np.float32))]
+    tc = dict(nms_pre=60, score_thr=0.05, nms=dict(iou_thr=0.1), max_per_img=100)
+    for tag, rescale in (('plain', False), ('rescale', True)):
+        res = h.get_bboxes(cls, reg, ang, ctr, pts, metas, cfg=tc, rescale=rescale, with_nms=False)
+        for b in range(2):
+            bb, sc = res[b]
+            assert bb.shape == (150, 5) and sc.shape == (150, 10)
+            np.testing.assert_allclose(bb.numpy(), E[f'out_{tag}_bboxes{b}'], rtol=1e-6, atol=1e-6)
+            np.testing.assert_array_equal(sc.numpy(), E[f'out_{tag}_scores{b}'])
+            assert (E[f'out_{tag}_factors{b}'] == 1).all()
