@@ -60,6 +60,7 @@ def install():
 
 
 def inputs(seed=17, B=3, C=8, A=9):
+    """(for B != 3 only the head-shaped tensors are meaningful)"""
     g = torch.Generator().manual_seed(seed)
     cls = [torch.randn(B, A * C, h, w, generator=g) * 1.5 - 2.0 for h, w in SIZES]
     reg = [torch.randn(B, A * 4, h, w, generator=g) * 0.3 for h, w in SIZES]
@@ -143,5 +144,44 @@ def main():
     G.save('retina_baseline', **out)
 
 
+def gen_decode():
+    """anchor_head.py get_bboxes / _get_bboxes (:503-739) with `with_nms=False`: per level top `nms_pre` by the best class
+    score, DeltaXYWHBBoxCoder.decode with clipping to each image, rescale, background column
+    -> tests/golden/retina_eval_decode.npz"""
+    ag, mi, ps, ah, rh = install()
+    import types
+    import warnings
+    dc = L.ref('core.bbox.coder.delta_xywh_bbox_coder')
+    ex = L._pkg('mmdet.core.export')
+    ex.get_k_for_topk = lambda k, size: int(k) if 0 < int(k) < size else -1      # core/export/onnx_helper.py outside ONNX export
+    f = ah.AnchorHead.get_bboxes
+    if hasattr(f, '__wrapped__'):
+        ah.AnchorHead.get_bboxes = f.__wrapped__
+    h = object.__new__(rh.RetinaHead)
+    torch.nn.Module.__init__(h)
+    h.num_classes = h.cls_out_channels = 8
+    h.use_sigmoid_cls, h.rf_based, h.decay = True, False, 1
+    h.anchor_generator = ag.AnchorGenerator(octave_base_scale=4, scales_per_octave=3, ratios=[0.5, 1.0, 2.0], strides=STRIDES)
+    h.bbox_coder = dc.DeltaXYWHBBoxCoder(target_means=[.0, .0, .0, .0], target_stds=[1.0, 1.0, 1.0, 1.0])
+    cls, reg, _, _, (H, W) = inputs(seed=29, B=2)
+    metas = [dict(img_shape=(150, 180, 3), scale_factor=np.array([1.5, 1.25, 1.5, 1.25], np.float32)),
+             dict(img_shape=(H, W, 3), scale_factor=np.array([1.0, 1.0, 1.0, 1.0], np.float32))]
+    cfg = types.SimpleNamespace(score_thr=0.05, nms=dict(type='nms', iou_threshold=0.5), max_per_img=100)
+    cfg.get = lambda k, d=None: dict(nms_pre=200).get(k, d)
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for tag, rescale in (('plain', False), ('rescale', True)):
+            res = h.get_bboxes(cls, reg, metas, cfg=cfg, rescale=rescale, with_nms=False)
+            for b in range(2):
+                out[f'out_{tag}_bboxes{b}'], out[f'out_{tag}_scores{b}'] = res[b]
+    for i in range(len(SIZES)):
+        out[f'in_cls{i}'], out[f'in_reg{i}'] = cls[i], reg[i]
+    G.save('retina_eval_decode', **out)
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'decode':
+        gen_decode()
+    else:
+        main()

@@ -202,3 +202,24 @@ def test_max_iou_assign_full_size():
         assert torch.equal(mo[b], m)
         assert torch.equal(inds[b].long(), want)
         assert int((inds[b] > 0).sum()) >= g.shape[0] * 0.5
+
+
+@pytest.mark.gpu
+def test_retina_eval_decode_vs_reference():
+    """RetinaHead.get_bboxes(with_nms=False) - per-level top-k, `pt_delta2bbox_fwd` with clipping, rescale, background
+    column - against the reference's own AnchorHead.get_bboxes output (tests/golden/retina_eval_decode.npz)."""
+    E = load_golden('retina_eval_decode')
+    dev = torch.device('cuda:0')
+    h = _head(dev)
+    cls = [E.t(f'in_cls{i}').to(dev) for i in range(NL)]
+    reg = [E.t(f'in_reg{i}').to(dev) for i in range(NL)]
+    metas = [dict(img_shape=(150, 180, 3), scale_factor=np.array([1.5, 1.25, 1.5, 1.25], np.float32)),
+             dict(img_shape=(160, 192, 3), scale_factor=np.array([1.0, 1.0, 1.0, 1.0], np.float32))]
+    cfg = dict(nms_pre=200, score_thr=0.05, nms=dict(type='nms', iou_threshold=0.5), max_per_img=100)
+    for tag, rescale in (('plain', False), ('rescale', True)):
+        res = h.get_bboxes(cls, reg, metas, cfg=cfg, rescale=rescale, with_nms=False)
+        for b in range(2):
+            bb, sc = res[b]
+            assert bb.shape == E[f"out_{tag}_bboxes{b}"].shape == (200 + 200 + 200, 4)
+            np.testing.assert_allclose(bb.cpu().numpy(), E[f'out_{tag}_bboxes{b}'], rtol=1e-5, atol=1e-4)
+            np.testing.assert_allclose(sc.cpu().numpy(), E[f'out_{tag}_scores{b}'], rtol=1e-6, atol=1e-7)   # sigmoid on the GPU: 1 ulp
