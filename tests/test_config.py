@@ -57,3 +57,14 @@ def test_shipped_obb_config_loads_and_builds():
 @pytest.mark.skipif(not os.path.isfile(OBB_REF), reason='reference tree not present (GPU box)')
 def test_reference_obb_config_loads_and_matches_mirror():
     assert Config.fromfile(OBB_REF).to_dict() == Config.fromfile(OBB_MINE).to_dict()
+
+
+BASE_REF = '/root/reference/HBB_TOD/configs/baselines'
+BASE_MINE = os.path.join(ROOT, 'point_teacher_amd', 'configs', 'baselines')
+
+
+@pytest.mark.skipif(not os.path.isdir(BASE_REF), reason='reference tree not present (GPU box)')
+@pytest.mark.parametrize('name', ['aitodv2_fcos_r50_1x.py', 'aitodv2_retinanet_r50_1x.py'])
+def test_reference_baseline_config_loads_and_matches_mirror(name):
+    """Row N4: the reference's own baseline configs parse (their absolute `_base_` paths remapped) to the shipped mirrors."""
+    assert Config.fromfile(os.path.join(BASE_REF, name)).to_dict() == Config.fromfile(os.path.join(BASE_MINE, name)).to_dict()
