@@ -280,6 +280,31 @@ class SODAAEvaluator(AITODEvaluator):
         return out
 
 
+def collect_results(result_part, size):
+    """apis/test.py:105-171 (collect_results_cpu / _gpu): rank r holds the results of samples r, r + world, ... (the
+    DistributedSampler of the test loader); rank 0 gets them interleaved back into dataset order and cut to `size` (the
+    sampler pads by wrap-around), the other ranks get None.  One all_gather_object instead of a temp dir or padded byte
+    tensors."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return list(result_part)[:size]
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, list(result_part))
+    if dist.get_rank() != 0:
+        return None
+    ordered = []
+    for res in zip(*parts):
+        ordered.extend(list(res))
+    return ordered[:size]
+
+
+def multi_gpu_test(model, loader, size):
+    """apis/test.py:68-103: every rank runs its shard of the test loader (`build_dataloader(dist=True, shuffle=False)`), rank 0
+    returns the whole dataset's results."""
+    it = iter(loader)
+    return collect_results(single_gpu_test(model, lambda _: next(it), len(loader)), size)
+
+
 def single_gpu_test(model, batches, n_batches):
     """apis/test.py:16-66 for this path: `model(return_loss=False, rescale=True, **data)` over the data, results
     collected in dataset order (one list of per-class arrays per image)."""

@@ -103,6 +103,14 @@ def _worker(rank, world, port, q):
             assert ds.flag[pair_[0]] == ds.flag[pair_[1]]
         lt = build_dataloader(ds, samples_per_gpu=1, workers_per_gpu=1, dist=True, shuffle=False, device='cpu')
         assert isinstance(lt.sampler, DistributedSampler) and list(iter(lt.sampler)) == [i % 21 for i in range(rank, 22, world)]
+        # sharded evaluation: rank r evaluated samples r, r + world, ... of a 7-sample set (padded to 8); rank 0 restores the order
+        from point_teacher_amd.evaluation import collect_results
+        part = [[np.full((1, 5), float(i % 7))] for i in range(rank, 8, world)]
+        whole = collect_results(part, 7)
+        if rank == 0:
+            assert len(whole) == 7 and [float(r[0][0, 0]) for r in whole] == [0., 1., 2., 3., 4., 5., 6.]
+        else:
+            assert whole is None
         # normalisers: every rank sees the mean of the per-rank counts
         npos = reduce_mean(torch.tensor(float(10 + 4 * rank)))
         assert float(npos) == pytest.approx(sum(10 + 4 * r for r in range(world)) / world)

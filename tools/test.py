@@ -2,6 +2,7 @@
 """Evaluate a checkpoint (the counterpart of the reference's tools/test.py for this path).
 
     python tools/test.py <config.py> <checkpoint.pth> [--synthetic N] [--iou-thr 0.5]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/test.py <config.py> <checkpoint.pth> ...
 
 Runs `simple_test` of the TEACHER over the data (apis/test.py:16-66) and reports the reference's metrics: AI-TOD
 COCO-style `bbox_mAP*` / `AR*` for the horizontal configs (datasets/aitod.py), DOTA-style `mAP` for the oriented one
@@ -28,9 +29,14 @@ def main():
     ap.add_argument('--img-prefix', default=None)
     ap.add_argument('--ori-ann-file', default=None)
     args = ap.parse_args()
-    dev = torch.device('cuda', 0)
+    rank, world, local = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:                                        # sharded evaluation (apis/test.py multi_gpu_test): RCCL for the gather
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
     import point_teacher_amd as pta
-    from point_teacher_amd.evaluation import AITODEvaluator, eval_rbbox_map, single_gpu_test
+    from point_teacher_amd.evaluation import AITODEvaluator, eval_rbbox_map, multi_gpu_test, single_gpu_test
     from point_teacher_amd.synthetic import SyntheticTiles
     cfg = pta.Config.fromfile(args.config)
     model = pta.build_detector(cfg.model).to(dev)
@@ -38,7 +44,7 @@ def main():
         state = torch.load(args.checkpoint, map_location=dev, weights_only=False)
         model.load_state_dict(state['model'] if 'model' in state else state.get('state_dict', state))
     oriented = cfg.model.type == 'RotatedFCOS_TS'
-    K = cfg.model._model_.bbox_head.num_classes
+    K = cfg.model.get('_model_', cfg.model)['bbox_head']['num_classes']      # TS wrappers nest the detector under `_model_`
     B = cfg.data.samples_per_gpu
     tcfg = dict(cfg.data.test)
     for k, v in (('ann_file', args.ann_file), ('img_prefix', args.img_prefix), ('ori_ann_file', args.ori_ann_file)):
@@ -48,12 +54,16 @@ def main():
         from point_teacher_amd.datasets import build_dataloader, build_dataset
         tcfg['test_mode'] = True
         dataset = build_dataset(tcfg)
-        loader = build_dataloader(dataset, 1, cfg.data.workers_per_gpu, dist=False, shuffle=False, device=dev)
-        it = iter(loader)
-        results = single_gpu_test(model, lambda _: next(it), len(loader))
-        out = dataset.evaluate(results)              # the dataset's own protocol: AI-TOD COCO-style / SODA-A / DOTA-style mAP
-        print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in out.items()})
+        loader = build_dataloader(dataset, 1, cfg.data.workers_per_gpu, dist=world > 1, shuffle=False, device=dev)
+        results = multi_gpu_test(model, loader, len(dataset))        # world 1: the plain test loop
+        if rank == 0:
+            out = dataset.evaluate(results)          # the dataset's own protocol: AI-TOD COCO-style / SODA-A / DOTA-style mAP
+            print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in out.items()})
+        if world > 1:
+            dist.destroy_process_group()
         return
+    assert world == 1, 'the synthetic stand-in is a single-process check'
+
     data = SyntheticTiles(n=args.synthetic, size=1200 if oriented else 800, mean_objects=args.objects, seed=1, device=dev,
                           oriented=oriented, num_classes=K)
     results = single_gpu_test(model, lambda it: data.batch(it, B), args.synthetic // B)

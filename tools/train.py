@@ -44,7 +44,8 @@ def main():
     cfg = pta.Config.fromfile(args.config)
     torch.manual_seed(0)
     model = pta.build_detector(cfg.model).to(dev)
-    benchmark_init_(model)                 # no network for the pretrained backbones: see its docstring
+    if hasattr(model, 'student'):
+        benchmark_init_(model)             # no network for the pretrained backbones: see its docstring
     model.train()
     oriented = cfg.model.type == 'RotatedFCOS_TS'
     size = 1200 if oriented else 800
@@ -65,7 +66,7 @@ def main():
     else:
         ipe = args.iters_per_epoch or max(args.synthetic // (cfg.data.samples_per_gpu * world), 1)
         data = SyntheticTiles(n=max(args.synthetic // world, 2), size=size, mean_objects=args.objects, seed=0, device=dev,
-                              rank=rank, world=world, oriented=oriented, num_classes=cfg.model._model_.bbox_head.num_classes)
+                              rank=rank, world=world, oriented=oriented, num_classes=cfg.model.get('_model_', cfg.model)['bbox_head']['num_classes'])
         batches = data.batch
     trainer = pta.Trainer(model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config, iters_per_epoch=ipe, channels_last=True)
     torch.backends.cudnn.benchmark = True
