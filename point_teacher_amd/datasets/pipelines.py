@@ -654,6 +654,7 @@ class MultiScaleFlipAug:
             self.scale_key = 'scale_factor'
         self.flip = flip
         self.flip_direction = flip_direction if isinstance(flip_direction, list) else [flip_direction]
+        assert all(isinstance(d, str) for d in self.flip_direction)
         if not self.flip and self.flip_direction != ['horizontal']:
             warnings.warn('flip_direction has no effect when flip is set to False')
         if self.flip and not any(t['type'] in ('RandomFlip', 'RRandomFlip') for t in transforms):

@@ -650,3 +650,123 @@ def test_host_side_helpers():
         D.LazyImage(np.zeros((4, 4), np.uint8))
     with pytest.raises(TypeError):
         D.LazyImage(torch.zeros(4, 4, 3, dtype=torch.uint8))                 # a cached image must live on the GPU
+
+
+def test_reference_pipeline_known_answers():
+    """The known answers the reference's own pipeline tests hold (HBB_TOD/tests/test_data/test_pipelines/test_transform/
+    test_transform.py: test_resize :14-80, test_flip :82-181, test_pad :356-393, test_normalize :396-422,
+    test_multi_scale_flip_aug :595-686), on a generated image of the size of their `color.jpg` (288x512 - the file itself is
+    not in the reference snapshot; every expected number below depends on the size only)."""
+    import copy
+    build = lambda cfg: D.PIPELINES.build(cfg)                    # noqa: E731
+    # constructor contracts
+    for bad in (dict(type='Resize', img_scale=[1333, 800], keep_ratio=True),
+                dict(type='Resize', img_scale=[(1333, 800), (1333, 600)], ratio_range=(0.9, 1.1), keep_ratio=True),
+                dict(type='Resize', img_scale=[(1333, 800), (1333, 600)], keep_ratio=True, multiscale_mode='2333'),
+                dict(type='RandomFlip', flip_ratio=1.5),
+                dict(type='RandomFlip', flip_ratio=[0.7, 0.8], direction=['horizontal', 'vertical']),
+                dict(type='RandomFlip', flip_ratio=[0.4, 0.5]),
+                dict(type='RandomFlip', flip_ratio=1., direction='horizonta'),
+                dict(type='Pad'),
+                dict(type='MultiScaleFlipAug', scale_factor=1.0, img_scale=[(1333, 800)], transforms=[dict(type='Resize')]),
+                dict(type='MultiScaleFlipAug', scale_factor=None, img_scale=None, transforms=[dict(type='Resize')]),
+                dict(type='MultiScaleFlipAug', img_scale=[1333, 800], transforms=[dict(type='Resize')]),
+                dict(type='MultiScaleFlipAug', img_scale=[(1333, 800)], flip_direction=1, transforms=[dict(type='Resize')])):
+        with pytest.raises(AssertionError):
+            build(bad)
+    r = np.random.RandomState(0)
+    pix = r.randint(0, 256, (288, 512, 3)).astype(np.uint8)
+
+    def fresh(fields=('img',)):
+        res = dict(img_shape=pix.shape, ori_shape=pix.shape, pad_shape=pix.shape, img_fields=list(fields))
+        for f in fields:
+            res[f] = D.LazyImage(pix)
+        return res
+    # test_resize: scale and scale_factor cannot both be set; keep_ratio=False takes the scale as is
+    res = fresh()
+    res['scale'], res['scale_factor'] = (1333, 800), 1.0
+    with pytest.raises(AssertionError):
+        build(dict(type='Resize', img_scale=(1333, 800), keep_ratio=True))(res)
+    res = build(dict(type='Resize', img_scale=(1333, 800), keep_ratio=True))(fresh(('img', 'img2')))
+    assert res['img'].shape == res['img2'].shape == (750, 1333, 3) and res['img_shape'] == (750, 1333, 3)
+    res = build(dict(type='Resize', img_scale=(1280, 800), multiscale_mode='value', keep_ratio=False))(fresh())
+    assert res['img_shape'] == (800, 1280, 3)
+    # test_flip: two flips restore the image state; the drawn direction is recorded
+    flip = build(dict(type='RandomFlip', flip_ratio=1.))
+    res = dict(fresh(), scale_factor=1.0)
+    res = flip(res)
+    assert res['flip'] and res['flip_direction'] == 'horizontal' and res['img'].flip == 1
+    res.pop('flip'), res.pop('flip_direction')
+    res = build(dict(type='RandomFlip', flip_ratio=1.))(res)
+    assert res['img'].flip == 0
+    for cfg in (dict(type='RandomFlip', flip_ratio=0.9, direction=['horizontal', 'vertical', 'diagonal']),
+                dict(type='RandomFlip', flip_ratio=[0.3, 0.3, 0.2], direction=['horizontal', 'vertical', 'diagonal'])):
+        res = build(cfg)(dict(fresh(), scale_factor=1.0))
+        assert res['img'].flip == ({None: 0, 'horizontal': 1, 'vertical': 2, 'diagonal': 3}[res['flip_direction']] if res['flip'] else 0)
+    # test_pad: already divisible -> unchanged; after the resize -> the next multiples of 32
+    pad = build(dict(type='Pad', size_divisor=32))
+    res = pad(dict(fresh(), scale_factor=1.0))
+    assert res['img'].shape == (288, 512, 3) and res['pad_shape'] == (288, 512, 3)
+    res = pad(build(dict(type='Resize', img_scale=(1333, 800), keep_ratio=True))(fresh()))
+    assert res['img'].shape == (768, 1344, 3) and res['img'].shape[0] % 32 == 0 and res['img'].shape[1] % 32 == 0
+    # test_normalize: the recorded configuration (the arithmetic itself is checked on the GPU against the oracle)
+    res = build(dict(type='Normalize', mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True))(fresh())
+    assert res['img'].dtype == np.float32 and res['img_norm_cfg']['to_rgb'] is True
+    np.testing.assert_allclose(res['img_norm_cfg']['mean'], [123.675, 116.28, 103.53], rtol=1e-6)
+    # test_multi_scale_flip_aug
+    ms = build(dict(type='MultiScaleFlipAug', img_scale=[(1333, 800), (1333, 640)], transforms=[dict(type='Resize', keep_ratio=True)]))
+    out = ms(copy.copy(fresh()))
+    assert len(out['img']) == 2 and out['img'][0].shape == (750, 1333, 3) and out['img_shape'][0] == (750, 1333, 3)
+    assert out['img'][1].shape == (640, 1138, 3) and out['img_shape'][1] == (640, 1138, 3)
+    ms = build(dict(type='MultiScaleFlipAug', scale_factor=[0.8, 1.0, 1.2], transforms=[dict(type='Resize', keep_ratio=False)]))
+    out = ms(copy.copy(fresh()))
+    assert [im.shape for im in out['img']] == [(230, 409, 3), (288, 512, 3), (345, 614, 3)]
+    assert out['img_shape'] == [(230, 409, 3), (288, 512, 3), (345, 614, 3)]
+    # the coco_detection test pipeline on the same image size (:668-685): shapes and the float32 scale factor
+    ms = build(dict(type='MultiScaleFlipAug', img_scale=(1333, 800), flip=False,
+                    transforms=[dict(type='Resize', keep_ratio=True), dict(type='RandomFlip'),
+                                dict(type='Normalize', mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True),
+                                dict(type='Pad', size_divisor=32), dict(type='ImageToTensor', keys=['img']),
+                                dict(type='Collect', keys=['img'])]))
+    res = dict(fresh(), filename='color.jpg', ori_filename='color.jpg')
+    out = ms(res)
+    assert len(out['img']) == 1 and len(out['img_metas']) == 1 and isinstance(out['img_metas'][0], D.DataContainer)
+    meta = out['img_metas'][0].data
+    assert meta['ori_shape'] == (288, 512, 3) and meta['img_shape'] == (750, 1333, 3) and meta['pad_shape'] == (768, 1344, 3)
+    assert meta['scale_factor'].tolist() == [2.603515625, 2.6041667461395264, 2.603515625, 2.6041667461395264]
+
+
+def test_reference_dataset_known_answers(tmp_path):
+    """The dataset tests the reference holds (HBB_TOD/tests/test_data/test_datasets/test_coco_dataset.py:10-58 duplicate
+    annotation ids; test_custom_dataset.py:18-100 `classes` as tuple / list / file / None; test_common.py:335-360 empty-image
+    filtering per class subset - on a generated stand-in for their missing `coco_sample.json`: 3 images, bus in two, car in one)."""
+    def write(name, images, anns, cats):
+        p = os.path.join(str(tmp_path), name)
+        json.dump(dict(images=images, annotations=anns, categories=cats), open(p, 'w'))
+        return p
+    bad = write('dup.json', [dict(id=0, width=640, height=640, file_name='fake_name.jpg')],
+                [dict(id=1, image_id=0, category_id=0, area=400, bbox=[50, 60, 20, 20], iscrowd=0),
+                 dict(id=1, image_id=0, category_id=0, area=900, bbox=[100, 120, 30, 30], iscrowd=0)],
+                [dict(id=0, name='car', supercategory='car')])
+    with pytest.raises(AssertionError):
+        D.CocoDataset(ann_file=bad, classes=('car',), pipeline=[])
+    imgs = [dict(id=i, width=100, height=80, file_name=f'{i}.jpg') for i in range(3)]
+    cats = [dict(id=1, name='bus', supercategory='v'), dict(id=2, name='car', supercategory='v')]
+    anns = [dict(id=1, image_id=0, category_id=1, area=100, bbox=[10, 10, 10, 10], iscrowd=0),
+            dict(id=2, image_id=1, category_id=1, area=100, bbox=[20, 10, 10, 10], iscrowd=0),
+            dict(id=3, image_id=1, category_id=2, area=100, bbox=[30, 10, 10, 10], iscrowd=0)]
+    sample = write('sample.json', imgs, anns, cats)
+    for classes, expected in ((['bus'], 2), (['car'], 1), (['bus', 'car'], 2)):
+        filtered = D.CocoDataset(ann_file=sample, img_prefix='', pipeline=[], classes=classes, filter_empty_gt=True)
+        full = D.CocoDataset(ann_file=sample, img_prefix='', pipeline=[], classes=classes, filter_empty_gt=False)
+        assert len(filtered) == len(filtered.img_ids) == expected and len(full) == len(full.img_ids) == 3
+        assert filtered.CLASSES == classes and full.CLASSES == classes
+    # `classes`: tuple, list, not a subset of the defaults, None (defaults), a file with one name per line
+    mk = lambda c: D.AITODDataset(ann_file=sample, pipeline=[], classes=c, test_mode=True)      # noqa: E731
+    assert mk(('bus', 'car')).CLASSES == ('bus', 'car') and mk(['bus', 'car']).CLASSES == ['bus', 'car'] and mk(['foo']).CLASSES == ['foo']
+    assert mk(None).CLASSES == D.AITODDataset.CLASSES
+    names = os.path.join(str(tmp_path), 'classes.txt')
+    open(names, 'w').write('bus\ncar\n')
+    assert mk(names).CLASSES == ['bus', 'car']
+    with pytest.raises(ValueError):
+        mk(0.5)
