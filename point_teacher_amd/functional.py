@@ -144,6 +144,8 @@ def max_iou_assign(anchors, gt_boxes, off, B, pos_iou_thr, neg_iou_thr, min_pos_
     """pt_max_iou_assign -> (assigned_gt_inds int32 [B, A] (-1 ignore, 0 background, i+1 = box i of the image), max_overlaps [B, A])."""
     A = anchors.shape[0]
     dev = anchors.device
+    if A == 0:                                             # a network that predicts no box (max_iou_assigner.py:137-151)
+        return torch.empty((B, 0), dtype=i32, device=dev), torch.empty((B, 0), dtype=f32, device=dev)
     lo, hi = (0.0, float(neg_iou_thr)) if isinstance(neg_iou_thr, float) else (float(neg_iou_thr[0]), float(neg_iou_thr[1]))
     mo = torch.empty((B, A), dtype=f32, device=dev)
     am = torch.empty((B, A), dtype=i32, device=dev)

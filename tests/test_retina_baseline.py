@@ -223,3 +223,27 @@ def test_retina_eval_decode_vs_reference():
             assert bb.shape == E[f"out_{tag}_bboxes{b}"].shape == (200 + 200 + 200, 4)
             np.testing.assert_allclose(bb.cpu().numpy(), E[f'out_{tag}_bboxes{b}'], rtol=1e-5, atol=1e-4)
             np.testing.assert_allclose(sc.cpu().numpy(), E[f'out_{tag}_scores{b}'], rtol=1e-6, atol=1e-7)   # sigmoid on the GPU: 1 ulp
+
+
+KNOWN_BOXES = [[0, 0, 10, 10], [10, 10, 20, 20], [5, 5, 15, 15], [32, 32, 38, 42]]
+KNOWN_GTS = [[0, 0, 10, 9], [0, 10, 10, 19]]
+
+
+def test_oracle_reference_known_answers():
+    """The known answers of the reference's own assigner tests (HBB_TOD/tests/test_utils/test_assigner.py:15-36 and :66-82)."""
+    b, g = torch.FloatTensor(KNOWN_BOXES), torch.FloatTensor(KNOWN_GTS)
+    assert RR.max_iou_assign(b, g, 0.5, 0.5)[0].tolist() == [1, 0, 2, 0]
+    assert RR.max_iou_assign(b, torch.empty(0, 4), 0.5, 0.5)[0].tolist() == [0, 0, 0, 0]
+
+
+@pytest.mark.gpu
+def test_assigner_reference_known_answers():
+    """The same known answers through `MaxIoUAssigner.assign` / pt_max_iou_assign, plus the empty-prediction case (:85-106)."""
+    from point_teacher_amd.retina_baseline import MaxIoUAssigner
+    dev = torch.device('cuda:0')
+    a = MaxIoUAssigner(pos_iou_thr=0.5, neg_iou_thr=0.5)
+    b, g = torch.FloatTensor(KNOWN_BOXES).to(dev), torch.FloatTensor(KNOWN_GTS).to(dev)
+    assert a.assign(b, g)[0].tolist() == [1, 0, 2, 0]
+    assert a.assign(b, torch.empty(0, 4, device=dev))[0].tolist() == [0, 0, 0, 0]
+    inds, mo = a.assign(torch.empty(0, 4, device=dev), g)
+    assert len(inds) == 0 and len(mo) == 0
