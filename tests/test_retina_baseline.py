@@ -247,3 +247,22 @@ def test_assigner_reference_known_answers():
     assert a.assign(b, torch.empty(0, 4, device=dev))[0].tolist() == [0, 0, 0, 0]
     inds, mo = a.assign(torch.empty(0, 4, device=dev), g)
     assert len(inds) == 0 and len(mo) == 0
+
+
+def test_anchor_generator_reference_known_answers():
+    """The reference's own `test_retina_anchor` (HBB_TOD/tests/test_utils/test_anchor.py:455-552): base anchors of the
+    RetinaNet generator, valid-flag counts at 640x640, anchors per location."""
+    from point_teacher_amd.retina_baseline import AnchorGenerator
+    gen = AnchorGenerator(octave_base_scale=4, scales_per_octave=3, ratios=[0.5, 1.0, 2.0], strides=[8, 16, 32, 64, 128])
+    level0 = torch.Tensor([[-22.6274, -11.3137, 22.6274, 11.3137], [-28.5088, -14.2544, 28.5088, 14.2544],
+                           [-35.9188, -17.9594, 35.9188, 17.9594], [-16.0000, -16.0000, 16.0000, 16.0000],
+                           [-20.1587, -20.1587, 20.1587, 20.1587], [-25.3984, -25.3984, 25.3984, 25.3984],
+                           [-11.3137, -22.6274, 11.3137, 22.6274], [-14.2544, -28.5088, 14.2544, 28.5088],
+                           [-17.9594, -35.9188, 17.9594, 35.9188]])
+    for i, base in enumerate(gen.base_anchors):                     # every level is level 0 scaled by 2^i (the reference lists all five)
+        assert base.allclose(level0 * 2 ** i, rtol=1e-5, atol=1e-3)
+    assert gen.base_anchors[4][2].allclose(torch.Tensor([-574.7006, -287.3503, 574.7006, 287.3503]), atol=1e-3)
+    sizes = [(80, 80), (40, 40), (20, 20), (10, 10), (5, 5)]
+    flags = gen.valid_flags(sizes, (640, 640), 'cpu')
+    assert [int(f.sum()) for f in flags] == [57600, 14400, 3600, 900, 225]
+    assert gen.num_base_anchors == [9, 9, 9, 9, 9] and len(gen.grid_anchors(sizes, 'cpu')) == 5
