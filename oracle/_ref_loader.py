@@ -117,7 +117,14 @@ def install():
     runner = _pkg('mmcv.runner')
     runner.force_fp32 = _identity_decorator
     runner.auto_fp16 = _identity_decorator
-    runner.BaseModule = nn.Module
+
+    class BaseModule(nn.Module):
+        """mmcv.runner.BaseModule: an nn.Module whose constructor takes `init_cfg` (weight-init bookkeeping only)."""
+
+        def __init__(self, init_cfg=None):
+            super().__init__()
+            self.init_cfg = init_cfg
+    runner.BaseModule = BaseModule
     runner.OptimizerHook = object
     cnn = _pkg('mmcv.cnn')
 
@@ -129,7 +136,36 @@ def install():
         def forward(self, x):
             return x * self.scale
     cnn.Scale = Scale
-    cnn.ConvModule = None
+
+    class ConvModule(nn.Module):
+        """mmcv.cnn.ConvModule for the cases this path builds: Conv2d -> (GN | BN) -> ReLU, bias='auto' = no bias
+        under a norm layer, sub-module names `conv` / `gn` / `bn` as in mmcv (so checkpoints keep their keys).  A
+        composition of torch modules - no arithmetic of the reference is restated."""
+
+        def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias='auto',
+                     conv_cfg=None, norm_cfg=None, act_cfg=dict(type='ReLU'), inplace=True, **kw):
+            super().__init__()
+            assert conv_cfg is None, 'plain convolutions only'
+            self.with_norm = norm_cfg is not None
+            if bias == 'auto':
+                bias = not self.with_norm
+            self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias=bias)
+            self.norm_name = None
+            if self.with_norm:
+                if norm_cfg['type'] == 'GN':
+                    self.gn, self.norm_name = nn.GroupNorm(norm_cfg['num_groups'], out_channels), 'gn'
+                else:
+                    assert norm_cfg['type'] == 'BN'
+                    self.bn, self.norm_name = nn.BatchNorm2d(out_channels), 'bn'
+            self.with_activation = act_cfg is not None
+            assert act_cfg is None or act_cfg['type'] == 'ReLU'
+
+        def forward(self, x):
+            x = self.conv(x)
+            if self.norm_name:
+                x = getattr(self, self.norm_name)(x)
+            return torch.relu(x) if self.with_activation else x
+    cnn.ConvModule = ConvModule
     cnn.MODELS = _Registry('model')
     # arithmetic-free stubs: every name resolves to None (never called here)
     _pkg('mmcv.ops', stub=True)
@@ -260,8 +296,7 @@ def install_obb():
             _pkg(n, stub=True)
     # names the HBB shim did not need
     mmcv_cnn = sys.modules['mmcv.cnn']
-    if getattr(mmcv_cnn, 'ConvModule', None) is None:
-        mmcv_cnn.ConvModule = nn.Module
+    assert getattr(mmcv_cnn, 'ConvModule', None) is not None
     _pkg('mmdet.core.anchor', stub=True)
     _pkg('mmdet.core.anchor.point_generator', stub=True)
     _pkg('mmdet.models.roi_heads', stub=True)

@@ -91,6 +91,18 @@ def init_detector_state(seed=0, num_stages=1):
     return sd
 
 
+def damp_mil_logits(sd, scale):
+    """Scale the bag classifier's last layers (fc_cls / fc_ins) in place.  At random initialisation their logits have a
+    standard deviation of ~10 (unnormalised 0-255 pixels under a random ResNet), i.e. every sigmoid saturates and the
+    bag loss sits on its `log(1 - p + 1e-6)` cliff, where one fp32 ulp of `p` moves the value by per cents; a trained
+    head has moderate logits.  Whole-iteration fixtures use a damped head so that they compare arithmetic, not the
+    amplification of rounding noise."""
+    for k in sd:
+        if '.fc_cls.' in k or '.fc_ins.' in k:
+            sd[k] = sd[k] * scale
+    return sd
+
+
 def is_param(name):
     return not (name.endswith('running_mean') or name.endswith('running_var') or name.endswith('num_batches_tracked'))
 
@@ -305,8 +317,12 @@ def mil_stage(sd, feat, stage, cfg, ext_cfg, pb_t, gb_t, pl_t, img_hw, neg_u, al
     return losses, list(torch.split(merged, [b.shape[0] for b in pb_t]))
 
 
-def forward_train_step2(sd_s, sd_t, img, gt_bboxes, gt_labels, gt_points, cfg, inject):
-    """fcos_p2b_teacher_student.py:213-252.  `inject`: dict(neg0=[B,4,n] uniforms, aug=(flips, scales))."""
+def forward_train_step2(sd_s, sd_t, img, gt_bboxes, gt_labels, gt_points, cfg, inject, origin_points=None):
+    """fcos_p2b_teacher_student.py:213-252.  `inject`: dict(neg0=[B,4,n] uniforms, aug=(flips, scales)).
+    `gt_points`: what genrate_points returns (:504-519: the refined points once an image has been seen);
+    `origin_points`: the first-visit points `self.gt_bboxes_point[...]`, which update_points blends with EVERY
+    time (:270-271) - they differ from `gt_points` from the second visit on when lamda < 1."""
+    origin_points = gt_points if origin_points is None else origin_points
     B, _, H, W = img.shape
     img_hw = (H, W)
     pts = grid_points(H // STRIDE, W // STRIDE)
@@ -332,7 +348,7 @@ def forward_train_step2(sd_s, sd_t, img, gt_bboxes, gt_labels, gt_points, cfg, i
         pb_r[i][:k] = pb_t[i]
         pp_r[i][:k] = R.bbox_xyxy_to_cxcywh(pb_t[i])[:, :2]
     # update_points (:266-274) - lamda blend; the caller keeps the dictionaries
-    new_points = [(1 - cfg['lamda']) * R.bbox_xyxy_to_cxcywh(pb_r[i])[:, :2] + cfg['lamda'] * gt_points[i] for i in range(B)]
+    new_points = [(1 - cfg['lamda']) * R.bbox_xyxy_to_cxcywh(pb_r[i])[:, :2] + cfg['lamda'] * origin_points[i] for i in range(B)]
     real = R.bbox_xyxy_to_cxcywh(torch.cat(gt_bboxes))
     losses['refined_points_distance'] = (torch.sqrt((torch.cat(new_points) - real[:, :2]) ** 2)
                                          / torch.sqrt((real[:, 2:] / 2) ** 2)).mean()
@@ -352,15 +368,21 @@ def _aug_loss(sd_s, img, gt_points, gt_labels, pp, pl, pb, aug, pts):
                          [o[4] for o in outs], [o[5] for o in outs])
 
 
-def forward_train_step1(sd_s, sd_t, img, gt_bboxes, gt_labels, gt_points, cfg, inject):
+def forward_train_step1(sd_s, sd_t, img, gt_bboxes, gt_labels, gt_points, cfg, inject, origin_points=None):
     """fcos_p2b_teacher_student.py:141-211.  The synthetic images/boxes are INPUTS here
-    (inject['img_syn'], inject['syn_boxes']): the rasteriser is parity-unpinned and is checked
-    separately (tests/test_hip_ops.py::test_fill_quads, test_black_paper)."""
+    (inject['img_syn'], inject['syn_boxes']) or are generated from inject['syn'] (per-image draw dictionaries,
+    ref_ops.generate_black_paper).  `origin_points`: see forward_train_step2."""
+    origin_points = gt_points if origin_points is None else origin_points
     B, _, H, W = img.shape
     img_hw = (H, W)
     pts = grid_points(H // STRIDE, W // STRIDE)
     losses = {}
-    img_syn, syn_boxes = inject['img_syn'], inject['syn_boxes']
+    if 'syn' in inject:           # genrate_syn :469-502 with the draws of this iteration
+        prior = torch.tensor(cfg['shape_list'], dtype=torch.float32)
+        gen = [R.generate_black_paper(img[i], gt_bboxes[i], prior, inject['syn'][i]) for i in range(B)]
+        img_syn, syn_boxes = torch.stack([g[0] for g in gen]), [g[1] for g in gen]
+    else:
+        img_syn, syn_boxes = inject['img_syn'], inject['syn_boxes']
     feat_all = extract_feat(sd_s, torch.cat([img_syn, img]))
     feat_syn, feat_ori = feat_all[:B], feat_all[B:]
     cls_s, reg_s, ctr_s = head_forward(sd_s, feat_syn)
@@ -381,7 +403,7 @@ def forward_train_step1(sd_s, sd_t, img, gt_bboxes, gt_labels, gt_points, cfg, i
                                  inject[f'neg{stage}'], cfg['alpha'], cfg['top_k'], cfg['beta'], syn=(feat_syn, syn_t))
             losses[f'stage{stage}_refine_bboxes_iou'] = R.bbox_overlaps(torch.cat(pb_t), torch.cat(gb_t), is_aligned=True).mean()
             losses.update(ml)
-        new_points = [(1 - cfg['lamda']) * R.bbox_xyxy_to_cxcywh(pb_c[i])[:, :2] + cfg['lamda'] * gt_points[i] for i in range(B)]
+        new_points = [(1 - cfg['lamda']) * R.bbox_xyxy_to_cxcywh(pb_c[i])[:, :2] + cfg['lamda'] * origin_points[i] for i in range(B)]
         real = R.bbox_xyxy_to_cxcywh(torch.cat(gt_bboxes))
         losses['refined_points_distance'] = (torch.sqrt((torch.cat(new_points) - real[:, :2]) ** 2)
                                              / torch.sqrt((real[:, 2:] / 2) ** 2)).mean()
@@ -418,10 +440,24 @@ def sgd_clip_step(sd_s, grads, mom, lr, first, momentum=0.9, wd=1e-4, max_norm=3
 
 
 # ---------------------------------------------------------------- CPU baseline --
+SHAPE_LIST = [[20, 20, 0.5, 0.5], [10, 20, 0.5, 0.5], [30, 80, 0.5, 0.5], [20, 50, 0.5, 0.5], [30, 120, 0.5, 0.5],
+              [30, 40, 0.5, 0.5]]                      # configs/point_teacher/aitodv2_point_teacher_0%.py (shape_list)
 MODEL_CFG = dict(num_stages=1, num_training_burninstep1=100, num_training_burninstep2=100, lamda=1.0, alpha=[0.01, 0.25],
-                 top_k=1, beta=0.25,
+                 top_k=1, beta=0.25, shape_list=SHAPE_LIST,
                  fine_proposal_cfg=[dict(base_ratios=[1.0], shake_ratio=None, min_scale=0)],
                  fine_proposal_extensive_cfg=[dict(base_ratios=[1.0, 1.2, 1.3, 0.8, 0.7], shake_ratio=None, min_scale=4)])
+
+
+def model_cfg_from(model):
+    """The keys the oracle reads, out of a `TS_P2B_FCOS` config dictionary (configs/point_teacher/*.py: plain data)."""
+    tc = model['train_cfg']
+    pick = lambda c: dict(base_ratios=c['base_ratios'], shake_ratio=c['shake_ratio'], min_scale=c['min_scale'])   # noqa: E731
+    return dict(num_stages=model['num_stages'], num_training_burninstep1=model['num_training_burninstep1'],
+                num_training_burninstep2=model['num_training_burninstep2'], lamda=model['lamda'], alpha=list(model['alpha']),
+                top_k=model['_model_']['bbox_head']['top_k'], beta=model['_model_']['bbox_head']['beta'],
+                shape_list=[list(s) for s in model['shape_list']], point=model['_point_'],
+                fine_proposal_cfg=[pick(c) for c in tc['fine_proposal_cfg']],
+                fine_proposal_extensive_cfg=[pick(c) for c in tc['fine_proposal_extensive_cfg']])
 
 
 def _synthetic_batch(batch, size, objects, seed=7):

@@ -804,6 +804,70 @@ def fill_convex_quads(polys_int, H, W):
     return mask
 
 
+def generate_black_paper(img, gt_bboxes, prior_size, draws, imgsize=None):
+    """Burn-in step 1 "white rectangle" generator for ONE image: detectors/fcos_p2b_teacher_student.py:469-502
+    (`genrate_syn.synthesis_single`) around detectors/syn_images_generator_v2.py:591-690 (`generate_black_paper`),
+    with every random draw supplied in `draws` (per-object arrays: `cls` = the torch.randint prior index :473,
+    `scale` :597, `x`,`y` :613, `wn` :616, `rn` :619, `a` :625, `boost` = np.random.random() :640, `itv` / `dev` =
+    the two torch.rand of :643-645 / :654-656; only read for objects whose boost fires).
+
+    Returns (img_syn [C,H,W], hull boxes xyxy [M,4] in the reference's `bb[keep]` order, keep indices into
+    [real objects | candidate rectangles], mask [H,W] uint8).  Restated one object at a time, python floats
+    rounded through float32 tensors exactly where the reference holds tensors."""
+    C, H, W = img.shape
+    imgsize = min(H, W) if imgsize is None else imgsize
+    prior = prior_size.float()
+    n_dense = int(prior.shape[0] / 2)                                   # dense_cls = range(len(pattern)/2), :483
+    G = gt_bboxes.shape[0]
+    f32 = torch.float32
+    cxcy = bbox_xyxy_to_cxcywh(gt_bboxes.float())
+    rows = []                                                           # candidate rectangles [x,y,w,h,a,score]
+    adj = 2
+    lo, hi = 50.0, float(imgsize - 50)
+    for j in range(G):
+        c = int(draws['cls'][j])
+        base = draws['scale'][j].to(f32) * 2.0 + 0.5                    # :597
+        x = draws['x'][j].to(f32) * (hi - lo) + lo                      # :613-614
+        y = draws['y'][j].to(f32) * (hi - lo) + lo
+        w = base * torch.exp((draws['wn'][j].to(f32) * 0.4).clamp(-1, 1) * prior[c, 2])     # :615-617
+        h = w * torch.exp((draws['rn'][j].to(f32) * 0.4).clamp(-1, 1) * prior[c, 3])        # :618-621
+        w = w * prior[c, 0]
+        h = h * prior[c, 1]
+        a = draws['a'][j].to(f32) * math.pi - math.pi / 2                # :625 (torch.pi = math.pi, :582)
+        # Tensor.clip(min, max) = min(max(x, lo), hi): the upper bound wins when the bounds cross (:627-628)
+        x = torch.minimum(torch.maximum(x, 0.71 * w), imgsize - 1 - 0.71 * w)
+        y = torch.minimum(torch.maximum(y, 0.71 * h), imgsize - 1 - 0.71 * h)
+        score = (w * h) / imgsize / imgsize + 0.1
+        rows.append([x, y, w, h, a, score])
+        if float(draws['boost'][j]) < 0.2 and adj > 0:                   # :640-663
+            adj -= 1
+            if c < n_dense:
+                itv, dev, n = draws['itv'][j].to(f32) * 4 + 2, draws['dev'][j].to(f32) * 8 - 4, 5
+            else:
+                itv, dev, n = draws['itv'][j].to(f32) * 40 + 10, draws['dev'][j].to(f32) * 0, 3
+            ofx = (h + itv) * torch.sin(-a) + dev * torch.cos(a)
+            ofy = (h + itv) * torch.cos(a) + dev * torch.sin(a)
+            for k in range(1, n + 1):
+                rows.append([x + k * ofx, y + k * ofy, w, h, a, (w * h) / imgsize / imgsize + 0.1 - 0.001 * k])
+    cand = torch.tensor([[float(v) for v in r] for r in rows], dtype=f32).reshape(-1, 6)      # torch.tensor(bb), :665
+    cls = draws['cls'].long()
+    occ = torch.stack([cxcy[:, 0], cxcy[:, 1], prior[cls, 0] * 0.7, prior[cls, 0] * 0.7, torch.zeros(G), torch.ones(G)], 1)
+    allb = torch.cat([occ, cand], 0)                                     # :666
+    keep = nms_rotated(allb[:, :5], allb[:, 5], 0.05)                    # :667 (mmcv op: parity unpinned)
+    bb = allb[keep]
+    bb = bb[bb[:, 5] < 1]                                                # the real objects leave, :669
+    xyxy = obb2xyxy(bb)
+    inside = (xyxy.min(-1)[0] >= 0) & (xyxy.max(-1)[0] <= imgsize - 1)   # :671-675
+    bb = bb[inside]
+    polys = obb2poly_le90(bb[:, :5])
+    mask = fill_convex_quads(polys.numpy().astype(np.int32), H, W)       # cv2.fillPoly on int32-truncated corners, :678-683
+    img_syn = img.clone()
+    img_syn[:, torch.from_numpy(mask) == 1] = 255                        # :686-688
+    px, py = polys[:, 0::2], polys[:, 1::2]
+    hull = torch.stack([px.min(1)[0], py.min(1)[0], px.max(1)[0], py.max(1)[0]], 1) if bb.shape[0] else bb.new_zeros((0, 4))
+    return img_syn, hull, keep, mask
+
+
 # ----------------------------------------------------------------------------
 # EMA / optimizer      detectors/fcos_p2b_teacher_student.py:254-257; mmcv OptimizerHook
 # ----------------------------------------------------------------------------

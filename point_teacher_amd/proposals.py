@@ -259,8 +259,9 @@ def generate_black_paper_masked(img, gt_bboxes, prior_size, dense_cls, imgsize, 
     w = w * pr[:, 0]
     h = h * pr[:, 1]
     a = draw('a', (G,)) * math.pi - math.pi / 2
-    x = torch.maximum(torch.minimum(x, imgsize - 1 - 0.71 * w), 0.71 * w)     # Tensor.clip(lo, hi)
-    y = torch.maximum(torch.minimum(y, imgsize - 1 - 0.71 * h), 0.71 * h)
+    # Tensor.clip(lo, hi) = min(max(x, lo), hi): the UPPER bound wins when a rectangle is so large that the bounds cross
+    x = torch.minimum(torch.maximum(x, 0.71 * w), imgsize - 1 - 0.71 * w)
+    y = torch.minimum(torch.maximum(y, 0.71 * h), imgsize - 1 - 0.71 * h)
     score = (w * h) / imgsize / imgsize + 0.1
     syn = torch.stack([x, y, w, h, a, score], 1)                                # [G,6]
 

@@ -46,3 +46,59 @@ def test_product_does_not_import_oracle():
         if f.endswith('.py'):
             src = open(os.path.join(ROOT, 'tools', f)).read()
             assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
+
+
+def _integration_stub():
+    """The python code block of INTEGRATION.md section 1, pointed at the built library."""
+    from point_teacher_amd import hip
+    md = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    blocks = re.findall(r'```python\n(.*?)```', md, flags=re.S)
+    assert len(blocks) == 1
+    return blocks[0].replace('/path/to/point_teacher_amd/libpt_hip.so', hip.LIB_PATH)
+
+
+def test_integration_stub_matches_header():
+    """Every `argtypes` list the document tells a maintainer to write has the header's arity and kinds, and every
+    call in the stub passes that many arguments."""
+    from point_teacher_amd import hip
+    src = _integration_stub()
+    ns = {}
+    exec(compile(src, 'INTEGRATION.md', 'exec'), ns)             # defines the wrappers; nothing is launched
+    lib = ns['_lib']
+    bound = re.findall(r'_lib\.(pt_\w+)\.argtypes', src)
+    assert set(bound) >= {'pt_topk_assign', 'pt_roi_align_fwd'}
+    for name in bound:
+        want = [t for t, _ in hip.PROTOS[name][1]]
+        got = list(getattr(lib, name).argtypes)
+        assert len(got) == len(want), (name, len(got), len(want))
+        for g, w in zip(got, want):
+            assert g is w, (name, g, w)
+        call = re.search(r'_lib\.' + name + r'\((.*?)\),\s*\n?\s*\'' + name, src, flags=re.S).group(1)
+        depth, nargs = 0, 1
+        for ch in call:
+            depth += ch in '([' 
+            depth -= ch in ')]'
+            nargs += (ch == ',' and depth == 0)
+        assert nargs == len(want), (name, nargs, len(want))
+
+
+@pytest.mark.gpu
+def test_integration_stub_runs_on_gpu():
+    """The documented binding, executed as written, equals the package's own wrappers."""
+    import torch
+    from point_teacher_amd import functional as F
+    ns = {}
+    exec(compile(_integration_stub(), 'INTEGRATION.md', 'exec'), ns)
+    dev = 'cuda'
+    g = torch.Generator().manual_seed(0)
+    ys, xs = torch.meshgrid(torch.arange(20.), torch.arange(20.), indexing='ij')
+    pts = (torch.stack((xs.reshape(-1) * 8, ys.reshape(-1) * 8), -1) + 4).to(dev)
+    gt = (torch.rand(11, 2, generator=g) * 150 + 3.3).to(dev)
+    off, _ = F.make_offsets([6, 5], dev)
+    a = ns['topk_assign'](pts, gt, off, 2, 3)
+    b = F.topk_assign(pts, gt, off, 2, 3)
+    assert torch.equal(a.reshape(-1), b.reshape(-1).to(a.dtype))
+    feat = torch.randn(2, 16, 20, 20, generator=g).to(dev)
+    rois = torch.tensor([[0, 8., 8., 40., 56.], [1, 20.3, 11.1, 23.9, 14.2], [1, 1., 1., 150., 150.]], device=dev)
+    o = ns['roi_align_forward'](feat, rois, 7, 0.125)
+    torch.testing.assert_close(o, F.roi_align(feat, rois, 7, 0.125), rtol=1e-6, atol=1e-6)

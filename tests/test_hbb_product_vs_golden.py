@@ -1,0 +1,167 @@
+"""HBB product classes DIRECTLY against the fixtures the reference itself produced (oracle/gen_golden.py) - not
+through the oracle.  Rows a8 / a10 / a19 of SURVEY section 8: `TS_P2BFCOSHead.get_pseudo_bbox / loss_pseudo / loss`
+(values and gradients), the match-cost classes, `CrossEntropyLoss(use_sigmoid)`, `strong_augmentation`,
+`random_point_in_quadrilateral`, `update_points` with lamda 0.5.  The oriented twin of this file is
+tests/test_obb_parity.py::test_product_vs_reference_goldens."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = 'cuda'
+
+
+def close(a, b, rtol=1e-3, atol=1e-5):
+    a = torch.as_tensor(a).detach().cpu().double()
+    b = torch.as_tensor(np.asarray(b) if not isinstance(b, torch.Tensor) else b.detach().cpu()).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    torch.testing.assert_close(a, b, rtol=rtol, atol=atol, equal_nan=True)
+
+
+def _head():
+    import point_teacher_amd as pta
+    cfg = pta.Config.fromfile(os.path.join(ROOT, 'point_teacher_amd', 'configs', 'point_teacher', 'aitodv2_point_teacher_0.py'))
+    hc = dict(cfg.model['_model_']['bbox_head'])
+    hc.update(train_cfg=cfg.model['train_cfg'], test_cfg=cfg.model['test_cfg'])
+    hc['num_stages'] = 0                      # no MIL FC stacks: this test feeds head-shaped tensors straight into the loss methods
+    return pta.registry.build_head(hc).to(DEV)
+
+
+@pytest.mark.parametrize('name', ['small', 'mid'])
+def test_head_pseudo_boxes_and_losses_vs_reference(name):
+    """fcos_head_p2b_ts.py:357-375 (get_pseudo_bbox), :380-465 (loss_pseudo), :470-534 (loss): the golden holds what the
+    reference's own methods returned for these maps, with gradients."""
+    g = load_golden('head_' + name)
+    head = _head()
+    cls = g.t('in_cls').to(DEV).requires_grad_(True)
+    reg = g.t('in_reg').to(DEV).requires_grad_(True)
+    ctr = g.t('in_ctr').to(DEV).requires_grad_(True)
+    pts = g.t('in_points').to(DEV)
+    B = cls.shape[0]
+    size = int(cls.shape[2] * 8)
+    gp = [g.t(f'in_gt_points{i}').to(DEV) for i in range(B)]
+    gl = [g.t(f'in_gt_labels{i}').to(DEV) for i in range(B)]
+    gb = [g.t(f'in_gt_bboxes{i}').to(DEV) for i in range(B)]
+    metas = [dict(ori_filename=f'i{i}.png', img_shape=(size, size, 3)) for i in range(B)]
+    pb, pp, pl, miou, _ = head.get_pseudo_bbox([cls.detach()], [reg.detach()], [ctr.detach()], [pts], gp, gl, gb, 0.0, metas, [None] * B)
+    for i in range(B):
+        close(pb[i], g[f'out_pseudo_bboxes{i}'], rtol=1e-4, atol=1e-3)
+        close(pp[i], g[f'out_pseudo_points{i}'], rtol=1e-4, atol=1e-3)
+        assert torch.equal(pl[i], gl[i])
+    close(miou, g['out_mean_iou'], rtol=1e-4)
+    pb2 = [g.t(f'in_pseudo_bboxes_jit{i}').to(DEV) for i in range(B)]
+    pp2 = [(b[:, :2] + b[:, 2:]) / 2 for b in pb2]
+    lc, lb, lt = head.loss_pseudo([cls], [reg], [ctr], [pts], gp, gl, pp2, pl, pb2, [None] * B, metas, [None] * B, False)
+    close(lc, g['out_loss_cls'], rtol=1e-4)
+    close(lb, g['out_loss_bbox'], rtol=1e-4)
+    close(lt, g['out_loss_ctr'], rtol=1e-4)
+    gr = torch.autograd.grad(lc + lb + lt, [cls, reg, ctr])
+    for got, key in zip(gr, ('out_grad_cls', 'out_grad_reg', 'out_grad_ctr')):
+        ref = g.t(key)
+        assert float((got.cpu() - ref).norm() / ref.norm()) < 1e-4, key
+        close(got, ref, rtol=1e-3, atol=1e-6 * float(ref.abs().max()) + 1e-9)
+    sb, sc = head.loss([cls], [reg], [ctr], [pts], gb, metas)
+    close(sb, g['out_syn_loss_bbox'], rtol=1e-4)
+    close(sc, g['out_syn_loss_ctr'], rtol=1e-4)
+    gs = torch.autograd.grad(sb + sc, [reg, ctr])
+    for got, key in zip(gs, ('out_syn_grad_reg', 'out_syn_grad_ctr')):
+        ref = g.t(key)
+        assert float((got.cpu() - ref).norm() / ref.norm()) < 1e-4, key
+
+
+def test_match_cost_classes_vs_reference():
+    """match_cost.py:54-99, :188-214, :217-252 through the registry's classes (the training path fuses them into the
+    assigner kernels; the classes are the drop-in surface a config names)."""
+    from point_teacher_amd.core import FocalLossCost, InsiderCost, PointCost
+    g = load_golden('costs')
+    bx, gt = g.t('in_boxes_cxcywh').to(DEV), g.t('in_gt_cxcywh').to(DEV)
+    close(PointCost('L1', 1.0)(bx, gt), g['out_point_l1'], rtol=1e-6, atol=1e-5)
+    close(PointCost('L2', 2.0)(bx, gt), g['out_point_l2'], rtol=1e-5, atol=1e-5)
+    close(FocalLossCost(weight=1.0)(g.t('in_cls').to(DEV), g.t('in_labels').to(DEV)), g['out_focal'], rtol=1e-4, atol=1e-6)
+    assert torch.equal(InsiderCost(weight=1.0)(bx, gt).cpu(), g.t('out_insider'))
+
+
+def test_centerness_bce_vs_reference():
+    """cross_entropy_loss.py:142-214 `CrossEntropyLoss(use_sigmoid=True)` on 1-D logits with soft targets."""
+    from point_teacher_amd.losses import CrossEntropyLoss
+    g = load_golden('loss_bce')
+    x = g.t('in_logits').to(DEV).requires_grad_(True)
+    loss = CrossEntropyLoss(use_sigmoid=True, loss_weight=1.0)(x, g.t('in_target').to(DEV), avg_factor=float(g['avg_factor']))
+    close(loss, g['out_loss'], rtol=1e-5)
+    gd, = torch.autograd.grad(loss, x)
+    close(gd, g['out_grad'], rtol=1e-4, atol=1e-8)
+
+
+def test_strong_augmentation_vs_reference():
+    """syn_images_generator_v2.py:24-132: the reference's own output for injected (flip, scale) draws - pixels bit for
+    bit (bilinear resize + torch.round), points / boxes / the filtered label lists."""
+    from point_teacher_amd.proposals import strong_augmentation, strong_augmentation_masked
+    g = load_golden('strong_aug')
+    img = g.t('in_img').to(DEV)
+    B = img.shape[0]
+    gp = [g.t(f'in_gt_points{i}').to(DEV) for i in range(B)]
+    gl = [g.t(f'in_gt_labels{i}').to(DEV) for i in range(B)]
+    pb = [g.t(f'in_pseudo_bboxes{i}').to(DEV) for i in range(B)]
+    pp = [(b[:, :2] + b[:, 2:]) / 2 for b in pb]
+    params = ([str(f) for f in g['flips']], [float(s) for s in g['scales']])
+    ia, _, agp, agl, app, apl, apb = strong_augmentation(img, gp, gl, pp, [l.clone() for l in gl], pb, params=params)
+    assert float((ia.cpu() - g.t('out_img')).abs().max()) <= 1.0          # torch.round of a bilinear value: at most one grey level
+    assert float((ia.cpu() != g.t('out_img')).float().mean()) < 2e-3      # ... and only where the interpolant sits on x.5
+    for i in range(B):
+        close(agp[i], g[f'out_gt_points{i}'], rtol=1e-6, atol=1e-4)
+        assert torch.equal(agl[i].cpu(), g.t(f'out_gt_labels{i}'))
+        close(app[i], g[f'out_pseudo_points{i}'], rtol=1e-6, atol=1e-4)
+        assert torch.equal(apl[i].cpu(), g.t(f'out_pseudo_labels{i}'))
+        close(apb[i], g[f'out_pseudo_bboxes{i}'], rtol=1e-6, atol=1e-4)
+    # the masked (sync-free) form the training loop uses keeps every row and flags the reference's survivors
+    out = strong_augmentation_masked(img, gp, gl, pp, [l.clone() for l in gl], pb, params=params)
+    for i in range(B):
+        assert int(out[7][i].sum()) == g[f'out_gt_points{i}'].shape[0]
+        assert int(out[8][i].sum()) == g[f'out_pseudo_bboxes{i}'].shape[0]
+        close(out[2][i][out[7][i]], g[f'out_gt_points{i}'], rtol=1e-6, atol=1e-4)
+        close(out[6][i][out[8][i]], g[f'out_pseudo_bboxes{i}'], rtol=1e-6, atol=1e-4)
+
+
+def test_random_point_in_quadrilateral_vs_reference():
+    """data_augument_bank.py:1471-1493 with the two torch.rand draws injected (position = `_point_` of the 0/30/100 % configs)."""
+    from point_teacher_amd.proposals import random_point_in_quadrilateral
+    g = load_golden('bbox_math')
+    a, u = g.t('in_a').to(DEV), g.t('in_u').to(DEV)
+    for pos in (0.0, 0.3, 1.0):
+        close(random_point_in_quadrilateral(a, pos, u[0], u[1]), g[f'out_rpq_{int(pos * 100)}'], rtol=1e-6, atol=1e-5)
+
+
+def test_update_points_lamda_half_vs_reference_iteration():
+    """fcos_p2b_teacher_student.py:266-274 with lamda = 0.5 (30/60/100 % configs): the refined point is ALWAYS blended
+    with the first-visit point `gt_bboxes_point`, never with the previous refinement.  Checked on the product's method
+    with the stored points of the reference's two-iteration run (tests/golden/ref_iter_p100.npz): feeding iteration 1's
+    stored result back through `update_points` with the pseudo centres implied by it reproduces it, and blending with
+    the previous refinement instead would not."""
+    import point_teacher_amd as pta
+    G = load_golden('ref_iter_p100')
+    cfg = pta.Config.fromfile(os.path.join(ROOT, 'point_teacher_amd', 'configs', 'point_teacher', 'aitodv2_point_teacher_100.py'))
+    assert cfg.model['lamda'] == 0.5 and cfg.model['_point_'] == 1.0
+    from point_teacher_amd.proposals import random_point_in_quadrilateral
+    det = pta.registry.DETECTORS.get('TS_P2B_FCOS')
+    m = det.__new__(det)                       # the method under test reads only these attributes
+    m.lamda, m.gt_bboxes_point, m.refined_gt_bboxes_point = 0.5, {}, {}
+    metas = [dict(ori_filename=f'g{i}.png') for i in range(2)]
+    boxes = [G.t(f'in_gt_bboxes{i}').to(DEV) for i in range(2)]
+    for i in range(2):
+        u = G.t(f'it0_draw_point_u{i}').to(DEV)
+        m.gt_bboxes_point[f'g{i}.png'] = random_point_in_quadrilateral(boxes[i], 1.0, u[0], u[1])
+    for it in range(2):
+        stored = [G.t(f'it{it}_out_points{i}').to(DEV) for i in range(2)]
+        centres = [2 * s - m.gt_bboxes_point[f'g{i}.png'] for i, s in enumerate(stored)]      # invert the blend
+        pseudo = [torch.cat([c - 3, c + 3], 1) for c in centres]
+        out = det.update_points(m, 2, metas, pseudo)
+        for i in range(2):
+            close(out[i], stored[i], rtol=1e-6, atol=1e-4)
+            close(m.refined_gt_bboxes_point[f'g{i}.png'], stored[i], rtol=1e-6, atol=1e-4)
+    moved = max(float((G.t(f'it1_out_points{i}') - G.t(f'it0_out_points{i}')).abs().max()) for i in range(2))
+    assert moved > 0.05       # the two iterations really refined to different places

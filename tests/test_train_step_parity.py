@@ -1,7 +1,8 @@
 """Whole-iteration parity on the GPU: the product's `TS_P2B_FCOS.train_step` (HIP kernels +
 MIOpen convs) against the CPU oracle `oracle/ref_model.py` on the SAME weights, inputs and
 injected random draws.  Every entry of the loss dict within 1e-3 relative (north_star),
-gradients of representative parameters by cosine similarity."""
+gradients of representative parameters within 1e-3 of the gradient's norm, in BOTH phases.
+(The oracle's whole iteration is itself pinned to the reference: tests/test_reference_iteration.py.)"""
 import os
 
 import numpy as np
@@ -23,8 +24,24 @@ def _build(dev, phase2):
     cfg.model['burn_in_step'] = -1 if phase2 else 10 ** 9
     model = pta.build_detector(cfg.model).to(dev)
     benchmark_init_(model, phase2=True)
+    with torch.no_grad():      # moderate bag logits, as in a trained head (oracle/ref_model.damp_mil_logits explains why)
+        for det in (model.student, model.teacher):
+            for m in list(det.bbox_head.fc_cls) + list(det.bbox_head.fc_ins):
+                m.weight.mul_(0.1); m.bias.mul_(0.1)
     model.train()
     return pta, cfg, model
+
+
+def _syn_draws(G, seed, n_prior=6):
+    """Per-object draws of the step-1 rectangle generator (TS_P2B_FCOS._inject['syn'][i] / ref_ops.generate_black_paper)."""
+    g = torch.Generator().manual_seed(seed)
+    d = dict(cls=torch.randint(0, n_prior, (G,), generator=g))
+    for n in ('scale', 'x', 'y', 'a', 'boost', 'itv', 'dev'):
+        d[n] = torch.rand(G, generator=g)
+    for n in ('wn', 'rn'):
+        d[n] = torch.randn(G, generator=g)
+    d['itv2'] = d['itv']
+    return d
 
 
 def _data(dev, size=256, n_obj=(23, 17), seed=5):
@@ -53,9 +70,19 @@ def _check(losses_gpu, losses_ref, keys=None):
         assert abs(a - b) <= 1e-3 * max(abs(b), 1e-2) + 1e-5, (k, a, b)
 
 
-def _cos(a, b):
+def _rel(a, b):
+    """|a - b| / |b| over the whole tensor (an element-wise relative test is meaningless for entries that cancel to ~0)."""
     a, b = a.double().reshape(-1), b.double().reshape(-1)
-    return float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _check_grads(model, ref_loss, params, tol=1e-3):
+    gr = torch.autograd.grad(ref_loss, [params[k] for k in GRAD_KEYS])
+    gs = dict(model.student.named_parameters())
+    errs = {k: _rel(gs[k].grad.cpu(), gref) for k, gref in zip(GRAD_KEYS, gr)}
+    print('gradient errors |g - g_ref| / |g_ref|:', {k: f'{v:.1e}' for k, v in errs.items()})
+    for k, e in errs.items():
+        assert e < tol, (k, e)
 
 
 GRAD_KEYS = ['bbox_head.conv_cls.weight', 'bbox_head.conv_reg.weight', 'bbox_head.reg_convs.3.conv.weight',
@@ -92,30 +119,25 @@ def test_step2_loss_dict_and_grads():
     t_gpu = _strip(model.state_dict(), 'teacher.')
     for k in ('bbox_head.conv_cls.weight', 'backbone.layer3.1.conv2.weight', 'backbone.bn1.weight'):
         torch.testing.assert_close(t_gpu[k], sd_t[k], rtol=1e-6, atol=1e-7)
-    names = [k for k in GRAD_KEYS]
-    gr = torch.autograd.grad(ref['loss'], [params[k] for k in names])
-    gs = dict(model.student.named_parameters())
-    for k, gref in zip(names, gr):
-        c = _cos(gs[k].grad.cpu(), gref)
-        assert c > 0.999, (k, c)
-        ratio = float(gs[k].grad.cpu().norm() / (gref.norm() + 1e-30))
-        assert abs(ratio - 1) < 2e-2, (k, ratio)
+    _check_grads(model, ref['loss'], params)
     for n, p in model.teacher.named_parameters():
         assert p.grad is None, n                                     # the teacher never receives gradients
 
 
-def test_step1_loss_dict():
+def test_step1_loss_dict_and_grads():
+    """Burn-in step 1.  Product and oracle each run their OWN rectangle generator on the same injected draws
+    (nothing the HIP path produced is handed to the oracle); loss dict 1e-3, gradients 1e-3 of their norm."""
     dev = torch.device('cuda:0')
     pta, cfg, model = _build(dev, phase2=False)
     img, boxes, labels, metas = _data(dev, seed=6)
     g = torch.Generator().manual_seed(12)
     neg_u = torch.rand(2, 4, 200, generator=g)
     aug = (['vertical', 'None'], [1.2, 0.8])
-    model._inject = dict(neg0=neg_u.to(dev), aug=aug)
+    syn = [_syn_draws(b.shape[0], 40 + i) for i, b in enumerate(boxes)]
+    model._inject = dict(neg0=neg_u.to(dev), aug=aug, syn=[{k: v.to(dev) for k, v in d.items()} for d in syn])
     sd_s0 = _strip(model.state_dict(), 'student.')
     sd_t0 = _strip(model.state_dict(), 'teacher.')
     data = dict(img=img.to(dev), img_metas=metas, gt_bboxes=[b.to(dev) for b in boxes], gt_labels=[l.to(dev) for l in labels])
-    # capture what the GPU generator produced so the oracle sees the same synthetic images/boxes
     captured = {}
     orig = model.genrate_syn
 
@@ -125,20 +147,23 @@ def test_step1_loss_dict():
         return r
     model.genrate_syn = spy
     out = model.train_step(data, None)
+    out['loss'].backward()
     lv = out['log_vars'].materialize()
-    n = cfg.model['num_training_burninstep1']
-    syn = [b[a].cpu() for b, a in zip(captured['boxes'], captured['alive'])]
-    assert all(0 < s.shape[0] for s in syn)
-    # the white rectangles really are in the image
-    assert float((captured['img_syn'] == 255).float().mean()) > float((data['img'] == 255).float().mean())
     params = {k: (v.clone().requires_grad_(True) if M.trainable(k) else v) for k, v in sd_s0.items()}
     sd_t = M.ema(sd_t0, sd_s0)
     gp = [R.bbox_xyxy_to_cxcywh(b)[:, :2] for b in boxes]
-    ref, _ = M.forward_train_step1(params, sd_t, img, boxes, labels, gp, dict(M.MODEL_CFG),
-                                   dict(neg0=neg_u, aug=aug, img_syn=captured['img_syn'].cpu(), syn_boxes=syn))
+    ref, _ = M.forward_train_step1(params, sd_t, img, boxes, labels, gp, dict(M.MODEL_CFG), dict(neg0=neg_u, aug=aug, syn=syn))
     ref['loss'] = M.total_loss(ref)
+    # the generator itself: same survivors in the same order, same hulls, same painted pixels
+    prior = torch.tensor(M.SHAPE_LIST)
+    for i in range(2):
+        img_syn, hull, _, _ = R.generate_black_paper(img[i], boxes[i], prior, syn[i])
+        assert hull.shape[0] > 0
+        torch.testing.assert_close(captured['boxes'][i][captured['alive'][i]].cpu(), hull, rtol=1e-5, atol=1e-3)
+        assert torch.equal(captured['img_syn'][i].cpu(), img_syn)
     assert set(ref.keys()) == set(lv.keys()), set(ref.keys()) ^ set(lv.keys())
     _check(lv, ref)
+    _check_grads(model, ref['loss'], params)
 
 
 def test_teacher_bn_affine_follows_ema():
