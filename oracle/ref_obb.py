@@ -228,17 +228,29 @@ def mil_bag_select_obb(cls, ins, valid, labels, bags5, pseudo5, img_hw, topk=3, 
     return (1 - beta) * b + beta * pseudo5
 
 
-def mil_select_gap(cls, ins, valid, labels, topk=3):
-    """Relative gap between the last selected and the first rejected bag score of every gt.  A gap
-    below the fp32 noise of the 12544-long FC dot products (~1e-4) means the reference's own
-    `topk` pick is decided by rounding: tests use this to mark such rows as ambiguous."""
+def mil_select_margin(cls, ins, valid, labels, bags5, topk=3):
+    """How far every gt's selection is from being decided by rounding.  Returns (gap [N], shift [N]): `gap` = relative
+    distance between the last selected and the first rejected bag score; `shift` = how far (px / rad, max over the five
+    columns) the weighted-mean box would move if those two swapped.  A row is ROUNDING-SENSITIVE when gap is below the
+    fp32 noise of the 12544-long FC dot products (a few 1e-4 relative between two GEMM implementations) AND shift is
+    visible.  Rows whose rejected candidate has the same score because it is the same box, or a zero score because it
+    is an invalid proposal, have shift = 0 and are not sensitive.  Whole-iteration tests assert that their fixtures
+    contain NO sensitive row, so that every selection is independent evidence."""
     N, U1, U2, C = cls.shape
     v = valid.reshape(N, U1, U2, 1).to(cls.dtype)
     c = cls.detach().reshape(N, U1 * U2, C).sigmoid()
     i = F.normalize(ins.detach().softmax(2) * v, dim=2, p=1).reshape(N, U1 * U2, C)
     ar = torch.arange(N)
-    t = (c[ar, :, labels] * i[ar, :, labels]).topk(topk + 1, dim=1)[0]
-    return (t[:, topk - 1] - t[:, topk]) / t[:, topk - 1].clamp(min=1e-20)
+    t, idx = (c[ar, :, labels] * i[ar, :, labels]).topk(topk + 1, dim=1)
+    gap = (t[:, topk - 1] - t[:, topk]) / t[:, topk - 1].clamp(min=1e-20)
+    fb = bags5.reshape(N, U1 * U2, 5)
+
+    def mean_box(sel_t, sel_i):
+        w = sel_t / (sel_t.sum(1, keepdim=True) + 1e-8)
+        return (fb[ar[:, None], sel_i] * w[..., None]).sum(1)
+    keep = list(range(topk - 1)) + [topk]
+    shift = (mean_box(t[:, :topk], idx[:, :topk]) - mean_box(t[:, keep], idx[:, keep])).abs().max(1)[0]
+    return gap, shift
 
 
 def mil_bag_loss_obb(cls, ins, valid, labels, neg_cls, neg_w):
@@ -436,13 +448,10 @@ def _rra(feat, rois):
     return R.roi_align_rotated(feat, rois, 7, 1.0 / STRIDE, 2, True, True)
 
 
-def mil_stage_obb(sd, feat, stage, cfg, ext_cfg, pb_t, gb_t, pl_t, img_hw, neg_u, alpha, topk, beta, syn=None, hint=None,
-                  stats=None):
+def mil_stage_obb(sd, feat, stage, cfg, ext_cfg, pb_t, gb_t, pl_t, img_hw, neg_u, alpha, topk, beta, syn=None, stats=None):
     """One MIL stage (detectors/rotated_fcos_teacher_student.py:473-506 + dense_heads :1285-1448).
-    `hint` [N,5] (optional): merged boxes from the implementation under test; rows whose top-k pick is
-    numerically ambiguous (mil_select_gap < 2e-3) take the hint's row so that one rounding-decided
-    pick does not fan out into every later entry of the loss dict.  Unambiguous rows never read it.
-    `stats` (dict) receives the number of ambiguous rows."""
+    `stats` (dict, optional) receives the oracle's own merged boxes and the rounding margins of the selection
+    (mil_select_margin)."""
     losses = {}
     B = len(pb_t)
     U1 = len(cfg['base_ratios']) ** 2 * (1 + 4 * len(cfg['shake_ratio'] or []))
@@ -482,13 +491,9 @@ def mil_stage_obb(sd, feat, stage, cfg, ext_cfg, pb_t, gb_t, pl_t, img_hw, neg_u
     losses[f'stage{stage}_loss_mil_bags'] = mil_bag_loss_obb(cls, ins, valid[:, None], labels, ncls,
                                                              torch.cat([n[1] for n in negs])) * alpha[1]
     merged = mil_bag_select_obb(cls, ins, valid[:, None], labels, refined, torch.cat(pb_t), img_hw, topk, beta)
-    if hint is not None:
-        amb = mil_select_gap(cls, ins, valid[:, None], labels, topk) < 2e-3
-        if stats is not None:
-            stats[f'ambiguous{stage}'] = (int(amb.sum()), int(amb.numel()))
-            stats[f'own{stage}'] = merged.clone()
-            stats[f'amb_mask{stage}'] = amb
-        merged = torch.where(amb[:, None], hint, merged)
+    if stats is not None:
+        stats[f'merged{stage}'] = merged.clone()
+        stats[f'gap{stage}'], stats[f'shift{stage}'] = mil_select_margin(cls, ins, valid[:, None], labels, refined, topk)
     return losses, list(torch.split(merged, [b.shape[0] for b in pb_t]))
 
 
@@ -516,7 +521,7 @@ def _points_distance(new_points, gt_bboxes):
 
 def forward_train_step2(sd_s, sd_t, img, gt_bboxes, gt_labels, gt_points, cfg, inject):
     """detectors/rotated_fcos_teacher_student.py:207-252.  inject: neg0 [B,5,n], aug=(flips, angles, scales);
-    optional mil_hint0 / stats, see mil_stage_obb."""
+    optional `stats`, see mil_stage_obb."""
     B, _, H, W = img.shape
     pts = M.grid_points(H // STRIDE, W // STRIDE)
     losses = {}
@@ -529,7 +534,7 @@ def forward_train_step2(sd_s, sd_t, img, gt_bboxes, gt_labels, gt_points, cfg, i
     for stage in range(cfg['num_stages']):
         ml, pb_t = mil_stage_obb(sd_s, feat, stage, cfg['fine_proposal_cfg'][stage], cfg['fine_proposal_extensive_cfg'][stage],
                                  pb_t, gb_t, pl_t, (H, W), inject[f'neg{stage}'], cfg['alpha'], cfg['top_k'], cfg['beta'],
-                                 hint=inject.get(f'mil_hint{stage}'), stats=inject.get('stats'))
+                                 stats=inject.get('stats'))
         losses[f'stage{stage}_refine_bboxes_iou'] = R.box_iou_rotated(torch.cat(pb_t), torch.cat(gb_t), aligned=True).mean()
         losses.update(ml)
     pb_r, pp_r = [b.clone() for b in pb_c], [p.clone() for p in pp_c]
@@ -545,12 +550,18 @@ def forward_train_step2(sd_s, sd_t, img, gt_bboxes, gt_labels, gt_points, cfg, i
 
 
 def forward_train_step1(sd_s, sd_t, img, gt_bboxes, gt_labels, gt_points, cfg, inject):
-    """detectors/rotated_fcos_teacher_student.py:149-205; the synthetic image / boxes are inputs
-    (inject['img_syn'], inject['syn_boxes'] [n_i,5]) - the rasteriser is parity-unpinned."""
+    """detectors/rotated_fcos_teacher_student.py:149-205; the synthetic image / boxes are generated from
+    inject['syn'] (per-image draw dictionaries, ref_ops.generate_black_paper(oriented=True)) or given as inputs
+    (inject['img_syn'], inject['syn_boxes'] [n_i,5])."""
     B, _, H, W = img.shape
     pts = M.grid_points(H // STRIDE, W // STRIDE)
     losses = {}
-    img_syn, syn_boxes = inject['img_syn'], inject['syn_boxes']
+    if 'syn' in inject:
+        prior = torch.tensor(cfg['shape_list'], dtype=torch.float32)
+        gen = [R.generate_black_paper(img[i], gt_bboxes[i], prior, inject['syn'][i], oriented=True) for i in range(B)]
+        img_syn, syn_boxes = torch.stack([g[0] for g in gen]), [g[1] for g in gen]
+    else:
+        img_syn, syn_boxes = inject['img_syn'], inject['syn_boxes']
     feat_all = extract_feat(sd_s, torch.cat([img_syn, img]))
     feat_syn, feat_ori = feat_all[:B], feat_all[B:]
     _, reg_s, ang_s, ctr_s = head_forward_obb(sd_s, feat_syn)
@@ -565,7 +576,7 @@ def forward_train_step1(sd_s, sd_t, img, gt_bboxes, gt_labels, gt_points, cfg, i
         ml, pb_t = mil_stage_obb(sd_s, feat_ori, stage, cfg['fine_proposal_cfg'][stage],
                                  cfg['fine_proposal_extensive_cfg'][stage], pb_t, gb_t, pl_t, (H, W), inject[f'neg{stage}'],
                                  cfg['alpha'], cfg['top_k'], cfg['beta'], syn=(feat_syn, syn_t),
-                                 hint=inject.get(f'mil_hint{stage}'), stats=inject.get('stats'))
+                                 stats=inject.get('stats'))
         losses[f'stage{stage}_refine_bboxes_iou'] = R.box_iou_rotated(torch.cat(pb_t), torch.cat(gb_t), aligned=True).mean()
         losses.update(ml)
     new_points = [(1 - cfg['lamda']) * pb_c[i][:, :2] + cfg['lamda'] * gt_points[i] for i in range(B)]
@@ -577,5 +588,7 @@ def forward_train_step1(sd_s, sd_t, img, gt_bboxes, gt_labels, gt_points, cfg, i
 
 MODEL_CFG = dict(num_stages=1, num_training_burninstep1=100, num_training_burninstep2=100, lamda=1.0, alpha=[0.01, 0.25],
                  top_k=3, beta=0.25,
+                 shape_list=[[20, 20, 0.5, 0.5], [10, 20, 0.5, 0.5], [10, 30, 0.5, 0.5], [40, 20, 0.5, 0.5], [30, 10, 0.5, 0.5],
+                             [20, 50, 0.5, 0.5], [30, 20, 0.5, 0.5], [35, 40, 0.6, 0.5]],   # sodaa_fcos_pointteacher_1x.py:22-24
                  fine_proposal_cfg=[dict(base_ratios=[1.0], shake_ratio=None, min_scale=0)],
                  fine_proposal_extensive_cfg=[dict(base_ratios=[1.0, 1.2, 1.3, 0.8, 0.6], shake_ratio=None, min_scale=4)])

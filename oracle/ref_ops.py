@@ -804,7 +804,7 @@ def fill_convex_quads(polys_int, H, W):
     return mask
 
 
-def generate_black_paper(img, gt_bboxes, prior_size, draws, imgsize=None):
+def generate_black_paper(img, gt_bboxes, prior_size, draws, imgsize=None, oriented=False):
     """Burn-in step 1 "white rectangle" generator for ONE image: detectors/fcos_p2b_teacher_student.py:469-502
     (`genrate_syn.synthesis_single`) around detectors/syn_images_generator_v2.py:591-690 (`generate_black_paper`),
     with every random draw supplied in `draws` (per-object arrays: `cls` = the torch.randint prior index :473,
@@ -813,14 +813,19 @@ def generate_black_paper(img, gt_bboxes, prior_size, draws, imgsize=None):
 
     Returns (img_syn [C,H,W], hull boxes xyxy [M,4] in the reference's `bb[keep]` order, keep indices into
     [real objects | candidate rectangles], mask [H,W] uint8).  Restated one object at a time, python floats
-    rounded through float32 tensors exactly where the reference holds tensors."""
+    rounded through float32 tensors exactly where the reference holds tensors.
+
+    oriented=True: the OBB twin (OBB_TOD/mmrotate/models/detectors/rotated_fcos_teacher_student.py:391-414 around
+    OBB_TOD/.../syn_images_generator_v2.py generate_black_paper, identical up to its last statement): `gt_bboxes` are
+    (cx,cy,w,h,a) rows of which only the centre is read, the rectangles are painted with the IMAGE MAXIMUM and returned
+    as (cx,cy,w,h,a) rows instead of their hulls."""
     C, H, W = img.shape
     imgsize = min(H, W) if imgsize is None else imgsize
     prior = prior_size.float()
     n_dense = int(prior.shape[0] / 2)                                   # dense_cls = range(len(pattern)/2), :483
     G = gt_bboxes.shape[0]
     f32 = torch.float32
-    cxcy = bbox_xyxy_to_cxcywh(gt_bboxes.float())
+    cxcy = gt_bboxes.float() if oriented else bbox_xyxy_to_cxcywh(gt_bboxes.float())
     rows = []                                                           # candidate rectangles [x,y,w,h,a,score]
     adj = 2
     lo, hi = 50.0, float(imgsize - 50)
@@ -862,7 +867,9 @@ def generate_black_paper(img, gt_bboxes, prior_size, draws, imgsize=None):
     polys = obb2poly_le90(bb[:, :5])
     mask = fill_convex_quads(polys.numpy().astype(np.int32), H, W)       # cv2.fillPoly on int32-truncated corners, :678-683
     img_syn = img.clone()
-    img_syn[:, torch.from_numpy(mask) == 1] = 255                        # :686-688
+    img_syn[:, torch.from_numpy(mask) == 1] = img.max() if oriented else 255          # :686-688
+    if oriented:
+        return img_syn, bb[:, :5], keep, mask
     px, py = polys[:, 0::2], polys[:, 1::2]
     hull = torch.stack([px.min(1)[0], py.min(1)[0], px.max(1)[0], py.max(1)[0]], 1) if bb.shape[0] else bb.new_zeros((0, 4))
     return img_syn, hull, keep, mask

@@ -257,8 +257,18 @@ def _build(dev, phase2):
                 fc.bias.zero_()
             m.bbox_head.conv_reg.bias.fill_(1.0)
             m.bbox_head.conv_angle.bias.fill_(0.2)
+            # Trained-like bag scores: at random initialisation the class logits of a bag share one large offset (std 12
+            # over the batch: every sigmoid saturated) and differ by only 0.3 inside a bag, so the top-3 of 25 would be
+            # decided by rounding.  Damp the class logits, spread the instance logits (their softmax runs over the bag).
+            for fc in m.bbox_head.fc_cls:
+                fc.weight.mul_(0.1); fc.bias.mul_(0.1)
+            for fc in m.bbox_head.fc_ins:
+                fc.weight.mul_(10.0)
     model.train()
     return pta, cfg, model
+
+
+STEP2_SEED, STEP1_SEED = 5, 6      # data seeds without a rounding-decided bag selection (see _check_selection)
 
 
 def _data(size=256, n_obj=(21, 15), seed=5):
@@ -282,7 +292,7 @@ def _check(losses_gpu, losses_ref):
 
 
 def _spy_selection(model, cap):
-    """Record the merged boxes of every MIL stage (the tie-break hint of ref_obb.mil_stage_obb)."""
+    """Record the merged boxes of every MIL stage."""
     head = model.student.bbox_head
     orig = head.mil_bag_selection
 
@@ -293,21 +303,39 @@ def _spy_selection(model, cap):
     head.mil_bag_selection = spy
 
 
+NOISE = 2e-3          # relative score gap below which two GEMM implementations may order two bag scores differently
+
+
 def _check_selection(cap, stats, stage=0):
-    """Rows the oracle calls unambiguous must agree with the HIP selection on their own; at random
-    initialisation the 25 bag scores of a gt are nearly uniform, so a few rows are decided by fp32
-    rounding in the reference too - those are the only ones allowed to take the hint."""
-    n_amb, n = stats[f'ambiguous{stage}']
-    assert n_amb <= 0.35 * n, (n_amb, n)
-    own, amb = stats[f'own{stage}'], stats[f'amb_mask{stage}']
-    close(cap['merged'][stage][~amb], own[~amb], atol=2e-3)
+    """With `top_k = 3` the selection takes the 3 best of 25 bag scores.  The fixtures of these tests (seeds, damped /
+    spread logits in `_build`) are chosen so that NO gt's pick is decided by rounding: for every row either the gap
+    between the last selected and the first rejected score is above NOISE, or swapping the two would not move the box
+    (ref_obb.mil_select_margin).  So every row of the HIP selection must equal the oracle's OWN selection - nothing of
+    the implementation under test is handed to the oracle."""
+    gap, shift = stats[f'gap{stage}'], stats[f'shift{stage}']
+    sensitive = (gap < NOISE) & (shift > 1e-3)
+    assert int(sensitive.sum()) == 0, (gap[sensitive], shift[sensitive])
+    close(cap['merged'][stage], stats[f'merged{stage}'], atol=2e-3)
 
 
-def _cos(a, b):
+def _rel(a, b):
     a, b = a.double().reshape(-1), b.double().reshape(-1)
-    return float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+    return float((a - b).norm() / (b.norm() + 1e-30))
 
 
+def _syn_draws(G, seed, n_prior=8):
+    """Per-object draws of the step-1 rectangle generator (RotatedFCOS_TS._inject['syn'][i] / ref_ops.generate_black_paper)."""
+    g = torch.Generator().manual_seed(seed)
+    d = dict(cls=torch.randint(0, n_prior, (G,), generator=g))
+    for n in ('scale', 'x', 'y', 'a', 'boost', 'itv', 'dev'):
+        d[n] = torch.rand(G, generator=g)
+    for n in ('wn', 'rn'):
+        d[n] = torch.randn(G, generator=g)
+    d['itv2'] = d['itv']
+    return d
+
+
+GRAD_TOL = 3e-3       # see tests/test_reference_iteration.py GRAD_TOL: the fp32 conditioning of the reference's own iteration
 GRAD_KEYS = ['bbox_head.conv_cls.weight', 'bbox_head.conv_reg.weight', 'bbox_head.conv_angle.weight',
              'bbox_head.reg_convs.3.conv.weight', 'bbox_head.reg_convs.0.gn.weight', 'bbox_head.fc_cls.0.weight',
              'bbox_head.fc_ins.0.weight', 'bbox_head.fc_reg.0.weight', 'bbox_head.shared_fcs_bag.0.1.weight',
@@ -318,7 +346,7 @@ GRAD_KEYS = ['bbox_head.conv_cls.weight', 'bbox_head.conv_reg.weight', 'bbox_hea
 def test_obb_step2_loss_dict_and_grads():
     dev = torch.device('cuda:0')
     pta, cfg, model = _build(dev, phase2=True)
-    img, boxes, labels, metas = _data()
+    img, boxes, labels, metas = _data(seed=STEP2_SEED)
     g = torch.Generator().manual_seed(11)
     neg_u = torch.rand(2, 5, 200, generator=g)
     aug = (['horizontal', 'None'], [5, 13], [0.9, 1.1])
@@ -336,18 +364,17 @@ def test_obb_step2_loss_dict_and_grads():
     sd_t = M.ema(sd_t0, sd_s0)
     gp = [b[:, :2] for b in boxes]                                  # _point_ = 'center'
     ref, _ = O.forward_train_step2(params, sd_t, img, boxes, labels, gp, dict(O.MODEL_CFG),
-                                   dict(neg0=neg_u, aug=aug, mil_hint0=cap['merged'][0], stats=stats))
+                                   dict(neg0=neg_u, aug=aug, stats=stats))
     ref['loss'] = M.total_loss(ref)
     assert set(ref.keys()) == set(lv.keys()), set(ref.keys()) ^ set(lv.keys())
     _check_selection(cap, stats)
     _check(lv, ref)
     gr = torch.autograd.grad(ref['loss'], [params[k] for k in GRAD_KEYS])
     gs = dict(model.student.named_parameters())
-    for k, gref in zip(GRAD_KEYS, gr):
-        c = _cos(gs[k].grad.cpu(), gref)
-        assert c > 0.999, (k, c)
-        ratio = float(gs[k].grad.cpu().norm() / (gref.norm() + 1e-30))
-        assert abs(ratio - 1) < 2e-2, (k, ratio)
+    errs = {k: _rel(gs[k].grad.cpu(), gref) for k, gref in zip(GRAD_KEYS, gr)}
+    print('gradient errors |g - g_ref| / |g_ref|:', {k: f'{v:.1e}' for k, v in errs.items()})
+    for k, e in errs.items():
+        assert e < GRAD_TOL, (k, e)
     for n, p in model.teacher.named_parameters():
         assert p.grad is None, n
     # frozen stem / layer1 (frozen_stages=1) receive nothing, trainable BN affine does
@@ -356,13 +383,16 @@ def test_obb_step2_loss_dict_and_grads():
 
 
 def test_obb_step1_loss_dict():
+    """Burn-in step 1 of the oriented variant.  Product and oracle run their OWN rectangle generators on the same injected
+    draws and their own bag selections; nothing the HIP path produced is handed to the oracle."""
     dev = torch.device('cuda:0')
     pta, cfg, model = _build(dev, phase2=False)
-    img, boxes, labels, metas = _data(seed=6)
+    img, boxes, labels, metas = _data(seed=STEP1_SEED)
     g = torch.Generator().manual_seed(12)
     neg_u = torch.rand(2, 5, 200, generator=g)
     aug = (['vertical', 'diagonal'], [3, 17], [1.2, 0.8])
-    model._inject = dict(neg0=neg_u.to(dev), aug=aug)
+    syn = [_syn_draws(b.shape[0], 60 + i) for i, b in enumerate(boxes)]
+    model._inject = dict(neg0=neg_u.to(dev), aug=aug, syn=[{k: v.to(dev) for k, v in d.items()} for d in syn])
     sd_s0 = _strip(model.state_dict(), 'student.')
     sd_t0 = _strip(model.state_dict(), 'teacher.')
     data = dict(img=img.to(dev), img_metas=metas, gt_bboxes=[b.to(dev) for b in boxes], gt_labels=[l.to(dev) for l in labels])
@@ -378,20 +408,20 @@ def test_obb_step1_loss_dict():
     _spy_selection(model, cap)
     out = model.train_step(data, None)
     lv = out['log_vars'].materialize()
-    syn = [b[a].cpu() for b, a in zip(captured['boxes'], captured['alive'])]
-    assert all(0 < s.shape[0] and s.shape[1] == 5 for s in syn)
-    # the rectangles are painted with the image maximum (syn_images_generator_v2.py:722)
-    for i in range(2):
-        mx = float(img[i].max())
-        assert float(captured['img_syn'][i].max()) == mx
-        assert float((captured['img_syn'][i] == mx).float().mean()) > 10 * float((img[i] == mx).float().mean())
     params = {k: (v.clone().requires_grad_(True) if O.trainable_obb(k) else v) for k, v in sd_s0.items()}
     sd_t = M.ema(sd_t0, sd_s0)
     gp = [b[:, :2] for b in boxes]
     ref, _ = O.forward_train_step1(params, sd_t, img, boxes, labels, gp, dict(O.MODEL_CFG),
-                                   dict(neg0=neg_u, aug=aug, img_syn=captured['img_syn'].cpu(), syn_boxes=syn,
-                                        mil_hint0=cap['merged'][0], stats=stats))
+                                   dict(neg0=neg_u, aug=aug, syn=syn, stats=stats))
     ref['loss'] = M.total_loss(ref)
+    # the generator: same survivors in the same order, painted with the image maximum (syn_images_generator_v2.py:722)
+    prior = torch.tensor(O.MODEL_CFG['shape_list'])
+    for i in range(2):
+        img_syn, obb5, _, _ = R.generate_black_paper(img[i], boxes[i], prior, syn[i], oriented=True)
+        assert obb5.shape[0] > 0
+        close(captured['boxes'][i][captured['alive'][i]], obb5, rtol=1e-5, atol=1e-3)
+        assert torch.equal(captured['img_syn'][i].cpu(), img_syn)
+        assert float(img_syn.max()) == float(img[i].max())
     assert set(ref.keys()) == set(lv.keys()), set(ref.keys()) ^ set(lv.keys())
     _check_selection(cap, stats)
     _check(lv, ref)

@@ -7,7 +7,7 @@ and the three absent mmcv / cv2 ops that were bound to the oracle).
   whole iteration (generator, MIL stage, point update, augmentation, losses) is PINNED, not only its pieces.
 * GPU (`-m gpu`): the product (HIP kernels + MIOpen) reproduces the same golden from the same seeds and draws:
   every entry of the loss dict within 1e-3 relative (north_star), the stored points within 1e-3 px, the synthetic
-  rectangles' keep-set bit for bit, gradients within 1e-3 of the gradient norm.
+  rectangles' keep-set bit for bit, gradients within GRAD_TOL (3e-3, see there) of the gradient norm.
 
 Configs: 0 % (centre points, U1 = 1, U2 = 25, lamda 1) and 100 % (random points, U1 = 9, U2 = 45 with shake,
 lamda 0.5: `update_points` moves the points between the two iterations)."""
@@ -29,6 +29,12 @@ GRAD_KEYS = ['bbox_head.conv_cls.weight', 'bbox_head.conv_reg.weight', 'bbox_hea
              'neck_agg.lateral_convs.4.conv.weight', 'neck.fpn_convs.0.conv.weight', 'neck.lateral_convs.2.conv.bias',
              'backbone.layer4.2.conv3.weight', 'backbone.layer3.0.downsample.0.weight', 'backbone.layer2.0.conv1.weight']
 CAP = 4096        # oracle/gen_golden_iter.py grad_sample
+# Gradient tolerance of the GPU test, |g - g_ref| / |g_ref| per tensor.  The reference's OWN fp32 arithmetic is not better
+# conditioned than this: the same oracle iteration evaluated in float64 instead of float32 (CPU, 100 % config, step 1)
+# moves these gradients by 8e-4 ... 1.9e-3 (neck / backbone) and one tower gradient by 1.7e-2, while every loss value
+# moves by < 3e-6 - strong_augmentation rounds a bilinear resize of integer pixels (`torch.round`, :111), many values sit
+# exactly on x.5 and one ulp decides the grey level.  Measured on MI355X vs the golden: 3e-7 ... 1.1e-3.
+GRAD_TOL = 3e-3
 
 
 def _cfg(percent):
@@ -188,7 +194,7 @@ def test_product_iteration_vs_reference(percent):
             torch.testing.assert_close(model.refined_gt_bboxes_point[metas[i]['ori_filename']].cpu(),
                                        G.t(f'it{it}_out_points{i}'), rtol=1e-5, atol=1e-3)
         grads = {k: p.grad for k, p in model.student.named_parameters() if k in GRAD_KEYS}
-        report[it] = _check_grads(grads, G, it, rel=1e-3)
+        report[it] = _check_grads(grads, G, it, rel=GRAD_TOL)
         if it == 0:            # a20 through the product: alive set in the reference's order, hull boxes, painted pixels
             mask_ref = np.unpackbits(G['it0_out_syn_mask'], axis=-1)[:, :, :img.shape[-1]]
             for i, (im, hull, alive) in enumerate(seen['syn']):

@@ -260,6 +260,55 @@ def test_full_size_iteration_properties():
         torch.cuda.set_sync_debug_mode('default')
 
 
+@pytest.mark.parametrize('percent', [30, 100])
+def test_full_size_noisy_point_configs(percent):
+    """aitodv2_point_teacher_{30,100}% at BASELINE size (bs 2, 800x800, ~300 points/image): `_point_` > 0 (random initial
+    points), lamda 0.5, U1 = 9 coarse boxes x U2 = 45 shaken boxes per object -> K = 2 x 75 x 405 = 60 750 RoIs per
+    RoIAlign call, a 3.05 GB [K,256,7,7] block per branch (SURVEY section 7 "Memory at the 100 % config"; it simply
+    fits - 288 GB of HBM - so nothing is chunked).  Both phases: finite loss dict with the full key set, the RoI count
+    the reference would produce, points that move between visits (lamda 0.5), no host synchronisation."""
+    from point_teacher_amd.synthetic import SyntheticTiles, benchmark_init_
+    import point_teacher_amd as pta
+    dev = torch.device('cuda:0')
+    torch.manual_seed(7)
+    cfg = pta.Config.fromfile(os.path.join(ROOT, 'point_teacher_amd', 'configs', 'point_teacher', f'aitodv2_point_teacher_{percent}.py'))
+    assert cfg.model['lamda'] == 0.5 and cfg.model['_point_'] == percent / 100 and cfg.model['num_training_burninstep2'] == 75
+    cfg.model['burn_in_step'] = 1                                   # iterations 0, 1 = phase 1; 2, 3 = phase 2
+    model = pta.build_detector(cfg.model).to(dev)
+    benchmark_init_(model, phase2=True)
+    model.train()
+    trainer = pta.Trainer(model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config, channels_last=True)
+    data = SyntheticTiles(n=2, size=800, mean_objects=300, seed=2, device=dev)
+    ks = []
+    ext = model.student.bbox_head.bbox_roi_extractor
+    hook = ext.register_forward_hook(lambda m, i, o: ks.append(int(o.shape[0])))
+    torch.cuda.reset_peak_memory_stats()
+    keys = None
+    pts_seen = []
+    for it in range(4):
+        if it == 3:
+            torch.cuda.synchronize()
+            torch.cuda.set_sync_debug_mode('error')                  # a steady-state phase-2 iteration may not touch the host
+        try:
+            out = trainer.step(data.batch(0, 2))                     # the SAME two tiles every time: the point dictionaries are reused
+        finally:
+            torch.cuda.set_sync_debug_mode('default')
+        lv = out['log_vars'].materialize()
+        assert all(v == v and abs(v) != float('inf') for v in lv.values()), (it, lv)
+        keys = set(lv) if keys is None else keys
+        assert set(lv) == keys
+        pts_seen.append(torch.cat([v.clone() for _, v in sorted(model.refined_gt_bboxes_point.items())]))
+    hook.remove()
+    assert {'stage0_loss_mil_bbox', 'stage0_loss_mil_bags', 'loss_cls', 'loss_bbox', 'loss_centerness', 'refined_points_distance'} <= keys
+    U = 9 * 45
+    assert max(ks) == 2 * 75 * U, (max(ks), 2 * 75 * U)             # every real-bag RoIAlign call sees the whole 60 750-box batch
+    assert model.count == 4 and len(model.gt_bboxes_point) == 2
+    first = torch.cat([v for _, v in sorted(model.gt_bboxes_point.items())])
+    assert float((pts_seen[-1] - first).abs().max()) > 0.1           # lamda 0.5: refined points left the first-visit points ...
+    assert float((pts_seen[-1] - pts_seen[-2]).abs().max()) > 1e-3  # ... and keep following the teacher between visits
+    print(f'{percent} %: peak HBM {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB, RoIs per call {sorted(set(ks))}')
+
+
 def test_runner_checkpoint_resume(tmp_path):
     """runner.Runner: log lines, checkpoint and a resume that continues in the same phase with the same counters,
     point dictionaries, momentum and weights (the reference loses `count` and the dictionaries)."""
