@@ -127,18 +127,16 @@ int pt_delta2bbox_bwd(const float* rois, const float* deltas, const float* grad_
  * called fcos_head_p2b_ts.py:1202,1243,1268.  rois[K,5] = (batch, x1,y1,x2,y2).
  * feat is [B,C,H,W] when channels_last == 0 and [B,H,W,C] when 1 (same for grad_feat);
  * out / grad_out are always [K,C,out,out] (the layout the FC stack flattens).
- * bwd ACCUMULATES into grad_feat (zero it first).  `group` (>= 1) is a locality hint for
- * the channels_last kernels: that many CONSECUTIVE RoIs (the U1*U2 boxes of one MIL bag)
- * share a workgroup; bags whose taps fall on <= 5x5 feature pixels take a register-resident
- * fast path, the rest the generic kernel.  group_ws: K int32 of workspace (may be NULL:
- * generic kernel only).  Any group value gives the same result. */
+ * bwd ACCUMULATES into grad_feat (zero it first).  `group` (>= 1) says how many CONSECUTIVE RoIs belong together
+ * (the U2 shaken boxes of one MIL bag overlap): the channels_last out-7 kernels give a workgroup a run of such RoIs
+ * (the largest divisor of `group` up to 16); a run whose taps fall on <= 5x5 feature pixels is reduced in registers,
+ * any other RoI takes the separable path inside the same launch.  Any group value gives the same result. */
 int pt_roi_align_fwd(const float* feat, const float* rois, int B, int C, int H, int W, int K,
                      int out_size, float spatial_scale, int sampling_ratio, int aligned,
-                     int channels_last, int group, int32_t* group_ws, float* out, void* stream);
+                     int channels_last, int group, float* out, void* stream);
 int pt_roi_align_bwd(const float* grad_out, const float* rois, int B, int C, int H, int W, int K,
                      int out_size, float spatial_scale, int sampling_ratio, int aligned,
-                     int channels_last, int group, int32_t* group_ws, float* grad_feat,
-                     void* stream);
+                     int channels_last, int group, float* grad_feat, void* stream);
 
 /* ------------------------------------------------------------------ MIL bags --
  * fine_proposals_from_cfg (detectors/syn_images_generator_v2.py:262-324) for a batch:
@@ -396,6 +394,34 @@ int pt_max_iou_assign(const float* anchors, int A, const float* gt_boxes, const 
                       float pos_iou_thr, float neg_iou_lo, float neg_iou_hi, float min_pos_iou,
                       int match_low_quality, int gt_max_assign_all, float* max_overlaps,
                       int32_t* argmax_ws, uint64_t* gt_best_ws, int32_t* assigned_gt_inds, void* stream);
+
+/* ------------------------------------------------------------------ glue (csrc/glue.hip) --
+ * Fused replacements of launch-bound torch chains of the detector logic; no arithmetic beyond the cited lines.
+ * pt_box_convert: core/bbox/transforms.py:250-262 (mode 0, xyxy -> cxcywh) / :236-247 (mode 1); in / out [n,4]. */
+int pt_box_convert(const float* in, float* out, int n, int mode, void* stream);
+
+/* Geometry half of strong_augmentation (detectors/syn_images_generator_v2.py:41-92, :114-120) for all rows of a batch:
+ * in / out [N, ncoord] (ncoord 2 = points, 4 = boxes: corners re-ordered after the flips), images delimited by off[B+1];
+ * params [B,6] = (flip_x, flip_y, scale, margin_w, margin_h, scale >= 1) per image.  valid (uint8 [N], points only, may be
+ * NULL): the point stays inside the centre crop (:78-79, :84-85). */
+int pt_aug_geometry(const float* in, float* out, uint8_t* valid, const int32_t* off, int B, int N, int ncoord,
+                    const float* params, float H, float W, void* stream);
+
+/* Burn-in step 1, the candidate table of generate_black_paper (syn_images_generator_v2.py:597-663) for the whole batch.
+ * gt [sumG, gt_cols] xyxy boxes of the real objects (images delimited by goff[B+1]); prior [L,4] = shape_list;
+ * draws [10, sumG] = the reference's per-object draws (scale, x, y, wn, rn, a, boost, itv, itv2, dev); cls [sumG] the
+ * prior index of every object (:473).  Per image the table holds [G real objects | G rectangles | 2 x 5 adjacency copies]
+ * = 2 G + 10 rows (x, y, w, h, a, score), image b starting at row 2 goff[b] + 10 b.  exist: row is present; key: int64
+ * whose ascending stable sort orders the batch image-major by descending score (rows that do not exist last). */
+int pt_black_paper_rects(const float* gt, int gt_cols, const int32_t* goff, int B, const float* prior, int L, int dense_n,
+                         const float* draws, const int32_t* cls, int sumG, float imgsize, float* table, int64_t* key,
+                         uint8_t* exist, void* stream);
+
+/* Rows in sorted order (order [T] from the sort of `key`): sorted [T,6]; nms_in [T,5] (absent rows -> a far-away
+ * speck; input of pt_nms_rotated_sorted per image, :667); polys [T,8] (data_augument_bank.py:516-541); hull [T,4]
+ * (fcos_p2b_teacher_student.py:486-492); pre [T] = exists & score < 1 & inside the image (:669-675). */
+int pt_black_paper_sorted(const float* table, const int64_t* order, const uint8_t* exist, int T, float imgsize,
+                          float* sorted, float* nms_in, float* polys, float* hull, uint8_t* pre, void* stream);
 
 #ifdef __cplusplus
 }

@@ -48,14 +48,22 @@ def reduce_mean_many(*scalars):
 
 
 # -------------------------------------------------------------------- box codecs --
+def _fusable(bbox):
+    return bbox.is_cuda and bbox.dim() == 2 and bbox.shape[1] == 4 and bbox.dtype == torch.float32 and not bbox.requires_grad
+
+
 def bbox_xyxy_to_cxcywh(bbox):
-    """core/bbox/transforms.py:250-262"""
+    """core/bbox/transforms.py:250-262 (one launch through pt_box_convert when no gradient is needed)"""
+    if _fusable(bbox):
+        return F.box_convert(bbox, 0)
     x1, y1, x2, y2 = bbox.split((1, 1, 1, 1), dim=-1)
     return torch.cat([(x1 + x2) / 2, (y1 + y2) / 2, (x2 - x1), (y2 - y1)], dim=-1)
 
 
 def bbox_cxcywh_to_xyxy(bbox):
     """core/bbox/transforms.py:236-247"""
+    if _fusable(bbox):
+        return F.box_convert(bbox, 1)
     cx, cy, w, h = bbox.split((1, 1, 1, 1), dim=-1)
     return torch.cat([(cx - 0.5 * w), (cy - 0.5 * h), (cx + 0.5 * w), (cy + 0.5 * h)], dim=-1)
 
@@ -81,16 +89,17 @@ def distance2bbox(points, distance, max_shape=None):
 
 
 def bbox2roi(bbox_list):
-    """core/bbox/transforms.py:58-78"""
-    rois_list = []
-    for img_id, bboxes in enumerate(bbox_list):
-        if bboxes.size(0) > 0:
-            img_inds = bboxes.new_full((bboxes.size(0), 1), img_id)
-            rois = torch.cat([img_inds, bboxes[:, :4]], dim=-1)
-        else:
-            rois = bboxes.new_zeros((0, 5))
-        rois_list.append(rois)
-    return torch.cat(rois_list, 0)
+    """core/bbox/transforms.py:58-78.  The batch-index column comes from the host-known list lengths (one asynchronous
+    upload from the pinned ring) instead of a new_full + cat per image."""
+    counts = [int(b.size(0)) for b in bbox_list]
+    if sum(counts) == 0:
+        return bbox_list[0].new_zeros((0, 5))
+    boxes = torch.cat([b[:, :4] for b in bbox_list], 0)
+    if not boxes.is_cuda:
+        ids = torch.cat([b.new_full((b.size(0), 1), i) for i, b in enumerate(bbox_list)], 0)
+        return torch.cat([ids, boxes], dim=-1)
+    ids = F.upload_f32(np.repeat(np.arange(len(counts)), counts), boxes.device).to(boxes.dtype)
+    return torch.cat([ids[:, None], boxes], dim=-1)
 
 
 def bbox2result(bboxes, labels, num_classes):

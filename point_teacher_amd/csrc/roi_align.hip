@@ -2,14 +2,22 @@
 // dense_heads/fcos_head_p2b_ts.py:1202,1243,1268; aligned=True, avg pooling,
 // adaptive sampling grid ceil(roi/bin)).
 //
-// channels_last path (the one the training loop uses): one workgroup per RoI, one
-// thread per channel.  All sample coordinates are wave-uniform, every neighbour read is a
-// 256-float contiguous row of the [B,H,W,C] map (1 KiB coalesced, L2/MALL resident: the
-// whole map is 20 MB), the 49 x C tile is transposed through LDS (row stride C+1 words,
-// conflict-free) and stored as the contiguous 49*C block of out[K,C,7,7] that the FC stack
-// flattens.  HBM traffic ~= the output bytes (K*C*49*4).  Backward mirrors it: the RoI's
-// grad block is read contiguously into LDS and scattered with f32 atomics whose wave
-// footprint is 256 contiguous bytes (the full-rate shape on gfx950).
+// channels_last path (the one the training loop uses), out_size 7 (every config): ONE launch per
+// direction (roi_align7_fwd / roi_align7_bwd).  A workgroup takes a run of consecutive RoIs of one
+// MIL bag (they overlap), one thread per channel; every neighbour read is a 256-float contiguous
+// row of the [B,H,W,C] map (1 KiB coalesced per wave), all sample coordinates are wave-uniform.
+// The [C][49] block of a RoI is transposed through LDS (lane stride 49 words: conflict-free) and
+// moved with 16-byte-per-lane fully coalesced stores / loads - it is the contiguous 49*C block of
+// out[K,C,7,7] that the FC stack flattens, so HBM traffic ~= those bytes (K*C*49*4).  Three paths,
+// chosen per workgroup / per RoI inside the launch:
+//   A  the run's taps fall on <= 5x5 feature pixels (a bag of a tiny object - the common case): the
+//      footprint of channel c lives in 25 registers for the whole run; the backward keeps 25
+//      accumulators across the run and issues 25 coalesced atomics per thread at the end;
+//   B  any RoI up to 64x64 feature pixels: separable per-axis weights (one thread per (axis, bin), no
+//      atomics) in LDS, (g+1)^2 pixel reads per bin instead of 4 g^2 taps; the backward issues ONE f32
+//      atomic per footprint pixel and channel (256 contiguous bytes per wave instruction);
+//   C  larger RoIs: direct per-sample taps (correct, slow, never seen in training).
+// Other out_sizes keep the generic one-workgroup-per-RoI kernels (roi_align_fwd_cl / _bwd_cl).
 #include "pt_common.h"
 
 namespace pt {
@@ -116,12 +124,10 @@ __device__ void axis_weights(float start, float bin, int grid, int L, int out_si
 
 __global__ void __launch_bounds__(256)
     roi_align_fwd_cl(const float* __restrict__ feat, const float* __restrict__ rois, int B, int C, int H, int W,
-                     int out_size, float scale, int sampling_ratio, int aligned, float* __restrict__ out,
-                     const int* __restrict__ fallback, int group) {
+                     int out_size, float scale, int sampling_ratio, int aligned, float* __restrict__ out) {
   extern __shared__ float tile[];  // [bins][C+1]
   __shared__ AxisW AX, AY;
   const int k = blockIdx.x;
-  if (fallback && !fallback[k]) return;   // this RoI was done by the small-footprint kernel
   const RoiGeom g = roi_geom(rois + (size_t)k * 5, out_size, scale, sampling_ratio, aligned, B);
   const int bins = out_size * out_size;
   const int ld = C + 1;
@@ -153,114 +159,6 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// Both axes at once, zeroing only the columns the RoI touches (3 barriers, ~7*(nx+ny) LDS words cleared
-// instead of 2*7*256).  Same arithmetic as axis_weights().
-__device__ void axis_weights2(float sx, float bx, int gx, int Lx, float sy, float by, int gy, int Ly, int out_size,
-                              AxisW* AX, AxisW* AY) {
-  if (threadIdx.x < NB) { AX->lo[threadIdx.x] = 1 << 30; AX->hi[threadIdx.x] = -1; }
-  else if (threadIdx.x < 2 * NB) { AY->lo[threadIdx.x - NB] = 1 << 30; AY->hi[threadIdx.x - NB] = -1; }
-  if (threadIdx.x == 32) { AX->o = 1 << 30; AX->e = -1; AY->o = 1 << 30; AY->e = -1; }
-  __syncthreads();
-  const int nxs = out_size * gx, nys = out_size * gy;
-  for (int t = threadIdx.x; t < nxs + nys; t += blockDim.x) {   // pass 1: extents
-    const bool isx = t < nxs;
-    const int u = isx ? t : t - nxs, grid = isx ? gx : gy, L = isx ? Lx : Ly;
-    const float start = isx ? sx : sy, bin = isx ? bx : by;
-    AxisW* A = isx ? AX : AY;
-    const int p = u / grid, i = u - p * grid;
-    float v = start + p * bin + (i + .5f) * bin / (float)grid;
-    if (v < -1.0f || v > (float)L) continue;
-    if (v <= 0.f) v = 0.f;
-    int l = (int)v, h;
-    if (l >= L - 1) { h = l = L - 1; } else { h = l + 1; }
-    atomicMin(&A->o, l);
-    atomicMax(&A->e, h);
-  }
-  __syncthreads();
-  const int ox = AX->o, oy = AY->o;
-  const int nx = max(AX->e - ox + 1, 0), ny = max(AY->e - oy + 1, 0);
-  for (int t = threadIdx.x; t < NB * (nx + ny); t += blockDim.x) {   // clear only what is used
-    if (t < NB * nx) AX->w[t / nx][t % nx] = 0.f;
-    else { const int u = t - NB * nx; AY->w[u / ny][u % ny] = 0.f; }
-  }
-  __syncthreads();
-  for (int t = threadIdx.x; t < nxs + nys; t += blockDim.x) {   // pass 2: weights and bands
-    const bool isx = t < nxs;
-    const int u = isx ? t : t - nxs, grid = isx ? gx : gy, L = isx ? Lx : Ly, o = isx ? ox : oy;
-    const float start = isx ? sx : sy, bin = isx ? bx : by;
-    AxisW* A = isx ? AX : AY;
-    const int p = u / grid, i = u - p * grid;
-    float v = start + p * bin + (i + .5f) * bin / (float)grid;
-    if (v < -1.0f || v > (float)L) continue;
-    if (v <= 0.f) v = 0.f;
-    int l = (int)v, h;
-    if (l >= L - 1) { h = l = L - 1; v = (float)l; } else { h = l + 1; }
-    const float fl = v - (float)l, fh = 1.f - fl;
-    atomicAdd(&A->w[p][l - o], fh);
-    atomicAdd(&A->w[p][h - o], fl);
-    atomicMin(&A->lo[p], l - o);
-    atomicMax(&A->hi[p], h - o);
-  }
-  __syncthreads();
-}
-
-// Forward for out_size == 7 (every config): the 49 bin sums of channel c live in 49 REGISTERS of thread c.
-// Per footprint pixel: one coalesced global read + 7 FMAs against the dense per-bin column weights (LDS
-// broadcast), per footprint row: 49 FMAs against the row weights.  The LDS tile is written once, for the
-// transpose to the [C][49] output order.
-__global__ void __launch_bounds__(256)
-    roi_align_fwd_cl7(const float* __restrict__ feat, const float* __restrict__ rois, int B, int C, int H, int W,
-                      float scale, int sampling_ratio, int aligned, float* __restrict__ out,
-                      const int* __restrict__ fallback) {
-  extern __shared__ float tile[];  // [49][C+1]
-  __shared__ AxisW AX, AY;
-  const int k = blockIdx.x;
-  if (fallback && !fallback[k]) return;   // this RoI was done by the small-footprint kernel
-  const RoiGeom g = roi_geom(rois + (size_t)k * 5, 7, scale, sampling_ratio, aligned, B);
-  const int ld = C + 1;
-  axis_weights2(g.start_w, g.bin_w, g.grid_w, W, g.start_h, g.bin_h, g.grid_h, H, 7, &AX, &AY);
-  const float* fb = feat + (size_t)g.b * H * W * C;
-  const int ny = AY.e - AY.o + 1, nx = AX.e - AX.o + 1;
-  const float inv = 1.f / g.inv_count;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float acc[7][7];
-#pragma unroll
-    for (int a = 0; a < 7; ++a)
-#pragma unroll
-      for (int b = 0; b < 7; ++b) acc[a][b] = 0.f;
-    if (nx > 0 && ny > 0) {
-      for (int py = 0; py < ny; ++py) {
-        const float* row = fb + ((size_t)(AY.o + py) * W + AX.o) * C + c;
-        float t[7];
-#pragma unroll
-        for (int b = 0; b < 7; ++b) t[b] = 0.f;
-        for (int px = 0; px < nx; ++px) {
-          const float v = row[(size_t)px * C];
-#pragma unroll
-          for (int b = 0; b < 7; ++b) t[b] += AX.w[b][px] * v;
-        }
-#pragma unroll
-        for (int a = 0; a < 7; ++a) {
-          const float wy = AY.w[a][py];
-#pragma unroll
-          for (int b = 0; b < 7; ++b) acc[a][b] += wy * t[b];
-        }
-      }
-    }
-#pragma unroll
-    for (int a = 0; a < 7; ++a)
-#pragma unroll
-      for (int b = 0; b < 7; ++b) tile[(a * 7 + b) * ld + c] = acc[a][b] / g.inv_count;
-  }
-  (void)inv;
-  __syncthreads();
-  float* ob = out + (size_t)k * C * 49;
-  for (int o = threadIdx.x; o < C * 49; o += blockDim.x) {
-    const int c = o / 49, bin = o - c * 49;
-    ob[o] = tile[bin * ld + c];
-  }
-}
-
 // Backward, channels_last, generic: one workgroup per RoI; with the separable weights a RoI issues
 // ONE f32 atomic per footprint pixel and channel (256 contiguous bytes per wave instruction - the
 // full-rate shape) instead of 4 per bilinear tap.  RoIs whose bag was reduced on chip by the
@@ -268,11 +166,10 @@ __global__ void __launch_bounds__(256)
 __global__ void __launch_bounds__(256)
     roi_align_bwd_cl(const float* __restrict__ gout, const float* __restrict__ rois, int B, int C, int H, int W, int K,
                      int group, int out_size, float scale, int sampling_ratio, int aligned,
-                     float* __restrict__ gfeat, const int* __restrict__ fallback) {
+                     float* __restrict__ gfeat) {
   extern __shared__ float tile[];  // [bins][C+1] grad tile
   __shared__ AxisW AX, AY;
   const int k = blockIdx.x;
-  if (fallback && !fallback[k / group]) return;   // done by the small-footprint kernel
   const int bins = out_size * out_size;
   const int ld = C + 1;
   const RoiGeom g = roi_geom(rois + (size_t)k * 5, out_size, scale, sampling_ratio, aligned, B);
@@ -281,7 +178,8 @@ __global__ void __launch_bounds__(256)
     const int c = o / bins, bin = o - c * bins;
     tile[bin * ld + c] = gb[o];
   }
-  axis_weights2(g.start_w, g.bin_w, g.grid_w, W, g.start_h, g.bin_h, g.grid_h, H, out_size, &AX, &AY);   // ends with a barrier
+  axis_weights(g.start_w, g.bin_w, g.grid_w, W, out_size, &AX);
+  axis_weights(g.start_h, g.bin_h, g.grid_h, H, out_size, &AY);   // ends with a barrier
   const int ny = AY.e - AY.o + 1, nx = AX.e - AX.o + 1;
   if (ny <= 0 || nx <= 0) return;
   float* fb = gfeat + (size_t)g.b * H * W * C;
@@ -308,198 +206,396 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// ------------------------------------------------ small-footprint bag fast path --
-// The U2 jittered boxes of one MIL bag of a tiny object (the common case: AI-TOD objects are
-// ~12 px = 1.5 feature pixels) all fall on the same <= 5x5 feature pixels.  One workgroup owns
-// the bag: the 25 footprint pixels of channel c live in 25 REGISTERS of thread c (loaded once
-// for the whole bag), the separable per-axis weights of every member are precomputed into LDS
-// by the first threads (one thread per (member, axis, bin): no atomics), and each member costs
-// 420 register FMAs per thread - no barriers, no LDS tile, no per-tap memory traffic.  The
-// backward keeps the 25 footprint accumulators in registers across the whole bag and issues 25
-// coalesced atomics per thread at the end.  A workgroup falls back to the generic kernels
-// (flag in `fallback[blockIdx]`) when its union footprint is larger or spans two images.
-constexpr int SF = 5;            // footprint side
-constexpr int SMALL_GROUP = 32;  // members per workgroup (>= U1*U2 of the 0 % config)
+// ------------------------------------------------------------ unified out_size 7 path --
+constexpr int SF = 5;      // side of the register-resident footprint (path A)
+constexpr int GS = 16;     // most consecutive RoIs one workgroup takes
+constexpr int MAXE = 64;   // per-axis extent (feature pixels) path B holds in LDS
 
-struct SmallW {
-  float ax[SMALL_GROUP][NB][SF];
-  float ay[SMALL_GROUP][NB][SF];   // already divided by the sample count
-  int ub[6];                       // x0, y0, x1, y1, batch, ok
+struct Roi7Lds {
+  union {
+    struct { float ax[GS][NB][SF]; float ay[GS][NB][SF]; } a;   // path A: per member, relative to the run's origin; ay / count
+    struct { float wx[MAXE][8]; float wy[MAXE][8]; } b;         // path B: [pixel - origin][bin], one RoI at a time; wy / count
+  } w;
+  int ub[6];                  // path A: x0, y0, x1, y1 of the run's taps, batch index, ok
+  int lo[2][NB], hi[2][NB];   // path B: band of every bin per axis (absolute pixel index; hi < lo: empty)
+  int ext[4];                 // path B: ox, nx, oy, ny
 };
 
 __device__ __forceinline__ void small_tap(float v, int L, int& l, int& h, float& fl, bool& valid) {
-  valid = !(v < -1.0f || v > (float)L);
+  valid = !(v < -1.0f || v > (float)L);       // mirrors bilin(): v <= 0 -> 0; l >= L-1 -> l = h = L-1, frac 0
   if (v <= 0.f) v = 0.f;
   l = (int)v;
   if (l >= L - 1) { h = l = L - 1; v = (float)l; } else { h = l + 1; }
   fl = v - (float)l;
 }
 
-// Fills S for RoIs [k0,k1).  Returns (via S->ub[5]) whether the fast path applies.
-__device__ void small_setup(const float* __restrict__ rois, int k0, int k1, int B, int H, int W, int out_size,
-                            float scale, int sampling_ratio, int aligned, SmallW* S) {
-  if (threadIdx.x == 0) { S->ub[0] = 1 << 30; S->ub[1] = 1 << 30; S->ub[2] = -1; S->ub[3] = -1; S->ub[4] = -1; S->ub[5] = 1; }
+// Path A set-up for RoIs [k0, k0+n): exact union of the taps, then one thread per (member, axis, bin) writes that
+// bin's <= 5 weights (no atomics).  S.ub[5] says whether the run qualifies.  Ends with a barrier.
+__device__ void run_setup(const float* __restrict__ rois, int k0, int n, int B, int H, int W, float scale,
+                          int sampling_ratio, int aligned, Roi7Lds& S) {
+  if (threadIdx.x == 0) { S.ub[0] = 1 << 30; S.ub[1] = 1 << 30; S.ub[2] = -1; S.ub[3] = -1; S.ub[4] = -1; S.ub[5] = 1; }
   __syncthreads();
-  const int n = (k1 - k0) * 2 * out_size;
-  for (int t = threadIdx.x; t < n; t += blockDim.x) {      // pass 1: exact union of the taps
-    const int r = t / (2 * out_size), a = (t / out_size) & 1, p = t % out_size;
-    const RoiGeom g = roi_geom(rois + (size_t)(k0 + r) * 5, out_size, scale, sampling_ratio, aligned, B);
-    const float start = a ? g.start_h : g.start_w, bin = a ? g.bin_h : g.bin_w;
-    const int grid = a ? g.grid_h : g.grid_w, L = a ? H : W;
-    if (grid > 8) S->ub[5] = 0;
+  const int nt = n * 2 * NB;                       // <= 224 threads
+  const int t = threadIdx.x;
+  const int r = t / (2 * NB), a = (t / NB) & 1, p = t % NB;
+  RoiGeom g;
+  float start = 0.f, bin = 0.f;
+  int grid = 0, L = 1;
+  if (t < nt) {
+    g = roi_geom(rois + (size_t)(k0 + r) * 5, NB, scale, sampling_ratio, aligned, B);
+    start = a ? g.start_h : g.start_w; bin = a ? g.bin_h : g.bin_w;
+    grid = a ? g.grid_h : g.grid_w; L = a ? H : W;
+    if (grid > 8) S.ub[5] = 0;                     // such a bin alone spans more than the footprint
     for (int i = 0; i < grid && i < 8; ++i) {
       int l, h; float fl; bool valid;
       small_tap(start + p * bin + (i + .5f) * bin / (float)grid, L, l, h, fl, valid);
       if (!valid) continue;
-      atomicMin(&S->ub[a], l);
-      atomicMax(&S->ub[2 + a], h);
+      atomicMin(&S.ub[a], l);
+      atomicMax(&S.ub[2 + a], h);
     }
     if (a == 0 && p == 0) {
-      const int old = atomicCAS(&S->ub[4], -1, g.b);
-      if (old != -1 && old != g.b) S->ub[5] = 0;
+      const int old = atomicCAS(&S.ub[4], -1, g.b);
+      if (old != -1 && old != g.b) S.ub[5] = 0;    // the run spans two images
     }
   }
   __syncthreads();
-  const int ox = S->ub[0], oy = S->ub[1];
-  const bool ok = S->ub[5] && (S->ub[2] - ox < SF) && (S->ub[3] - oy < SF);
+  const int ox = S.ub[0], oy = S.ub[1];
+  const bool ok = S.ub[5] && (S.ub[2] - ox < SF) && (S.ub[3] - oy < SF);
   __syncthreads();
-  if (threadIdx.x == 0) S->ub[5] = ok ? 1 : 0;
-  if (ok) {
-    for (int t = threadIdx.x; t < n; t += blockDim.x) {    // pass 2: one thread per (member, axis, bin)
-      const int r = t / (2 * out_size), a = (t / out_size) & 1, p = t % out_size;
-      const RoiGeom g = roi_geom(rois + (size_t)(k0 + r) * 5, out_size, scale, sampling_ratio, aligned, B);
-      const float start = a ? g.start_h : g.start_w, bin = a ? g.bin_h : g.bin_w;
-      const int grid = a ? g.grid_h : g.grid_w, L = a ? H : W, o = a ? oy : ox;
-      float* w = a ? S->ay[r][p] : S->ax[r][p];
+  if (threadIdx.x == 0) S.ub[5] = ok ? 1 : 0;
+  if (ok && t < nt) {
+    const int o = a ? oy : ox;
+    float w[SF];
 #pragma unroll
-      for (int i = 0; i < SF; ++i) w[i] = 0.f;
-      for (int i = 0; i < grid; ++i) {
-        int l, h; float fl; bool valid;
-        small_tap(start + p * bin + (i + .5f) * bin / (float)grid, L, l, h, fl, valid);
-        if (!valid) continue;
-        w[l - o] += 1.f - fl;
-        w[h - o] += fl;
-      }
-      if (a) {
+    for (int i = 0; i < SF; ++i) w[i] = 0.f;
+    for (int i = 0; i < grid; ++i) {
+      int l, h; float fl; bool valid;
+      small_tap(start + p * bin + (i + .5f) * bin / (float)grid, L, l, h, fl, valid);
+      if (!valid) continue;
 #pragma unroll
-        for (int i = 0; i < SF; ++i) w[i] = w[i] / g.inv_count;
+      for (int j = 0; j < SF; ++j) {               // register array: static indices only
+        if (j == l - o) w[j] += 1.f - fl;
+        if (j == h - o) w[j] += fl;
       }
     }
+    float* dst = a ? S.w.a.ay[r][p] : S.w.a.ax[r][p];
+#pragma unroll
+    for (int i = 0; i < SF; ++i) dst[i] = a ? w[i] / g.inv_count : w[i];
   }
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(256)
-    roi_align_small_fwd(const float* __restrict__ feat, const float* __restrict__ rois, int B, int C, int H, int W,
-                        int K, int group, int out_size, float scale, int sampling_ratio, int aligned,
-                        float* __restrict__ out, int* __restrict__ fallback) {
-  __shared__ SmallW S;
-  group = 1;   // the forward has nothing to share between bag members: one RoI per workgroup for parallelism
-  const int k0 = blockIdx.x * group, k1 = min(k0 + group, K);
-  small_setup(rois, k0, k1, B, H, W, out_size, scale, sampling_ratio, aligned, &S);
-  if (!S.ub[5]) { if (threadIdx.x == 0) fallback[blockIdx.x] = 1; return; }
-  if (threadIdx.x == 0) fallback[blockIdx.x] = 0;
-  const int ox = S.ub[0], oy = S.ub[1], b = S.ub[4];
-  const int bins = out_size * out_size;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float f[SF][SF];
-#pragma unroll
-    for (int y = 0; y < SF; ++y)
-#pragma unroll
-      for (int x = 0; x < SF; ++x) {
-        const int yy = min(oy + y, H - 1), xx = min(ox + x, W - 1);   // rows/cols beyond the union have zero weight
-        f[y][x] = feat[(((size_t)b * H + yy) * W + xx) * C + c];
-      }
-    for (int k = k0; k < k1; ++k) {
-      const int r = k - k0;
-      float* ob = out + ((size_t)k * C + c) * bins;
-      float T[SF][NB];
-#pragma unroll
-      for (int y = 0; y < SF; ++y)
-#pragma unroll
-        for (int pw = 0; pw < NB; ++pw) {
-          float t = 0.f;
-          if (pw < out_size) {
-#pragma unroll
-            for (int x = 0; x < SF; ++x) t = fmaf(S.ax[r][pw][x], f[y][x], t);
-          }
-          T[y][pw] = t;
-        }
-#pragma unroll
-      for (int ph = 0; ph < NB; ++ph) {
-        if (ph < out_size) {
-#pragma unroll
-          for (int pw = 0; pw < NB; ++pw) {
-            if (pw < out_size) {
-              float v = 0.f;
-#pragma unroll
-              for (int y = 0; y < SF; ++y) v = fmaf(S.ay[r][ph][y], T[y][pw], v);
-              ob[ph * out_size + pw] = v;
-            }
-          }
-        }
-      }
+// Path B set-up for ONE RoI: bands, extent, dense per-pixel weight rows.  Every thread of the block calls it; ends
+// with a barrier.  S.ext: nx or ny <= 0 -> the RoI samples nothing inside the map; > MAXE -> path C.
+__device__ void roi_setup(const RoiGeom& g, int H, int W, Roi7Lds& S) {
+  const int t = threadIdx.x, a = t / NB, p = t % NB;
+  const float start = a ? g.start_h : g.start_w, bin = a ? g.bin_h : g.bin_w;
+  const int grid = a ? g.grid_h : g.grid_w, L = a ? H : W;
+  if (t < 2 * NB) {
+    int lo = 1 << 30, hi = -1;
+    for (int i = 0; i < grid; ++i) {
+      int l, h; float fl; bool valid;
+      small_tap(start + p * bin + (i + .5f) * bin / (float)grid, L, l, h, fl, valid);
+      if (!valid) continue;
+      lo = min(lo, l); hi = max(hi, h);
     }
+    S.lo[a][p] = lo; S.hi[a][p] = hi;
+  }
+  __syncthreads();
+  if (t < 2) {
+    int o = 1 << 30, e = -1;
+    for (int q = 0; q < NB; ++q)
+      if (S.hi[t][q] >= S.lo[t][q]) { o = min(o, S.lo[t][q]); e = max(e, S.hi[t][q]); }
+    S.ext[2 * t] = o; S.ext[2 * t + 1] = e >= o ? e - o + 1 : 0;
+  }
+  __syncthreads();
+  const int ox = S.ext[0], nx = S.ext[1], oy = S.ext[2], ny = S.ext[3];
+  if (nx <= 0 || ny <= 0 || nx > MAXE || ny > MAXE) return;      // block-uniform
+  for (int i = t; i < (nx + ny) * 8; i += blockDim.x) {
+    if (i < nx * 8) (&S.w.b.wx[0][0])[i] = 0.f; else (&S.w.b.wy[0][0])[i - nx * 8] = 0.f;
+  }
+  __syncthreads();
+  if (t < 2 * NB) {                                 // column p of axis a belongs to this thread alone
+    float (*w)[8] = a ? S.w.b.wy : S.w.b.wx;
+    const int o = a ? oy : ox;
+    for (int i = 0; i < grid; ++i) {
+      int l, h; float fl; bool valid;
+      small_tap(start + p * bin + (i + .5f) * bin / (float)grid, L, l, h, fl, valid);
+      if (!valid) continue;
+      w[l - o][p] += 1.f - fl;
+      w[h - o][p] += fl;
+    }
+    if (a) for (int q = S.lo[1][p]; q <= S.hi[1][p]; ++q) w[q - o][p] = w[q - o][p] / g.inv_count;
+  }
+  __syncthreads();
+}
+
+// LDS tile [nc][49] (thread-major) <-> the contiguous nc*49 floats of one RoI's block, 16 bytes per lane.
+__device__ __forceinline__ void tile_store(const float* __restrict__ tile, float* __restrict__ dst, int nf) {
+  if (((nf & 3) == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+    const float4* t4 = reinterpret_cast<const float4*>(tile);
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    for (int i = threadIdx.x; i < (nf >> 2); i += blockDim.x) d4[i] = t4[i];
+  } else {
+    for (int i = threadIdx.x; i < nf; i += blockDim.x) dst[i] = tile[i];
+  }
+}
+__device__ __forceinline__ void tile_load(float* __restrict__ tile, const float* __restrict__ src, int nf) {
+  if (((nf & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+    float4* t4 = reinterpret_cast<float4*>(tile);
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    for (int i = threadIdx.x; i < (nf >> 2); i += blockDim.x) t4[i] = s4[i];
+  } else {
+    for (int i = threadIdx.x; i < nf; i += blockDim.x) tile[i] = src[i];
   }
 }
 
 __global__ void __launch_bounds__(256)
-    roi_align_small_bwd(const float* __restrict__ gout, const float* __restrict__ rois, int B, int C, int H, int W,
-                        int K, int group, int out_size, float scale, int sampling_ratio, int aligned,
-                        float* __restrict__ gfeat, int* __restrict__ fallback) {
-  __shared__ SmallW S;
-  const int k0 = blockIdx.x * group, k1 = min(k0 + group, K);
-  small_setup(rois, k0, k1, B, H, W, out_size, scale, sampling_ratio, aligned, &S);
-  if (!S.ub[5]) { if (threadIdx.x == 0) fallback[blockIdx.x] = 1; return; }
-  if (threadIdx.x == 0) fallback[blockIdx.x] = 0;
-  const int ox = S.ub[0], oy = S.ub[1], b = S.ub[4];
-  const int bins = out_size * out_size;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float acc[SF][SF];
-#pragma unroll
-    for (int y = 0; y < SF; ++y)
-#pragma unroll
-      for (int x = 0; x < SF; ++x) acc[y][x] = 0.f;
-    for (int k = k0; k < k1; ++k) {
-      const int r = k - k0;
-      const float* gb = gout + ((size_t)k * C + c) * bins;
-      float Sy[SF][NB];
-#pragma unroll
-      for (int y = 0; y < SF; ++y)
-#pragma unroll
-        for (int pw = 0; pw < NB; ++pw) Sy[y][pw] = 0.f;
-#pragma unroll
-      for (int ph = 0; ph < NB; ++ph) {
-        if (ph < out_size) {
-#pragma unroll
-          for (int pw = 0; pw < NB; ++pw) {
-            if (pw < out_size) {
-              const float g = gb[ph * out_size + pw];
-#pragma unroll
-              for (int y = 0; y < SF; ++y) Sy[y][pw] = fmaf(S.ay[r][ph][y], g, Sy[y][pw]);
-            }
-          }
-        }
-      }
+    roi_align7_fwd(const float* __restrict__ feat, const float* __restrict__ rois, int B, int C, int H, int W, int K,
+                   int gs, float scale, int sampling_ratio, int aligned, float* __restrict__ out, int tile_bytes) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  float* tile = reinterpret_cast<float*>(smem);                       // [<=256][49]
+  Roi7Lds& S = *reinterpret_cast<Roi7Lds*>(smem + tile_bytes);
+  const int k0 = blockIdx.x * gs, n = min(gs, K - k0);
+  run_setup(rois, k0, n, B, H, W, scale, sampling_ratio, aligned, S);
+  const bool path_a = S.ub[5] != 0;
+  const int ux = S.ub[0], uy = S.ub[1], ub = S.ub[4];
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    const int nc = min(256, C - c0), c = c0 + threadIdx.x;
+    const bool act = (int)threadIdx.x < nc;
+    float* my = tile + threadIdx.x * 49;
+    if (path_a) {
+      float f[SF][SF];
 #pragma unroll
       for (int y = 0; y < SF; ++y)
 #pragma unroll
         for (int x = 0; x < SF; ++x) {
-          float v = acc[y][x];
-#pragma unroll
-          for (int pw = 0; pw < NB; ++pw)
-            if (pw < out_size) v = fmaf(S.ax[r][pw][x], Sy[y][pw], v);
-          acc[y][x] = v;
+          const int yy = min(uy + y, H - 1), xx = min(ux + x, W - 1);   // rows / columns beyond the union carry zero weight
+          f[y][x] = act ? feat[(((size_t)ub * H + yy) * W + xx) * C + c] : 0.f;
         }
-    }
+      for (int r = 0; r < n; ++r) {
+        if (act) {
+          float T[SF][NB];
 #pragma unroll
-    for (int y = 0; y < SF; ++y)
+          for (int y = 0; y < SF; ++y)
 #pragma unroll
-      for (int x = 0; x < SF; ++x) {
-        const float v = acc[y][x];
-        if (v != 0.f && oy + y < H && ox + x < W)
-          atomicAdd(&gfeat[(((size_t)b * H + oy + y) * W + ox + x) * C + c], v);
+            for (int pw = 0; pw < NB; ++pw) {
+              float t = 0.f;
+#pragma unroll
+              for (int x = 0; x < SF; ++x) t = fmaf(S.w.a.ax[r][pw][x], f[y][x], t);
+              T[y][pw] = t;
+            }
+#pragma unroll
+          for (int ph = 0; ph < NB; ++ph)
+#pragma unroll
+            for (int pw = 0; pw < NB; ++pw) {
+              float v = 0.f;
+#pragma unroll
+              for (int y = 0; y < SF; ++y) v = fmaf(S.w.a.ay[r][ph][y], T[y][pw], v);
+              my[ph * NB + pw] = v;
+            }
+        }
+        __syncthreads();
+        tile_store(tile, out + ((size_t)(k0 + r) * C + c0) * 49, nc * 49);
+        __syncthreads();
       }
+    } else {
+      for (int r = 0; r < n; ++r) {
+        const RoiGeom g = roi_geom(rois + (size_t)(k0 + r) * 5, NB, scale, sampling_ratio, aligned, B);
+        roi_setup(g, H, W, S);
+        const int ox = S.ext[0], nx = S.ext[1], oy = S.ext[2], ny = S.ext[3];
+        if (act) {
+          const float* fb = feat + (size_t)g.b * H * W * C + c;
+          if (nx <= 0 || ny <= 0) {
+#pragma unroll
+            for (int i = 0; i < 49; ++i) my[i] = 0.f;
+          } else if (nx <= MAXE && ny <= MAXE) {                        // path B
+            float acc[NB][NB];
+#pragma unroll
+            for (int a = 0; a < NB; ++a)
+#pragma unroll
+              for (int b = 0; b < NB; ++b) acc[a][b] = 0.f;
+            for (int py = 0; py < ny; ++py) {
+              const float* row = fb + ((size_t)(oy + py) * W + ox) * C;
+              float t[NB];
+#pragma unroll
+              for (int b = 0; b < NB; ++b) t[b] = 0.f;
+              int px = 0;
+              for (; px + 8 <= nx; px += 8) {                          // 8 independent loads in flight
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = row[(size_t)(px + j) * C];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  const float4 wa = *reinterpret_cast<const float4*>(&S.w.b.wx[px + j][0]);
+                  const float4 wb = *reinterpret_cast<const float4*>(&S.w.b.wx[px + j][4]);
+                  t[0] = fmaf(wa.x, v[j], t[0]); t[1] = fmaf(wa.y, v[j], t[1]); t[2] = fmaf(wa.z, v[j], t[2]);
+                  t[3] = fmaf(wa.w, v[j], t[3]); t[4] = fmaf(wb.x, v[j], t[4]); t[5] = fmaf(wb.y, v[j], t[5]);
+                  t[6] = fmaf(wb.z, v[j], t[6]);
+                }
+              }
+              for (; px < nx; ++px) {
+                const float v = row[(size_t)px * C];
+                const float4 wa = *reinterpret_cast<const float4*>(&S.w.b.wx[px][0]);
+                const float4 wb = *reinterpret_cast<const float4*>(&S.w.b.wx[px][4]);
+                t[0] = fmaf(wa.x, v, t[0]); t[1] = fmaf(wa.y, v, t[1]); t[2] = fmaf(wa.z, v, t[2]);
+                t[3] = fmaf(wa.w, v, t[3]); t[4] = fmaf(wb.x, v, t[4]); t[5] = fmaf(wb.y, v, t[5]);
+                t[6] = fmaf(wb.z, v, t[6]);
+              }
+              const float4 ya = *reinterpret_cast<const float4*>(&S.w.b.wy[py][0]);
+              const float4 yb = *reinterpret_cast<const float4*>(&S.w.b.wy[py][4]);
+              const float wy[NB] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z};
+#pragma unroll
+              for (int a = 0; a < NB; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[a][b] = fmaf(wy[a], t[b], acc[a][b]);
+            }
+#pragma unroll
+            for (int a = 0; a < NB; ++a)
+#pragma unroll
+              for (int b = 0; b < NB; ++b) my[a * NB + b] = acc[a][b];
+          } else {                                                      // path C: direct taps
+            const float* fc = fb;
+            for (int ph = 0; ph < NB; ++ph)
+              for (int pw = 0; pw < NB; ++pw) {
+                float acc = 0.f;
+                for (int iy = 0; iy < g.grid_h; ++iy) {
+                  const float y = g.start_h + ph * g.bin_h + (iy + .5f) * g.bin_h / (float)g.grid_h;
+                  for (int ix = 0; ix < g.grid_w; ++ix) {
+                    const float x = g.start_w + pw * g.bin_w + (ix + .5f) * g.bin_w / (float)g.grid_w;
+                    const Bilin q = bilin(y, x, H, W);
+                    if (q.valid)
+                      acc += q.w1 * fc[((size_t)q.y0 * W + q.x0) * C] + q.w2 * fc[((size_t)q.y0 * W + q.x1) * C] +
+                             q.w3 * fc[((size_t)q.y1 * W + q.x0) * C] + q.w4 * fc[((size_t)q.y1 * W + q.x1) * C];
+                  }
+                }
+                my[ph * NB + pw] = acc / g.inv_count;
+              }
+          }
+        }
+        __syncthreads();
+        tile_store(tile, out + ((size_t)(k0 + r) * C + c0) * 49, nc * 49);
+        __syncthreads();
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    roi_align7_bwd(const float* __restrict__ gout, const float* __restrict__ rois, int B, int C, int H, int W, int K,
+                   int gs, float scale, int sampling_ratio, int aligned, float* __restrict__ gfeat, int tile_bytes) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  float* tile = reinterpret_cast<float*>(smem);
+  Roi7Lds& S = *reinterpret_cast<Roi7Lds*>(smem + tile_bytes);
+  const int k0 = blockIdx.x * gs, n = min(gs, K - k0);
+  run_setup(rois, k0, n, B, H, W, scale, sampling_ratio, aligned, S);
+  const bool path_a = S.ub[5] != 0;
+  const int ux = S.ub[0], uy = S.ub[1], ub = S.ub[4];
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    const int nc = min(256, C - c0), c = c0 + threadIdx.x;
+    const bool act = (int)threadIdx.x < nc;
+    const float* my = tile + threadIdx.x * 49;
+    if (path_a) {
+      float acc[SF][SF];
+#pragma unroll
+      for (int y = 0; y < SF; ++y)
+#pragma unroll
+        for (int x = 0; x < SF; ++x) acc[y][x] = 0.f;
+      for (int r = 0; r < n; ++r) {
+        tile_load(tile, gout + ((size_t)(k0 + r) * C + c0) * 49, nc * 49);
+        __syncthreads();
+        if (act) {
+          float Sy[SF][NB];
+#pragma unroll
+          for (int y = 0; y < SF; ++y)
+#pragma unroll
+            for (int pw = 0; pw < NB; ++pw) Sy[y][pw] = 0.f;
+#pragma unroll
+          for (int ph = 0; ph < NB; ++ph)
+#pragma unroll
+            for (int pw = 0; pw < NB; ++pw) {
+              const float gv = my[ph * NB + pw];
+#pragma unroll
+              for (int y = 0; y < SF; ++y) Sy[y][pw] = fmaf(S.w.a.ay[r][ph][y], gv, Sy[y][pw]);
+            }
+#pragma unroll
+          for (int y = 0; y < SF; ++y)
+#pragma unroll
+            for (int x = 0; x < SF; ++x) {
+              float v = acc[y][x];
+#pragma unroll
+              for (int pw = 0; pw < NB; ++pw) v = fmaf(S.w.a.ax[r][pw][x], Sy[y][pw], v);
+              acc[y][x] = v;
+            }
+        }
+        __syncthreads();
+      }
+      if (act) {
+#pragma unroll
+        for (int y = 0; y < SF; ++y)
+#pragma unroll
+          for (int x = 0; x < SF; ++x) {
+            const float v = acc[y][x];
+            if (v != 0.f && uy + y < H && ux + x < W)
+              atomicAdd(&gfeat[(((size_t)ub * H + uy + y) * W + ux + x) * C + c], v);
+          }
+      }
+    } else {
+      for (int r = 0; r < n; ++r) {
+        const RoiGeom g = roi_geom(rois + (size_t)(k0 + r) * 5, NB, scale, sampling_ratio, aligned, B);
+        tile_load(tile, gout + ((size_t)(k0 + r) * C + c0) * 49, nc * 49);
+        roi_setup(g, H, W, S);                                          // its barriers also publish the tile
+        const int ox = S.ext[0], nx = S.ext[1], oy = S.ext[2], ny = S.ext[3];
+        if (act && nx > 0 && ny > 0) {
+          float* fb = gfeat + (size_t)g.b * H * W * C + c;
+          if (nx <= MAXE && ny <= MAXE) {                               // path B
+            float gv[49];
+#pragma unroll
+            for (int i = 0; i < 49; ++i) gv[i] = my[i];
+            for (int py = 0; py < ny; ++py) {
+              const float4 ya = *reinterpret_cast<const float4*>(&S.w.b.wy[py][0]);
+              const float4 yb = *reinterpret_cast<const float4*>(&S.w.b.wy[py][4]);
+              const float wy[NB] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z};
+              float s7[NB];
+#pragma unroll
+              for (int pw = 0; pw < NB; ++pw) {
+                float t = 0.f;
+#pragma unroll
+                for (int ph = 0; ph < NB; ++ph) t = fmaf(wy[ph], gv[ph * NB + pw], t);
+                s7[pw] = t;
+              }
+              float* row = fb + ((size_t)(oy + py) * W + ox) * C;
+              for (int px = 0; px < nx; ++px) {
+                const float4 wa = *reinterpret_cast<const float4*>(&S.w.b.wx[px][0]);
+                const float4 wb = *reinterpret_cast<const float4*>(&S.w.b.wx[px][4]);
+                const float v = wa.x * s7[0] + wa.y * s7[1] + wa.z * s7[2] + wa.w * s7[3] + wb.x * s7[4] + wb.y * s7[5] +
+                                wb.z * s7[6];
+                if (v != 0.f) atomicAdd(&row[(size_t)px * C], v);
+              }
+            }
+          } else {                                                      // path C: direct taps
+            for (int ph = 0; ph < NB; ++ph)
+              for (int pw = 0; pw < NB; ++pw) {
+                const float gvv = my[ph * NB + pw] / g.inv_count;
+                for (int iy = 0; iy < g.grid_h; ++iy) {
+                  const float y = g.start_h + ph * g.bin_h + (iy + .5f) * g.bin_h / (float)g.grid_h;
+                  for (int ix = 0; ix < g.grid_w; ++ix) {
+                    const float x = g.start_w + pw * g.bin_w + (ix + .5f) * g.bin_w / (float)g.grid_w;
+                    const Bilin q = bilin(y, x, H, W);
+                    if (q.valid) {
+                      atomicAdd(&fb[((size_t)q.y0 * W + q.x0) * C], gvv * q.w1);
+                      atomicAdd(&fb[((size_t)q.y0 * W + q.x1) * C], gvv * q.w2);
+                      atomicAdd(&fb[((size_t)q.y1 * W + q.x0) * C], gvv * q.w3);
+                      atomicAdd(&fb[((size_t)q.y1 * W + q.x1) * C], gvv * q.w4);
+                    }
+                  }
+                }
+              }
+          }
+        }
+        __syncthreads();                                                // the tile is reloaded for the next RoI
+      }
+    }
   }
 }
 
@@ -563,53 +659,71 @@ static int roi_check(const char* fn, const void* a, const void* rois, const void
   PT_REQUIRE(a && rois && o, PT_EINVAL, "%s: NULL pointer", fn);
   PT_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && K > 0, PT_EINVAL, "%s: bad size", fn);
   PT_REQUIRE(out_size >= 1 && out_size * out_size <= MAX_BINS, PT_ELIMIT, "%s: out_size=%d above 7", fn, out_size);
-  if (channels_last) {
+  if (channels_last && out_size != NB) {
     PT_REQUIRE((size_t)(C + 1) * out_size * out_size * 4 + 2 * sizeof(pt::AxisW) <= 150 * 1024, PT_ELIMIT,
                "%s: C=%d too large for the LDS tile", fn, C);
-    PT_REQUIRE(H <= pt::MAXR && W <= pt::MAXR, PT_ELIMIT, "%s: channels_last path supports maps up to %dx%d", fn,
+    PT_REQUIRE(H <= pt::MAXR && W <= pt::MAXR, PT_ELIMIT, "%s: out_size != 7 supports maps up to %dx%d", fn,
                pt::MAXR, pt::MAXR);
   }
   return PT_OK;
 }
 
+// The out_size-7 kernels always ask for the same dynamic LDS (a [256][49] tile + Roi7Lds), so the attribute is
+// set once per process through a thread-safe function-local static.
+static constexpr int ROI7_TILE_BYTES = 256 * 49 * 4;
+static constexpr int ROI7_LDS = ROI7_TILE_BYTES + (int)((sizeof(pt::Roi7Lds) + 15) / 16 * 16);
+static hipError_t roi7_attr() {
+  static const hipError_t rc = [] {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align7_fwd),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, ROI7_LDS);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align7_bwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               ROI7_LDS);
+  }();
+  return rc;
+}
+static hipError_t roi_generic_attr() {
+  static const hipError_t rc = [] {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_cl),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_bwd_cl), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               100 * 1024);
+  }();
+  return rc;
+}
+
+// Run length = a divisor of the bag size (runs never straddle two bags), as long as possible while the launch keeps
+// at least `min_wgs` workgroups.  The forward shares only L2-resident loads inside a run, so it prefers many
+// workgroups (2048 = 4 per CU at 2 resident); the backward saves one atomic pass per run, so it prefers long runs.
+static int run_length(int group, int K, int min_wgs) {
+  if (group < 1) group = 1;
+  int gs = 1;
+  for (int d = 1; d <= GS; ++d)
+    if (group % d == 0 && (d == 1 || K / d >= min_wgs)) gs = d;
+  return gs;
+}
+
 extern "C" int pt_roi_align_fwd(const float* feat, const float* rois, int B, int C, int H, int W, int K, int out_size,
                                 float spatial_scale, int sampling_ratio, int aligned, int channels_last, int group,
-                                int32_t* group_ws, float* out, void* stream) {
+                                float* out, void* stream) {
   if (K == 0) return PT_OK;
   int rc = roi_check("pt_roi_align_fwd", feat, rois, out, B, C, H, W, K, out_size, channels_last);
   if (rc) return rc;
   hipStream_t s = as_stream(stream);
-  if (channels_last) {
+  if (channels_last && out_size == NB) {
+    hipError_t e = roi7_attr();
+    if (e != hipSuccess) { set_error("pt_roi_align_fwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+    const int gs = run_length(group, K, 2048);
+    hipLaunchKernelGGL(roi_align7_fwd, dim3(cdiv(K, gs)), dim3(256), ROI7_LDS, s, feat, rois, B, C, H, W, K, gs,
+                       spatial_scale, sampling_ratio, aligned, out, ROI7_TILE_BYTES);
+  } else if (channels_last) {
     const size_t lds = (size_t)(C + 1) * out_size * out_size * sizeof(float);
-    static size_t attr_bytes = 0;
-    if (lds > attr_bytes) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_cl),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) { set_error("pt_roi_align_fwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
-      attr_bytes = lds;
-    }
-    const int* fb = nullptr;
-    if (group < 1) group = 1;
-    if (group_ws && out_size <= NB) {
-      hipLaunchKernelGGL(roi_align_small_fwd, dim3(K), dim3(256), 0, s, feat, rois, B, C, H, W, K, 1,
-                         out_size, spatial_scale, sampling_ratio, aligned, out, group_ws);
-      PT_LAUNCH_CHECK("pt_roi_align_fwd(small)");
-      fb = group_ws;
-    }
-    if (out_size == 7) {
-      static size_t attr7 = 0;
-      if (lds > attr7) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_cl7),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { set_error("pt_roi_align_fwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr7 = lds;
-      }
-      hipLaunchKernelGGL(roi_align_fwd_cl7, dim3(K), dim3(256), lds, s, feat, rois, B, C, H, W, spatial_scale,
-                         sampling_ratio, aligned, out, fb);
-    } else {
-      hipLaunchKernelGGL(roi_align_fwd_cl, dim3(K), dim3(256), lds, s, feat, rois, B, C, H, W, out_size, spatial_scale,
-                         sampling_ratio, aligned, out, fb, group);
-    }
+    hipError_t e = roi_generic_attr();
+    if (e != hipSuccess) { set_error("pt_roi_align_fwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+    PT_REQUIRE(lds <= 100 * 1024, PT_ELIMIT, "pt_roi_align_fwd: C=%d too large for the LDS tile", C);
+    hipLaunchKernelGGL(roi_align_fwd_cl, dim3(K), dim3(256), lds, s, feat, rois, B, C, H, W, out_size, spatial_scale,
+                       sampling_ratio, aligned, out);
   } else {
     const long total = (long)K * C * out_size * out_size;
     int nb = cdiv(total, 256);
@@ -623,32 +737,24 @@ extern "C" int pt_roi_align_fwd(const float* feat, const float* rois, int B, int
 
 extern "C" int pt_roi_align_bwd(const float* grad_out, const float* rois, int B, int C, int H, int W, int K,
                                 int out_size, float spatial_scale, int sampling_ratio, int aligned,
-                                int channels_last, int group, int32_t* group_ws, float* grad_feat, void* stream) {
+                                int channels_last, int group, float* grad_feat, void* stream) {
   if (K == 0) return PT_OK;
   int rc = roi_check("pt_roi_align_bwd", grad_out, rois, grad_feat, B, C, H, W, K, out_size, channels_last);
   if (rc) return rc;
   hipStream_t s = as_stream(stream);
-  if (channels_last) {
+  if (channels_last && out_size == NB) {
+    hipError_t e = roi7_attr();
+    if (e != hipSuccess) { set_error("pt_roi_align_bwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+    const int gs = run_length(group, K, 512);
+    hipLaunchKernelGGL(roi_align7_bwd, dim3(cdiv(K, gs)), dim3(256), ROI7_LDS, s, grad_out, rois, B, C, H, W, K, gs,
+                       spatial_scale, sampling_ratio, aligned, grad_feat, ROI7_TILE_BYTES);
+  } else if (channels_last) {
     const size_t lds = (size_t)(C + 1) * out_size * out_size * sizeof(float);
-    PT_REQUIRE(lds + 2 * sizeof(AxisW) <= 160 * 1024, PT_ELIMIT, "pt_roi_align_bwd: C=%d too large for the LDS tiles", C);
-    static size_t attr_bytes = 0;
-    if (lds > attr_bytes) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_bwd_cl),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) { set_error("pt_roi_align_bwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
-      attr_bytes = lds;
-    }
-    if (group < 1) group = 1;
-    if (group > 64) group = 64;
-    const int* fb = nullptr;
-    if (group_ws && group > 1 && group <= SMALL_GROUP && out_size <= NB) {
-      hipLaunchKernelGGL(roi_align_small_bwd, dim3(cdiv(K, group)), dim3(256), 0, s, grad_out, rois, B, C, H, W, K,
-                         group, out_size, spatial_scale, sampling_ratio, aligned, grad_feat, group_ws);
-      PT_LAUNCH_CHECK("pt_roi_align_bwd(small)");
-      fb = group_ws;
-    }
-    hipLaunchKernelGGL(roi_align_bwd_cl, dim3(K), dim3(256), lds, s, grad_out, rois, B, C, H, W, K, group,
-                       out_size, spatial_scale, sampling_ratio, aligned, grad_feat, fb);
+    hipError_t e = roi_generic_attr();
+    if (e != hipSuccess) { set_error("pt_roi_align_bwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+    PT_REQUIRE(lds <= 100 * 1024, PT_ELIMIT, "pt_roi_align_bwd: C=%d too large for the LDS tile", C);
+    hipLaunchKernelGGL(roi_align_bwd_cl, dim3(K), dim3(256), lds, s, grad_out, rois, B, C, H, W, K, 1,
+                       out_size, spatial_scale, sampling_ratio, aligned, grad_feat);
   } else {
     const long total = (long)K * C * out_size * out_size;
     int nb = cdiv(total, 256);

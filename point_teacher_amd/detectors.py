@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from . import functional as F
 from .core import bbox2result, bbox_overlaps, bbox_xyxy_to_cxcywh, mean0
-from .proposals import (MIL_gen_proposals_from_cfg, gen_negative_proposals, generate_black_paper_masked,
+from .proposals import (MIL_gen_proposals_from_cfg, gen_negative_proposals, generate_black_paper_batch,
                         load_basic_shape, random_point_in_quadrilateral, strong_augmentation_images,
                         strong_augmentation_masked)
 from .nn_modules import refresh_bn_affines
@@ -68,7 +68,7 @@ class BaseDetector(nn.Module):
         log_vars = LazyLogVars()
         for name, value in losses.items():
             if isinstance(value, torch.Tensor):
-                log_vars[name] = value.mean()
+                log_vars[name] = value if value.dim() == 0 else value.mean()      # (.mean() of a scalar is one more launch)
             elif isinstance(value, list):
                 log_vars[name] = sum(v.mean() for v in value)
             else:
@@ -163,9 +163,9 @@ class TS_P2B_FCOS(BaseDetector):
             self._prior_dev = self.prior_size.to(dev)
         return self._prior_dev
 
-    def _black_paper(self, img, gt_bboxes, imgsize, draws):
-        return generate_black_paper_masked(img, gt_bboxes, self._prior_on(img.device), range(int(len(self.pattern) / 2)),
-                                           imgsize, draws=draws)
+    def _black_paper(self, imgs, gt_bboxes, imgsize, draws):
+        return generate_black_paper_batch(imgs, gt_bboxes, self._prior_on(imgs[0].device), range(int(len(self.pattern) / 2)),
+                                          imgsize, draws=draws)
 
     def _initial_points(self, gt_bboxes, u):
         return random_point_in_quadrilateral(gt_bboxes, self._point_, *(u if u is not None else (None, None)))
@@ -362,10 +362,10 @@ class TS_P2B_FCOS(BaseDetector):
         """:425-466"""
         n = self.num_training_burninstep2
         losses = {}
-        pb_t = [b[:n].clone() for b in pseudo_bboxes]
-        gb_t = [b[:n].clone() for b in gt_bboxes]
-        pp_t = [p[:n].clone() for p in pseudo_points]
-        pl_t = [l[:n].clone() for l in pseudo_labels]
+        pb_t = [b[:n] for b in pseudo_bboxes]          # (the reference clones these, :430-433; nothing below writes into them)
+        gb_t = [b[:n] for b in gt_bboxes]
+        pp_t = [p[:n] for p in pseudo_points]
+        pl_t = [l[:n] for l in pseudo_labels]
         refined_b = [b.clone() for b in pseudo_bboxes]
         refined_p = [p.clone() for p in pseudo_points]
         gb_cat = torch.cat(gb_t, dim=0)
@@ -390,12 +390,9 @@ class TS_P2B_FCOS(BaseDetector):
     # --------------------------------------------------------------- burn-in step 1 --
     def genrate_syn(self, num_img, img_list, gt_bboxes, gt_labels):
         """:469-502 on the device: (img_syn [B,C,H,W], list, syn boxes list, alive masks list)."""
-        imgs, boxes, alive = [], [], []
-        draws = self._inject.get('syn')
-        for i in range(num_img):
-            C, H, W = img_list[i].shape
-            im, bx, al = self._black_paper(img_list[i], gt_bboxes[i], min(H, W), draws[i] if draws is not None else None)
-            imgs.append(im); boxes.append(bx); alive.append(al)
+        C, H, W = img_list[0].shape
+        res = self._black_paper(list(img_list[:num_img]), list(gt_bboxes[:num_img]), min(H, W), self._inject.get('syn'))
+        imgs, boxes, alive = [r[0] for r in res], [r[1] for r in res], [r[2] for r in res]
         return torch.stack(imgs, dim=0), imgs, boxes, alive
 
     def forward_train_burn_in_step1(self, num_img, img, img_list, img_metas, gt_bboxes, gt_points, gt_labels,

@@ -335,9 +335,8 @@ class _RoIAlign(torch.autograd.Function):
         rois = _f(rois)
         K = rois.shape[0]
         out = torch.empty((K, C, out_size, out_size), dtype=f32, device=feat.device)
-        ws = torch.empty((K,), dtype=i32, device=feat.device) if cl else None
         hip.call('pt_roi_align_fwd', fbuf, rois, B, C, H, W, K, out_size, float(scale), sampling_ratio,
-                 int(aligned), int(cl), int(group), ws, out)
+                 int(aligned), int(cl), int(group), out)
         ctx.save_for_backward(rois)
         ctx.cfg = (B, C, H, W, out_size, float(scale), sampling_ratio, int(aligned), cl, int(group), in_dtype)
         return out
@@ -351,15 +350,15 @@ class _RoIAlign(torch.autograd.Function):
             gbuf = torch.zeros((B, H, W, C), dtype=f32, device=g.device)
         else:
             gbuf = torch.zeros((B, C, H, W), dtype=f32, device=g.device)
-        ws = torch.empty((K,), dtype=i32, device=g.device) if (cl and group > 1) else None
-        hip.call('pt_roi_align_bwd', _f(g), rois, B, C, H, W, K, out_size, scale, sr, aligned, int(cl), group, ws, gbuf)
+        hip.call('pt_roi_align_bwd', _f(g), rois, B, C, H, W, K, out_size, scale, sr, aligned, int(cl), group, gbuf)
         gfeat = gbuf.permute(0, 3, 1, 2) if cl else gbuf
         return gfeat.to(in_dtype), None, None, None, None, None, None
 
 
 def roi_align(feat, rois, output_size=7, spatial_scale=1.0, sampling_ratio=0, aligned=True, group=1):
     """mmcv.ops.roi_align(input, rois, output_size, spatial_scale, sampling_ratio, 'avg', aligned).
-    `group`: locality hint for the backward (consecutive RoIs that overlap, e.g. one MIL bag)."""
+    `group`: how many consecutive RoIs belong together (the U2 boxes of one MIL bag overlap); a locality hint, any value
+    gives the same result."""
     return _RoIAlign.apply(feat, rois, int(output_size), spatial_scale, int(sampling_ratio), bool(aligned), int(group))
 
 
@@ -642,11 +641,12 @@ def nms_rotated(dets, scores, iou_threshold):
     return torch.cat([dets[keep], scores[keep, None]], 1), keep
 
 
-def nms_rotated_mask(dets_sorted, iou_threshold):
-    """Sync-free form: dets already sorted by descending score -> keep mask (uint8 [N])."""
+def nms_rotated_mask(dets_sorted, iou_threshold, keep_out=None):
+    """Sync-free form: dets already sorted by descending score -> keep mask (uint8 [N]).  keep_out: a contiguous uint8 [N]
+    buffer already filled with ones (a slice of a batch buffer) to receive the mask."""
     N = dets_sorted.shape[0]
     ws = torch.empty((max(N, 1) * ((N + 63) // 64 + 1),), dtype=torch.int64, device=dets_sorted.device)
-    keep_m = torch.ones((N,), dtype=u8, device=dets_sorted.device)
+    keep_m = keep_out if keep_out is not None else torch.ones((N,), dtype=u8, device=dets_sorted.device)
     if N:
         hip.call('pt_nms_rotated_sorted', _f(dets_sorted[:, :5]), N, float(iou_threshold), ws, keep_m)
     return keep_m
@@ -659,6 +659,52 @@ def fill_quads_(img, quads, alive, value=255.0):
     hip.call('pt_fill_quads', img, C, H, W, _f(quads), alive.to(u8).contiguous() if alive is not None else None, Q,
              float(value))
     return img
+
+
+# ---------------------------------------------------------------- glue (csrc/glue.hip) --
+def box_convert(boxes, mode):
+    """pt_box_convert: mode 0 xyxy -> cxcywh, mode 1 cxcywh -> xyxy; boxes [n,4] (no gradient)."""
+    b = _f(boxes)
+    out = torch.empty_like(b)
+    hip.call('pt_box_convert', b, out, b.shape[0], int(mode))
+    return out
+
+
+def aug_geometry(rows, off, B, params, H, W, want_valid=False):
+    """pt_aug_geometry: rows [N,2] points or [N,4] boxes of the whole batch, off int32 [B+1], params f32 [B,6]."""
+    r = _f(rows)
+    N, nc = r.shape
+    out = torch.empty_like(r)
+    valid = torch.empty((N,), dtype=u8, device=r.device) if want_valid else None
+    hip.call('pt_aug_geometry', r, out, valid, off, B, N, nc, params, float(H), float(W))
+    return (out, valid) if want_valid else out
+
+
+def black_paper_rects(gt, goff, B, prior, dense_n, draws, cls, imgsize):
+    """pt_black_paper_rects -> (table [T,6], key int64 [T], exist uint8 [T]) with T = 2 sumG + 10 B."""
+    sumG = gt.shape[0]
+    T = 2 * sumG + 10 * B
+    dev = prior.device
+    table = torch.empty((T, 6), dtype=f32, device=dev)
+    key = torch.empty((T,), dtype=torch.int64, device=dev)
+    exist = torch.empty((T,), dtype=u8, device=dev)
+    hip.call('pt_black_paper_rects', _f(gt) if sumG else None, gt.shape[1] if sumG else 4, goff, B, _f(prior), prior.shape[0],
+             int(dense_n), _f(draws) if sumG else None, cls.to(i32).contiguous() if sumG else None, sumG, float(imgsize), table,
+             key, exist)
+    return table, key, exist
+
+
+def black_paper_sorted(table, order, exist, imgsize):
+    """pt_black_paper_sorted -> (sorted [T,6], nms_in [T,5], polys [T,8], hull [T,4], pre uint8 [T])."""
+    T = table.shape[0]
+    dev = table.device
+    srt = torch.empty((T, 6), dtype=f32, device=dev)
+    nms_in = torch.empty((T, 5), dtype=f32, device=dev)
+    polys = torch.empty((T, 8), dtype=f32, device=dev)
+    hull = torch.empty((T, 4), dtype=f32, device=dev)
+    pre = torch.empty((T,), dtype=u8, device=dev)
+    hip.call('pt_black_paper_sorted', table, order.contiguous(), exist, T, float(imgsize), srt, nms_in, polys, hull, pre)
+    return srt, nms_in, polys, hull, pre
 
 
 # ------------------------------------------------- oriented boxes (OBB variant) --

@@ -284,8 +284,9 @@ class TS_P2BFCOSHead(nn.Module):
 
     @staticmethod
     def _bag_group(U1, U2):
-        """All U1*U2 boxes of one gt are consecutive and overlap; the kernel takes at most 64 per workgroup."""
-        return U1 * U2 if U1 * U2 <= 32 else (U2 if U2 <= 32 else 1)
+        """The U2 boxes shaken out of one coarse box are consecutive and overlap: the RoIAlign kernels hand runs of
+        them to one workgroup."""
+        return U2
 
     def mil_bag_extensive(self, num_gt, num_gt_pre_image, x, img_metas, proposals_list, proposals_valid_list,
                           proposals_reference_list, proposals_real_list, bbox_results, fine_proposal_cfg, stage,

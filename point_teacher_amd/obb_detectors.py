@@ -13,7 +13,7 @@ import torch
 
 from .detectors import Student_FCOS, TS_P2B_FCOS
 from .obb import rbbox_overlaps
-from .obb_proposals import (MIL_gen_proposals_from_cfg, gen_negative_proposals, generate_black_paper_obb_masked,
+from .obb_proposals import (MIL_gen_proposals_from_cfg, gen_negative_proposals, generate_black_paper_obb_batch,
                             obb2poly, strong_augmentation_images, strong_augmentation_masked)
 from .registry import DETECTORS
 
@@ -90,9 +90,9 @@ class RotatedFCOS_TS(TS_P2B_FCOS):
                                           self.angle_version, params=params if params is not None else self._inject.get('aug'),
                                           imgs=imgs)
 
-    def _black_paper(self, img, gt_bboxes, imgsize, draws):
-        return generate_black_paper_obb_masked(img, gt_bboxes, self._prior_on(img.device), range(int(len(self.pattern) / 2)),
-                                               imgsize, draws=draws)
+    def _black_paper(self, imgs, gt_bboxes, imgsize, draws):
+        return generate_black_paper_obb_batch(imgs, gt_bboxes, self._prior_on(imgs[0].device), range(int(len(self.pattern) / 2)),
+                                              imgsize, draws=draws)
 
     def _initial_points(self, gt_bboxes, u):
         """genrate_points :381-396"""

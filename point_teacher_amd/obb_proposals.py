@@ -17,7 +17,7 @@ import torch.nn.functional as TF
 from . import functional as F
 from .core import bbox_cxcywh_to_xyxy, bbox_xyxy_to_cxcywh
 from .obb import norm_angle, rbbox_overlaps
-from .proposals import fine_proposals_from_cfg, generate_black_paper_masked, obb2poly_le90
+from .proposals import fine_proposals_from_cfg, generate_black_paper_batch, obb2poly_le90
 
 
 # ------------------------------------------------------------------ transforms --
@@ -226,12 +226,11 @@ def strong_augmentation(img, gt_points, gt_labels, pseudo_points, pseudo_labels,
 
 
 # ------------------------------------------------- burn-in step 1: white rectangles --
-def generate_black_paper_obb_masked(img, gt_bboxes, prior_size, dense_cls, imgsize, draws=None):
-    """syn_images_generator_v2.py:625-724 for ONE normalised image [C,H,W] whose real objects are the
-    oriented boxes gt_bboxes [G,5]: the same generator as the HBB one (the real objects only
+def generate_black_paper_obb_batch(imgs, gt_bboxes, prior_size, dense_cls, imgsize, draws=None):
+    """syn_images_generator_v2.py:625-724 for a batch of normalised images [C,H,W] whose real objects are the
+    oriented boxes gt_bboxes[i] [G,5]: the same generator as the HBB one (the real objects only
     contribute their centres) except that the rectangles are painted with the image maximum
     (:722) and come back as oriented boxes `bb[:, :5]`.
-    Returns (img_syn, syn_obb [M,5], alive [M])."""
-    xyxy = torch.cat([gt_bboxes[:, :2], gt_bboxes[:, :2]], dim=1)          # only the centres are read (:633-636)
-    return generate_black_paper_masked(img, xyxy, prior_size, dense_cls, imgsize, draws=draws, fill='max',
-                                       return_obb=True)
+    Returns per image (img_syn, syn_obb [M,5], alive [M])."""
+    xyxy = [torch.cat([g[:, :2], g[:, :2]], dim=1) for g in gt_bboxes]          # only the centres are read (:633-636)
+    return generate_black_paper_batch(imgs, xyxy, prior_size, dense_cls, imgsize, draws=draws, fill='max', return_obb=True)

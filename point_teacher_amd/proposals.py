@@ -128,53 +128,6 @@ def _aug_image(img, flip, scale):
     return torch.round(out)
 
 
-def _aug_geometry(pts, boxes, flip, scale, H, W):
-    """Transform points [n,2] and boxes [m,4] (either may be None); returns transformed
-    tensors and the 'still inside the crop' masks (all True when scale < 1)."""
-    sH, sW = int(H * scale), int(W * scale)
-    if scale < 1.0:
-        bh, bw = int((H - sH) / 2), int((W - sW) / 2)
-    else:
-        bh, bw = int((sH - H) / 2), int((sW - W) / 2)
-
-    def tf(xy):          # xy [n, 2k] interleaved x,y -> (scaled, scaled+shifted); python-scalar ops only
-        xy = xy.clone()
-        if flip in ('horizontal', 'diagonal'):
-            xy[:, 0::2] = W - xy[:, 0::2]
-        if flip in ('vertical', 'diagonal'):
-            xy[:, 1::2] = H - xy[:, 1::2]
-        scaled = xy * scale
-        out = scaled.clone()
-        if scale >= 1.0:
-            out[:, 0::2] -= bw
-            out[:, 1::2] -= bh
-        else:
-            out[:, 0::2] += bw
-            out[:, 1::2] += bh
-        return scaled, out
-    out_p = out_b = mask = None
-    if boxes is not None:
-        out_b = tf(boxes)[1]
-    if pts is not None:
-        q, out_p = tf(pts)
-        if scale >= 1.0:   # tested on the scaled, un-shifted point (:78-79, :84-85)
-            mask = (q[:, 0] >= bw) & (q[:, 0] < W + bw) & (q[:, 1] >= bh) & (q[:, 1] < H + bh)
-        else:
-            mask = torch.ones(pts.shape[0], dtype=torch.bool, device=pts.device)
-    return out_p, out_b, mask
-
-
-def _refine_boxes(b):
-    """:114-120 (re-order corners after flips)"""
-    if b.shape[0] == 0:
-        return b
-    w = (b[:, 0] - b[:, 2]).abs().reshape(-1, 1)
-    h = (b[:, 1] - b[:, 3]).abs().reshape(-1, 1)
-    x = torch.minimum(b[:, 0], b[:, 2]).reshape(-1, 1)     # (a python-list index would be uploaded with a blocking copy)
-    y = torch.minimum(b[:, 1], b[:, 3]).reshape(-1, 1)
-    return bbox_cxcywh_to_xyxy(torch.cat([x + w / 2, y + h / 2, w, h], dim=1))
-
-
 def strong_augmentation_images(img, params=None):
     """The pixel half of strong_augmentation (:41-63, :93-111): it depends only on the input image and the
     (flip, scale) draws, so the detector can produce it BEFORE the MIL stage and push clean and augmented
@@ -184,23 +137,43 @@ def strong_augmentation_images(img, params=None):
     return params, [_aug_image(img[i], params[0][i], params[1][i]) for i in range(B)]
 
 
+def _aug_params(flips, scales, H, W):
+    """Per-image row of pt_aug_geometry: (flip_x, flip_y, scale, margin_w, margin_h, scale >= 1); the integer margins are
+    computed on the host exactly as :66-71 does."""
+    rows = []
+    for flip, scale in zip(flips, scales):
+        sH, sW = int(H * scale), int(W * scale)
+        if scale < 1.0:
+            bh, bw = int((H - sH) / 2), int((W - sW) / 2)
+        else:
+            bh, bw = int((sH - H) / 2), int((sW - W) / 2)
+        rows.append([float(flip in ('horizontal', 'diagonal')), float(flip in ('vertical', 'diagonal')), float(scale),
+                     float(bw), float(bh), float(scale >= 1.0)])
+    return rows
+
+
 def strong_augmentation_masked(img, gt_points, gt_labels, pseudo_points, pseudo_labels, pseudo_bboxes, params=None,
                                imgs=None):
     """Sync-free strong_augmentation: nothing is filtered; instead `gt_valid` / `pseudo_valid`
     masks say which entries the reference would have kept (order is preserved, so assigning
     with the masks equals assigning the filtered lists).  `imgs`: the augmented images when they
-    were already produced by strong_augmentation_images with the same `params`."""
+    were already produced by strong_augmentation_images with the same `params`.  The geometry of all
+    points and boxes of the batch is three launches of pt_aug_geometry."""
     B, C, H, W = img.shape
     flips, scales = params if params is not None else draw_strong_aug_params(B)
     pre = imgs
-    imgs, gp_l, pp_l, pb_l, gv_l, pv_l = [], [], [], [], [], []
-    for i in range(B):
-        imgs.append(pre[i] if pre is not None else _aug_image(img[i], flips[i], scales[i]))
-        gp, _, gv = _aug_geometry(gt_points[i], None, flips[i], scales[i], H, W)
-        pp, pb, pv = _aug_geometry(pseudo_points[i], pseudo_bboxes[i], flips[i], scales[i], H, W)
-        gp_l.append(gp); gv_l.append(gv)
-        pp_l.append(pp); pb_l.append(_refine_boxes(pb)); pv_l.append(pv)
-    return torch.stack(imgs, 0), imgs, gp_l, gt_labels, pp_l, pseudo_labels, pb_l, gv_l, pv_l
+    imgs = [pre[i] if pre is not None else _aug_image(img[i], flips[i], scales[i]) for i in range(B)]
+    dev = img.device
+    prm = F.upload_f32(_aug_params(flips, scales, H, W), dev)
+    gc = [p.shape[0] for p in gt_points]
+    pc = [p.shape[0] for p in pseudo_points]
+    goff, _ = F.make_offsets(gc, dev)
+    poff, _ = F.make_offsets(pc, dev)
+    gp, gv = F.aug_geometry(torch.cat(gt_points), goff, B, prm, H, W, want_valid=True)
+    pp, pv = F.aug_geometry(torch.cat(pseudo_points), poff, B, prm, H, W, want_valid=True)
+    pb = F.aug_geometry(torch.cat(pseudo_bboxes), poff, B, prm, H, W)
+    return (torch.stack(imgs, 0), imgs, _split(gp, gc), gt_labels, _split(pp, pc), pseudo_labels, _split(pb, pc),
+            _split(gv.bool(), gc), _split(pv.bool(), pc))
 
 
 def strong_augmentation(img, gt_points, gt_labels, pseudo_points, pseudo_labels, pseudo_bboxes, params=None):
@@ -217,10 +190,12 @@ def strong_augmentation(img, gt_points, gt_labels, pseudo_points, pseudo_labels,
 
 
 # ------------------------------------------------- burn-in step 1: white rectangles --
-def generate_black_paper_masked(img, gt_bboxes, prior_size, dense_cls, imgsize, max_extra=10, draws=None, fill=255.0,
-                                return_obb=False):
-    """GPU, sync-free form of generate_black_paper (syn_images_generator_v2.py:591-690) for ONE
-    image [C,H,W] whose real objects are gt_bboxes [G,4] (xyxy).
+DRAW_ROWS = ('scale', 'x', 'y', 'wn', 'rn', 'a', 'boost', 'itv', 'itv2', 'dev')      # row order of pt_black_paper_rects
+
+
+def generate_black_paper_batch(imgs, gt_bboxes, prior_size, dense_cls, imgsize, draws=None, fill=255.0, return_obb=False):
+    """GPU, sync-free form of generate_black_paper (syn_images_generator_v2.py:591-690) for a BATCH of images
+    [C,H,W] whose real objects are gt_bboxes[i] [G_i,4] (xyxy).
 
     For every real object one rotated rectangle is drawn from the `prior_size` shape priors
     (:610-629), the first two objects whose Bernoulli(0.2) draw fires also spawn a row of 3 or
@@ -228,94 +203,54 @@ def generate_black_paper_masked(img, gt_bboxes, prior_size, dense_cls, imgsize, 
     (score 1, so they always win) and each other (:665-669), rectangles leaving the image
     are dropped (:671-675) and the survivors are rasterised with value 255 (:678-688).
 
-    Returns (img_syn, syn_xyxy [M,4], alive bool [M]) with M = 2G + max_extra fixed; rows
+    Returns per image (img_syn, syn_xyxy [M,4], alive bool [M]) with M = 2G + 10 fixed; rows
     are in the order the reference's `bb[keep]` would have (descending score), `alive`
     marks the rows that exist in the reference's output.  The rasteriser contract is
     "pixels inside or on the int32-truncated quadrilateral" (cv2.fillPoly is not
     available: parity unpinned at pixel level).
 
+    The candidate table of the whole batch is ONE launch (pt_black_paper_rects), every image's score order ONE stable
+    int64 sort, rows / polygons / hulls / filters one more launch (pt_black_paper_sorted); per image remain the rotated
+    NMS and the rasteriser.  `draws` (tests): per image a dict of per-object draws named as DRAW_ROWS + 'cls'.
+
     fill='max' paints with the image maximum instead of 255 (the OBB generator,
     OBB_TOD/.../syn_images_generator_v2.py:722, whose inputs are mean/std-normalised);
     return_obb=True returns the rectangles as (cx,cy,w,h,a) rows instead of their hulls."""
-    C, H, W = img.shape
-    dev = img.device
-    G = gt_bboxes.shape[0]
+    B = len(imgs)
+    C, H, W = imgs[0].shape
+    dev = imgs[0].device
+    counts = [int(b.shape[0]) for b in gt_bboxes]
+    sumG = sum(counts)
     L = prior_size.shape[0]
     prior = prior_size if prior_size.device == dev else prior_size.to(dev)   # callers on the training path pass a device copy
-    d = draws or {}
-
-    def draw(name, shape, kind='rand'):
-        if name in d:
-            return d[name].to(dev)
-        return torch.rand(shape, device=dev) if kind == 'rand' else torch.randn(shape, device=dev)
-    cls_idx = d['cls'].to(dev) if 'cls' in d else torch.randint(0, L, (G,), device=dev)
-    scale_vary = draw('scale', (G,)) * 2.0 + 0.5
-    cen_lo, cen_hi = 50.0, imgsize - 50.0
-    x = draw('x', (G,)) * (cen_hi - cen_lo) + cen_lo
-    y = draw('y', (G,)) * (cen_hi - cen_lo) + cen_lo
-    pr = prior[cls_idx]
-    w = scale_vary * torch.exp((draw('wn', (G,), 'randn') * 0.4).clamp(-1, 1) * pr[:, 2])
-    h = w * torch.exp((draw('rn', (G,), 'randn') * 0.4).clamp(-1, 1) * pr[:, 3])
-    w = w * pr[:, 0]
-    h = h * pr[:, 1]
-    a = draw('a', (G,)) * math.pi - math.pi / 2
-    # Tensor.clip(lo, hi) = min(max(x, lo), hi): the UPPER bound wins when a rectangle is so large that the bounds cross
-    x = torch.minimum(torch.maximum(x, 0.71 * w), imgsize - 1 - 0.71 * w)
-    y = torch.minimum(torch.maximum(y, 0.71 * h), imgsize - 1 - 0.71 * h)
-    score = (w * h) / imgsize / imgsize + 0.1
-    syn = torch.stack([x, y, w, h, a, score], 1)                                # [G,6]
-
-    # adjacency boost: the first two objects (in order) whose np.random.random() < 0.2
-    fire = (d['boost'].to(dev) if 'boost' in d else torch.rand(G, device=dev)) < 0.2
-    rank = torch.cumsum(fire.int(), 0)
-    dense = cls_idx < len(dense_cls)
-    itv = torch.where(dense, draw('itv', (G,)) * 4 + 2, draw('itv2', (G,)) * 40 + 10)
-    devi = torch.where(dense, draw('dev', (G,)) * 8 - 4, torch.zeros(G, device=dev))
-    ofx = (h + itv) * torch.sin(-a) + devi * torch.cos(a)
-    ofy = (h + itv) * torch.cos(a) + devi * torch.sin(a)
-    ncopy = torch.where(dense, 5, 3)
-    kk = torch.arange(1, 6, device=dev, dtype=torch.float32)
-    ex = torch.stack([x[:, None] + kk * ofx[:, None], y[:, None] + kk * ofy[:, None], w[:, None].expand(G, 5),
-                      h[:, None].expand(G, 5), a[:, None].expand(G, 5), score[:, None] - 0.001 * kk], 2)   # [G,5,6]
-    eok = kk[None, :] <= ncopy[:, None]                                          # [G,5]
-    extras, extras_ok = [], []
-    for r in (1, 2):                       # adjboost = 2: only the first two firing objects spawn a row
-        hit = fire & (rank == r)
-        idx = torch.argmax(hit.int()) if G else None          # first hit (0 when there is none)
-        has = hit.any() if G else None
-        if G:                                  # index_select: `ex[idx]` with a 0-dim device index reads it back to the host
-            extras.append(ex.index_select(0, idx.reshape(1))[0])
-            extras_ok.append(eok.index_select(0, idx.reshape(1))[0] & has)
-        else:
-            extras.append(torch.zeros(5, 6, device=dev))
-            extras_ok.append(torch.zeros(5, dtype=torch.bool, device=dev))
-    extra = torch.cat(extras, 0)
-    extra_ok = torch.cat(extras_ok, 0)
-
-    # real objects: fixed 0.7*prior[0] squares, angle 0, score 1 (:599-602, bb_occupied[:,5]=1)
-    gc = bbox_xyxy_to_cxcywh(gt_bboxes)
-    occ_wh = prior[cls_idx][:, 0] * 0.7
-    occ = torch.stack([gc[:, 0], gc[:, 1], occ_wh, occ_wh, torch.zeros(G, device=dev), torch.ones(G, device=dev)], 1)
-    allb = torch.cat([occ, syn, extra], 0)                                       # [2G+10, 6]
-    exist = torch.cat([torch.ones(2 * G, dtype=torch.bool, device=dev), extra_ok])
-    sc = torch.where(exist, allb[:, 5], torch.full_like(allb[:, 5], -1.0))
-    order = torch.sort(sc, descending=True, stable=True)[1]
-    sb = allb[order]
-    far = sb.new_zeros(6)                      # a box nowhere near the image for the rows that do not exist
-    far[:2] = -1e4
-    far[2:4] = 1e-3
-    keep = F.nms_rotated_mask(torch.where(exist[order][:, None], sb, far), 0.05).bool()
-    xyxy = obb2xyxy(sb)
-    inside = (xyxy.min(-1)[0] >= 0) & (xyxy.max(-1)[0] <= imgsize - 1)
-    alive = keep & exist[order] & (sb[:, 5] < 1) & inside
-    polys = obb2poly_le90(sb[:, :5])
-    if fill == 'max':      # device-side value: rasterise a 0/1 mask, then select (no host read of img.max())
-        mask = F.fill_quads_(torch.zeros((1, H, W), dtype=img.dtype, device=dev), polys, alive, 1.0)
-        img_syn = torch.where(mask == 1, img.max(), img)
+    if draws is None:
+        D = torch.rand(len(DRAW_ROWS), max(sumG, 1), device=dev)
+        D[3:5] = torch.randn(2, max(sumG, 1), device=dev)
+        cls = torch.randint(0, L, (max(sumG, 1),), device=dev, dtype=torch.int32)
     else:
-        img_syn = F.fill_quads_(img.clone().contiguous(), polys, alive, float(fill))
-    if return_obb:
-        return img_syn, sb[:, :5].contiguous(), alive
-    hull = torch.stack([polys[:, 0::2].min(1)[0], polys[:, 1::2].min(1)[0], polys[:, 0::2].max(1)[0],
-                        polys[:, 1::2].max(1)[0]], 1)
-    return img_syn, hull, alive
+        D = torch.stack([torch.cat([d[n].to(dev).float() for d in draws]) for n in DRAW_ROWS]) if sumG else torch.zeros(10, 1, device=dev)
+        cls = torch.cat([d['cls'].to(dev) for d in draws]).to(torch.int32) if sumG else torch.zeros(1, dtype=torch.int32, device=dev)
+    goff, _ = F.make_offsets(counts, dev)
+    gt = torch.cat(gt_bboxes) if sumG else torch.zeros((0, 4), device=dev)
+    table, key, exist = F.black_paper_rects(gt, goff, B, prior, len(dense_cls), D, cls, imgsize)
+    order = torch.sort(key, stable=True)[1]
+    sb, nms_in, polys, hull, pre = F.black_paper_sorted(table, order, exist, imgsize)
+    keep = torch.ones_like(pre)
+    out, t0 = [], 0
+    for i in range(B):
+        M = 2 * counts[i] + 10
+        F.nms_rotated_mask(nms_in[t0:t0 + M], 0.05, keep_out=keep[t0:t0 + M])
+        t0 += M
+    alive_all = (keep & pre).bool()
+    t0 = 0
+    for i in range(B):
+        M = 2 * counts[i] + 10
+        alive, pl = alive_all[t0:t0 + M], polys[t0:t0 + M]
+        if fill == 'max':      # device-side value: rasterise a 0/1 mask, then select (no host read of img.max())
+            mask = F.fill_quads_(torch.zeros((1, H, W), dtype=imgs[i].dtype, device=dev), pl, alive, 1.0)
+            img_syn = torch.where(mask == 1, imgs[i].max(), imgs[i])
+        else:
+            img_syn = F.fill_quads_(imgs[i].clone().contiguous(), pl, alive, float(fill))
+        out.append((img_syn, sb[t0:t0 + M, :5].contiguous() if return_obb else hull[t0:t0 + M], alive))
+        t0 += M
+    return out

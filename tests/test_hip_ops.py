@@ -393,6 +393,46 @@ def test_roi_align_bag_fast_path():
     close(out1, out, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize('C,H,W,group,out_size,sr', [(320, 24, 24, 45, 7, 0),      # two channel blocks (256 + 64); runs of 15
+                                                       (6, 24, 24, 25, 7, 0),        # 6*49 floats: not a multiple of 4 -> scalar tile copies
+                                                       (16, 120, 120, 7, 7, 0),      # map large enough for a > 64-pixel RoI: direct path C
+                                                       (16, 24, 24, 4, 7, 2),        # fixed sampling_ratio
+                                                       (16, 24, 24, 3, 5, 0)])       # out_size != 7: the generic per-RoI kernels
+def test_roi_align_every_path(C, H, W, group, out_size, sr):
+    """One launch per direction serves three paths (register footprint / separable / direct taps, roi_align.hip) and
+    any channel count and run length: all of them against the oracle, forward and backward, K not a multiple of the
+    run length, RoIs outside the map, zero-size RoIs, RoIs of 1, 20 and (when the map allows) 90 feature pixels."""
+    f = F()
+    gen = torch.Generator().manual_seed(31 + C)
+    B = 2
+    size = 8 * H
+    feat = torch.randn(B, C, H, W, generator=gen)
+    n_bag = 5
+    c = torch.rand(n_bag, 2, generator=gen) * (size - 60) + 30
+    wh = torch.exp(torch.randn(n_bag, 2, generator=gen) * 0.5 + np.log(11.))
+    wh[1] = torch.tensor([160., 90.])                              # separable path
+    if size > 800:
+        wh[2] = torch.tensor([720., 530.]); c[2] = torch.tensor([size / 2, size / 2])   # > 64 feature pixels: path C
+    base = torch.cat([c - wh / 2, c + wh / 2], 1)
+    jit = torch.randn(n_bag, group, 4, generator=gen) * 1.5
+    props = (base[:, None] + jit).reshape(-1, 4)
+    bi = torch.arange(n_bag).repeat_interleave(group).float()[:, None] % B
+    extra = torch.tensor([[0, -90., -90., -50., -40.], [1, 33., 41., 33., 41.], [1, size - 5., size - 9., size + 40., size + 30.]])
+    rois = torch.cat([torch.cat([bi, props], 1), extra])           # K = n_bag * group + 3: the last run is partial
+    fr = feat.clone().requires_grad_(True)
+    out_ref = R.roi_align(fr, rois, out_size, 0.125, sr)
+    wgt = torch.randn(out_ref.shape, generator=gen)
+    (out_ref * wgt).sum().backward()
+    fg = cu(feat).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    out = f.roi_align(fg, cu(rois), out_size, 0.125, sr, True, group)
+    close(out, out_ref, rtol=1e-4, atol=2e-5)
+    (out * cu(wgt)).sum().backward()
+    close(fg.grad, fr.grad, rtol=1e-4, atol=2e-4)
+    for other in (1, 16):                                          # the group hint only regroups the work
+        o2 = f.roi_align(fg.detach(), cu(rois), out_size, 0.125, sr, True, other)
+        close(o2, out, rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize('channels_last', [False, True])
 @pytest.mark.parametrize('relu,with_res', [(True, False), (True, True), (False, False)])
 def test_frozen_bn_epilogue(channels_last, relu, with_res):

@@ -177,8 +177,8 @@ def test_product_iteration_vs_reference(percent):
     real_bp = model._black_paper
 
     def spy(*a, **k):
-        r = real_bp(*a, **k)
-        seen.setdefault('syn', []).append(r)
+        r = real_bp(*a, **k)                 # one (img_syn, hull, alive) triple per image
+        seen['syn'] = list(r)
         return r
     model._black_paper = spy
     report = {}

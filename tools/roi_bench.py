@@ -11,11 +11,16 @@ B, C, H, W = 2, 256, 100, 100
 feat = torch.randn(B, C, H, W, device=dev).contiguous(memory_format=torch.channels_last)
 
 
-def bags(n_gt, wh_fn, U=25):
+def bags(n_gt, wh_fn, U=25, coarse=None):
     c = torch.rand(B * n_gt, 2, device=dev) * 700 + 50
     wh = wh_fn(B * n_gt)
     base = torch.cat([c - wh / 2, c + wh / 2], 1)
-    props, _ = F.fine_proposals(base, [1.0, 1.2, 1.3, 0.8, 0.7], None, 4, (800, 800))
+    if coarse is not None:          # the 100 % config: 9 coarse boxes per object, 45 shaken boxes per coarse box
+        base, _ = F.fine_proposals(base, coarse, None, 0, (800, 800))
+        props, _ = F.fine_proposals(base, [1.0, 1.3, 0.7], [0.1], 4, (800, 800))
+        U = 9 * 45
+    else:
+        props, _ = F.fine_proposals(base, [1.0, 1.2, 1.3, 0.8, 0.7], None, 4, (800, 800))
     bi = torch.arange(B, device=dev).repeat_interleave(n_gt * U).float()[:, None]
     return torch.cat([bi, props], 1)
 
@@ -23,6 +28,8 @@ def bags(n_gt, wh_fn, U=25):
 cases = {
     'step2 bags (12px objs)': (bags(100, lambda n: torch.exp(torch.randn(n, 2, device=dev) * 0.5 + math.log(12.)).clamp(2, 64)), 25),
     'step1 syn bags (hulls)': (bags(100, lambda n: (torch.rand(n, 2, device=dev) * 2 + 0.5) * torch.tensor([25., 55.], device=dev)), 25),
+    '100 % cfg bags (U1 9 x U2 45)': (bags(75, lambda n: torch.exp(torch.randn(n, 2, device=dev) * 0.5 + math.log(12.)).clamp(2, 64),
+                                           coarse=[1.0, 1.3, 0.8]), 45),
     'negatives (<=100px)': (torch.cat([torch.arange(B, device=dev).repeat_interleave(200).float()[:, None],
                                        (lambda x1: torch.cat([x1, x1 + torch.rand(400, 2, device=dev) * 100], 1))(torch.rand(400, 2, device=dev) * 640)], 1), 1),
 }
