@@ -39,7 +39,8 @@ def parse():
     ap.add_argument('--channels-last', type=int, default=1)
     ap.add_argument('--miopen-find', type=int, default=1)
     ap.add_argument('--fold-bn', type=int, default=0)
-    ap.add_argument('--cpu-baseline-iters', type=int, default=1)
+    ap.add_argument('--cpu-baseline-iters', type=int, default=3, help='timed oracle iterations (median is reported)')
+    ap.add_argument('--no-phase2', action='store_true', help='skip the extra steady-state (phase 2) measurement')
     ap.add_argument('--roofline-kernel', default='auto')
     return ap.parse_args()
 
@@ -58,6 +59,71 @@ def algorithmic_bytes(name, shapes):
     if name == 'pt_sqnorm_partial':
         return shapes['n'] * 4
     return None
+
+
+def iteration_flops(workload, cfg_model, batch, size, objects):
+    """Algorithmic FLOPs of one iteration (1 MAC = 2 FLOP), SURVEY Appendix B / BASELINE.md section 3: convolutions of the
+    teacher pass (forward only) and of the student passes (forward + 2x backward), plus the MIL FC stacks per RoI."""
+    a = (size / 800.0) ** 2
+    trunk, head = 60.2e9 * a, 47.5e9 * a                       # GMAC per image: R50 + FPN + PSAGG; dense head
+    n = cfg_model['num_training_burninstep2' if workload == 'step2' else 'num_training_burninstep1']
+    tc = cfg_model['train_cfg']
+    U = 1
+    for c in (tc['fine_proposal_cfg'][0], tc['fine_proposal_extensive_cfg'][0]):
+        U *= len(c['base_ratios']) ** 2 * (1 + 4 * len(c['shake_ratio'] or []))
+    K = batch * min(objects, n) * U
+    neg = batch * tc['fine_proposal_cfg'][0]['gen_num_neg']
+    fc = 12544 * 1024 + 1024 * 1024 + 1024 * 16                # MAC per RoI of one FC stack + its output layers
+    if workload == 'step2':
+        conv = batch * ((trunk + head) + 3 * trunk + 3 * (trunk + head))
+        mil = (3 * K + 3 * K + 3 * neg) * fc                   # regression and classifier branches, negatives; fwd + bwd
+    else:
+        conv = batch * ((trunk + head) + 3 * (trunk + head) + 3 * trunk + 3 * (trunk + head))
+        mil = (3 * K + K + 3 * K + 3 * neg) * fc               # synthetic regression branch trains, the real one is forward only
+    return 2.0 * (conv + mil)
+
+
+FAMILIES = {                                                    # op families for the roofline line
+    'pt_roi_align': ('pt_roi_align_fwd', 'pt_roi_align_bwd'),
+    'pt_roi_align_rotated': ('pt_roi_align_rotated_fwd', 'pt_roi_align_rotated_bwd'),
+    'pt_affine_relu': ('pt_affine_relu_fwd', 'pt_affine_relu_bwd', 'pt_affine_relu_bwd_train'),
+    'pt_optimizer (ema + sqnorm + sgd)': ('pt_ema_update', 'pt_sqnorm_partial', 'pt_sgd_step'),
+}
+
+
+def cpu_info():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    return 'unknown'
+
+
+def cpu_function_timings():
+    """Per-function CPU times of the oracle at BASELINE size: median of 5, milliseconds."""
+    import statistics
+    from oracle import ref_ops as R
+    g = torch.Generator().manual_seed(0)
+    ys, xs = torch.meshgrid(torch.arange(100.), torch.arange(100.), indexing='ij')
+    pts = torch.stack((xs.reshape(-1) * 8, ys.reshape(-1) * 8), -1) + 4
+    gt = torch.rand(300, 2, generator=g) * 780 + 10
+    lab = torch.randint(0, 8, (300,), generator=g)
+    cls = torch.randn(10000, 8, generator=g)
+    box = torch.cat([pts, torch.rand(10000, 2, generator=g) * 30 + 4], 1)
+    b4 = torch.cat([gt[:100] - 6, gt[:100] + 6], 1)
+    c = torch.randn(200, 1, 25, 8, generator=g)
+
+    def med(f):
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter(); f(); ts.append((time.perf_counter() - t0) * 1e3)
+        return round(statistics.median(ts), 2)
+    return {'a7 TopkAssigner(3,3) P=10000 G=300': med(lambda: R.topk_assign(pts, gt, lab, 3)),
+            'a6 FUSETopkAssigner P=10000 G=300': med(lambda: R.fuse_topk_assign(box, pts, cls, gt, lab)),
+            'a13 bag generation 100 -> 2500 boxes': med(lambda: R.fine_proposals(b4, [1.0, 1.2, 1.3, 0.8, 0.7], None, 4, (800, 800))),
+            'a16 bag loss [200,1,25,8]': med(lambda: R.mil_bag_loss(c, c * 0.5, torch.ones(5000, 1, dtype=torch.bool), lab[:200]))}
 
 
 def main():
@@ -172,27 +238,61 @@ def main():
     dt = float(tmax.item())
     log_vars = out['log_vars'].materialize()
 
-    # ---- roofline of the dominant custom kernel -------------------------------------
+    # ---- roofline of the dominant custom OP FAMILY (forward + backward of one op count together) ----------------
     kern = {}
     for fn, evs in prof.items():
         ms = [e0.elapsed_time(e1) for e0, e1, _ in evs]
         byts = [algorithmic_bytes(fn, s) if s else None for _, _, s in evs]
-        kern[fn] = dict(calls=len(ms), total_ms=sum(ms), avg_ms=sum(ms) / len(ms),
-                        bytes=(sum(b for b in byts if b) / len(byts)) if all(b for b in byts) else None)
-    timed = {k: v for k, v in kern.items() if v['bytes']}
-    dom = args.roofline_kernel if args.roofline_kernel != 'auto' else max(timed, key=lambda k: timed[k]['total_ms'])
-    d = timed[dom]
-    achieved = d['bytes'] / (d['avg_ms'] * 1e-3) / 1e9
-    traffic = None          # HBM bytes per launch from the committed PMC passes (same workload), else null
+        kern[fn] = dict(calls=len(ms), total_ms=sum(ms), bytes=sum(b for b in byts if b) if all(b for b in byts) else None)
+    fam = {}
+    for name, members in FAMILIES.items():
+        ks = [kern[m] for m in members if m in kern and kern[m]['bytes']]
+        if ks:
+            fam[name] = dict(calls=sum(k['calls'] for k in ks), total_ms=sum(k['total_ms'] for k in ks), bytes=sum(k['bytes'] for k in ks))
+    dom = args.roofline_kernel if args.roofline_kernel != 'auto' else max(fam, key=lambda k: fam[k]['total_ms'])
+    d = fam[dom]
+    # HIP-event pairs include ~5 us of event overhead per launch (event_pair_overhead_us); `achieved` keeps it in
+    # (conservative); rocprofv3's bare kernel time is shorter by about that much per launch
+    achieved = d['bytes'] / (d['total_ms'] * 1e-3) / 1e9
+    # HBM bytes from PMC passes: only when profiles/r02/pmc_traffic.json was taken with THIS kernel source (sha256 of the
+    # .hip file) and this workload; otherwise null (never a number measured on other code)
+    traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01', 'pmc_traffic.json')))
-        traffic = pmc.get(('obb_' if obb else '') + args.workload, {}).get(dom, {}).get('traffic')
+        import hashlib
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02', 'pmc_traffic.json')))
+        ent = pmc.get(('obb_' if obb else '') + args.workload + ('_bf16' if args.dtype == 'bf16' else ''), {}).get(dom)
+        if ent:
+            src = os.path.join(ROOT, 'point_teacher_amd', 'csrc', ent['source'])
+            if hashlib.sha256(open(src, 'rb').read()).hexdigest() == ent['source_sha256']:
+                traffic = ent['traffic_bytes_per_launch']
     except Exception:
         pass
     roofline = dict(bound='hbm', kernel=dom, achieved=round(achieved, 1), peak=8000.0, unit='GB/s',
-                    frac=round(achieved / 8000.0, 4), traffic=traffic, avg_launch_us=round(d['avg_ms'] * 1e3, 2),
-                    event_pair_overhead_us=round(event_overhead_us, 2),
-                    launches=d['calls'], bytes_per_launch=int(d['bytes']))
+                    frac=round(achieved / 8000.0, 4), traffic=traffic,
+                    avg_launch_us=round(d['total_ms'] / d['calls'] * 1e3, 2), event_pair_overhead_us=round(event_overhead_us, 2),
+                    launches=d['calls'], bytes_per_launch=int(d['bytes'] / d['calls']),
+                    families={k: dict(ms_per_step=round(v['total_ms'] / args.steps, 3),
+                                      achieved_GBps=round(v['bytes'] / (v['total_ms'] * 1e-3) / 1e9, 1)) for k, v in sorted(fam.items())})
+
+    # ---- the steady-state phase as well (94 % of a 12-epoch run is phase 2): same model, phase switch flipped ----
+    phase2 = None
+    if args.workload == 'step1' and not args.no_phase2:
+        model.burn_in_step = -1
+        for it in range(max(args.warmup, 3)):
+            trainer.step(data.batch(1000 + it, args.batch))
+        barrier()
+        t0 = time.perf_counter()
+        for it in range(args.steps):
+            trainer.step(data.batch(2000 + it, args.batch))
+        barrier()
+        dt2 = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(dt2, op=dist.ReduceOp.MAX)
+        dt2 = float(dt2.item())
+        f2 = iteration_flops('step2', cfg.to_dict()['model'], args.batch, args.size, args.objects)
+        phase2 = dict(workload='phase 2 (MIL on, steady state), same model and inputs', value=round(args.steps * world / dt2, 4), unit='iters/s',
+                      ms_per_step=round(dt2 / args.steps * 1e3, 3), flops=f2, achieved_tflops=round(f2 * args.steps / dt2 / 1e12, 2))
+        model.burn_in_step = 10 ** 9
 
     if rank == 0:
         cpu_baseline = None
@@ -205,12 +305,14 @@ def main():
                 from oracle import ref_model
                 cpu_baseline = ref_model.cpu_baseline(args.workload, args.batch, args.size, args.objects,
                                                       iters=args.cpu_baseline_iters)
+                cpu_baseline['cpu'] = cpu_info()
+                cpu_baseline['per_function_ms'] = cpu_function_timings()
             except Exception as e:  # the baseline is a reported side number; never fail the bench for it
                 cpu_baseline = dict(value=None, unit='iters/s', cores=os.cpu_count(), kind='port',
                                     sample=f'failed: {type(e).__name__}: {e}')
         iters_s = args.steps * 1.0 / dt
-        # BASELINE.md section 3 (0 % config, B = 2, 800x800); the conv towers dominate, so other tile sizes scale by area
-        flops_iter = 3.3e12 * (args.batch / 2) * (args.size / 800.0) ** 2
+        flops_iter = iteration_flops(args.workload, cfg.to_dict()['model'], args.batch, args.size, args.objects) if not obb \
+            else 3.3e12 * (args.batch / 2) * (args.size / 800.0) ** 2 * (1.3 if args.workload == 'step1' else 1.0)
         peak = 2.5e15 if args.dtype == 'bf16' else 157.3e12
         line = dict(
             metric=f'train iters/sec ({args.size}x{args.size}, ~{args.objects} pts/img)', value=round(iters_s * world, 4), unit='iters/s',
@@ -225,6 +327,7 @@ def main():
             roofline=roofline, cpu_baseline=cpu_baseline,
             iteration=dict(flops=flops_iter, achieved_tflops=round(flops_iter * iters_s / 1e12, 2),
                            mfma_peak_tflops=peak / 1e12, frac=round(flops_iter * iters_s / peak, 4)),
+            phase2=phase2,
             custom_kernels_ms_per_step={k: round(v['total_ms'] / args.steps, 3) for k, v in sorted(kern.items())},
             loss=round(log_vars.get('loss', float('nan')), 4))
         print(json.dumps(line))

@@ -384,32 +384,60 @@ def test_eval_path_detections():
                 torch.testing.assert_close(got[kg, :4], rb[kr], rtol=1e-3, atol=5e-2)
 
 
-def test_bf16_backbone_fp32_head():
+@pytest.mark.parametrize('phase2', [False, True])
+def test_bf16_backbone_fp32_head(phase2):
     """BASELINE configs[2] ("bf16 backbone + fp32 head"): with Trainer(autocast_dtype=bfloat16) the backbone / FPN / PSAGG
-    convolutions run in bf16, while the dense head, the MIL head and the losses see and produce fp32; both phases stay finite
-    and on the scale of the fp32 iteration."""
+    convolutions run in bf16 while the dense head, the MIL head and the losses see and produce fp32.
+    Checked against the ORACLE run with the same precision boundary (ref_model.bf16_backbone: bf16 operands and storage,
+    fp32 accumulation, one rounding per fused epilogue): every entry of the loss dict within BF16_TOL.  bf16 keeps 8
+    significant bits (one rounding = 4e-3 relative); product and oracle round the same quantities, but wherever two fp32
+    accumulation orders straddle a rounding boundary one of them lands an ulp (0.4 - 0.8 %) away, and the bias-carrying
+    FPN / PSAGG convolutions round twice in the product (convolution, then bias add).  The test also shows that it
+    discriminates: the fp32 oracle is further from the bf16 oracle than the product is."""
+    BF16_TOL = 2e-2
     dev = torch.device('cuda:0')
     seen = {}
-    for phase2 in (False, True):
-        pta, cfg, model = _build(dev, phase2=phase2)
-        ref_pta, _, ref_model = _build(dev, phase2=phase2)
-        tr = pta.Trainer(model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config, autocast_dtype=torch.bfloat16)
-        tr32 = ref_pta.Trainer(ref_model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config)
-        hooks = [model.student.backbone.layer2[0].conv1.register_forward_hook(lambda m, i, o: seen.__setitem__('backbone', o.dtype)),
-                 model.student.neck.fpn_convs[0].register_forward_hook(lambda m, i, o: seen.__setitem__('neck', o.dtype)),
-                 model.student.bbox_head.cls_convs[0].register_forward_hook(lambda m, i, o: seen.__setitem__('head', (i[0].dtype, o.dtype))),
-                 model.student.bbox_head.conv_reg.register_forward_hook(lambda m, i, o: seen.__setitem__('reg', o.dtype))]
-        img, boxes, labels, metas = _data(dev)
-        data = dict(img=img.to(dev), img_metas=metas, gt_bboxes=[b.to(dev) for b in boxes], gt_labels=[l.to(dev) for l in labels])
-        lv = tr.step(data)['log_vars'].materialize()
-        lv32 = tr32.step(data)['log_vars'].materialize()
-        for h in hooks:
-            h.remove()
-        assert seen['backbone'] == torch.bfloat16 and seen['neck'] == torch.bfloat16
-        assert seen['head'] == (torch.float32, torch.float32) and seen['reg'] == torch.float32
-        assert all(v == v and abs(v) != float('inf') for v in lv.values()), lv
-        # a randomly initialised net turns bf16 feature noise into different point->box decisions: same scale, not same value
-        assert lv['loss_cls'] == pytest.approx(lv32['loss_cls'], rel=0.1), (lv['loss_cls'], lv32['loss_cls'])
-        for k in ('loss_bbox', 'loss_centerness'):
-            assert 0.5 * lv32[k] < lv[k] < 2.0 * lv32[k], (k, lv[k], lv32[k])
-        assert torch.isfinite(tr.flat.student_flat).all()
+    pta, cfg, model = _build(dev, phase2=phase2)
+    tr = pta.Trainer(model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config, autocast_dtype=torch.bfloat16)
+    hooks = [model.student.backbone.layer2[0].conv1.register_forward_hook(lambda m, i, o: seen.__setitem__('backbone', o.dtype)),
+             model.student.neck.fpn_convs[0].register_forward_hook(lambda m, i, o: seen.__setitem__('neck', o.dtype)),
+             model.student.bbox_head.cls_convs[0].register_forward_hook(lambda m, i, o: seen.__setitem__('head', (i[0].dtype, o.dtype))),
+             model.student.bbox_head.conv_reg.register_forward_hook(lambda m, i, o: seen.__setitem__('reg', o.dtype))]
+    img, boxes, labels, metas = _data(dev, seed=6 if not phase2 else 5)
+    g = torch.Generator().manual_seed(13)
+    neg_u = torch.rand(2, 4, 200, generator=g)
+    aug = (['horizontal', 'vertical'], [0.9, 1.1])
+    inj = dict(neg0=neg_u, aug=aug)
+    if not phase2:
+        inj['syn'] = [_syn_draws(b.shape[0], 40 + i) for i, b in enumerate(boxes)]
+    model._inject = {k: (v.to(dev) if torch.is_tensor(v) else ([{n: t.to(dev) for n, t in d.items()} for d in v] if k == 'syn' else v))
+                     for k, v in inj.items()}
+    sd_s0 = _strip(model.state_dict(), 'student.')
+    sd_t0 = _strip(model.state_dict(), 'teacher.')
+    data = dict(img=img.to(dev), img_metas=metas, gt_bboxes=[b.to(dev) for b in boxes], gt_labels=[l.to(dev) for l in labels])
+    out = model.train_step(data, None)
+    out['loss'].backward()
+    lv = out['log_vars'].materialize()
+    for h in hooks:
+        h.remove()
+    assert seen['backbone'] == torch.bfloat16 and seen['neck'] == torch.bfloat16
+    assert seen['head'] == (torch.float32, torch.float32) and seen['reg'] == torch.float32
+    assert all(v == v and abs(v) != float('inf') for v in lv.values()), lv
+    gs = dict(model.student.named_parameters())
+    assert all(torch.isfinite(gs[k].grad).all() for k in GRAD_KEYS)
+    step = M.forward_train_step2 if phase2 else M.forward_train_step1
+    sd_t = M.ema(sd_t0, sd_s0)
+    gp = [R.bbox_xyxy_to_cxcywh(b)[:, :2] for b in boxes]
+    with torch.no_grad():
+        with M.bf16_backbone():
+            ref16, _ = step(dict(sd_s0), sd_t, img, boxes, labels, gp, dict(M.MODEL_CFG), inj)
+        ref32, _ = step(dict(sd_s0), sd_t, img, boxes, labels, gp, dict(M.MODEL_CFG), inj)
+    assert set(ref16.keys()) == set(lv.keys()) - {'loss'}
+    err = {k: abs(float(lv[k]) - float(ref16[k])) / max(abs(float(ref16[k])), 1e-2) for k in ref16}
+    gap = {k: abs(float(ref32[k]) - float(ref16[k])) / max(abs(float(ref16[k])), 1e-2) for k in ref16}
+    print('bf16 product vs bf16 oracle:', {k: f'{v:.1e}' for k, v in err.items()})
+    print('fp32 oracle  vs bf16 oracle:', {k: f'{v:.1e}' for k, v in gap.items()})
+    for k, e in err.items():
+        assert e < BF16_TOL, (k, e, float(lv[k]), float(ref16[k]))
+    assert sum(err.values()) < sum(gap.values())          # the product follows the bf16 oracle, not the fp32 one
+    del tr

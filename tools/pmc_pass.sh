@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
   out=gpurun_out/pmc_${tag}_$ctr
   rm -rf $out && mkdir -p $out
-  rocprofv3 --pmc $ctr --output-format csv -d $out -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline "$@" > $out/bench.json 2> $out/bench.err || { tail -5 $out/bench.err; exit 1; }
+  rocprofv3 --pmc $ctr --output-format csv -d $out -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-phase2 "$@" > $out/bench.json 2> $out/bench.err || { tail -5 $out/bench.err; exit 1; }
   python tools/pmc_summary.py $out > gpurun_out/pmc_${tag}_$ctr.txt
   rm -rf $out
 done
