@@ -49,7 +49,9 @@ def parse():
 def algorithmic_bytes(name, shapes):
     if name in ('pt_roi_align_fwd', 'pt_roi_align_bwd', 'pt_roi_align_rotated_fwd', 'pt_roi_align_rotated_bwd'):
         K, C, o = shapes['K'], shapes['C'], shapes['out']
-        return K * C * o * o * 4            # the [K,C,7,7] block written (fwd) / read (bwd); the map stays in L2/MALL
+        # the [K,C,7,7] block written (fwd) / read (bwd) + every RoI's footprint pixels read (fwd) / added to (bwd) once:
+        # SURVEY 8(d) "K*256*49*4 B written + feature pixels x 1 KB read per RoI" with the pixel count of the actual boxes
+        return K * C * o * o * 4 + shapes.get('footprint_px', 0) * C * 4
     if name in ('pt_affine_relu_fwd', 'pt_affine_relu_bwd', 'pt_affine_relu_bwd_train'):
         return shapes['n'] * 4 * shapes['streams']   # fp32 streams read + written per element (x, y, residual / g, y, gx, gres)
     if name == 'pt_ema_update':
@@ -197,7 +199,9 @@ def main():
             r = orig_call(fn, *a)
             e1.record()
             shp = None
-            if fn in ('pt_roi_align_fwd', 'pt_roi_align_bwd', 'pt_roi_align_rotated_fwd', 'pt_roi_align_rotated_bwd'):
+            if fn in ('pt_roi_align_fwd', 'pt_roi_align_bwd'):
+                shp = dict(K=a[6], C=a[3], out=a[7], rois=a[1], scale=a[8], H=a[4], W=a[5])    # footprints are counted after the timed loop
+            elif fn in ('pt_roi_align_rotated_fwd', 'pt_roi_align_rotated_bwd'):
                 shp = dict(K=a[6], C=a[3], out=a[7])
             elif fn == 'pt_affine_relu_fwd':
                 shp = dict(n=a[4], streams=2 + (a[3] is not None))
@@ -239,6 +243,20 @@ def main():
     log_vars = out['log_vars'].materialize()
 
     # ---- roofline of the dominant custom OP FAMILY (forward + backward of one op count together) ----------------
+    def footprint_px(r, scale, H, W):      # feature pixels an aligned RoI samples: the bilinear taps of its first and last sample
+        x1, y1, x2, y2 = (r[:, i] * scale - 0.5 for i in (1, 2, 3, 4))
+        nx = (x2.floor().clamp(0, W - 2) + 1) - x1.floor().clamp(0, W - 1) + 1
+        ny = (y2.floor().clamp(0, H - 2) + 1) - y1.floor().clamp(0, H - 1) + 1
+        return nx.clamp(min=1) * ny.clamp(min=1)
+    fp_total = []
+    for fn, evs in prof.items():
+        for _, _, shp in evs:
+            if shp and 'rois' in shp:
+                fp_total.append((shp, footprint_px(shp.pop('rois'), shp['scale'], shp['H'], shp['W']).sum()))
+    if fp_total:
+        vals = torch.stack([v for _, v in fp_total]).cpu().tolist()
+        for (shp, _), v in zip(fp_total, vals):
+            shp['footprint_px'] = int(v)
     kern = {}
     for fn, evs in prof.items():
         ms = [e0.elapsed_time(e1) for e0, e1, _ in evs]

@@ -615,9 +615,25 @@ def nms(boxes, scores, iou_threshold, class_ids=None):
     return torch.cat([boxes[keep], scores[keep, None]], 1), keep
 
 
+NMS_MAXN = 32768       # csrc/nms.hip: candidates whose suppression bitmasks one launch holds
+
+
 def batched_nms(boxes, scores, idxs, nms_cfg):
-    """mmcv.ops.batched_nms (class-aware) for nms_cfg = dict(type='nms', iou_threshold=...)."""
-    return nms(boxes, scores, nms_cfg.get('iou_threshold', 0.5), class_ids=idxs)
+    """mmcv.ops.batched_nms (class-aware) for nms_cfg = dict(type='nms', iou_threshold=...).  Above NMS_MAXN candidates
+    (a 5-level head at nms_pre 3000 x 8 classes can reach ~88 000 at a low score threshold) the classes are processed
+    one after the other, as mmcv does above its `split_thr`; a single class above the limit keeps its best NMS_MAXN."""
+    thr = nms_cfg.get('iou_threshold', 0.5)
+    if boxes.shape[0] <= NMS_MAXN:
+        return nms(boxes, scores, thr, class_ids=idxs)
+    keeps = []
+    for c in torch.unique(idxs).tolist():
+        sel = (idxs == c).nonzero(as_tuple=False).squeeze(1)
+        if sel.numel() > NMS_MAXN:
+            sel = sel[torch.topk(scores[sel], NMS_MAXN, sorted=False)[1]]
+        keeps.append(sel[nms(boxes[sel], scores[sel], thr)[1]])
+    keep = torch.cat(keeps)
+    keep = keep[torch.sort(scores[keep], descending=True, stable=True)[1]]
+    return torch.cat([boxes[keep], scores[keep, None]], 1), keep
 
 
 def box_iou_rotated(b1, b2, aligned=False):

@@ -7,6 +7,8 @@ Point-Teacher around them is in libpt_hip.so.
 Citations: /root/reference/HBB_TOD/mmdet/models/backbones/resnet.py,
 necks/fpn.py, necks/ps_fpn.py, roi_heads/roi_extractors/*.py.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as TF
@@ -106,6 +108,52 @@ class Scale(nn.Module):
 
 
 # ------------------------------------------------------------------------ ResNet --
+def resolve_checkpoint(name):
+    """A local file for a checkpoint name.  Plain paths are used as they are; model-zoo names (`open-mmlab://...`,
+    `torchvision://...`, http URLs: there is no network here) are looked up as `<dir>/<name with ':' and '/' -> '_'>.pth`
+    and `<dir>/<basename>.pth` under $PT_PRETRAINED_DIR (default ~/.cache/point_teacher_amd/pretrained)."""
+    if os.path.isfile(name):
+        return name
+    root = os.environ.get('PT_PRETRAINED_DIR', os.path.join(os.path.expanduser('~'), '.cache', 'point_teacher_amd', 'pretrained'))
+    flat = name.replace('://', '_').replace('/', '_').replace(':', '_')
+    for cand in (flat, flat + '.pth', os.path.basename(name), os.path.basename(name) + '.pth'):
+        path = os.path.join(root, cand)
+        if os.path.isfile(path):
+            return path
+    return None
+
+
+def load_pretrained(module, checkpoint, prefix=None):
+    """mmcv's `Pretrained` initialiser for this path: load `checkpoint` into `module` (non-strict, `state_dict` /
+    `model` wrappers and a `prefix` stripped).  When the file cannot be found the module KEEPS its random initialisation
+    and a loud warning says so - training from it does not reproduce the reference's recipe."""
+    import warnings
+    path = resolve_checkpoint(checkpoint)
+    if path is None:
+        warnings.warn(f'pretrained checkpoint {checkpoint!r} not found (set PT_PRETRAINED_DIR or pass a file path): '
+                      f'{type(module).__name__} stays RANDOMLY initialised', RuntimeWarning, stacklevel=2)
+        return False
+    sd = torch.load(path, map_location='cpu', weights_only=False)
+    for k in ('state_dict', 'model'):
+        if isinstance(sd, dict) and k in sd and isinstance(sd[k], dict):
+            sd = sd[k]
+    pre = (prefix.rstrip('.') + '.') if prefix else None
+    if pre is None and any(k.startswith('backbone.') for k in sd) and not any(k.startswith('backbone.') for k in module.state_dict()):
+        pre = 'backbone.'
+    if pre:
+        sd = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+    res = module.load_state_dict(sd, strict=False)
+    own = set(module.state_dict())
+    if not own & set(sd):
+        warnings.warn(f'{path}: no parameter name matches {type(module).__name__}', RuntimeWarning, stacklevel=2)
+        return False
+    missing = [k for k in res.missing_keys if 'num_batches_tracked' not in k]
+    if missing:
+        warnings.warn(f'{path}: {len(missing)} parameters of {type(module).__name__} not in the checkpoint, e.g. {missing[:3]}',
+                      RuntimeWarning, stacklevel=2)
+    return True
+
+
 def _bn_key(bn):
     """Everything the (scale, shift) of an eval-mode BatchNorm depends on.  Modules flagged
     `_affine_dynamic` (the teacher's: the flat EMA kernel rewrites their weight/bias through raw
@@ -250,15 +298,22 @@ class ResNet(nn.Module):
                     for p in m.parameters():
                         p.requires_grad = False
         self._freeze_stages()
+        self.init_cfg = init_cfg if init_cfg is not None else (dict(type='Pretrained', checkpoint=pretrained) if pretrained else None)
+        self.pretrained_loaded = None           # None: no checkpoint asked for; True / False: found and loaded / not found
         self.init_weights()
 
     def init_weights(self):
+        """Kaiming / constant init (resnet.py:612-628), then the `Pretrained` init_cfg of the configs
+        (`open-mmlab://detectron/resnet50_caffe`): see load_pretrained."""
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
             elif isinstance(m, nn.BatchNorm2d):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
+        cfg = self.init_cfg
+        if isinstance(cfg, dict) and cfg.get('type') == 'Pretrained' and cfg.get('checkpoint'):
+            self.pretrained_loaded = load_pretrained(self, cfg['checkpoint'], prefix=cfg.get('prefix'))
 
     def _freeze_stages(self):
         """resnet.py:612-628"""

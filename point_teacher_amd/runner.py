@@ -37,13 +37,22 @@ class Runner:
         self._eval = (dataset, loader, int(interval), eval_kwargs)
 
     def evaluate(self):
-        from .evaluation import single_gpu_test
+        """Every rank tests its shard (`build_dataloader(dist=True, shuffle=False)` under an initialised group), rank 0 gets
+        the whole dataset's results (apis/test.py:68-171) and scores them; the others return None.  A rank never waits in a
+        gradient all-reduce while another one evaluates."""
+        from .evaluation import multi_gpu_test, single_gpu_test
         dataset, loader, _, kw = self._eval
         model = self.trainer.model
         was_training = model.training
-        it = iter(loader)
-        results = single_gpu_test(model, lambda _: next(it), len(loader))
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        if world > 1:
+            results = multi_gpu_test(model, loader, len(dataset))
+        else:
+            it = iter(loader)
+            results = single_gpu_test(model, lambda _: next(it), len(loader))
         model.train(was_training)
+        if results is None:
+            return None
         metrics = dataset.evaluate(results, **kw)
         rec = dict(mode='val', epoch=self.epoch, iter=len(results))
         rec.update({k: v for k, v in metrics.items() if isinstance(v, (int, float, str))})
@@ -56,11 +65,15 @@ class Runner:
     # ---------------------------------------------------------------------- checkpoints --
     def save_checkpoint(self, name=None):
         """CheckpointHook: epoch_{n}.pth + latest.pth (rank 0 only)."""
+        extra = self._gather_point_state()                  # collective: every rank takes part
         if self.rank != 0:
             return None
         path = os.path.join(self.work_dir, name or f'epoch_{self.epoch}.pth')
         state = self.trainer.state_dict()
-        state['meta'] = dict(epoch=self.epoch, iter=self.trainer.iter, time=time.strftime('%Y-%m-%d %H:%M:%S'))
+        if extra is not None:
+            state['model']['_extra_state'] = extra
+        state['meta'] = dict(epoch=self.epoch, iter=self.trainer.iter, time=time.strftime('%Y-%m-%d %H:%M:%S'),
+                             loader_epoch=getattr(self.batches, 'epoch', None))
         torch.save(state, path)
         latest = os.path.join(self.work_dir, 'latest.pth')
         if os.path.lexists(latest):
@@ -68,11 +81,32 @@ class Runner:
         os.symlink(os.path.basename(path), latest)
         return path
 
+    def _gather_point_state(self):
+        """The detector keeps per-image point dictionaries (first-visit and refined points, keyed by file name) for the
+        images THIS rank has seen; a checkpoint written by rank 0 alone would lose the other shards' refinements and give
+        them fresh random points after a resume.  All ranks contribute theirs (one all_gather_object per checkpoint)."""
+        model = self.trainer.model
+        if not hasattr(model, 'get_extra_state') or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return None
+        mine = model.get_extra_state()
+        parts = [None] * dist.get_world_size()
+        dist.all_gather_object(parts, mine)
+        merged = dict(parts[0])
+        for k in ('gt_bboxes_point', 'refined_gt_bboxes_point'):
+            merged[k] = {}
+            for part in parts:
+                merged[k].update(part.get(k, {}))
+        return merged
+
     def resume(self, path):
-        """--resume-from: model (incl. count / point dictionaries), momentum, iteration, epoch."""
+        """--resume-from: model (incl. count / the point dictionaries of every rank), momentum, iteration, epoch, and the
+        data loader's position: the sampler continues with the shuffle of the epoch the run was in (`EpochBatches.epoch`)."""
         state = torch.load(path, map_location=self.trainer.flat.student_flat.device, weights_only=False)
         self.trainer.load_state_dict(state)
         self.epoch = state['meta']['epoch']
+        le = state['meta'].get('loader_epoch')
+        if le is not None and hasattr(self.batches, 'epoch'):
+            self.batches.epoch, self.batches._it = int(le), None
         return state['meta']
 
     # --------------------------------------------------------------------------- logging --
@@ -111,8 +145,8 @@ class Runner:
                 self.epoch += 1
                 if self.epoch % self.checkpoint_interval == 0:
                     self.save_checkpoint()
-                if self._eval is not None and self.epoch % self._eval[2] == 0 and self.rank == 0:
-                    self.evaluate()
+                if self._eval is not None and self.epoch % self._eval[2] == 0:
+                    self.evaluate()                         # every rank: sharded test loop
             if stop:
                 break
         return done

@@ -39,8 +39,16 @@ class FlatParams:
         teacher = dict(model.teacher.named_parameters()) if self.has_teacher else None
         assert teacher is None or [n for n, _ in student] == list(teacher.keys()), 'teacher/student parameter lists differ'
 
-        def is_bias(name, p):           # mmcv DefaultOptimizerConstructor: key name == 'bias' (norm layers are frozen here)
-            return name.endswith('.bias') or name == 'bias'
+        # mmcv DefaultOptimizerConstructor (optimizer/default_constructor.py): bias_lr_mult / bias_decay_mult apply to
+        # parameters NAMED 'bias' of every module EXCEPT normalisation layers; norm weights and biases keep lr x 1 and take
+        # weight_decay x norm_decay_mult (1 unless a config says otherwise) - i.e. they belong to the weights segment.
+        root = model.student if self.has_teacher else model
+        norm_owned = {id(p) for m in root.modules() if isinstance(m, (torch.nn.modules.batchnorm._BatchNorm, torch.nn.GroupNorm,
+                                                                    torch.nn.LayerNorm, torch.nn.modules.instancenorm._InstanceNorm))
+                      for p in m.parameters(recurse=False)}
+
+        def is_bias(name, p):
+            return (name.endswith('.bias') or name == 'bias') and id(p) not in norm_owned
         weights = [(n, p) for n, p in student if p.requires_grad and not is_bias(n, p)]
         biases = [(n, p) for n, p in student if p.requires_grad and is_bias(n, p)]
         frozen = [(n, p) for n, p in student if not p.requires_grad]
@@ -123,37 +131,6 @@ class FlatParams:
         return True
 
 
-class GradReducer:
-    """Mean of a flat gradient buffer over the data-parallel ranks: `chunks` large all-reduces
-    (RCCL over xGMI on the GPU, on a side stream; gloo in the CPU tests).  No data-path
-    collective other than this one exists on the path (images shard independently)."""
-
-    def __init__(self, chunks=4, device=None):
-        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        self.chunks = max(int(chunks), 1)
-        self.stream = torch.cuda.Stream(device=device) if (self.world > 1 and device is not None
-                                                           and device.type == 'cuda') else None
-
-    def reduce_(self, g):
-        if self.world == 1:
-            return g
-        n = g.numel()
-        step = (n + self.chunks - 1) // self.chunks
-        if self.stream is None:
-            g.div_(self.world)
-            for s in range(0, n, step):
-                dist.all_reduce(g[s:s + step])
-            return g
-        cur = torch.cuda.current_stream()
-        self.stream.wait_stream(cur)
-        with torch.cuda.stream(self.stream):
-            g.div_(self.world)
-            for s in range(0, n, step):
-                dist.all_reduce(g[s:s + step])
-        cur.wait_stream(self.stream)
-        return g
-
-
 class BucketedGradExchange:
     """Mean of the flat gradient over the data-parallel ranks, OVERLAPPED with backward.
 
@@ -162,7 +139,14 @@ class BucketedGradExchange:
     has been produced the bucket is copied into the flat buffer with one multi-tensor copy and its all-reduce
     (RCCL over xGMI; a few large messages, xGMI being point-to-point) is issued on a side stream while autograd
     keeps computing the earlier layers.  `finish()` flushes buckets whose parameters received no gradient in
-    this iteration (their segment stays zero) and joins the side stream.  gloo / CPU: same logic, synchronous."""
+    this iteration (their segment stays zero) and joins the side stream.  gloo / CPU: same logic, synchronous.
+
+    Collectives are ISSUED IN A FIXED ORDER (`issue_order`: buckets by the model position of their earliest parameter,
+    latest first - the order backward completes them in when every parameter receives a gradient).  A completed bucket
+    waits until every bucket ahead of it in that order has been issued, so two ranks on which gradients arrive in
+    different orders, or on which a parameter receives no gradient at all (an empty image, a data-dependent branch),
+    still enqueue the same sequence of equally sized all-reduces; `finish()` issues whatever is left in the same order
+    and asserts the sequence."""
 
     def __init__(self, flat, n_buckets=6, device=None):
         self.flat = flat
@@ -185,13 +169,19 @@ class BucketedGradExchange:
             self.buckets.append([start, off, cur])
         assert off == total, (off, total)
         self.bucket_of = {id(p): b for b, (_, _, ps) in enumerate(self.buckets) for p, _ in ps}
+        pos = {id(p): i for i, p in enumerate((flat.model.student if flat.has_teacher else flat.model).parameters())}
+        first = [min(pos[id(p)] for p, _ in ps) for _, _, ps in self.buckets]
+        self.issue_order = sorted(range(len(self.buckets)), key=lambda b: -first[b])
         self.left, self.done, self.active = [0] * len(self.buckets), [True] * len(self.buckets), False
+        self.ready, self.next, self.issued = [False] * len(self.buckets), 0, []
         for p in flat.train_params:
             p.register_post_accumulate_grad_hook(self._on_grad)
 
     def begin(self):
         self.left = [len(ps) for _, _, ps in self.buckets]
         self.done = [False] * len(self.buckets)
+        self.ready = [False] * len(self.buckets)
+        self.next, self.issued = 0, []
         self.active = True
 
     def _on_grad(self, p):
@@ -200,7 +190,13 @@ class BucketedGradExchange:
         b = self.bucket_of[id(p)]
         self.left[b] -= 1
         if self.left[b] == 0:
-            self._flush(b)
+            self.ready[b] = True
+            self._issue_ready()
+
+    def _issue_ready(self):
+        while self.next < len(self.issue_order) and self.ready[self.issue_order[self.next]]:
+            self._flush(self.issue_order[self.next])
+            self.next += 1
 
     def _flush(self, b):
         start, end, ps = self.buckets[b]
@@ -225,11 +221,13 @@ class BucketedGradExchange:
                     g.div_(self.world)
                     dist.all_reduce(g)
         self.done[b] = True
+        self.issued.append(b)
 
     def finish(self):
-        for b in range(len(self.buckets)):
-            if not self.done[b]:
-                self._flush(b)
+        while self.next < len(self.issue_order):            # buckets still waiting for a gradient that never came, in order
+            self._flush(self.issue_order[self.next])
+            self.next += 1
+        assert self.issued == self.issue_order, (self.issued, self.issue_order)
         self.active = False
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
@@ -276,6 +274,8 @@ class Trainer:
         self.weight_decay = optimizer_cfg.get('weight_decay', 0.0)
         pw = optimizer_cfg.get('paramwise_cfg', {}) or {}
         self.bias_lr_mult, self.bias_decay_mult = pw.get('bias_lr_mult', 1.0), pw.get('bias_decay_mult', 1.0)
+        assert pw.get('norm_decay_mult', 1.0) == 1.0 and not pw.get('custom_keys'), \
+            'paramwise_cfg: only bias_lr_mult / bias_decay_mult are on the Point-Teacher path (norm parameters decay like weights)'
         clip = (optimizer_config or {}).get('grad_clip') or {}
         assert clip.get('norm_type', 2) == 2
         self.max_norm = float(clip.get('max_norm', 0.0))
@@ -288,7 +288,6 @@ class Trainer:
         self._lr_host = None
         self.iter = 0
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        self.reducer = GradReducer(grad_chunks, dev)
         # N > 1: bucketed exchange overlapped with backward; N == 1: nothing to exchange, one gather after backward
         self.exchange = BucketedGradExchange(self.flat, max(grad_chunks, 1) + 2, dev) if self.world > 1 else None
         # BASELINE configs[2] "bf16 backbone + fp32 head": autocast covers backbone / FPN / PSAGG only (Student_FCOS.extract_feat)

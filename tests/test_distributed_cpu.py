@@ -22,17 +22,7 @@ def _worker(rank, world, port, q):
     try:
         from point_teacher_amd.core import reduce_mean
         from point_teacher_amd.detectors import LazyLogVars
-        from point_teacher_amd.runtime import GradReducer, StepLR
-        torch.manual_seed(100 + rank)
-        n = 1_000_003
-        g = torch.randn(n)
-        all_g = [torch.empty(n) for _ in range(world)]
-        dist.all_gather(all_g, g)
-        expect = sum(all_g) / world
-        red = GradReducer(chunks=4, device=torch.device('cpu'))
-        assert red.world == world and red.stream is None
-        out = red.reduce_(g.clone())
-        torch.testing.assert_close(out, expect, rtol=1e-6, atol=1e-6)
+        from point_teacher_amd.runtime import StepLR
         # bucketed exchange overlapped with backward (runtime.BucketedGradExchange) on a toy teacher/student pair
         from point_teacher_amd.runtime import BucketedGradExchange, FlatParams
 
@@ -69,6 +59,23 @@ def _worker(rank, world, port, q):
                 torch.testing.assert_close(flat.grad_flat[off:off + n], expect_named[o:o + n], rtol=1e-5, atol=1e-6)
                 o += n
             assert flat.check_views()
+            assert ex.issued == ex.issue_order
+        # ranks on which DIFFERENT parameters receive gradients (an empty image on one rank, a data-dependent branch): rank 0
+        # skips the middle layer's path entirely, rank 1 uses it; arrival orders differ, yet both ranks must enqueue the same
+        # sequence of all-reduces (a mismatch would hang or mix buckets) and end with the mean of what was produced
+        flat.zero_grad(); flat.detach_grads()
+        ex.begin()
+        if rank == 0:
+            (pair.student[4](torch.randn(16, 50)).pow(2).mean()).backward()      # only the last used layer
+        else:
+            pair.student[:5](x).pow(2).mean().backward()
+        ex.finish()
+        assert ex.issued == ex.issue_order
+        per_rank = [torch.empty_like(flat.grad_flat) for _ in range(world)]
+        dist.all_gather(per_rank, flat.grad_flat.clone())
+        torch.testing.assert_close(per_rank[0], per_rank[1], rtol=0, atol=0)     # identical reduced gradient on both ranks
+        off0, n0 = flat.slices['0.weight']
+        assert float(flat.grad_flat[off0:off0 + n0].abs().sum()) > 0              # rank 1's contribution / world arrived
         # a detector without a teacher (the supervised baselines of row N4): same flat layout, same exchange
         torch.manual_seed(9)
         solo = torch.nn.Sequential(torch.nn.Linear(11, 20), torch.nn.ReLU(), torch.nn.Linear(20, 4))

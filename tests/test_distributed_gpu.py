@@ -1,0 +1,95 @@
+"""N > 1 with the REAL model on the MI355X: two ranks (gloo rendezvous on 127.0.0.1, both on cuda:0 - the box has one card;
+on a node each rank owns a GPU and the backend is RCCL) run `Trainer.step` of the Point-Teacher detector through both phases
+on DIFFERENT data per rank, including the two cases that make ranks diverge in the reference: an image
+without objects and an iteration in which no synthetic rectangle survives.  After three steps both ranks must hold bit-identical
+student and teacher weights (same initial broadcast, same reduced gradients, same optimizer), the bucketed exchange must have
+issued its collectives in the fixed order on both, and the loss-key set must be the same on every rank and iteration."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import point_teacher_amd as pta
+        from point_teacher_amd.synthetic import SyntheticTiles, benchmark_init_
+        dev = torch.device('cuda:0')
+        torch.cuda.set_device(0)
+        torch.manual_seed(50 + rank)                                  # DIFFERENT initial weights: the Trainer must broadcast rank 0's
+        cfg = pta.Config.fromfile(os.path.join(ROOT, 'point_teacher_amd', 'configs', 'point_teacher', 'aitodv2_point_teacher_0.py'))
+        cfg.model['burn_in_step'] = 1                                 # steps 0, 1 = phase 1; step 2 = phase 2
+        model = pta.build_detector(cfg.model).to(dev)
+        benchmark_init_(model, phase2=True)
+        model.train()
+        tr = pta.Trainer(model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config, channels_last=True)
+        assert tr.world == world and tr.exchange is not None
+        data = SyntheticTiles(n=8, size=256, mean_objects=20, seed=11, device=dev, rank=rank, world=world)
+        keys = []
+        for it in range(3):
+            batch = data.batch(it, 2)
+            if rank == 1 and it == 0:                                 # an image without a single object on this rank only
+                batch['gt_bboxes'][1] = batch['gt_bboxes'][1][:0]
+                batch['gt_labels'][1] = batch['gt_labels'][1][:0]
+            if rank == 0 and it == 1:                                 # every rectangle leaves the image: zero synthetic boxes
+                draws = []
+                for b in batch['gt_bboxes']:
+                    G = b.shape[0]
+                    d = {n: torch.full((G,), 0.5, device=dev) for n in ('x', 'y', 'a', 'boost', 'itv', 'itv2', 'dev')}
+                    d.update(scale=torch.ones(G, device=dev), wn=torch.full((G,), 9.0, device=dev), rn=torch.full((G,), 9.0, device=dev),
+                             cls=torch.full((G,), 4, dtype=torch.long, device=dev))       # prior (30, 120) at its largest: > 256 px
+                    draws.append(d)
+                model._inject = dict(syn=draws)
+            else:
+                model._inject = {}
+            out = tr.step(batch)
+            lv = out['log_vars'].materialize()
+            assert all(v == v and abs(v) != float('inf') for v in lv.values()), (rank, it, lv)
+            keys.append(sorted(lv))
+            assert tr.exchange.issued == tr.exchange.issue_order
+        torch.cuda.synchronize()
+        s, t = tr.flat.student_flat.cpu(), tr.flat.teacher_flat.cpu()
+        both_s = [torch.empty_like(s) for _ in range(world)]
+        both_t = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(both_s, s)
+        dist.all_gather(both_t, t)
+        assert torch.equal(both_s[0], both_s[1]), float((both_s[0] - both_s[1]).abs().max())
+        assert torch.equal(both_t[0], both_t[1])
+        assert torch.isfinite(s).all() and keys[0] == keys[1] == keys[2]
+        klist = [None] * world
+        dist.all_gather_object(klist, keys)
+        assert klist[0] == klist[1]
+        q.put((rank, 'ok'))
+    except Exception:  # noqa
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_real_trainer_step():
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+    assert all(r[1] == 'ok' for r in res), res

@@ -30,6 +30,11 @@ def main():
     ap.add_argument('--img-prefix', default=None, help="override data.train.img_prefix")
     ap.add_argument('--ori-ann-file', default=None, help="override data.train.ori_ann_file (SODA-A)")
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--load-from', default=None, help='checkpoint to initialise the whole detector from (cfg.load_from)')
+    ap.add_argument('--benchmark-init', action='store_true',
+                    help='scaled random initialisation of synthetic.benchmark_init_ (the default on synthetic tiles)')
+    ap.add_argument('--allow-random-init', action='store_true',
+                    help='train on a real dataset although the pretrained backbone of the config was not found')
     ap.add_argument('--cache-gb', type=float, default=48.0, help='decoded uint8 tiles kept in HBM between epochs (0 = off)')
     args = ap.parse_args()
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
@@ -43,9 +48,7 @@ def main():
     from point_teacher_amd.synthetic import SyntheticTiles, benchmark_init_
     cfg = pta.Config.fromfile(args.config)
     torch.manual_seed(0)
-    model = pta.build_detector(cfg.model).to(dev)
-    if hasattr(model, 'student'):
-        benchmark_init_(model)             # no network for the pretrained backbones: see its docstring
+    model = pta.build_detector(cfg.model).to(dev)        # ResNet honours init_cfg=dict(type='Pretrained', ...) when the file exists
     model.train()
     oriented = cfg.model.type == 'RotatedFCOS_TS'
     size = 1200 if oriented else 800
@@ -54,6 +57,16 @@ def main():
         if v is not None:
             tcfg[k] = v
     real = os.path.exists(str(tcfg.get('ann_file', '')))
+    load_from = args.load_from or cfg.get('load_from')
+    if load_from:
+        from point_teacher_amd.nn_modules import load_pretrained
+        assert load_pretrained(model, load_from), f'--load-from {load_from}: not found'
+    loaded = [m.pretrained_loaded for m in model.modules() if getattr(m, 'pretrained_loaded', None) is not None]
+    if real and not load_from and loaded and not all(loaded) and not args.allow_random_init:
+        raise SystemExit('the pretrained backbone named by the config was not found (see the warning above): put it under '
+                         '$PT_PRETRAINED_DIR, pass --load-from, or pass --allow-random-init to train from scratch')
+    if hasattr(model, 'student') and (args.benchmark_init or (not real and not load_from and not any(loaded))):
+        benchmark_init_(model)             # synthetic tiles + random weights: keep activations O(1), see its docstring
     if real:
         from point_teacher_amd.datasets import EpochBatches, build_dataloader, build_dataset
         dataset = build_dataset(tcfg)
@@ -77,7 +90,7 @@ def main():
     if real and os.path.exists(str(vcfg.get('ann_file', ''))) and cfg.get('evaluation'):
         vcfg['test_mode'] = True
         vds = build_dataset(vcfg)
-        vld = build_dataloader(vds, 1, cfg.data.workers_per_gpu, dist=False, shuffle=False, device=dev)
+        vld = build_dataloader(vds, 1, cfg.data.workers_per_gpu, dist=world > 1, shuffle=False, device=dev)   # every rank tests its shard
         runner.register_eval(vds, vld, cfg.evaluation.get('interval', 1))
     if args.resume_from:
         meta = runner.resume(args.resume_from)
