@@ -1,3 +1,5 @@
+"""Probe behind profiles/r02/bf16_accuracy.txt (run on the GPU box: python tests/bf16_accuracy_probe.py): the bf16 backbone of
+configs[2] against the bf16-rounding oracle, layouts, run-to-run reproducibility and MIOpen settings.  Not a test (no test_ prefix)."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
