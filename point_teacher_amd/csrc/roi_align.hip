@@ -13,7 +13,7 @@
 //   A  the run's taps fall on <= 5x5 feature pixels (a bag of a tiny object - the common case): the
 //      footprint of channel c lives in 25 registers for the whole run; the backward keeps 25
 //      accumulators across the run and issues 25 coalesced atomics per thread at the end;
-//   B  any RoI up to 64x64 feature pixels: separable per-axis weights (one thread per (axis, bin), no
+//   B  any RoI up to 104x104 feature pixels: separable per-axis weights (one thread per (axis, bin), no
 //      atomics) in LDS, (g+1)^2 pixel reads per bin instead of 4 g^2 taps; the backward issues ONE f32
 //      atomic per footprint pixel and channel (256 contiguous bytes per wave instruction);
 //   C  larger RoIs: direct per-sample taps (correct, slow, never seen in training).
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(256)
 // ------------------------------------------------------------ unified out_size 7 path --
 constexpr int SF = 5;      // side of the register-resident footprint (path A)
 constexpr int GS = 16;     // most consecutive RoIs one workgroup takes
-constexpr int MAXE = 64;   // per-axis extent (feature pixels) path B holds in LDS
+constexpr int MAXE = 104;  // per-axis extent (feature pixels) path B holds in LDS: every RoI on a 100x100 map (800 px tiles)
 
 struct Roi7Lds {
   union {
@@ -232,7 +232,7 @@ __device__ __forceinline__ void small_tap(float v, int L, int& l, int& h, float&
 // Path A set-up for RoIs [k0, k0+n): exact union of the taps, then one thread per (member, axis, bin) writes that
 // bin's <= 5 weights (no atomics).  S.ub[5] says whether the run qualifies.  Ends with a barrier.
 __device__ void run_setup(const float* __restrict__ rois, int k0, int n, int B, int H, int W, float scale,
-                          int sampling_ratio, int aligned, Roi7Lds& S) {
+                          int sampling_ratio, int aligned, Roi7Lds& S, bool weights = true) {
   if (threadIdx.x == 0) { S.ub[0] = 1 << 30; S.ub[1] = 1 << 30; S.ub[2] = -1; S.ub[3] = -1; S.ub[4] = -1; S.ub[5] = 1; }
   __syncthreads();
   const int nt = n * 2 * NB;                       // <= 224 threads
@@ -263,7 +263,7 @@ __device__ void run_setup(const float* __restrict__ rois, int k0, int n, int B, 
   const bool ok = S.ub[5] && (S.ub[2] - ox < SF) && (S.ub[3] - oy < SF);
   __syncthreads();
   if (threadIdx.x == 0) S.ub[5] = ok ? 1 : 0;
-  if (ok && t < nt) {
+  if (ok && weights && t < nt) {
     const int o = a ? oy : ox;
     float w[SF];
 #pragma unroll
@@ -409,33 +409,60 @@ __global__ void __launch_bounds__(256)
           if (nx <= 0 || ny <= 0) {
 #pragma unroll
             for (int i = 0; i < 49; ++i) my[i] = 0.f;
-          } else if (nx <= MAXE && ny <= MAXE) {                        // path B: banded separable sums
-            // Bin b only touches the pixel columns of its band [lo_b, hi_b] (and bin a the rows of its band): the
-            // loops below visit exactly those, ~nx + 6 loads / LDS reads / FMAs per row instead of 7 nx FMAs, and two
-            // live row-bins per footprint row instead of seven.  Re-read boundary pixels hit L1.
+          } else if (nx <= MAXE && ny <= MAXE) {                        // path B: separable sums
+            // 4 footprint rows x 8 pixels = 32 independent 1-KiB row reads in flight per wave (the map is L2 / MALL
+            // resident: this path is bound by load latency, not by bytes); the 7 column weights of a pixel are read
+            // once (two broadcast ds_read_b128) and serve the 4 rows; a row then updates only the row-bins whose band
+            // holds it (wave-uniform test).
             float acc[NB][NB];
 #pragma unroll
             for (int a = 0; a < NB; ++a)
 #pragma unroll
               for (int b = 0; b < NB; ++b) acc[a][b] = 0.f;
-            int xlo[NB], xhi[NB], ylo[NB], yhi[NB];
+            int ylo[NB], yhi[NB];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) { xlo[b] = S.lo[0][b] - ox; xhi[b] = S.hi[0][b] - ox; ylo[b] = S.lo[1][b] - oy; yhi[b] = S.hi[1][b] - oy; }
-            for (int py = 0; py < ny; ++py) {
-              const float* row = fb + ((size_t)(oy + py) * W + ox) * C;
-              float t[NB];
+            for (int a = 0; a < NB; ++a) { ylo[a] = S.lo[1][a] - oy; yhi[a] = S.hi[1][a] - oy; }
+            for (int py0 = 0; py0 < ny; py0 += 4) {
+              float t[4][NB];
 #pragma unroll
-              for (int b = 0; b < NB; ++b) {
-                float tb = 0.f;
-                for (int px = xlo[b]; px <= xhi[b]; ++px) tb = fmaf(S.w.b.wx[px][b], row[(size_t)px * C], tb);
-                t[b] = tb;
+              for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) t[r4][b] = 0.f;
+              const float* row0 = fb + ((size_t)(oy + py0) * W + ox) * C;
+              for (int px0 = 0; px0 < nx; px0 += 8) {
+                float v[4][8];
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) {
+                    const bool in = (py0 + r4 < ny) && (px0 + j < nx);                        // wave-uniform
+                    v[r4][j] = in ? row0[((size_t)r4 * W + px0 + j) * C] : 0.f;
+                  }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  if (px0 + j < nx) {
+                    const float4 wa = *reinterpret_cast<const float4*>(&S.w.b.wx[px0 + j][0]);
+                    const float4 wb = *reinterpret_cast<const float4*>(&S.w.b.wx[px0 + j][4]);
+                    const float w7[NB] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z};
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+                      for (int b = 0; b < NB; ++b) t[r4][b] = fmaf(w7[b], v[r4][j], t[r4][b]);
+                  }
+                }
               }
 #pragma unroll
-              for (int a = 0; a < NB; ++a) {
-                if (py >= ylo[a] && py <= yhi[a]) {                     // wave-uniform
-                  const float wy = S.w.b.wy[py][a];
+              for (int r4 = 0; r4 < 4; ++r4) {
+                const int py = py0 + r4;
+                if (py < ny) {
 #pragma unroll
-                  for (int b = 0; b < NB; ++b) acc[a][b] = fmaf(wy, t[b], acc[a][b]);
+                  for (int a = 0; a < NB; ++a) {
+                    if (py >= ylo[a] && py <= yhi[a]) {
+                      const float wy = S.w.b.wy[py][a];
+#pragma unroll
+                      for (int b = 0; b < NB; ++b) acc[a][b] = fmaf(wy, t[r4][b], acc[a][b]);
+                    }
+                  }
                 }
               }
             }
@@ -473,12 +500,19 @@ __global__ void __launch_bounds__(256)
 __global__ void __launch_bounds__(256)
     roi_align7_bwd(const float* __restrict__ gout, const float* __restrict__ rois, int B, int C, int H, int W, int K,
                    int gs, float scale, int sampling_ratio, int aligned, float* __restrict__ gfeat, int tile_bytes) {
+  // grid (runs, gs): a run whose taps fit the register footprint is reduced by its workgroup y == 0 alone (one atomic
+  // pass for the whole run); in any other run workgroup y takes member y, so large RoIs - whose cost is their
+  // footprint's worth of atomics - are spread over gs times as many workgroups instead of queueing in one.
   extern __shared__ __align__(16) unsigned char smem[];
   float* tile = reinterpret_cast<float*>(smem);
   Roi7Lds& S = *reinterpret_cast<Roi7Lds*>(smem + tile_bytes);
   const int k0 = blockIdx.x * gs, n = min(gs, K - k0);
-  run_setup(rois, k0, n, B, H, W, scale, sampling_ratio, aligned, S);
+  const int y = blockIdx.y;
+  if (y >= n) return;
+  run_setup(rois, k0, n, B, H, W, scale, sampling_ratio, aligned, S, y == 0);
   const bool path_a = S.ub[5] != 0;
+  if (path_a && y != 0) return;
+  const int r_lo = path_a ? 0 : y, r_hi = path_a ? n : y + 1;
   const int ux = S.ub[0], uy = S.ub[1], ub = S.ub[4];
   for (int c0 = 0; c0 < C; c0 += 256) {
     const int nc = min(256, C - c0), c = c0 + threadIdx.x;
@@ -530,7 +564,7 @@ __global__ void __launch_bounds__(256)
           }
       }
     } else {
-      for (int r = 0; r < n; ++r) {
+      for (int r = r_lo; r < r_hi; ++r) {
         const RoiGeom g = roi_geom(rois + (size_t)(k0 + r) * 5, NB, scale, sampling_ratio, aligned, B);
         tile_load(tile, gout + ((size_t)(k0 + r) * C + c0) * 49, nc * 49);
         roi_setup(g, H, W, S);                                          // its barriers also publish the tile
@@ -735,7 +769,7 @@ extern "C" int pt_roi_align_bwd(const float* grad_out, const float* rois, int B,
     hipError_t e = roi7_attr();
     if (e != hipSuccess) { set_error("pt_roi_align_bwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
     const int gs = run_length(group, K, 512);
-    hipLaunchKernelGGL(roi_align7_bwd, dim3(cdiv(K, gs)), dim3(256), ROI7_LDS, s, grad_out, rois, B, C, H, W, K, gs,
+    hipLaunchKernelGGL(roi_align7_bwd, dim3(cdiv(K, gs), gs), dim3(256), ROI7_LDS, s, grad_out, rois, B, C, H, W, K, gs,
                        spatial_scale, sampling_ratio, aligned, grad_feat, ROI7_TILE_BYTES);
   } else if (channels_last) {
     const size_t lds = (size_t)(C + 1) * out_size * out_size * sizeof(float);

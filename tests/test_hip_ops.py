@@ -395,13 +395,13 @@ def test_roi_align_bag_fast_path():
 
 @pytest.mark.parametrize('C,H,W,group,out_size,sr', [(320, 24, 24, 45, 7, 0),      # two channel blocks (256 + 64); runs of 15
                                                        (6, 24, 24, 25, 7, 0),        # 6*49 floats: not a multiple of 4 -> scalar tile copies
-                                                       (16, 120, 120, 7, 7, 0),      # map large enough for a > 64-pixel RoI: direct path C
+                                                       (16, 120, 120, 7, 7, 0),      # map large enough for a > 104-pixel RoI: direct path C
                                                        (16, 24, 24, 4, 7, 2),        # fixed sampling_ratio
                                                        (16, 24, 24, 3, 5, 0)])       # out_size != 7: the generic per-RoI kernels
 def test_roi_align_every_path(C, H, W, group, out_size, sr):
     """One launch per direction serves three paths (register footprint / separable / direct taps, roi_align.hip) and
     any channel count and run length: all of them against the oracle, forward and backward, K not a multiple of the
-    run length, RoIs outside the map, zero-size RoIs, RoIs of 1, 20 and (when the map allows) 90 feature pixels."""
+    run length, RoIs outside the map, zero-size RoIs, RoIs of 1, 20 and (when the map allows) 115 feature pixels."""
     f = F()
     gen = torch.Generator().manual_seed(31 + C)
     B = 2
@@ -412,7 +412,7 @@ def test_roi_align_every_path(C, H, W, group, out_size, sr):
     wh = torch.exp(torch.randn(n_bag, 2, generator=gen) * 0.5 + np.log(11.))
     wh[1] = torch.tensor([160., 90.])                              # separable path
     if size > 800:
-        wh[2] = torch.tensor([720., 530.]); c[2] = torch.tensor([size / 2, size / 2])   # > 64 feature pixels: path C
+        wh[2] = torch.tensor([930., 900.]); c[2] = torch.tensor([size / 2, size / 2])   # > 104 feature pixels: path C
     base = torch.cat([c - wh / 2, c + wh / 2], 1)
     jit = torch.randn(n_bag, group, 4, generator=gen) * 1.5
     props = (base[:, None] + jit).reshape(-1, 4)

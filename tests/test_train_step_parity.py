@@ -394,9 +394,10 @@ def test_bf16_backbone_fp32_head(phase2):
     accumulation orders straddle a rounding boundary one of them lands an ulp (0.4 - 0.8 %) away, the bias-carrying
     FPN / PSAGG convolutions round twice in the product (convolution, then bias add), and MIOpen's bf16 convolutions are
     not run-to-run reproducible on this stack: the same input twice moves the PSAGG features by 1.1 % (norm-wise;
-    profiles/r02/bf16_accuracy.txt), the same size as the whole fp32 -> bf16 effect (1.6 %).  Hence BF16_TOL = 5 %; the
-    lines printed below show the product's distance next to the distance between the fp32 and the bf16 oracle."""
-    BF16_TOL = 5e-2
+    profiles/r02/bf16_accuracy.txt), the same size as the whole fp32 -> bf16 effect (1.6 %).  Hence BF16_TOL = 2 %
+    (measured: <= 0.45 % on every key in both phases); the test also shows that it discriminates: summed over the keys the
+    product is closer to the bf16 oracle than the fp32 oracle is."""
+    BF16_TOL = 2e-2
     dev = torch.device('cuda:0')
     seen = {}
     pta, cfg, model = _build(dev, phase2=phase2)
@@ -446,4 +447,4 @@ def test_bf16_backbone_fp32_head(phase2):
         f1 = model.teacher.extract_feat(x)[0].float()
         f2 = model.teacher.extract_feat(x)[0].float()
     print('bf16 features, same input twice: relative difference %.2e' % float((f1 - f2).norm() / f1.norm()))
-    assert tr.channels_last
+    assert tr.channels_last and sum(err.values()) < sum(gap.values())
