@@ -80,6 +80,6 @@ def benchmark_init_(model, phase2=False):
             for fc in m.bbox_head.fc_reg:
                 fc.weight.mul_(0.01)
                 fc.bias.zero_()
-            if phase2:
+            if phase2 and hasattr(m.bbox_head, 'conv_reg'):      # (an anchor-based head starts from its anchors: nothing to do)
                 m.bbox_head.conv_reg.bias.fill_(1.0)
     return model
