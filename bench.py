@@ -341,7 +341,8 @@ def main():
                                  + f'{"burn-in phase 1" if args.workload == "step1" else "phase 2 (MIL on)"}, '
                                  f'R50-FPN-PSAGG + {"TS_P2RBRotatedFCOSHead" if obb else "TS_P2BFCOSHead"}, bs {args.batch}/GPU, {args.size}x{args.size}, '
                                  f'~{args.objects} pts/img, {"fp32" if args.dtype == "fp32" else "bf16 autocast convs + fp32 head"}',
-                        global_batch=args.batch * world, parallelism=f'dp{world}', phase=args.workload),
+                        global_batch=args.batch * world, parallelism=f'dp{world}', phase=args.workload,
+                        gemm_solution_table=bool(trainer.tuned_gemms)),
             roofline=roofline, cpu_baseline=cpu_baseline,
             iteration=dict(flops=flops_iter, achieved_tflops=round(flops_iter * iters_s / 1e12, 2),
                            mfma_peak_tflops=peak / 1e12, frac=round(flops_iter * iters_s / peak, 4)),

@@ -18,6 +18,8 @@ configs/point_teacher/aitodv2_point_teacher_0%.py:212-223) with an MI355X-first 
 """
 import math
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -235,6 +237,24 @@ class BucketedGradExchange:
             p.grad = v
 
 
+TUNED_GEMMS = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuned', 'gemm_gfx950.csv')
+
+
+def enable_tuned_gemms(path=TUNED_GEMMS, tune_missing=False):
+    """The MIL FC stacks are plain library GEMMs (12544 -> 1024 -> 1024 over K RoIs, forward / dgrad / wgrad).  hipBLASLt's
+    default heuristic runs the large ones at 105 TFLOP/s; the best solution of rocBLAS / hipBLASLt for these exact shapes
+    reaches 147 TFLOP/s (0.93 of the fp32 MFMA peak).  PyTorch's TunableOp picks library solutions per shape from a results
+    file: `tuned/gemm_gfx950.csv` was recorded on an MI355X with this image's library versions (its Validator lines are
+    checked by PyTorch; on a mismatch, or for shapes it does not hold, the default heuristic is used).  Nothing is tuned at
+    run time unless `tune_missing`; `tools/tune_gemms.sh` re-records the file; PT_TUNED_GEMMS=0 turns the table off."""
+    if os.environ.get('PT_TUNED_GEMMS', '1') == '0' or not torch.cuda.is_available() or not os.path.exists(path):
+        return False
+    import torch.cuda.tunable as tunable
+    tunable.enable(True)
+    tunable.tuning_enable(bool(tune_missing))
+    return bool(tunable.read_file(path))
+
+
 class StepLR:
     """mmcv StepLrUpdaterHook with warm-up, by_epoch=True (lr_config of the configs)."""
 
@@ -295,6 +315,7 @@ class Trainer:
         for m in model.modules():
             if hasattr(m, 'backbone') and hasattr(m, 'extract_feat'):
                 m.backbone_autocast = autocast_dtype
+        self.tuned_gemms = enable_tuned_gemms()
         self._broadcast_initial_state()
 
     def _broadcast_initial_state(self):
