@@ -215,7 +215,9 @@ int pt_affine_relu_bwd(const float* grad_y, const float* y, const float* scale, 
  * output the forward read.  channels_last only ([N,H,W,C] flattened, n = N*H*W*C); C/4 must divide 256
  * or be a multiple of it.  No atomics: every workgroup writes a private row of
  * partial_ws[pt_affine_train_rows(n, C)][2*C] and a second launch adds the rows into sums[2*C]
- * (deterministic). */
+ * (deterministic).  x == NULL: the epilogue of a convolution with a trainable bias followed by ReLU (the FCOS towers,
+ * anchor_free_head.py:86-135 via mmcv ConvModule: conv -> +bias -> ReLU, three element-wise passes in the reference) with
+ * scale == 1: only sums[0..C) (the bias gradient) is meaningful, sums[C..2C) are zero. */
 int pt_affine_train_rows(int64_t n, int C);
 int pt_affine_relu_bwd_train(const float* grad_y, const float* y, const float* x, const float* scale,
                              int64_t n, int C, int relu, float* grad_x, float* grad_res, float* sums,

@@ -208,6 +208,8 @@ __global__ void __launch_bounds__(256)
 // (2 048 blocks x 8 float atomics per group on 2*C addresses cost more than the whole streaming pass).
 constexpr int AFF_THREADS = 256;
 
+// HAS_X = false: only the shift gradient is wanted (a convolution bias + ReLU epilogue, scale == 1): x is not read.
+template <bool HAS_X>
 __global__ void __launch_bounds__(AFF_THREADS)
     affine_relu_bwd_train_kernel(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ x,
                                  const float* __restrict__ scale, long n4, int C, int relu, float* __restrict__ gx,
@@ -230,9 +232,11 @@ __global__ void __launch_bounds__(AFF_THREADS)
       const float4 o = y4[i];
       v.x = o.x > 0.f ? v.x : 0.f; v.y = o.y > 0.f ? v.y : 0.f; v.z = o.z > 0.f ? v.z : 0.f; v.w = o.w > 0.f ? v.w : 0.f;
     }
-    const float4 xv = x4[i];
     s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
-    t0 += v.x * xv.x; t1 += v.y * xv.y; t2 += v.z * xv.z; t3 += v.w * xv.w;
+    if (HAS_X) {
+      const float4 xv = x4[i];
+      t0 += v.x * xv.x; t1 += v.y * xv.y; t2 += v.z * xv.z; t3 += v.w * xv.w;
+    }
     if (gres) gr4[i] = v;
     if (gx) gx4[i] = make_float4(v.x * sc.x, v.y * sc.y, v.z * sc.z, v.w * sc.w);
   }
@@ -412,7 +416,7 @@ extern "C" int pt_affine_relu_bwd_train(const float* grad_y, const float* y, con
                                         int64_t n, int C, int relu, float* grad_x, float* grad_res, float* sums,
                                         float* partial_ws, void* stream) {
   if (n == 0) return PT_OK;
-  PT_REQUIRE(grad_y && x && scale && sums && partial_ws && (!relu || y), PT_EINVAL,
+  PT_REQUIRE(grad_y && scale && sums && partial_ws && (!relu || y), PT_EINVAL,
              "pt_affine_relu_bwd_train: NULL pointer");
   PT_REQUIRE(n > 0 && C > 0 && C % 4 == 0 && n % C == 0, PT_EINVAL, "pt_affine_relu_bwd_train: bad size");
   const int G = C / 4;
@@ -420,8 +424,12 @@ extern "C" int pt_affine_relu_bwd_train(const float* grad_y, const float* y, con
              "pt_affine_relu_bwd_train: C/4=%d must divide or be a multiple of %d", G, AFF_THREADS);
   const int nb = affine_train_blocks(n, C);
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(affine_relu_bwd_train_kernel, dim3(nb), dim3(AFF_THREADS), 0, s, grad_y, y, x, scale,
-                     (long)(n / 4), C, relu, grad_x, grad_res, partial_ws);
+  if (x)
+    hipLaunchKernelGGL(affine_relu_bwd_train_kernel<true>, dim3(nb), dim3(AFF_THREADS), 0, s, grad_y, y, x, scale,
+                       (long)(n / 4), C, relu, grad_x, grad_res, partial_ws);
+  else                                 // sums[C..2C) come out as zeros
+    hipLaunchKernelGGL(affine_relu_bwd_train_kernel<false>, dim3(nb), dim3(AFF_THREADS), 0, s, grad_y, y, x, scale,
+                       (long)(n / 4), C, relu, grad_x, grad_res, partial_ws);
   PT_LAUNCH_CHECK("pt_affine_relu_bwd_train");
   hipLaunchKernelGGL(affine_train_finish, dim3(cdiv(2 * C, 16)), dim3(256), 0, s, partial_ws,
                      pt_affine_train_rows(n, C), 2 * C, sums);

@@ -6,6 +6,8 @@ SURVEY.md); the per-image python loops, CPU round trips and host synchronisation
 reference are replaced by batched launches into libpt_hip.so."""
 from collections import OrderedDict
 
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -206,6 +208,7 @@ class TS_P2B_FCOS(BaseDetector):
                 m._affine_dynamic = True
         # hooks for tests: inject the random draws of one iteration
         self._inject = {}
+        self.batch_head_passes = os.environ.get('PT_BATCH_HEAD', '0') == '1'
 
     # the reference keeps count/point dictionaries as plain attributes, so they are lost on resume
     # (SURVEY section 5); persisting them is a documented deviation.
@@ -307,16 +310,16 @@ class TS_P2B_FCOS(BaseDetector):
         return mean0(torch.sqrt((torch.cat(gt_points) - real[:, :2]) ** 2) / torch.sqrt((real[:, 2:4] / 2) ** 2))
 
     def _student_passes(self, img, extra=None):
-        """ONE batched student pass over [extra (synthetic) images | clean images | strongly augmented images].
+        """ONE batched student pass over [clean images | extra (synthetic) images | strongly augmented images].
         The reference runs them as separate passes (:146, :191 / :226, :243); every layer of the student is
         per-sample (BatchNorm in eval mode, GroupNorm), so the batched pass computes the same features with a
         third of the launches and one gradient accumulation per parameter.  The augmented PIXELS only depend on
         the input image and the draws (the boxes/points are transformed later, after the MIL stage, with the
-        same draws).  Returns (aug_pre, [feature tuples per group])."""
+        same draws).  Returns (aug_pre, [feature tuples per group], features of the whole batch)."""
         B = img.shape[0]
         params, aug_imgs = self._strong_aug_images(img)
         img_aug = torch.stack(aug_imgs, dim=0)
-        parts = ([extra] if extra is not None else []) + [img, img_aug]
+        parts = [img] + ([extra] if extra is not None else []) + [img_aug]
         if img.is_contiguous(memory_format=torch.channels_last) and not img.is_contiguous():
             parts = [p.contiguous(memory_format=torch.channels_last) for p in parts]
         feat_all = self.extract_feat(torch.cat(parts, dim=0), self.student)
@@ -324,15 +327,16 @@ class TS_P2B_FCOS(BaseDetector):
         for p in parts:
             groups.append(tuple(f[o:o + p.shape[0]] for f in feat_all))
             o += p.shape[0]
-        return (params, aug_imgs), groups
+        return (params, aug_imgs), groups, feat_all
 
     def _student_aug_loss(self, img, img_metas, gt_points, gt_labels, pseudo_points, pseudo_labels, pseudo_bboxes,
-                          gt_bboxes_ignore, aug_pre=None, feat_aug=None):
+                          gt_bboxes_ignore, aug_pre=None, feat_aug=None, outs=None):
         params, imgs = aug_pre if aug_pre is not None else (None, None)
         aug = self._strong_aug(img, gt_points, gt_labels, pseudo_points, pseudo_labels, pseudo_bboxes, params=params,
                                imgs=imgs)
         img_aug, img_aug_list, gp, gl, pp, pl, pb, gv, pv = aug
-        outs = self.student.bbox_head(feat_aug if feat_aug is not None else self.extract_feat(img_aug, self.student))
+        if outs is None:
+            outs = self.student.bbox_head(feat_aug if feat_aug is not None else self.extract_feat(img_aug, self.student))
         return self.student.bbox_head.loss_pseudo(*outs, gp, gl, pp, pl, pb, [None] * len(img_metas), img_metas,
                                                   img_aug_list, self.count <= self.burn_in_step, gt_bboxes_ignore,
                                                   gt_valid=gv, pseudo_valid=pv)
@@ -343,7 +347,7 @@ class TS_P2B_FCOS(BaseDetector):
         losses = {}
         pb_c, pp_c, pl_c, _, _ = self._teacher_pseudo(img, img_metas, img_list, gt_points, gt_labels, gt_bboxes,
                                                       gt_bboxes_ignore)
-        aug_pre, (feat, feat_aug) = self._student_passes(img)
+        aug_pre, (feat, feat_aug), _ = self._student_passes(img)
         mil_feat = self.student.bbox_head.forward_mil(feat)
         pb_r, pp_r, mil_losses = self.forward_mil_head_burn_in_step2(num_img, pb_c, pp_c, pl_c, gt_bboxes, img_metas,
                                                                      mil_feat)
@@ -401,9 +405,18 @@ class TS_P2B_FCOS(BaseDetector):
         losses = {}
         img_syn, _, syn_boxes, syn_alive = self.genrate_syn(num_img, img_list, gt_bboxes, gt_labels)
         head = self.student.bbox_head
-        aug_pre, (feat_syn, feat_ori, feat_aug) = self._student_passes(img, extra=img_syn)
+        aug_pre, (feat_ori, feat_syn, feat_aug), feat_all = self._student_passes(img, extra=img_syn)
         mil_syn, mil_ori = head.forward_mil(feat_syn), head.forward_mil(feat_ori)
-        outs_syn = head(feat_syn)
+        outs_aug = None
+        if self.batch_head_passes:
+            # the dense head ONCE over [synthetic | augmented] (neighbours in the batched pass; the reference calls it twice, :150
+            # and :243).  Off by default: measured slower on MI355X (MIOpen's choice for the B = 4 tower convolutions)
+            ns, no = feat_syn[0].shape[0], feat_ori[0].shape[0]
+            both = head(tuple(f[no:] for f in feat_all))
+            outs_syn = tuple([o[:ns] for o in lv] if torch.is_tensor(lv[0]) and lv[0].dim() == 4 else lv for lv in both)
+            outs_aug = tuple([o[ns:] for o in lv] if torch.is_tensor(lv[0]) and lv[0].dim() == 4 else lv for lv in both)
+        else:
+            outs_syn = head(feat_syn)
         loss_syn = head.loss(*outs_syn, syn_boxes, img_metas, gt_bboxes_ignore, gt_valid=syn_alive)
         pb_c, pp_c, pl_c, _, _ = self._teacher_pseudo(img, img_metas, img_list, gt_points, gt_labels, gt_bboxes,
                                                       gt_bboxes_ignore)
@@ -415,7 +428,7 @@ class TS_P2B_FCOS(BaseDetector):
             gt_points = self.update_points(num_img, img_metas, pb_r)
             losses['refined_points_distance'] = self._refined_points_distance(gt_points, gt_bboxes)
         lc, _, _ = self._student_aug_loss(img, img_metas, gt_points, gt_labels, pp_r, pl_c, pb_r, gt_bboxes_ignore,
-                                          aug_pre=aug_pre, feat_aug=feat_aug)
+                                          aug_pre=aug_pre, feat_aug=feat_aug, outs=outs_aug)
         losses['loss_cls'] = lc
         losses['loss_bbox'], losses['loss_centerness'] = loss_syn
         return losses

@@ -555,6 +555,53 @@ class _AffineReLUTrain(torch.autograd.Function):
         return gx, gw, sums[0], None, None, None, gres, None
 
 
+_ONES = {}
+
+
+class _BiasReLU(torch.autograd.Function):
+    """y = [relu](x + bias[c]) in place on a fresh fp32 channels_last convolution output; the backward produces grad_x and the
+    bias gradient in ONE pass (mmcv ConvModule does conv-with-bias then ReLU: add, clamp / threshold, channel sum)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, relu):
+        C = x.shape[1]
+        key = (C, x.device)
+        if key not in _ONES:
+            _ONES[key] = torch.ones(C, dtype=f32, device=x.device)
+        xb = x.permute(0, 2, 3, 1)
+        hip.call('pt_affine_relu_fwd', xb, _ONES[key], bias, None, x.numel(), C, 1, int(relu), xb)
+        ctx.mark_dirty(x)
+        ctx.save_for_backward(x if relu else None)
+        ctx.cfg = (C, bool(relu), key)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        y, = ctx.saved_tensors
+        C, relu, key = ctx.cfg
+        g = g.contiguous(memory_format=torch.channels_last)
+        gx = torch.empty_like(g) if ctx.needs_input_grad[0] else None
+        sums = torch.empty((2, C), dtype=f32, device=g.device)
+        ws = torch.empty((hip.call('pt_affine_train_rows', g.numel(), C), 2 * C), dtype=f32, device=g.device)
+        hip.call('pt_affine_relu_bwd_train', g.permute(0, 2, 3, 1), y.permute(0, 2, 3, 1) if y is not None else None, None,
+                 _ONES[key], g.numel(), C, int(relu), gx.permute(0, 2, 3, 1) if gx is not None else None, None, sums, ws)
+        return gx, sums[0], None
+
+
+def bias_relu_(x, bias, relu=True):
+    """Convolution-bias (+ ReLU) epilogue on a fresh conv output: x fp32 [N,C,H,W] channels_last with C/4 dividing 256 (or a
+    multiple of it); anything else must take the caller's unfused path (`bias_relu_ok`)."""
+    return _BiasReLU.apply(x, bias, relu)
+
+
+def bias_relu_ok(x, bias):
+    C = x.shape[1]
+    G = C // 4
+    return (x.is_cuda and x.dtype == f32 and bias is not None and bias.dtype == f32 and x.dim() == 4 and C % 4 == 0 and x.numel() > 0
+            and ((G <= 256 and 256 % G == 0) or G % 256 == 0)
+            and x.is_contiguous(memory_format=torch.channels_last) and (C == 1 or not x.is_contiguous()))
+
+
 def bn_eval_relu(x, bn, residual=None, relu=True):
     """Fused eval-mode BatchNorm with a TRAINABLE affine (+ residual) (+ ReLU); x: fp32, channels_last."""
     return _AffineReLUTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, residual, relu)

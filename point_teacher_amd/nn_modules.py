@@ -90,7 +90,14 @@ class ConvModule(nn.Module):
                 p.requires_grad = norm_cfg.get('requires_grad', True)
 
     def forward(self, x):
-        x = self.conv(x)
+        c = self.conv
+        if (type(c) is nn.Conv2d and c.bias is not None and not self.with_norm and self.with_activation and x.is_cuda
+                and not torch.is_autocast_enabled()):
+            y = TF.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
+            if F.bias_relu_ok(y, c.bias):
+                return F.bias_relu_(y, c.bias, True)          # bias + ReLU in one pass; backward: grad_x + bias gradient in one
+            return TF.relu(y + c.bias.view(1, -1, 1, 1), inplace=True)
+        x = c(x)
         if self.with_norm:
             x = self.gn(x)
         return TF.relu(x, inplace=True) if self.with_activation else x

@@ -534,6 +534,34 @@ def test_trainable_bn_epilogue(C, HW, relu, with_res):
     close(bng.bias.grad, bn.bias.grad, rtol=1e-3, atol=1e-4 * float(bn.bias.grad.abs().max()))
 
 
+@pytest.mark.parametrize('C,HW', [(256, (20, 30)), (64, (9, 11)), (1024, (5, 7))])
+def test_conv_bias_relu_epilogue(C, HW):
+    """ConvModule (conv + bias + ReLU, the FCOS towers): the fused epilogue (pt_affine_relu_fwd with unit scale in place,
+    pt_affine_relu_bwd_train with x == NULL) == torch conv2d(bias) -> relu: values, input / weight / bias gradients."""
+    import copy
+    from point_teacher_amd.nn_modules import ConvModule
+    torch.manual_seed(35)
+    H, W = HW
+    m = ConvModule(16, C, 3, padding=1, bias=True)
+    with torch.no_grad():
+        m.conv.bias.copy_(torch.randn(C) * 0.3)
+    x = torch.randn(2, 16, H, W)
+    wgt = torch.randn(2, C, H, W)
+    xr = x.clone().requires_grad_(True)
+    y = m(xr)                                                                   # CPU: plain torch path
+    (y * wgt).sum().backward()
+    mg = copy.deepcopy(m).to(DEV)
+    mg.zero_grad()
+    xg = cu(x).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    out = mg(xg)
+    assert out.grad_fn is not None and 'BiasReLU' in type(out.grad_fn).__name__, type(out.grad_fn).__name__
+    close(out, y.detach(), atol=2e-5)
+    (out * cu(wgt)).sum().backward()
+    close(xg.grad, xr.grad, atol=2e-5)
+    close(mg.conv.weight.grad, m.conv.weight.grad, rtol=1e-3, atol=1e-4 * float(m.conv.weight.grad.abs().max()))
+    close(mg.conv.bias.grad, m.conv.bias.grad, rtol=1e-3, atol=1e-4 * float(m.conv.bias.grad.abs().max()))
+
+
 @pytest.mark.parametrize('modulated,dg,stride,dil', [(True, 1, 1, 1), (True, 2, 2, 1), (False, 1, 1, 2), (True, 4, 1, 1)])
 def test_deform_conv(modulated, dg, stride, dil):
     """pt_deform_* + GEMM == the published (modulated) deformable convolution: values and every gradient against the

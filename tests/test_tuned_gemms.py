@@ -20,21 +20,43 @@ def test_table_is_well_formed():
     assert not enable_tuned_gemms() or torch.cuda.is_available()      # never switches anything on without a GPU
 
 
+def _fc_pass(k, fin, fout, seed):
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    x = (torch.randn(k, fin, device='cuda', generator=g) * 0.5).requires_grad_(True)
+    fc = torch.nn.Linear(fin, fout).cuda()
+    with torch.no_grad():
+        fc.weight.copy_(torch.randn(fout, fin, device='cuda', generator=g) * 0.02)
+        fc.bias.copy_(torch.randn(fout, device='cuda', generator=g) * 0.1)
+    y = fc(x)
+    gy = torch.randn(y.shape, device='cuda', generator=g)
+    gx, gw, gb = torch.autograd.grad(y, (x, fc.weight, fc.bias), gy)
+    return [t.detach() for t in (y, gx, gw, gb)]
+
+
 @pytest.mark.gpu
 def test_table_is_used_and_neutral():
+    """Every solution the table selects (forward, dgrad, wgrad of every FC of the MIL head at K = 400 / 5000 / 60750 RoIs) gives
+    the product the default solution gives: a tuned entry that computes something else would be a silent parity break."""
     import torch.cuda.tunable as tunable
-    torch.manual_seed(0)
-    x = torch.randn(5000, 12544, device='cuda')
-    fc = torch.nn.Linear(12544, 1024).cuda()
+    shapes = [(k, fin, fout) for k in (400, 5000, 60750) for fin, fout in ((12544, 1024), (1024, 1024), (1024, 8), (1024, 4), (1024, 9))]
     tunable.enable(False)
-    ref = fc(x)
+    ref = {s: _fc_pass(*s, seed=i) for i, s in enumerate(shapes) if s[0] != 60750 or s[1] != 12544}
+    big = (60750, 12544, 1024)
+    ref_big = [t.double().sum().item() for t in _fc_pass(*big, seed=99)] + [_fc_pass(*big, seed=99)[2]]
     assert enable_tuned_gemms()
     assert tunable.is_enabled() and not tunable.tuning_is_enabled()
     assert any('tn_1024_5000_12544' in r[1] for r in tunable.get_results())
-    out = fc(x)
-    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)        # another fp32 solution: same product, different summation order
+    for i, s in enumerate(shapes):
+        if s in ref:
+            for a, b in zip(_fc_pass(*s, seed=i), ref[s]):
+                torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-4 * float(b.abs().max()))   # another fp32 summation order
+    out = _fc_pass(*big, seed=99)
+    torch.testing.assert_close(out[2], ref_big[4], rtol=2e-4, atol=2e-4 * float(ref_big[4].abs().max()))
+    for a, b in zip(out, ref_big[:4]):
+        assert abs(a.double().sum().item() - b) <= 1e-3 * max(abs(b), float(a.abs().double().sum()) * 1e-3)
     os.environ['PT_TUNED_GEMMS'] = '0'
     try:
         assert not enable_tuned_gemms()
     finally:
         del os.environ['PT_TUNED_GEMMS']
+        tunable.enable(False)
