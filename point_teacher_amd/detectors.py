@@ -330,13 +330,14 @@ class TS_P2B_FCOS(BaseDetector):
         return (params, aug_imgs), groups, feat_all
 
     def _student_aug_loss(self, img, img_metas, gt_points, gt_labels, pseudo_points, pseudo_labels, pseudo_bboxes,
-                          gt_bboxes_ignore, aug_pre=None, feat_aug=None, outs=None):
+                          gt_bboxes_ignore, aug_pre=None, feat_aug=None, outs=None, branches='both'):
         params, imgs = aug_pre if aug_pre is not None else (None, None)
         aug = self._strong_aug(img, gt_points, gt_labels, pseudo_points, pseudo_labels, pseudo_bboxes, params=params,
                                imgs=imgs)
         img_aug, img_aug_list, gp, gl, pp, pl, pb, gv, pv = aug
         if outs is None:
-            outs = self.student.bbox_head(feat_aug if feat_aug is not None else self.extract_feat(img_aug, self.student))
+            outs = self.student.bbox_head(feat_aug if feat_aug is not None else self.extract_feat(img_aug, self.student),
+                                          branches=branches)
         return self.student.bbox_head.loss_pseudo(*outs, gp, gl, pp, pl, pb, [None] * len(img_metas), img_metas,
                                                   img_aug_list, self.count <= self.burn_in_step, gt_bboxes_ignore,
                                                   gt_valid=gv, pseudo_valid=pv)
@@ -416,7 +417,7 @@ class TS_P2B_FCOS(BaseDetector):
             outs_syn = tuple([o[:ns] for o in lv] if torch.is_tensor(lv[0]) and lv[0].dim() == 4 else lv for lv in both)
             outs_aug = tuple([o[ns:] for o in lv] if torch.is_tensor(lv[0]) and lv[0].dim() == 4 else lv for lv in both)
         else:
-            outs_syn = head(feat_syn)
+            outs_syn = head(feat_syn, branches='reg')          # `loss` reads the regression / centerness outputs only
         loss_syn = head.loss(*outs_syn, syn_boxes, img_metas, gt_bboxes_ignore, gt_valid=syn_alive)
         pb_c, pp_c, pl_c, _, _ = self._teacher_pseudo(img, img_metas, img_list, gt_points, gt_labels, gt_bboxes,
                                                       gt_bboxes_ignore)
@@ -428,7 +429,7 @@ class TS_P2B_FCOS(BaseDetector):
             gt_points = self.update_points(num_img, img_metas, pb_r)
             losses['refined_points_distance'] = self._refined_points_distance(gt_points, gt_bboxes)
         lc, _, _ = self._student_aug_loss(img, img_metas, gt_points, gt_labels, pp_r, pl_c, pb_r, gt_bboxes_ignore,
-                                          aug_pre=aug_pre, feat_aug=feat_aug, outs=outs_aug)
+                                          aug_pre=aug_pre, feat_aug=feat_aug, outs=outs_aug, branches='cls')
         losses['loss_cls'] = lc
         losses['loss_bbox'], losses['loss_centerness'] = loss_syn
         return losses

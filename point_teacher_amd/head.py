@@ -131,21 +131,37 @@ class TS_P2BFCOSHead(nn.Module):
             out.append(self._points_cache[key])
         return out
 
-    def forward(self, feats):
-        """fcos_head_p2b_ts.py:302-324 -> (cls_scores, bbox_preds, centernesses, points) lists per level."""
+    def forward(self, feats, branches='both'):
+        """fcos_head_p2b_ts.py:302-324 -> (cls_scores, bbox_preds, centernesses, points) lists per level.
+        `branches`: 'both' | 'cls' | 'reg' - the reference always evaluates both towers, but burn-in step 1 only reads the
+        regression / centerness outputs of the synthetic pass (`loss`, :470-534) and only the classification loss of the
+        augmented pass (:204-207 keeps `loss_cls` alone); the unread tower is dead work (its loss is never back-propagated)
+        and is skipped: the entries of the skipped outputs are None."""
         sizes = [f.size()[-2:] for f in feats]
         pts = self.get_points(sizes, feats[0].dtype if feats[0].dtype == torch.float32 else torch.float32,
                               feats[0].device)
-        return multi_apply(self.forward_single, feats, self.scales, self.strides, pts)
+        return multi_apply(self.forward_single, feats, self.scales, self.strides, pts, [branches] * len(feats))
 
-    def forward_single(self, x, scale, stride, points):
+    def _towers(self, x, branches):
+        """(cls_feat | None, reg_feat | None) as `branches` and `centerness_on_reg` need them."""
+        need_cls, need_reg = branches != 'reg', branches != 'cls'
+        cls_feat = reg_feat = None
+        if need_cls or (need_reg and not self.centerness_on_reg):
+            cls_feat = x
+            for l in self.cls_convs:
+                cls_feat = l(cls_feat)
+        if need_reg:
+            reg_feat = x
+            for l in self.reg_convs:
+                reg_feat = l(reg_feat)
+        return cls_feat, reg_feat
+
+    def forward_single(self, x, scale, stride, points, branches='both'):
         """fcos_head_p2b_ts.py:326-353"""
-        cls_feat = reg_feat = x
-        for l in self.cls_convs:
-            cls_feat = l(cls_feat)
-        cls_score = self.conv_cls(cls_feat)
-        for l in self.reg_convs:
-            reg_feat = l(reg_feat)
+        cls_feat, reg_feat = self._towers(x, branches)
+        cls_score = self.conv_cls(cls_feat) if branches != 'reg' else None
+        if reg_feat is None:
+            return cls_score, None, None, points
         bbox_pred = self.conv_reg(reg_feat)
         centerness = self.conv_centerness(reg_feat if self.centerness_on_reg else cls_feat)
         bbox_pred = scale(bbox_pred).float()
@@ -167,12 +183,15 @@ class TS_P2BFCOSHead(nn.Module):
 
     # --------------------------------------------------------------- flattening --
     def _flat(self, cls_scores, bbox_preds, centernesses):
-        """[B,C,H,W] per level -> [B, P, C] (all levels concatenated, image-major)."""
-        B = cls_scores[0].size(0)
-        fc = torch.cat([c.permute(0, 2, 3, 1).reshape(B, -1, self.cls_out_channels) for c in cls_scores], 1)
-        fr = torch.cat([r.permute(0, 2, 3, 1).reshape(B, -1, 4) for r in bbox_preds], 1)
-        ft = torch.cat([t.permute(0, 2, 3, 1).reshape(B, -1) for t in centernesses], 1)
-        return fc.float().contiguous(), fr.float().contiguous(), ft.float().contiguous()
+        """[B,C,H,W] per level -> [B, P, C] (all levels concatenated, image-major); None for a branch that was not evaluated."""
+        B = (cls_scores if cls_scores[0] is not None else bbox_preds)[0].size(0)
+        fc = fr = ft = None
+        if cls_scores[0] is not None:
+            fc = torch.cat([c.permute(0, 2, 3, 1).reshape(B, -1, self.cls_out_channels) for c in cls_scores], 1).float().contiguous()
+        if bbox_preds[0] is not None:
+            fr = torch.cat([r.permute(0, 2, 3, 1).reshape(B, -1, 4) for r in bbox_preds], 1).float().contiguous()
+            ft = torch.cat([t.permute(0, 2, 3, 1).reshape(B, -1) for t in centernesses], 1).float().contiguous()
+        return fc, fr, ft
 
     # -------------------------------------------------------------- pseudo boxes --
     def get_pseudo_bbox(self, cls_scores, bbox_preds, centernesses, all_level_points, gt_points, gt_labels, gt_bboxes,
@@ -210,6 +229,8 @@ class TS_P2BFCOSHead(nn.Module):
         pos = labels_reg < self.num_classes
         norms = reduce_mean_many(pos.sum(), ctr_t.sum().detach(), *([cls_pos] if cls_pos is not None else []))
         num_pos, ctr_den = norms[0].clamp(min=1.0), norms[1].clamp(min=1e-6)
+        if fr is None:                                 # regression branch not evaluated (burn-in step 1, augmented pass)
+            return None, None, norms[2].clamp(min=1.0)
         pts = points.repeat(B, 1)
         pred = distance2bbox(pts, fr.reshape(-1, 4))
         tgt = distance2bbox(pts, tg)
@@ -254,11 +275,11 @@ class TS_P2BFCOSHead(nn.Module):
     def loss(self, cls_scores, bbox_preds, centernesses, all_level_points, gt_bboxes, img_metas, gt_bboxes_ignore=None,
              gt_valid=None):
         """:470-534 (burn-in step 1: synthetic rectangles, syn_assigner (3,3), plain DIoU)."""
-        fc, fr, ft = self._flat(cls_scores, bbox_preds, centernesses)
-        B = fc.shape[0]
+        _, fr, ft = self._flat(cls_scores, bbox_preds, centernesses)
+        B = fr.shape[0]
         points = torch.cat(all_level_points, 0)
         counts = [int(b.shape[0]) for b in gt_bboxes]
-        off, _ = F.make_offsets(counts, fc.device)
+        off, _ = F.make_offsets(counts, fr.device)
         gb = torch.cat(gt_bboxes)
         gi = F.topk_assign(points, bbox_xyxy_to_cxcywh(gb), off, B, self.syn_assigner.num_pre,
                            gt_valid=_cat(gt_valid) if gt_valid is not None else None)

@@ -65,14 +65,12 @@ class TS_P2RBRotatedFCOSHead(TS_P2BFCOSHead):
             self.scale_angle = Scale(1.0)
 
     # ----------------------------------------------------------------- forward --
-    def forward_single(self, x, scale, stride, points):
-        """:356-391 -> (cls_score, bbox_pred, angle_pred, centerness, points)"""
-        cls_feat = reg_feat = x
-        for l in self.cls_convs:
-            cls_feat = l(cls_feat)
-        cls_score = self.conv_cls(cls_feat)
-        for l in self.reg_convs:
-            reg_feat = l(reg_feat)
+    def forward_single(self, x, scale, stride, points, branches='both'):
+        """:356-391 -> (cls_score, bbox_pred, angle_pred, centerness, points); `branches`: see TS_P2BFCOSHead.forward."""
+        cls_feat, reg_feat = self._towers(x, branches)
+        cls_score = self.conv_cls(cls_feat) if branches != 'reg' else None
+        if reg_feat is None:
+            return cls_score, None, None, None, points
         bbox_pred = self.conv_reg(reg_feat)
         centerness = self.conv_centerness(reg_feat if self.centerness_on_reg else cls_feat)
         bbox_pred = scale(bbox_pred).float()
@@ -86,13 +84,16 @@ class TS_P2RBRotatedFCOSHead(TS_P2BFCOSHead):
         return cls_score, bbox_pred, angle_pred, centerness, points
 
     def _flat5(self, cls_scores, bbox_preds, angle_preds, centernesses):
-        """concat_per_img (:1140-1161): [B,P,C], [B,P,5] = (l,t,r,b,angle), [B,P]."""
-        B = cls_scores[0].size(0)
-        fc = torch.cat([c.permute(0, 2, 3, 1).reshape(B, -1, self.cls_out_channels) for c in cls_scores], 1)
-        fr = torch.cat([torch.cat([r.permute(0, 2, 3, 1).reshape(B, -1, 4), a.permute(0, 2, 3, 1).reshape(B, -1, 1).float()], -1)
-                        for r, a in zip(bbox_preds, angle_preds)], 1)
-        ft = torch.cat([t.permute(0, 2, 3, 1).reshape(B, -1) for t in centernesses], 1)
-        return fc.float().contiguous(), fr.float().contiguous(), ft.float().contiguous()
+        """concat_per_img (:1140-1161): [B,P,C], [B,P,5] = (l,t,r,b,angle), [B,P]; None for a branch that was not evaluated."""
+        B = (cls_scores if cls_scores[0] is not None else bbox_preds)[0].size(0)
+        fc = fr = ft = None
+        if cls_scores[0] is not None:
+            fc = torch.cat([c.permute(0, 2, 3, 1).reshape(B, -1, self.cls_out_channels) for c in cls_scores], 1).float().contiguous()
+        if bbox_preds[0] is not None:
+            fr = torch.cat([torch.cat([r.permute(0, 2, 3, 1).reshape(B, -1, 4), a.permute(0, 2, 3, 1).reshape(B, -1, 1).float()], -1)
+                            for r, a in zip(bbox_preds, angle_preds)], 1).float().contiguous()
+            ft = torch.cat([t.permute(0, 2, 3, 1).reshape(B, -1) for t in centernesses], 1).float().contiguous()
+        return fc, fr, ft
 
     # -------------------------------------------------------------- pseudo boxes --
     def get_pseudo_bbox(self, cls_scores, bbox_preds, angle_preds, centernesses, all_level_points, gt_points, gt_labels,
@@ -128,6 +129,8 @@ class TS_P2RBRotatedFCOSHead(TS_P2BFCOSHead):
         pos = labels_reg < self.num_classes
         norms = reduce_mean_many(pos.sum(), ctr_t.sum().detach(), *([cls_pos] if cls_pos is not None else []))
         num_pos, ctr_den = norms[0].clamp(min=1.0), norms[1].clamp(min=1e-6)
+        if fr is None:                                 # regression branch not evaluated (burn-in step 1, augmented pass)
+            return None, None, norms[2].clamp(min=1.0)
         pts = points.repeat(B, 1)
         pred = self.bbox_coder.decode(pts, fr.reshape(-1, 5))
         tgt = self.bbox_coder.decode(pts, torch.cat([tg, ang], dim=-1))
@@ -171,11 +174,11 @@ class TS_P2RBRotatedFCOSHead(TS_P2BFCOSHead):
     def loss(self, cls_scores, bbox_preds, angle_preds, centernesses, all_level_points, gt_bboxes, img_metas,
              gt_bboxes_ignore=None, gt_valid=None):
         """:535-626 (burn-in step 1: synthetic oriented rectangles, syn_assigner)."""
-        fc, fr, ft = self._flat5(cls_scores, bbox_preds, angle_preds, centernesses)
-        B = fc.shape[0]
+        _, fr, ft = self._flat5(cls_scores, bbox_preds, angle_preds, centernesses)
+        B = fr.shape[0]
         points = torch.cat(all_level_points, 0)
         counts = [int(b.shape[0]) for b in gt_bboxes]
-        off, _ = F.make_offsets(counts, fc.device)
+        off, _ = F.make_offsets(counts, fr.device)
         gb = torch.cat(gt_bboxes)
         gi = F.topk_assign(points, gb, off, B, self.syn_assigner.num_pre,
                            gt_valid=_cat(gt_valid) if gt_valid is not None else None)

@@ -70,7 +70,8 @@ class TS_P2BRetinaHead(TS_P2BFCOSHead):
     def get_points(self, featmap_sizes, dtype, device, flatten=False):
         return [self._anchors(h, w, device)[1] for (h, w) in featmap_sizes]
 
-    def forward(self, feats):
+    def forward(self, feats, branches='both'):
+        """`branches` (TS_P2BFCOSHead.forward) is accepted and ignored: this student always evaluates both towers."""
         outs = [self.forward_single(x) for x in feats]
         return tuple(map(list, zip(*outs)))
 
