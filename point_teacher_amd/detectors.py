@@ -110,20 +110,26 @@ class Student_FCOS(BaseDetector):
 
     backbone_autocast = None      # torch.bfloat16 = BASELINE configs[2]: bf16 backbone / necks, fp32 head (set by the Trainer)
 
-    def extract_feat(self, img):
+    def backbone_stem(self, img):
+        """The frozen stem of the backbone (ResNet.forward_stem) under this detector's autocast setting."""
         if self.backbone_autocast is None:
-            x = self.backbone(img)
+            return self.backbone.forward_stem(img)
+        with torch.autocast('cuda', dtype=self.backbone_autocast):
+            return self.backbone.forward_stem(img)
+
+    def extract_feat(self, img, stem=None):
+        """`stem`: the output of `backbone_stem` for `img` (then `img` is not read)."""
+        def run():
+            x = self.backbone(img) if stem is None else self.backbone(None, stem=stem)
             if self.with_neck:
                 x = self.neck(x)
             if self.with_neck_agg:
                 x = self.neck_agg(x)
             return x
+        if self.backbone_autocast is None:
+            return run()
         with torch.autocast('cuda', dtype=self.backbone_autocast):
-            x = self.backbone(img)
-            if self.with_neck:
-                x = self.neck(x)
-            if self.with_neck_agg:
-                x = self.neck_agg(x)
+            x = run()
         return tuple(f.float() for f in x)          # the dense head, the MIL head and every loss run in fp32
 
     def forward_dummy(self, img):
@@ -208,6 +214,7 @@ class TS_P2B_FCOS(BaseDetector):
                 m._affine_dynamic = True
         # hooks for tests: inject the random draws of one iteration
         self._inject = {}
+        self._stem_shared = None          # decided at the first iteration (`_shared_stem`)
         self.batch_head_passes = os.environ.get('PT_BATCH_HEAD', '0') == '1'
 
     # the reference keeps count/point dictionaries as plain attributes, so they are lost on resume
@@ -225,8 +232,25 @@ class TS_P2B_FCOS(BaseDetector):
         self.gt_bboxes_point = {k: v.to(dev) for k, v in state.get('gt_bboxes_point', {}).items()}
         self.refined_gt_bboxes_point = {k: v.to(dev) for k, v in state.get('refined_gt_bboxes_point', {}).items()}
 
-    def extract_feat(self, img, model=None):
-        return model.extract_feat(img)
+    def extract_feat(self, img, model=None, stem=None):
+        return model.extract_feat(img) if stem is None else model.extract_feat(None, stem=stem)
+
+    def _shared_stem(self):
+        """True when the teacher provably computes the same frozen stem as the student: the parameters live in the Trainer's flat
+        buffers, the backbone freezes its stem (frozen_stages >= 0) and every frozen parameter and BatchNorm buffer of the two
+        models is bit-equal - the state of a run whose two detectors loaded the same pretrained backbone (the configs'
+        init_cfg).  Then the EMA of the frozen segment is the identity and is skipped (alpha*t + (1-alpha)*t rounds away from
+        t), and the stem of the clean images is evaluated once per iteration (`_student_inputs`).  PT_SHARE_STEM=0: off."""
+        if self._stem_shared is None:
+            ok = False
+            sb = getattr(self.student, 'backbone', None)
+            if (self._flat is not None and getattr(self, '_flat_n_train', None) is not None and hasattr(sb, 'forward_stem')
+                    and getattr(sb, 'frozen_stages', -1) >= 0 and os.environ.get('PT_SHARE_STEM', '1') != '0'):
+                n = self._flat_n_train
+                ok = bool(torch.equal(self._flat[0][n:], self._flat[1][n:]))
+                ok = ok and all(torch.equal(a, b) for a, b in zip(self.teacher.backbone.buffers(), sb.buffers()))
+            self._stem_shared = ok
+        return self._stem_shared
 
     def forward_dummy(self, img, model=None):
         return model.forward_dummy(img)
@@ -257,7 +281,8 @@ class TS_P2B_FCOS(BaseDetector):
         """:254-257: over parameters() only (buffers untouched), at the START of the iteration."""
         with torch.no_grad():
             if self._flat is not None:
-                F.ema_update_(self._flat[0], self._flat[1], ema_decay)
+                n = self._flat_n_train if self._shared_stem() else self._flat[0].numel()
+                F.ema_update_(self._flat[0][:n], self._flat[1][:n], ema_decay)
             else:   # parameters not flattened yet (unit tests / CPU construction): per-tensor form
                 F.PARAM_EPOCH[0] += 1
                 for t, s in zip(teacher_model.parameters(), student_model.parameters()):
@@ -298,9 +323,9 @@ class TS_P2B_FCOS(BaseDetector):
             img_list.append(img[i])
         return gt_points, img_list, img
 
-    def _teacher_pseudo(self, img, img_metas, img_list, gt_points, gt_labels, gt_bboxes, gt_bboxes_ignore):
+    def _teacher_pseudo(self, img, img_metas, img_list, gt_points, gt_labels, gt_bboxes, gt_bboxes_ignore, stem=None):
         with torch.no_grad():
-            feat = self.extract_feat(img, self.teacher)
+            feat = self.extract_feat(img, self.teacher, stem=stem)
             outs = self.teacher.bbox_head(feat)
             return self.teacher.bbox_head.get_pseudo_bbox(*outs, gt_points, gt_labels, gt_bboxes, self.filter_score,
                                                           img_metas, img_list, gt_bboxes_ignore)
@@ -309,25 +334,37 @@ class TS_P2B_FCOS(BaseDetector):
         real = self._cxcywh(torch.cat(gt_bboxes, dim=0))
         return mean0(torch.sqrt((torch.cat(gt_points) - real[:, :2]) ** 2) / torch.sqrt((real[:, 2:4] / 2) ** 2))
 
-    def _student_passes(self, img, extra=None):
-        """ONE batched student pass over [clean images | extra (synthetic) images | strongly augmented images].
-        The reference runs them as separate passes (:146, :191 / :226, :243); every layer of the student is
-        per-sample (BatchNorm in eval mode, GroupNorm), so the batched pass computes the same features with a
-        third of the launches and one gradient accumulation per parameter.  The augmented PIXELS only depend on
-        the input image and the draws (the boxes/points are transformed later, after the MIL stage, with the
-        same draws).  Returns (aug_pre, [feature tuples per group], features of the whole batch)."""
-        B = img.shape[0]
+    def _student_inputs(self, img, extra=None):
+        """The batch of ONE student pass, [clean images | extra (synthetic) images | strongly augmented images], and - when the
+        teacher shares the student's frozen stem (`_shared_stem`) - the stem of that batch, whose first rows are the teacher's.
+        The augmented PIXELS only depend on the input image and the draws (the boxes / points are transformed later, after the
+        MIL stage, with the same draws).  -> (aug_pre, parts, batch, stem | None, teacher stem | None)"""
         params, aug_imgs = self._strong_aug_images(img)
         img_aug = torch.stack(aug_imgs, dim=0)
         parts = [img] + ([extra] if extra is not None else []) + [img_aug]
         if img.is_contiguous(memory_format=torch.channels_last) and not img.is_contiguous():
             parts = [p.contiguous(memory_format=torch.channels_last) for p in parts]
-        feat_all = self.extract_feat(torch.cat(parts, dim=0), self.student)
+        batch = torch.cat(parts, dim=0)
+        stem = t_stem = None
+        if self._shared_stem():
+            with torch.no_grad():                      # no trainable parameter, no input that requires a gradient
+                stem = self.student.backbone_stem(batch)
+            B = img.shape[0]
+            t_stem = (stem[0][:B], [o[:B] for o in stem[1]])
+        return (params, aug_imgs), parts, batch, stem, t_stem
+
+    def _student_passes(self, img, extra=None, inputs=None):
+        """ONE batched student pass over the batch of `_student_inputs`.  The reference runs the groups as separate passes
+        (:146, :191 / :226, :243); every layer of the student is per-sample (BatchNorm in eval mode, GroupNorm), so the batched
+        pass computes the same features with a third of the launches and one gradient accumulation per parameter.
+        Returns (aug_pre, [feature tuples per group], features of the whole batch)."""
+        aug_pre, parts, batch, stem, _ = inputs if inputs is not None else self._student_inputs(img, extra)
+        feat_all = self.extract_feat(batch, self.student, stem=stem)
         groups, o = [], 0
         for p in parts:
             groups.append(tuple(f[o:o + p.shape[0]] for f in feat_all))
             o += p.shape[0]
-        return (params, aug_imgs), groups, feat_all
+        return aug_pre, groups, feat_all
 
     def _student_aug_loss(self, img, img_metas, gt_points, gt_labels, pseudo_points, pseudo_labels, pseudo_bboxes,
                           gt_bboxes_ignore, aug_pre=None, feat_aug=None, outs=None, branches='both'):
@@ -346,9 +383,11 @@ class TS_P2B_FCOS(BaseDetector):
                                     gt_bboxes_ignore, device):
         """:213-252"""
         losses = {}
+        inputs = self._student_inputs(img)
         pb_c, pp_c, pl_c, _, _ = self._teacher_pseudo(img, img_metas, img_list, gt_points, gt_labels, gt_bboxes,
-                                                      gt_bboxes_ignore)
-        aug_pre, (feat, feat_aug), _ = self._student_passes(img)
+                                                      gt_bboxes_ignore, stem=inputs[4])
+        aug_pre, (feat, feat_aug), _ = self._student_passes(img, inputs=inputs)
+        del inputs
         mil_feat = self.student.bbox_head.forward_mil(feat)
         pb_r, pp_r, mil_losses = self.forward_mil_head_burn_in_step2(num_img, pb_c, pp_c, pl_c, gt_bboxes, img_metas,
                                                                      mil_feat)
@@ -406,7 +445,10 @@ class TS_P2B_FCOS(BaseDetector):
         losses = {}
         img_syn, _, syn_boxes, syn_alive = self.genrate_syn(num_img, img_list, gt_bboxes, gt_labels)
         head = self.student.bbox_head
-        aug_pre, (feat_ori, feat_syn, feat_aug), feat_all = self._student_passes(img, extra=img_syn)
+        inputs = self._student_inputs(img, extra=img_syn)
+        t_stem = inputs[4]
+        aug_pre, (feat_ori, feat_syn, feat_aug), feat_all = self._student_passes(img, inputs=inputs)
+        del inputs
         mil_syn, mil_ori = head.forward_mil(feat_syn), head.forward_mil(feat_ori)
         outs_aug = None
         if self.batch_head_passes:
@@ -420,7 +462,8 @@ class TS_P2B_FCOS(BaseDetector):
             outs_syn = head(feat_syn, branches='reg')          # `loss` reads the regression / centerness outputs only
         loss_syn = head.loss(*outs_syn, syn_boxes, img_metas, gt_bboxes_ignore, gt_valid=syn_alive)
         pb_c, pp_c, pl_c, _, _ = self._teacher_pseudo(img, img_metas, img_list, gt_points, gt_labels, gt_bboxes,
-                                                      gt_bboxes_ignore)
+                                                      gt_bboxes_ignore, stem=t_stem)
+        del t_stem
         _, _, mil_losses = self.forward_mil_head_burn_in_step1(num_img, syn_boxes, syn_alive, pb_c, pp_c, pl_c, gt_bboxes,
                                                                img_metas, mil_syn, mil_ori, img)
         pb_r, pp_r = pb_c, pp_c                                   # the MIL output is discarded in step 1 (:187)

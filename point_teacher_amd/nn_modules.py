@@ -335,11 +335,24 @@ class ResNet(nn.Module):
             for p in m.parameters():
                 p.requires_grad = False
 
-    def forward(self, x):
+    def forward_stem(self, x):
+        """conv1 / bn1 / maxpool and the frozen stages: the part of the network no gradient reaches and no optimizer step
+        changes (frozen_stages >= 0).  -> (activation, outputs collected so far); `forward(None, stem=...)` continues from it.
+        A teacher that holds the same frozen weights as its student (both load the same pretrained file and the stem never
+        trains) computes the same stem on the same image: TS_P2B_FCOS evaluates it once."""
         x = self.maxpool(conv_bn(x, self.conv1, self.bn1, True))
         outs = []
-        for i, name in enumerate(self.res_layers):
-            x = getattr(self, name)(x)
+        for i in range(max(self.frozen_stages, 0)):
+            x = getattr(self, self.res_layers[i])(x)
+            if i in self.out_indices:
+                outs.append(x)
+        return x, outs
+
+    def forward(self, x, stem=None):
+        x, outs = self.forward_stem(x) if stem is None else stem
+        outs = list(outs)
+        for i in range(max(self.frozen_stages, 0), len(self.res_layers)):
+            x = getattr(self, self.res_layers[i])(x)
             if i in self.out_indices:
                 outs.append(x)
         return tuple(outs)

@@ -99,6 +99,8 @@ class FlatParams:
                 off += (n + 3) // 4 * 4
         if self.has_teacher:
             model._flat = (self.teacher_flat, self.student_flat)
+            model._flat_n_train = self.n_train          # [n_train, total) = the frozen parameters
+            model._stem_shared = None
 
     def zero_grad(self):
         self.grad_flat.zero_()
@@ -367,5 +369,7 @@ class Trainer:
 
     def load_state_dict(self, sd):
         self.model.load_state_dict(sd['model'])
+        if hasattr(self.model, '_stem_shared'):
+            self.model._stem_shared = None           # re-decided from the loaded state
         self.flat.mom_flat.copy_(sd['momentum'])
         self.iter = sd['iter']

@@ -71,7 +71,8 @@ def benchmark_init_(model, phase2=False):
     The MIL box-refinement layer `fc_reg` is scaled by 0.01 so that refined bags stay near the
     coarse boxes as they do in a trained model; torch's default Linear init makes it emit
     |dw| ~ 4 deltas, i.e. 60x larger boxes clipped to the whole image, which turns every RoI
-    into a 100x100-pixel crop with a 15x15 sampling grid per bin (225x the realistic RoIAlign work)."""
+    into a 100x100-pixel crop with a 15x15 sampling grid per bin (225x the realistic RoIAlign work).
+    The teacher's backbone is a copy of the student's, as after loading the configs' pretrained checkpoint into both."""
     import torch
     with torch.no_grad():
         for m in (model.student, model.teacher):
@@ -82,4 +83,6 @@ def benchmark_init_(model, phase2=False):
                 fc.bias.zero_()
             if phase2 and hasattr(m.bbox_head, 'conv_reg'):      # (an anchor-based head starts from its anchors: nothing to do)
                 m.bbox_head.conv_reg.bias.fill_(1.0)
+        # both detectors load the SAME pretrained backbone in a real run (init_cfg of the configs): same stand-in for both
+        model.teacher.backbone.load_state_dict(model.student.backbone.state_dict())
     return model

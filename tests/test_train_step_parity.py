@@ -448,3 +448,49 @@ def test_bf16_backbone_fp32_head(phase2):
         f2 = model.teacher.extract_feat(x)[0].float()
     print('bf16 features, same input twice: relative difference %.2e' % float((f1 - f2).norm() / f1.norm()))
     assert tr.channels_last and sum(err.values()) < sum(gap.values())
+
+
+@pytest.mark.parametrize('phase2', [False, True])
+def test_shared_frozen_stem(phase2, monkeypatch):
+    """Teacher and student hold the same frozen stem (both load the same pretrained backbone; conv1 / bn1 / layer1 never train,
+    BatchNorm never updates): TS_P2B_FCOS evaluates the stem of the clean images once and skips the (identity) EMA of the frozen
+    segment.  Same loss dict and gradients as the two-stem path (PT_SHARE_STEM=0) on the same weights, inputs and draws; a
+    teacher whose frozen weights differ is detected and keeps its own stem."""
+    dev = torch.device('cuda:0')
+    img, boxes, labels, metas = _data(dev, seed=6 if not phase2 else 5)
+    g = torch.Generator().manual_seed(13)
+    inj = dict(neg0=torch.rand(2, 4, 200, generator=g).to(dev), aug=(['horizontal', 'vertical'], [0.9, 1.1]))
+    if not phase2:
+        inj['syn'] = [{n: t.to(dev) for n, t in _syn_draws(b.shape[0], 40 + i).items()} for i, b in enumerate(boxes)]
+    data = dict(img=img.to(dev), img_metas=metas, gt_bboxes=[b.to(dev) for b in boxes], gt_labels=[l.to(dev) for l in labels])
+
+    def run(share, perturb=False):
+        monkeypatch.setenv('PT_SHARE_STEM', '1' if share else '0')
+        pta, cfg, model = _build(dev, phase2=phase2)
+        if perturb:
+            with torch.no_grad():
+                model.teacher.backbone.layer1[0].conv1.weight.mul_(1.001)
+        tr = pta.Trainer(model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config, channels_last=True)
+        model._inject = dict(inj)
+        calls = []
+        h = model.teacher.backbone.conv1.register_forward_hook(lambda m, i, o: calls.append(1))
+        tr.flat.zero_grad(); tr.flat.detach_grads()
+        out = model.train_step(dict(data, img=data['img'].contiguous(memory_format=torch.channels_last)), None)
+        out['loss'].backward()
+        h.remove()
+        lv = out['log_vars'].materialize()
+        return model._stem_shared, len(calls), lv, tr.flat.grad_flat.clone(), tr.flat.teacher_flat.clone(), tr.flat
+
+    shared, calls, lv, grad, teacher, flat = run(True)
+    assert shared is True and calls == 0                              # the teacher never ran its own stem
+    shared0, calls0, lv0, grad0, teacher0, _ = run(False)
+    assert shared0 is False and calls0 == 1
+    for k in lv0:
+        assert abs(lv[k] - lv0[k]) <= 1e-5 * max(abs(lv0[k]), 1e-2), (k, lv[k], lv0[k])
+    assert _rel(grad, grad0) < 1e-4
+    n = flat.n_train
+    torch.testing.assert_close(teacher[:n], teacher0[:n], rtol=0, atol=0)           # trainable segment: the same EMA
+    assert torch.equal(teacher[n:], flat.student_flat[n:])                         # frozen segment: still the student's, bit for bit
+    torch.testing.assert_close(teacher0[n:], teacher[n:], rtol=1e-6, atol=1e-9)     # (the EMA of equal values only rounds)
+    shared2, calls2, _, _, _, _ = run(True, perturb=True)
+    assert shared2 is False and calls2 == 1
