@@ -18,6 +18,10 @@ from .proposals import (MIL_gen_proposals_from_cfg, gen_negative_proposals, gene
                         load_basic_shape, random_point_in_quadrilateral, strong_augmentation_images,
                         strong_augmentation_masked)
 from .nn_modules import refresh_bn_affines
+def img_is_cuda(t):
+    return torch.is_tensor(t) and t.is_cuda
+
+
 from .registry import DETECTORS, build_backbone, build_detector, build_head, build_neck
 
 
@@ -215,6 +219,8 @@ class TS_P2B_FCOS(BaseDetector):
         # hooks for tests: inject the random draws of one iteration
         self._inject = {}
         self._stem_shared = None          # decided at the first iteration (`_shared_stem`)
+        self.teacher_stream = os.environ.get('PT_TEACHER_STREAM', '1') == '1'
+        self._side_stream = None
         self.batch_head_passes = os.environ.get('PT_BATCH_HEAD', '0') == '1'
 
     # the reference keeps count/point dictionaries as plain attributes, so they are lost on resume
@@ -330,6 +336,34 @@ class TS_P2B_FCOS(BaseDetector):
             return self.teacher.bbox_head.get_pseudo_bbox(*outs, gt_points, gt_labels, gt_bboxes, self.filter_score,
                                                           img_metas, img_list, gt_bboxes_ignore)
 
+    def _teacher_fork(self, *args, **kw):
+        """Start the teacher pass on a second HIP stream (PT_TEACHER_STREAM=0 turns it off): it has no gradient and nothing of the student's
+        batched pass depends on it until the MIL stage, so its small-batch kernels (B = 2 at 25x25 / 50x50 leave most of the 256
+        CUs idle) overlap the student's forward.  -> a callable that joins the stream and returns the pseudo boxes."""
+        if not self.teacher_stream or not img_is_cuda(args[0]):
+            res = self._teacher_pseudo(*args, **kw)
+            return lambda: res
+        main = torch.cuda.current_stream()
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream()
+        side = self._side_stream
+        side.wait_stream(main)
+        stem = kw.get('stem')
+        if stem is not None:                       # views of a tensor the main stream allocated and will free
+            for t in [stem[0]] + list(stem[1]):
+                t.record_stream(side)
+        with torch.cuda.stream(side):
+            res = self._teacher_pseudo(*args, **kw)
+
+        def join():
+            main.wait_stream(side)
+            for item in res:
+                for t in (item if isinstance(item, (list, tuple)) else [item]):
+                    if torch.is_tensor(t):
+                        t.record_stream(main)
+            return res
+        return join
+
     def _refined_points_distance(self, gt_points, gt_bboxes):
         real = self._cxcywh(torch.cat(gt_bboxes, dim=0))
         return mean0(torch.sqrt((torch.cat(gt_points) - real[:, :2]) ** 2) / torch.sqrt((real[:, 2:4] / 2) ** 2))
@@ -384,10 +418,11 @@ class TS_P2B_FCOS(BaseDetector):
         """:213-252"""
         losses = {}
         inputs = self._student_inputs(img)
-        pb_c, pp_c, pl_c, _, _ = self._teacher_pseudo(img, img_metas, img_list, gt_points, gt_labels, gt_bboxes,
-                                                      gt_bboxes_ignore, stem=inputs[4])
+        teacher = self._teacher_fork(img, img_metas, img_list, gt_points, gt_labels, gt_bboxes, gt_bboxes_ignore,
+                                     stem=inputs[4])
         aug_pre, (feat, feat_aug), _ = self._student_passes(img, inputs=inputs)
         del inputs
+        pb_c, pp_c, pl_c, _, _ = teacher()
         mil_feat = self.student.bbox_head.forward_mil(feat)
         pb_r, pp_r, mil_losses = self.forward_mil_head_burn_in_step2(num_img, pb_c, pp_c, pl_c, gt_bboxes, img_metas,
                                                                      mil_feat)
@@ -446,7 +481,8 @@ class TS_P2B_FCOS(BaseDetector):
         img_syn, _, syn_boxes, syn_alive = self.genrate_syn(num_img, img_list, gt_bboxes, gt_labels)
         head = self.student.bbox_head
         inputs = self._student_inputs(img, extra=img_syn)
-        t_stem = inputs[4]
+        teacher = self._teacher_fork(img, img_metas, img_list, gt_points, gt_labels, gt_bboxes, gt_bboxes_ignore,
+                                     stem=inputs[4])
         aug_pre, (feat_ori, feat_syn, feat_aug), feat_all = self._student_passes(img, inputs=inputs)
         del inputs
         mil_syn, mil_ori = head.forward_mil(feat_syn), head.forward_mil(feat_ori)
@@ -461,9 +497,7 @@ class TS_P2B_FCOS(BaseDetector):
         else:
             outs_syn = head(feat_syn, branches='reg')          # `loss` reads the regression / centerness outputs only
         loss_syn = head.loss(*outs_syn, syn_boxes, img_metas, gt_bboxes_ignore, gt_valid=syn_alive)
-        pb_c, pp_c, pl_c, _, _ = self._teacher_pseudo(img, img_metas, img_list, gt_points, gt_labels, gt_bboxes,
-                                                      gt_bboxes_ignore, stem=t_stem)
-        del t_stem
+        pb_c, pp_c, pl_c, _, _ = teacher()
         _, _, mil_losses = self.forward_mil_head_burn_in_step1(num_img, syn_boxes, syn_alive, pb_c, pp_c, pl_c, gt_bboxes,
                                                                img_metas, mil_syn, mil_ori, img)
         pb_r, pp_r = pb_c, pp_c                                   # the MIL output is discarded in step 1 (:187)

@@ -71,8 +71,9 @@ class FCOSHead(TS_P2BFCOSHead):
         self.conv_centerness = nn.Conv2d(self.feat_channels, 1, 3, padding=1)
         self.scales = nn.ModuleList([Scale(1.0) for _ in self.strides])
 
-    def forward_single(self, x, scale, stride, points):
-        """fcos_head.py:195-252: with norm_on_bbox the regression is in units of the stride while training."""
+    def forward_single(self, x, scale, stride, points, branches='both'):
+        """fcos_head.py:195-252: with norm_on_bbox the regression is in units of the stride while training.  (`branches` of
+        TS_P2BFCOSHead.forward is accepted and ignored: the supervised head always reads both towers.)"""
         cls_feat = reg_feat = x
         for l in self.cls_convs:
             cls_feat = l(cls_feat)

@@ -376,12 +376,16 @@ def test_eval_path_detections():
             got = torch.from_numpy(res[b][c])
             rs, rb = all_s[all_c == c], all_b[all_c == c]
             assert abs(got.shape[0] - rs.numel()) <= 2, (b, c, got.shape, rs.numel())
-            if got.shape[0] == rs.numel() and rs.numel():
-                torch.testing.assert_close(got[:, 4], rs, rtol=2e-3, atol=2e-4)
-                # near-equal scores may swap neighbours: compare the detections as a set (keyed by box centre)
-                kg = torch.argsort((got[:, 0] + got[:, 2]) * 4096 + (got[:, 1] + got[:, 3]))
-                kr = torch.argsort((rb[:, 0] + rb[:, 2]) * 4096 + (rb[:, 1] + rb[:, 3]))
-                torch.testing.assert_close(got[kg, :4], rb[kr], rtol=1e-3, atol=5e-2)
+            if got.shape[0] and rs.numel():
+                # detections as a SET: a greedy NMS decision within rounding of the IoU threshold (MIOpen's split-K convolutions
+                # accumulate with atomics, the scores move in the 7th digit from run to run) swaps single detections, so every
+                # detection must have a partner (box within 0.05 px, score within 2e-3) except for a handful
+                d = (got[:, None, :4] - rb[None, :, :].float()).abs().amax(-1)              # [n_got, n_ref]
+                j = d.argmin(1)
+                ok = (d[torch.arange(len(j)), j] <= 5e-2 + 1e-3 * rb[j].abs().amax(-1)) & \
+                     ((got[:, 4] - rs[j]).abs() <= 2e-3 * rs[j] + 2e-4)
+                assert int((~ok).sum()) <= max(2, got.shape[0] // 100), (b, c, int((~ok).sum()), got.shape[0])
+                assert j[ok].unique().numel() >= int(ok.sum()) - 2                            # partners are distinct
 
 
 @pytest.mark.parametrize('phase2', [False, True])
