@@ -208,6 +208,17 @@ int pt_affine_relu_fwd(const float* x, const float* scale, const float* shift,
 int pt_affine_relu_bwd(const float* grad_y, const float* y, const float* scale, int64_t n, int C,
                        int64_t inner, int relu, float* grad_x, float* grad_res, void* stream);
 
+/* Top-down step of the necks on channels_last maps ([N,H,W,C], fp32 or bf16 = uint16 bit patterns when `bf16`):
+ * out = a + nearest_upsample(b) with a, out [N,Ha,Wa,C] and b [N,Hb,Wb,C] - `laterals[i-1] += F.interpolate(laterals[i],
+ * size=..., mode='nearest')` of HBB_TOD/mmdet/models/necks/fpn.py:165-173 and `inputs[index-1] + F.interpolate(...)` of
+ * necks/ps_fpn.py:64-72; source index min(floor(dst * (float)in / out), in - 1) as torch's 'nearest'.
+ * Backward: grad_a is grad_out itself; pt_upsample_add_bwd writes grad_b (sum over the pixels that read each source
+ * pixel, fp32 accumulation, no atomics).  C % 4 == 0 (fp32) / C % 8 == 0 (bf16); N*Ha <= 65535. */
+int pt_upsample_add_fwd(const void* a, const void* b, int N, int Ha, int Wa, int Hb, int Wb, int C, int bf16,
+                        void* out, void* stream);
+int pt_upsample_add_bwd(const void* grad_out, int N, int Ha, int Wa, int Hb, int Wb, int C, int bf16,
+                        void* grad_b, void* stream);
+
 /* The same epilogue for an eval-mode BatchNorm whose affine TRAINS (OBB config 5:
  * norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, OBB_TOD/configs/point teacher/
  * sodaa_fcos_pointteacher_1x.py:36-38): one pass produces grad_x / grad_res as pt_affine_relu_bwd and

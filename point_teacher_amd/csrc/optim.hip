@@ -354,6 +354,84 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---- top-down step of FPN / PSAGG on NHWC maps: out = a + nearest_upsample(b -> size of a) (necks/fpn.py:165-173,
+// necks/ps_fpn.py:64-72; torch's 'nearest': src = min(floor(dst * (float)in / out), in - 1)).  torch runs an upsample
+// kernel (96 us for a [4,256,100,100] channels_last output on MI355X: 0.4 TB/s) and an add; this is one streaming pass.
+// One workgroup row per output row (blockIdx.y = n * Ha + y), 16 bytes per thread.  V = float4 (fp32) or BF8 (bf16).
+__device__ __forceinline__ int nearest_src(int dst, float scale, int in) {
+  const int s = (int)floorf((float)dst * scale);
+  return s < in - 1 ? s : in - 1;
+}
+__device__ __forceinline__ float4 vadd(const float4 a, const float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ BF8 vadd(const BF8 a, const BF8 b) {
+  BF8 o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o.v[k] = f2bf(bf2f(a.v[k]) + bf2f(b.v[k]));
+  return o;
+}
+
+template <typename V>
+__global__ void __launch_bounds__(256)
+    upsample_add_fwd_kernel(const V* __restrict__ a, const V* __restrict__ b, int Ha, int Wa, int Hb, int Wb, int CG,
+                            float sh, float sw, V* __restrict__ out) {
+  const int row = blockIdx.y;                       // n * Ha + y
+  const int n = row / Ha, y = row - n * Ha;
+  const int ys = nearest_src(y, sh, Hb);
+  const V* brow = b + ((size_t)n * Hb + ys) * Wb * CG;
+  const size_t base = (size_t)row * Wa * CG;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < Wa * CG; t += gridDim.x * blockDim.x) {
+    const int x = t / CG, cg = t - x * CG;
+    out[base + t] = vadd(a[base + t], brow[(size_t)nearest_src(x, sw, Wb) * CG + cg]);
+  }
+}
+
+// grad_b[n, yb, xb, :] = sum of grad_out over the output pixels whose nearest source is (yb, xb) (grad_a is grad_out itself).
+// The pre-image of a source row / column is a contiguous range; found with the forward's own index function.
+__device__ __forceinline__ void preimage(int src, float scale, int in, int out, int& lo, int& hi) {
+  int d = (int)((float)src / scale);
+  d = d < out ? d : out;
+  while (d > 0 && nearest_src(d - 1, scale, in) >= src) --d;
+  while (d < out && nearest_src(d, scale, in) < src) ++d;
+  lo = d;
+  while (d < out && nearest_src(d, scale, in) == src) ++d;
+  hi = d;
+}
+
+template <bool BF>
+__global__ void __launch_bounds__(256)
+    upsample_add_bwd_kernel(const void* __restrict__ g_, int Ha, int Wa, int Hb, int Wb, int CG, float sh, float sw,
+                            void* __restrict__ gb_) {
+  const int row = blockIdx.y;                       // n * Hb + yb
+  const int n = row / Hb, yb = row - n * Hb;
+  int y0, y1;
+  preimage(yb, sh, Hb, Ha, y0, y1);
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < Wb * CG; t += gridDim.x * blockDim.x) {
+    const int xb = t / CG, cg = t - xb * CG;
+    int x0, x1;
+    preimage(xb, sw, Wb, Wa, x0, x1);
+    if (BF) {
+      const BF8* g = reinterpret_cast<const BF8*>(g_);
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) {
+          const BF8 v = g[(((size_t)n * Ha + y) * Wa + x) * CG + cg];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) acc[k] += bf2f(v.v[k]);
+        }
+      BF8 o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o.v[k] = f2bf(acc[k]);
+      reinterpret_cast<BF8*>(gb_)[(size_t)row * Wb * CG + t] = o;
+    } else {
+      const float4* g = reinterpret_cast<const float4*>(g_);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) acc = vadd(acc, g[(((size_t)n * Ha + y) * Wa + x) * CG + cg]);
+      reinterpret_cast<float4*>(gb_)[(size_t)row * Wb * CG + t] = acc;
+    }
+  }
+}
+
 }  // namespace pt
 
 static int affine_check(const char* fn, int64_t n, int C, int64_t inner) {
@@ -458,5 +536,49 @@ extern "C" int pt_affine_relu_bwd_bf16(const uint16_t* grad_y, const uint16_t* y
                      reinterpret_cast<const BF8*>(grad_y), reinterpret_cast<const BF8*>(y), scale, (long)(n / 8), C, relu,
                      reinterpret_cast<BF8*>(grad_x), reinterpret_cast<BF8*>(grad_res));
   PT_LAUNCH_CHECK("pt_affine_relu_bwd_bf16");
+  return PT_OK;
+}
+
+static int upsample_check(const char* fn, int N, int Ha, int Wa, int Hb, int Wb, int C, int bf16) {
+  PT_REQUIRE(N > 0 && Ha > 0 && Wa > 0 && Hb > 0 && Wb > 0 && C > 0 && C % (bf16 ? 8 : 4) == 0, PT_EINVAL,
+             "%s: bad shape (channels_last, C %% %d == 0)", fn, bf16 ? 8 : 4);
+  PT_REQUIRE((long)N * Ha <= 65535 && (long)N * Hb <= 65535, PT_ELIMIT, "%s: N*H = %ld rows exceed the grid limit 65535", fn,
+             (long)N * (Ha > Hb ? Ha : Hb));
+  return PT_OK;
+}
+
+extern "C" int pt_upsample_add_fwd(const void* a, const void* b, int N, int Ha, int Wa, int Hb, int Wb, int C, int bf16,
+                                   void* out, void* stream) {
+  PT_REQUIRE(a && b && out, PT_EINVAL, "pt_upsample_add_fwd: NULL pointer");
+  int rc = upsample_check("pt_upsample_add_fwd", N, Ha, Wa, Hb, Wb, C, bf16);
+  if (rc != PT_OK) return rc;
+  const int CG = C / (bf16 ? 8 : 4);
+  const float sh = (float)Hb / (float)Ha, sw = (float)Wb / (float)Wa;
+  const dim3 grid(cdiv(Wa * CG, 256), N * Ha);
+  if (bf16)
+    hipLaunchKernelGGL(upsample_add_fwd_kernel<BF8>, grid, dim3(256), 0, as_stream(stream), (const BF8*)a, (const BF8*)b, Ha, Wa,
+                       Hb, Wb, CG, sh, sw, (BF8*)out);
+  else
+    hipLaunchKernelGGL(upsample_add_fwd_kernel<float4>, grid, dim3(256), 0, as_stream(stream), (const float4*)a,
+                       (const float4*)b, Ha, Wa, Hb, Wb, CG, sh, sw, (float4*)out);
+  PT_LAUNCH_CHECK("pt_upsample_add_fwd");
+  return PT_OK;
+}
+
+extern "C" int pt_upsample_add_bwd(const void* grad_out, int N, int Ha, int Wa, int Hb, int Wb, int C, int bf16, void* grad_b,
+                                   void* stream) {
+  PT_REQUIRE(grad_out && grad_b, PT_EINVAL, "pt_upsample_add_bwd: NULL pointer");
+  int rc = upsample_check("pt_upsample_add_bwd", N, Ha, Wa, Hb, Wb, C, bf16);
+  if (rc != PT_OK) return rc;
+  const int CG = C / (bf16 ? 8 : 4);
+  const float sh = (float)Hb / (float)Ha, sw = (float)Wb / (float)Wa;
+  const dim3 grid(cdiv(Wb * CG, 256), N * Hb);
+  if (bf16)
+    hipLaunchKernelGGL(upsample_add_bwd_kernel<true>, grid, dim3(256), 0, as_stream(stream), grad_out, Ha, Wa, Hb, Wb, CG, sh, sw,
+                       grad_b);
+  else
+    hipLaunchKernelGGL(upsample_add_bwd_kernel<false>, grid, dim3(256), 0, as_stream(stream), grad_out, Ha, Wa, Hb, Wb, CG, sh,
+                       sw, grad_b);
+  PT_LAUNCH_CHECK("pt_upsample_add_bwd");
   return PT_OK;
 }

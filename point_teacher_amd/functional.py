@@ -602,6 +602,48 @@ def bias_relu_ok(x, bias):
             and x.is_contiguous(memory_format=torch.channels_last) and (C == 1 or not x.is_contiguous()))
 
 
+class _UpsampleAdd(torch.autograd.Function):
+    """out = a + nearest_upsample(b -> a's size) on channels_last maps (pt_upsample_add_*): one pass instead of torch's
+    upsample kernel + add; backward: grad_a is grad_out itself, grad_b one gather pass."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        N, C, Ha, Wa = a.shape
+        Hb, Wb = b.shape[2:]
+        out = torch.empty_like(a)
+        bf = a.dtype == torch.bfloat16
+        hip.call('pt_upsample_add_fwd', a.permute(0, 2, 3, 1), b.permute(0, 2, 3, 1), N, Ha, Wa, Hb, Wb, C, int(bf),
+                 out.permute(0, 2, 3, 1))
+        ctx.cfg = (N, C, Ha, Wa, Hb, Wb, bf)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        N, C, Ha, Wa, Hb, Wb, bf = ctx.cfg
+        gb = None
+        if ctx.needs_input_grad[1]:
+            g = g.contiguous(memory_format=torch.channels_last)
+            gb = torch.empty((N, C, Hb, Wb), dtype=g.dtype, device=g.device).contiguous(memory_format=torch.channels_last)
+            hip.call('pt_upsample_add_bwd', g.permute(0, 2, 3, 1), N, Ha, Wa, Hb, Wb, C, int(bf), gb.permute(0, 2, 3, 1))
+        return (g if ctx.needs_input_grad[0] else None), gb
+
+
+def _cl_dense(t):
+    """A 4-D tensor whose memory is dense NHWC (a [N,1,H,W] or [N,C,1,1] tensor is both layouts at once)."""
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)
+
+
+def upsample_add(a, b):
+    """a + F.interpolate(b, size=a.shape[2:], mode='nearest') (necks/fpn.py:165-173, ps_fpn.py:64-72).  The fused kernel takes
+    CUDA channels_last fp32 / bf16 maps of one dtype; any other layout takes torch's two kernels."""
+    C = a.shape[1]
+    if (a.is_cuda and a.dtype == b.dtype and a.dtype in (f32, torch.bfloat16) and _cl_dense(a) and _cl_dense(b)
+            and a.shape[:2] == b.shape[:2] and C % (8 if a.dtype == torch.bfloat16 else 4) == 0
+            and a.shape[0] * max(a.shape[2], b.shape[2]) <= 65535 and a.numel() > 0):
+        return _UpsampleAdd.apply(a, b)
+    return a + torch.nn.functional.interpolate(b, size=a.shape[2:], mode='nearest')
+
+
 def bn_eval_relu(x, bn, residual=None, relu=True):
     """Fused eval-mode BatchNorm with a TRAINABLE affine (+ residual) (+ ReLU); x: fp32, channels_last."""
     return _AffineReLUTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, residual, relu)

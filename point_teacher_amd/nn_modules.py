@@ -423,6 +423,8 @@ class FPN(nn.Module):
         for i in range(n - 1, 0, -1):
             if 'scale_factor' in self.upsample_cfg:
                 laterals[i - 1] = laterals[i - 1] + TF.interpolate(laterals[i], **self.upsample_cfg)
+            elif self.upsample_cfg.get('mode', 'nearest') == 'nearest' and len(self.upsample_cfg) <= 1:
+                laterals[i - 1] = F.upsample_add(laterals[i - 1], laterals[i])        # one fused pass on NHWC maps
             else:
                 laterals[i - 1] = laterals[i - 1] + TF.interpolate(laterals[i], size=laterals[i - 1].shape[2:],
                                                                    **self.upsample_cfg)
@@ -466,11 +468,13 @@ class PSAGG(nn.Module):
         for i in range(self.num_aggregation):
             index = self.num_aggregation - i - 1
             if index != 0:
-                if 'scale_factor' in self.upsample_cfg:
-                    up = TF.interpolate(inputs[index], **self.upsample_cfg)
+                if self.upsample_cfg.get('mode', 'nearest') == 'nearest' and len(self.upsample_cfg) <= 1:
+                    summed = F.upsample_add(inputs[index - 1], inputs[index])            # one fused pass on NHWC maps
+                elif 'scale_factor' in self.upsample_cfg:
+                    summed = inputs[index - 1] + TF.interpolate(inputs[index], **self.upsample_cfg)
                 else:
-                    up = TF.interpolate(inputs[index], size=inputs[index - 1].shape[2:], **self.upsample_cfg)
-                inputs[index - 1] = self.lateral_convs[i + 1](inputs[index - 1] + up)
+                    summed = inputs[index - 1] + TF.interpolate(inputs[index], size=inputs[index - 1].shape[2:], **self.upsample_cfg)
+                inputs[index - 1] = self.lateral_convs[i + 1](summed)
         return tuple([inputs[0]])
 
 

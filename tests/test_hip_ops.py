@@ -534,6 +534,34 @@ def test_trainable_bn_epilogue(C, HW, relu, with_res):
     close(bng.bias.grad, bn.bias.grad, rtol=1e-3, atol=1e-4 * float(bn.bias.grad.abs().max()))
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(2, 256, (100, 100), (50, 50)), (3, 64, (25, 25), (13, 13)), (2, 8, (13, 9), (7, 5)),
+                                   (1, 16, (7, 7), (4, 4)), (2, 32, (10, 12), (10, 12)), (1, 8, (19, 10), (10, 5))])
+def test_upsample_add(shape, dtype):
+    """pt_upsample_add_* == a + F.interpolate(b, size=a.shape[2:], mode='nearest') of torch (the FPN / PSAGG top-down step),
+    values bit for bit and both gradients, on the pyramid's size pairs (even, odd: 25 <- 13, 13 <- 7, 7 <- 4, equal sizes)."""
+    f = F()
+    N, C, (Ha, Wa), (Hb, Wb) = shape
+    gen = torch.Generator().manual_seed(61)
+    a = torch.randn(N, C, Ha, Wa, generator=gen).to(dtype)
+    b = torch.randn(N, C, Hb, Wb, generator=gen).to(dtype)
+    w = torch.randn(N, C, Ha, Wa, generator=gen).to(dtype)
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = ar + torch.nn.functional.interpolate(br, size=(Ha, Wa), mode='nearest')
+    (ref.float() * w.float()).sum().backward()
+    ag = cu(a).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bg = cu(b).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    out = f.upsample_add(ag, bg)
+    assert 'UpsampleAdd' in type(out.grad_fn).__name__
+    assert torch.equal(out.detach().cpu(), ref.detach())
+    (out.float() * cu(w).float()).sum().backward()
+    assert torch.equal(ag.grad.cpu(), ar.grad)
+    if dtype == torch.float32:
+        close(bg.grad, br.grad, atol=1e-5)
+    else:                                        # torch sums the (up to 4) contributions in bf16, the kernel in fp32 then rounds
+        close(bg.grad.float(), br.grad.float(), rtol=2e-2, atol=2e-2)
+
+
 @pytest.mark.parametrize('C,HW', [(256, (20, 30)), (64, (9, 11)), (1024, (5, 7))])
 def test_conv_bias_relu_epilogue(C, HW):
     """ConvModule (conv + bias + ReLU, the FCOS towers): the fused epilogue (pt_affine_relu_fwd with unit scale in place,
