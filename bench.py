@@ -183,8 +183,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    trace = os.environ.get('PT_BENCH_TRACE') == '1'          # diagnostics: per-iteration loss dict on stderr (synchronises)
+
+    def traced(it, out):
+        if trace:
+            lv = out['log_vars'].materialize()
+            pts = [p for d in (model.gt_bboxes_point, model.refined_gt_bboxes_point) for p in d.values()] if hasattr(model, 'gt_bboxes_point') else []
+            bad = sum(int((~torch.isfinite(p)).sum()) for p in pts)
+            big = max([float(p.abs().max()) for p in pts if p.numel()] + [0.0])
+            print(f'[trace] it {it} non-finite points {bad} max |coord| {big:.1f} ' + ' '.join(f'{k}={v:.4g}' for k, v in lv.items()), file=sys.stderr, flush=True)
+
     for it in range(args.warmup):
-        trainer.step(data.batch(it, args.batch))
+        traced(it, trainer.step(data.batch(it, args.batch)))
     barrier()
 
     # per-kernel HIP-event timing of the custom kernels inside the timed region (torch's current
@@ -232,6 +242,7 @@ def main():
     t0 = time.perf_counter()
     for it in range(args.steps):
         out = trainer.step(data.batch(args.warmup + it, args.batch))
+        traced(args.warmup + it, out)
     barrier()
     dt = time.perf_counter() - t0
     hip.call = orig_call

@@ -219,7 +219,7 @@ class TS_P2B_FCOS(BaseDetector):
         # hooks for tests: inject the random draws of one iteration
         self._inject = {}
         self._stem_shared = None          # decided at the first iteration (`_shared_stem`)
-        self.teacher_stream = os.environ.get('PT_TEACHER_STREAM', '1') == '1'
+        self.teacher_stream = os.environ.get('PT_TEACHER_STREAM', '0') == '1'
         self._side_stream = None
         self.batch_head_passes = os.environ.get('PT_BATCH_HEAD', '0') == '1'
 
@@ -337,7 +337,7 @@ class TS_P2B_FCOS(BaseDetector):
                                                           img_metas, img_list, gt_bboxes_ignore)
 
     def _teacher_fork(self, *args, **kw):
-        """Start the teacher pass on a second HIP stream (PT_TEACHER_STREAM=0 turns it off): it has no gradient and nothing of the student's
+        """Start the teacher pass on a second HIP stream (opt-in, PT_TEACHER_STREAM=1; off by default): it has no gradient and nothing of the student's
         batched pass depends on it until the MIL stage, so its small-batch kernels (B = 2 at 25x25 / 50x50 leave most of the 256
         CUs idle) overlap the student's forward.  -> a callable that joins the stream and returns the pseudo boxes."""
         if not self.teacher_stream or not img_is_cuda(args[0]):

@@ -17,33 +17,51 @@ def _f(x):
 
 
 class _PinnedRing:
-    """Persistent pinned staging ring for small host->device index uploads (offsets, batch
-    ids).  A fresh pageable upload would serialise the host behind the stream every
-    iteration; copies from this ring are truly asynchronous.  The ring is large enough
-    (256K words) that a slot is reused only thousands of iterations after the GPU consumed it."""
+    """Persistent pinned staging ring for small host->device index uploads (offsets, batch ids).  A fresh pageable upload
+    would serialise the host behind the stream every iteration; copies from this ring are truly asynchronous.
+    A staged slot may only be rewritten after the copy that read it has executed, and the host runs ahead of the GPU by whole
+    iterations: the ring is cut into SEG segments, an event is recorded on the stream when the writer leaves a segment and
+    awaited before the writer enters that segment again (normally long complete: no stall).  Uploads that would take a large
+    share of a segment (the batch ids of 60 750 RoIs at the 100 % configuration: an unguarded 256 K-word ring wrapped inside
+    ONE iteration there and handed kernels overwritten offsets - a GPU memory fault), uploads from another stream than the
+    default one, and host targets go through torch's own pinned allocator / a plain copy instead."""
+    SEG = 8
 
     def __init__(self, words=1 << 18):
         self.words = words
+        self.seg_words = words // self.SEG
         self.buf = None
         self.pos = 0
+        self.events = [None] * self.SEG
 
     def upload(self, arr, device, dtype):
-        arr = np.ascontiguousarray(arr)
+        np_dtype = np.int32 if dtype == torch.int32 else np.float32
+        arr = np.ascontiguousarray(arr, dtype=np_dtype)
         n = arr.size
+        device = torch.device(device)
+        if device.type != 'cuda':
+            return torch.from_numpy(arr.copy())
+        stream = torch.cuda.current_stream(device)
+        if n > self.seg_words // 4 or stream != torch.cuda.default_stream(device):
+            # torch's caching host allocator keeps the staging block alive until the stream has executed the copy
+            return torch.from_numpy(arr).pin_memory().to(device, non_blocking=True)
         if self.buf is None:
             self.buf = torch.empty(self.words, dtype=torch.int32).pin_memory()
-        if n > self.words:
-            return torch.from_numpy(arr).to(device)
-        if self.pos + n > self.words:
-            self.pos = 0
+        seg = self.pos // self.seg_words
+        if self.pos - seg * self.seg_words + n > self.seg_words:
+            ev = self.events[seg] or torch.cuda.Event()
+            ev.record(stream)                              # covers every copy staged in the segment being left
+            self.events[seg] = ev
+            seg = (seg + 1) % self.SEG
+            self.pos = seg * self.seg_words
+            if self.events[seg] is not None:
+                self.events[seg].synchronize()             # the previous lap's copies out of this segment have executed
         view = self.buf[self.pos:self.pos + n]
         self.pos += n
-        if dtype == torch.int32:
-            view.numpy()[:] = arr.astype(np.int32).reshape(-1)
-            return view.to(device, non_blocking=True).reshape(arr.shape)
-        fv = view.view(torch.float32)
-        fv.numpy()[:] = arr.astype(np.float32).reshape(-1)
-        return fv.to(device, non_blocking=True).reshape(arr.shape)
+        if dtype != torch.int32:
+            view = view.view(torch.float32)
+        view.numpy()[:] = arr.reshape(-1)
+        return view.to(device, non_blocking=True).reshape(arr.shape)
 
 
 _ring = _PinnedRing()

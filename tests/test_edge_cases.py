@@ -61,3 +61,32 @@ def test_iteration_with_dcn_on_last_conv():
     w1 = model.student.bbox_head.reg_convs[3].conv.conv_offset.weight.detach()
     assert float((w1 - w0).abs().max()) > 0            # the offset predictor trains
     assert torch.isfinite(trainer.flat.student_flat).all()
+
+
+@pytest.mark.gpu
+def test_pinned_upload_ring_survives_a_busy_stream():
+    """Index uploads (offsets, RoI batch ids) are asynchronous copies out of a pinned ring; the host runs ahead of the GPU, so a
+    staged slot must outlive the copy that reads it.  With the stream kept busy, more words than the whole ring are uploaded
+    in small and large pieces; every device tensor must hold what was uploaded (the 100 % configuration - 60 750 batch ids per
+    RoIAlign call - wrapped the unguarded ring inside one iteration and faulted)."""
+    import numpy as np
+    from point_teacher_amd import functional as Fn
+    dev = torch.device('cuda:0')
+    a = torch.randn(8192, 8192, device=dev)
+    rng = np.random.default_rng(0)
+    for _ in range(12):                                   # ~0.1 s of queued GEMMs: the copies below wait behind them
+        a = (a @ a) * 1e-4
+    srcs, outs = [], []
+    for i in range(400):
+        n = [7, 301, 5000, 60750][i % 4]
+        v = rng.integers(0, 1 << 20, n).astype(np.int32)
+        srcs.append(v)
+        outs.append(Fn.upload_i32(v, dev) if i % 3 else Fn.upload_f32(v.astype(np.float32), dev))
+    torch.cuda.synchronize()
+    assert sum(s.size for s in srcs) > 4 * Fn._ring.words
+    for s, o in zip(srcs, outs):
+        assert np.array_equal(o.cpu().numpy().astype(np.int64), s.astype(np.int64))
+    assert float(a.abs().sum()) >= 0
+    # host targets get their own memory (no alias of the ring)
+    h1 = Fn.upload_i32([1, 2, 3], 'cpu'); h2 = Fn.upload_i32([4, 5, 6], 'cpu')
+    assert h1.tolist() == [1, 2, 3] and h2.tolist() == [4, 5, 6]
