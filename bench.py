@@ -63,11 +63,15 @@ def algorithmic_bytes(name, shapes):
     return None
 
 
-def iteration_flops(workload, cfg_model, batch, size, objects):
-    """Algorithmic FLOPs of one iteration (1 MAC = 2 FLOP), SURVEY Appendix B / BASELINE.md section 3: convolutions of the
-    teacher pass (forward only) and of the student passes (forward + 2x backward), plus the MIL FC stacks per RoI."""
+def iteration_flops(workload, cfg_model, batch, size, objects, executed=True):
+    """FLOPs of one iteration (1 MAC = 2 FLOP), SURVEY Appendix B / BASELINE.md section 3, counted per pass:
+    forward = the layer's MACs, backward = dgrad + wgrad = 2x forward for every layer a gradient reaches.  The frozen stem
+    (conv1 + layer1, 10.2 of the trunk's 60.2 GMAC / image) has no backward.  `executed=True` counts what THIS implementation
+    runs: the teacher continues from the student's stem (no teacher stem), and in burn-in step 1 each student head pass
+    evaluates one of the two towers (forward 0.5 + backward 1.0 head units).  `executed=False` counts what the reference runs
+    (teacher stem; both towers forward, the read one backward: 2.0 head units per student head pass of step 1)."""
     a = (size / 800.0) ** 2
-    trunk, head = 60.2e9 * a, 47.5e9 * a                       # GMAC per image: R50 + FPN + PSAGG; dense head
+    trunk, stem, head = 60.2e9 * a, 10.2e9 * a, 47.5e9 * a     # GMAC per image: R50 + FPN + PSAGG; its frozen stem; dense head
     n = cfg_model['num_training_burninstep2' if workload == 'step2' else 'num_training_burninstep1']
     tc = cfg_model['train_cfg']
     U = 1
@@ -76,11 +80,14 @@ def iteration_flops(workload, cfg_model, batch, size, objects):
     K = batch * min(objects, n) * U
     neg = batch * tc['fine_proposal_cfg'][0]['gen_num_neg']
     fc = 12544 * 1024 + 1024 * 1024 + 1024 * 16                # MAC per RoI of one FC stack + its output layers
+    student_trunk = trunk + 2 * (trunk - stem)                 # forward + backward of the trainable part
+    teacher = (trunk - stem if executed else trunk) + head
     if workload == 'step2':
-        conv = batch * ((trunk + head) + 3 * trunk + 3 * (trunk + head))
+        conv = batch * (teacher + student_trunk + (student_trunk + 3 * head))       # teacher | clean (MIL only) | augmented
         mil = (3 * K + 3 * K + 3 * neg) * fc                   # regression and classifier branches, negatives; fwd + bwd
     else:
-        conv = batch * ((trunk + head) + 3 * (trunk + head) + 3 * trunk + 3 * (trunk + head))
+        half = (1.5 if executed else 2.0) * head               # one tower trains per pass; the other is (reference) forward only
+        conv = batch * (teacher + (student_trunk + half) + student_trunk + (student_trunk + half))   # teacher | synthetic | clean | augmented
         mil = (3 * K + K + 3 * K + 3 * neg) * fc               # synthetic regression branch trains, the real one is forward only
     return 2.0 * (conv + mil)
 
@@ -341,7 +348,9 @@ def main():
                                     sample=f'failed: {type(e).__name__}: {e}')
         iters_s = args.steps * 1.0 / dt
         flops_iter = iteration_flops(args.workload, cfg.to_dict()['model'], args.batch, args.size, args.objects) if not obb \
-            else 3.3e12 * (args.batch / 2) * (args.size / 800.0) ** 2 * (1.3 if args.workload == 'step1' else 1.0)
+            else 3.0e12 * (args.batch / 2) * (args.size / 800.0) ** 2 * (1.2 if args.workload == 'step1' else 1.0)
+        flops_ref = iteration_flops(args.workload, cfg.to_dict()['model'], args.batch, args.size, args.objects, executed=False) \
+            if not obb else None
         peak = 2.5e15 if args.dtype == 'bf16' else 157.3e12
         line = dict(
             metric=f'train iters/sec ({args.size}x{args.size}, ~{args.objects} pts/img)', value=round(iters_s * world, 4), unit='iters/s',
@@ -355,7 +364,7 @@ def main():
                         global_batch=args.batch * world, parallelism=f'dp{world}', phase=args.workload,
                         gemm_solution_table=bool(trainer.tuned_gemms)),
             roofline=roofline, cpu_baseline=cpu_baseline,
-            iteration=dict(flops=flops_iter, achieved_tflops=round(flops_iter * iters_s / 1e12, 2),
+            iteration=dict(flops=flops_iter, flops_reference=flops_ref, achieved_tflops=round(flops_iter * iters_s / 1e12, 2),
                            mfma_peak_tflops=peak / 1e12, frac=round(flops_iter * iters_s / peak, 4)),
             phase2=phase2,
             custom_kernels_ms_per_step={k: round(v['total_ms'] / args.steps, 3) for k, v in sorted(kern.items())},

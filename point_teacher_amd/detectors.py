@@ -221,7 +221,6 @@ class TS_P2B_FCOS(BaseDetector):
         self._stem_shared = None          # decided at the first iteration (`_shared_stem`)
         self.teacher_stream = os.environ.get('PT_TEACHER_STREAM', '0') == '1'
         self._side_stream = None
-        self.batch_head_passes = os.environ.get('PT_BATCH_HEAD', '0') == '1'
 
     # the reference keeps count/point dictionaries as plain attributes, so they are lost on resume
     # (SURVEY section 5); persisting them is a documented deviation.
@@ -337,7 +336,7 @@ class TS_P2B_FCOS(BaseDetector):
                                                           img_metas, img_list, gt_bboxes_ignore)
 
     def _teacher_fork(self, *args, **kw):
-        """Start the teacher pass on a second HIP stream (opt-in, PT_TEACHER_STREAM=1; off by default): it has no gradient and nothing of the student's
+        """Start the teacher pass on a second HIP stream (opt-in: PT_TEACHER_STREAM=1, -0.7 ms per iteration; off by default so that the per-kernel HIP-event timings of bench.py are not stretched by co-scheduled teacher kernels): it has no gradient and nothing of the student's
         batched pass depends on it until the MIL stage, so its small-batch kernels (B = 2 at 25x25 / 50x50 leave most of the 256
         CUs idle) overlap the student's forward.  -> a callable that joins the stream and returns the pseudo boxes."""
         if not self.teacher_stream or not img_is_cuda(args[0]):
@@ -401,14 +400,13 @@ class TS_P2B_FCOS(BaseDetector):
         return aug_pre, groups, feat_all
 
     def _student_aug_loss(self, img, img_metas, gt_points, gt_labels, pseudo_points, pseudo_labels, pseudo_bboxes,
-                          gt_bboxes_ignore, aug_pre=None, feat_aug=None, outs=None, branches='both'):
+                          gt_bboxes_ignore, aug_pre=None, feat_aug=None, branches='both'):
         params, imgs = aug_pre if aug_pre is not None else (None, None)
         aug = self._strong_aug(img, gt_points, gt_labels, pseudo_points, pseudo_labels, pseudo_bboxes, params=params,
                                imgs=imgs)
         img_aug, img_aug_list, gp, gl, pp, pl, pb, gv, pv = aug
-        if outs is None:
-            outs = self.student.bbox_head(feat_aug if feat_aug is not None else self.extract_feat(img_aug, self.student),
-                                          branches=branches)
+        outs = self.student.bbox_head(feat_aug if feat_aug is not None else self.extract_feat(img_aug, self.student),
+                                      branches=branches)
         return self.student.bbox_head.loss_pseudo(*outs, gp, gl, pp, pl, pb, [None] * len(img_metas), img_metas,
                                                   img_aug_list, self.count <= self.burn_in_step, gt_bboxes_ignore,
                                                   gt_valid=gv, pseudo_valid=pv)
@@ -483,19 +481,10 @@ class TS_P2B_FCOS(BaseDetector):
         inputs = self._student_inputs(img, extra=img_syn)
         teacher = self._teacher_fork(img, img_metas, img_list, gt_points, gt_labels, gt_bboxes, gt_bboxes_ignore,
                                      stem=inputs[4])
-        aug_pre, (feat_ori, feat_syn, feat_aug), feat_all = self._student_passes(img, inputs=inputs)
+        aug_pre, (feat_ori, feat_syn, feat_aug), _ = self._student_passes(img, inputs=inputs)
         del inputs
         mil_syn, mil_ori = head.forward_mil(feat_syn), head.forward_mil(feat_ori)
-        outs_aug = None
-        if self.batch_head_passes:
-            # the dense head ONCE over [synthetic | augmented] (neighbours in the batched pass; the reference calls it twice, :150
-            # and :243).  Off by default: measured slower on MI355X (MIOpen's choice for the B = 4 tower convolutions)
-            ns, no = feat_syn[0].shape[0], feat_ori[0].shape[0]
-            both = head(tuple(f[no:] for f in feat_all))
-            outs_syn = tuple([o[:ns] for o in lv] if torch.is_tensor(lv[0]) and lv[0].dim() == 4 else lv for lv in both)
-            outs_aug = tuple([o[ns:] for o in lv] if torch.is_tensor(lv[0]) and lv[0].dim() == 4 else lv for lv in both)
-        else:
-            outs_syn = head(feat_syn, branches='reg')          # `loss` reads the regression / centerness outputs only
+        outs_syn = head(feat_syn, branches='reg')          # `loss` reads the regression / centerness outputs only
         loss_syn = head.loss(*outs_syn, syn_boxes, img_metas, gt_bboxes_ignore, gt_valid=syn_alive)
         pb_c, pp_c, pl_c, _, _ = teacher()
         _, _, mil_losses = self.forward_mil_head_burn_in_step1(num_img, syn_boxes, syn_alive, pb_c, pp_c, pl_c, gt_bboxes,
@@ -506,7 +495,7 @@ class TS_P2B_FCOS(BaseDetector):
             gt_points = self.update_points(num_img, img_metas, pb_r)
             losses['refined_points_distance'] = self._refined_points_distance(gt_points, gt_bboxes)
         lc, _, _ = self._student_aug_loss(img, img_metas, gt_points, gt_labels, pp_r, pl_c, pb_r, gt_bboxes_ignore,
-                                          aug_pre=aug_pre, feat_aug=feat_aug, outs=outs_aug, branches='cls')
+                                          aug_pre=aug_pre, feat_aug=feat_aug, branches='cls')
         losses['loss_cls'] = lc
         losses['loss_bbox'], losses['loss_centerness'] = loss_syn
         return losses
