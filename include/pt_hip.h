@@ -334,6 +334,20 @@ int pt_deform_col2im_coord(const float* grad_col, const float* x, const float* o
                            int stride_h, int stride_w, int dil_h, int dil_w, int deform_groups,
                            float* grad_offset, float* grad_mask, void* stream);
 
+/* The same operator on the layout the training path keeps its maps in (channels_last): x[B,H,W,C],
+ * offset[B,Ho,Wo,2*dg*kh*kw], mask[B,Ho,Wo,dg*kh*kw] or NULL, col / grad_col[B*Ho*Wo, kh*kw, C] - so that the GEMM
+ * col[B*L, K*C] x weight[O, kh, kw, C]^T reads and writes NHWC without a transpose.  One wavefront per (pixel, tap,
+ * deformable group), 4 channels per lane (C / dg must be a multiple of 4): contiguous 1-KiB gathers / stores / atomics.
+ * pt_deform_col2im_cl does the whole backward of the gather in one pass: it ACCUMULATES into grad_x (NULL: skipped) and
+ * writes grad_offset and (mask != NULL) grad_mask. */
+int pt_deform_im2col_cl(const float* x, const float* offset, const float* mask, int B, int C, int H, int W,
+                        int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h,
+                        int dil_w, int deform_groups, float* col, void* stream);
+int pt_deform_col2im_cl(const float* grad_col, const float* x, const float* offset, const float* mask, int B,
+                        int C, int H, int W, int kh, int kw, int pad_h, int pad_w, int stride_h,
+                        int stride_w, int dil_h, int dil_w, int deform_groups, float* grad_x,
+                        float* grad_offset, float* grad_mask, void* stream);
+
 /* -------------------------------------------------------- evaluator (next row N1) --
  * evaluateImg of the COCO / AI-TOD protocol (aitodpycocotools.cocoeval.COCOeval, called at
  * HBB_TOD/mmdet/datasets/aitod.py:109-146): greedy matching of the detections of every (image,

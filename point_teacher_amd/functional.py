@@ -890,25 +890,40 @@ def roi_align_rotated(feat, rois, out_size, spatial_scale, sample_num=0, aligned
 
 # ------------------------------------------------------ (modulated) deformable conv --
 class _DeformConv(torch.autograd.Function):
-    """mmcv.ops.(modulated_)deform_conv2d, groups = 1: gather (HIP) -> GEMM (hipBLASLt) and the mirrored backward."""
+    """mmcv.ops.(modulated_)deform_conv2d, groups = 1: gather (HIP) -> GEMM (hipBLASLt) and the mirrored backward.
+    A channels_last input (the training layout) stays NHWC end to end (pt_deform_*_cl: wave-wide contiguous gathers, col
+    [B*L, K*C], output written as NHWC by the GEMM); an NCHW input takes the NCHW kernels."""
 
     @staticmethod
     def forward(ctx, x, offset, mask, weight, bias, stride, padding, dilation, deform_groups):
-        x, offset = _f(x), _f(offset)
-        mask = _f(mask) if mask is not None else None
         B, C, H, W = x.shape
         O, _, kh, kw = weight.shape
         Ho = (H + 2 * padding[0] - (dilation[0] * (kh - 1) + 1)) // stride[0] + 1
         Wo = (W + 2 * padding[1] - (dilation[1] * (kw - 1) + 1)) // stride[1] + 1
         assert offset.shape == (B, 2 * deform_groups * kh * kw, Ho, Wo), (offset.shape, (B, 2 * deform_groups * kh * kw, Ho, Wo))
-        col = torch.empty((B, C * kh * kw, Ho * Wo), dtype=f32, device=x.device)
         geo = (B, C, H, W, kh, kw, padding[0], padding[1], stride[0], stride[1], dilation[0], dilation[1], deform_groups)
+        cl = (x.is_cuda and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+              and (C // deform_groups) % 4 == 0)
+        ctx.geo, ctx.has_bias, ctx.cl = geo, bias is not None, cl
+        if cl:
+            x = x.float()
+            offset = offset.float().contiguous(memory_format=torch.channels_last)
+            mask = mask.float().contiguous(memory_format=torch.channels_last) if mask is not None else None
+            col = torch.empty((B * Ho * Wo, kh * kw * C), dtype=f32, device=x.device)
+            hip.call('pt_deform_im2col_cl', x.permute(0, 2, 3, 1), offset.permute(0, 2, 3, 1),
+                     mask.permute(0, 2, 3, 1) if mask is not None else None, *geo, col)
+            wm = weight.float().permute(0, 2, 3, 1).reshape(O, -1)                     # [O, kh*kw*C]: a view of a channels_last weight
+            out = torch.nn.functional.linear(col, wm, bias.float() if bias is not None else None)
+            ctx.save_for_backward(x, offset, mask, weight, col)
+            return out.view(B, Ho, Wo, O).permute(0, 3, 1, 2)
+        x, offset = _f(x), _f(offset)
+        mask = _f(mask) if mask is not None else None
+        col = torch.empty((B, C * kh * kw, Ho * Wo), dtype=f32, device=x.device)
         hip.call('pt_deform_im2col', x, offset, mask, *geo, col)
         out = torch.matmul(weight.float().reshape(O, -1), col).reshape(B, O, Ho, Wo)
         if bias is not None:
             out = out + bias.float().view(1, -1, 1, 1)
         ctx.save_for_backward(x, offset, mask, weight, col)
-        ctx.geo, ctx.has_bias = geo, bias is not None
         return out
 
     @staticmethod
@@ -917,13 +932,30 @@ class _DeformConv(torch.autograd.Function):
         geo = ctx.geo
         B, C, H, W, kh, kw = geo[:6]
         O = weight.shape[0]
-        g2 = _f(g).reshape(B, O, -1)
         gx = goff = gmask = gw = gb = None
+        need_in = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or (mask is not None and ctx.needs_input_grad[2])
+        if ctx.cl:
+            g2 = g.float().contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(-1, O)     # [B*L, O]
+            if ctx.needs_input_grad[3]:
+                gw = torch.matmul(g2.t(), col).view(O, kh, kw, C).permute(0, 3, 1, 2)
+            if ctx.has_bias and ctx.needs_input_grad[4]:
+                gb = g2.sum(0)
+            if need_in:
+                gcol = torch.matmul(g2, weight.float().permute(0, 2, 3, 1).reshape(O, -1))                      # [B*L, K*C]
+                gx = torch.zeros_like(x) if ctx.needs_input_grad[0] else None                                    # channels_last
+                goff = torch.empty_like(offset)
+                gmask = torch.empty_like(mask) if mask is not None else None
+                hip.call('pt_deform_col2im_cl', gcol, x.permute(0, 2, 3, 1), offset.permute(0, 2, 3, 1),
+                         mask.permute(0, 2, 3, 1) if mask is not None else None, *geo,
+                         gx.permute(0, 2, 3, 1) if gx is not None else None, goff.permute(0, 2, 3, 1),
+                         gmask.permute(0, 2, 3, 1) if gmask is not None else None)
+            return gx, goff, gmask, gw, gb, None, None, None, None
+        g2 = _f(g).reshape(B, O, -1)
         if ctx.needs_input_grad[3]:
             gw = torch.matmul(g2, col.transpose(1, 2)).sum(0).reshape(weight.shape)
         if ctx.has_bias and ctx.needs_input_grad[4]:
             gb = g2.sum((0, 2))
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or (mask is not None and ctx.needs_input_grad[2]):
+        if need_in:
             gcol = torch.matmul(weight.float().reshape(O, -1).t(), g2).contiguous()          # [B, C*K, L]
             if ctx.needs_input_grad[0]:
                 gx = torch.zeros_like(x)

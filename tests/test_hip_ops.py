@@ -590,10 +590,13 @@ def test_conv_bias_relu_epilogue(C, HW):
     close(mg.conv.bias.grad, m.conv.bias.grad, rtol=1e-3, atol=1e-4 * float(m.conv.bias.grad.abs().max()))
 
 
+@pytest.mark.parametrize('layout', ['nchw', 'nhwc'])
 @pytest.mark.parametrize('modulated,dg,stride,dil', [(True, 1, 1, 1), (True, 2, 2, 1), (False, 1, 1, 2), (True, 4, 1, 1)])
-def test_deform_conv(modulated, dg, stride, dil):
+def test_deform_conv(modulated, dg, stride, dil, layout):
     """pt_deform_* + GEMM == the published (modulated) deformable convolution: values and every gradient against the
-    torch-gather oracle; zero offsets and unit mask reduce to a plain convolution; samples far outside contribute 0."""
+    torch-gather oracle; zero offsets and unit mask reduce to a plain convolution; samples far outside contribute 0.
+    `nhwc`: channels_last input (the training layout) -> the wave-per-tap kernels pt_deform_*_cl (C / dg a multiple of 4;
+    dg = 4 with C = 8 falls back to the NCHW kernels), output channels_last."""
     f = F()
     gen = torch.Generator().manual_seed(51)
     B, C, H, W, O, k = 2, 8, 13, 17, 6, 3
@@ -613,13 +616,16 @@ def test_deform_conv(modulated, dg, stride, dil):
     ref = R.modulated_deform_conv2d(xr, offr, mr, wr, br, stride, pad, dil, dg)
     gout = torch.randn(ref.shape, generator=gen)
     (ref * gout).sum().backward()
-    xg, offg, wg = cu(x).requires_grad_(True), cu(off).requires_grad_(True), cu(wgt).requires_grad_(True)
-    mg = cu(mask).requires_grad_(True) if modulated else None
+    fmt = (lambda t: t.contiguous(memory_format=torch.channels_last)) if layout == 'nhwc' else (lambda t: t)
+    xg, offg, wg = fmt(cu(x)).requires_grad_(True), fmt(cu(off)).requires_grad_(True), fmt(cu(wgt)).requires_grad_(True)
+    mg = fmt(cu(mask)).requires_grad_(True) if modulated else None
     bg = cu(bias).requires_grad_(True) if bias is not None else None
     if modulated:
         out = f.modulated_deform_conv2d(xg, offg, mg, wg, bg, stride, pad, dil, 1, dg)
     else:
         out = f.deform_conv2d(xg, offg, wg, stride, pad, dil, 1, dg)
+    if layout == 'nhwc' and (C // dg) % 4 == 0:
+        assert out.is_contiguous(memory_format=torch.channels_last)
     close(out, ref, atol=1e-4)
     (out * cu(gout)).sum().backward()
     close(xg.grad, xr.grad, atol=1e-4)
@@ -631,10 +637,37 @@ def test_deform_conv(modulated, dg, stride, dil):
     # zero offsets (+ unit mask) == plain convolution
     z = torch.zeros_like(off)
     if modulated:
-        y0 = f.modulated_deform_conv2d(cu(x), cu(z), cu(torch.ones_like(mask)), cu(wgt), cu(bias), stride, pad, dil, 1, dg)
+        y0 = f.modulated_deform_conv2d(fmt(cu(x)), cu(z), cu(torch.ones_like(mask)), cu(wgt), cu(bias), stride, pad, dil, 1, dg)
     else:
-        y0 = f.deform_conv2d(cu(x), cu(z), cu(wgt), stride, pad, dil, 1, dg)
+        y0 = f.deform_conv2d(fmt(cu(x)), cu(z), cu(wgt), stride, pad, dil, 1, dg)
     close(y0, torch.nn.functional.conv2d(x, wgt, bias, stride, pad, dil), atol=1e-4)
+
+
+@pytest.mark.parametrize('C,stride,dil,sigma', [(256, 1, 1, 1.5), (64, 2, 1, 3.0), (64, 1, 2, 0.3), (128, 1, 1, 6.0)])
+def test_deform_conv_tower_shape(C, stride, dil, sigma):
+    """Tower-like shapes (C -> C, 3x3, dg 1) on a 40x40 map, NHWC kernels (wave-per-tap gather; grad_x staged in LDS per 8x8
+    tile with a 2-pixel halo, far samples - sigma 3 / 6 px offsets - through global atomics) against the NCHW kernels of
+    the same library, which the oracle test above pins: values and all gradients."""
+    f = F()
+    gen = torch.Generator().manual_seed(52)
+    B, H, W, O = 2, 40, 40, C
+    pad = dil
+    Ho = (H + 2 * pad - (dil * 2 + 1)) // stride + 1
+    x = torch.randn(B, C, H, W, generator=gen)
+    wgt = torch.randn(O, C, 3, 3, generator=gen) * 0.02
+    bias = torch.randn(O, generator=gen)
+    off = torch.randn(B, 18, Ho, Ho, generator=gen) * sigma + 0.013
+    mask = torch.rand(B, 9, Ho, Ho, generator=gen)
+    gout = torch.randn(B, O, Ho, Ho, generator=gen)
+    res = []
+    for cl in (False, True):
+        fmt = (lambda t: t.contiguous(memory_format=torch.channels_last)) if cl else (lambda t: t)
+        xs = [fmt(cu(t)).requires_grad_(True) for t in (x, off, mask, wgt)] + [cu(bias).requires_grad_(True)]
+        out = f.modulated_deform_conv2d(xs[0], xs[1], xs[2], xs[3], xs[4], stride, pad, dil, 1, 1)
+        (out * cu(gout)).sum().backward()
+        res.append([out.detach()] + [t.grad for t in xs])
+    for a, b in zip(res[0], res[1]):
+        close(b, a, rtol=1e-3, atol=1e-3 * float(a.abs().max()))
 
 
 def test_dcn_on_last_conv_head():
