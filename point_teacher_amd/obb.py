@@ -5,7 +5,6 @@ The rotated head / detector classes that compose them are the next row to build 
 section 2); everything here runs on the HIP kernels of csrc/rotated.hip and csrc/nms.hip.
 Citations are relative to /root/reference/OBB_TOD/mmrotate/.
 """
-import math
 
 import numpy as np
 import torch

@@ -4,7 +4,6 @@ proposals, strong augmentation and the burn-in step-1 "white rectangle" generato
 
 List-of-tensors signatures are kept; sizes that the reference discovers with `.nonzero()`
 (host sync) are carried as validity masks instead, see the *_masked variants."""
-import math
 import random
 
 import numpy as np

@@ -16,7 +16,6 @@ configs/point_teacher/aitodv2_point_teacher_0%.py:212-223) with an MI355X-first 
   of never-written gradients as well, SURVEY section 2.4);
 * no host synchronisation anywhere in `step()`.
 """
-import math
 
 import os
 
