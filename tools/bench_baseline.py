@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Iterations/s of the supervised baselines of row N4 on one MI355X - `--model fcos` (configs/baselines/aitodv2_fcos_r50_1x.py)
-or `--model retinanet` (aitodv2_retinanet_r50_1x.py): the same synthetic 800x800 tiles, batch 2, fp32 and flat-parameter
+`--model retinanet` (aitodv2_retinanet_r50_1x.py) or `--model faster_rcnn` (aitodv2_faster_rcnn_r50_1x.py): the same synthetic 800x800 tiles, batch 2, fp32 and flat-parameter
 Trainer as bench.py uses for the Point-Teacher iteration."""
 import json
 import os
