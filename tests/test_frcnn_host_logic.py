@@ -141,3 +141,42 @@ def test_config_builds_with_mmdet_names():
     assert m.roi_head.bbox_head.fc_cls.out_features == 9 and m.roi_head.bbox_head.fc_reg.out_features == 32
     assert m.rpn_head.num_anchors == 3 and len(m.roi_head.bbox_roi_extractor.roi_layers) == 4
     assert sum(p.numel() for p in m.parameters()) == 41_384_056
+
+
+def test_images_without_boxes_and_without_proposals(cpu_kernels):
+    """An image without annotations contributes negatives only (RPN and R-CNN); an image whose RPN returns nothing yields an
+    empty result; the losses stay finite and differentiable."""
+    g = _g()
+    rpn, roi = _model()
+    torch.manual_seed(0)
+    cls = [g[f'in_cls{i}'].clone().requires_grad_(True) for i in range(3)]
+    reg = [g[f'in_reg{i}'].clone().requires_grad_(True) for i in range(3)]
+    empty = torch.zeros((0, 4))
+    boxes, labels = [g['in_gt_bboxes0'], empty], [g['in_gt_labels0'], torch.zeros((0,), dtype=torch.long)]
+    H, W = [int(v) for v in g['in_img_hw']]
+    metas = [dict(img_shape=(H, W, 3), pad_shape=(H, W, 3), scale_factor=np.ones(4, np.float32)) for _ in boxes]
+    losses = rpn.loss(cls, reg, boxes, metas)
+    total = sum(losses['loss_rpn_cls']) + sum(losses['loss_rpn_bbox'])
+    assert torch.isfinite(total)
+    total.backward()
+    anchors = torch.cat(rpn.anchor_generator.grid_anchors([c.shape[-2:] for c in cls], 'cpu'))
+    lab, lw, bt, bw, npos, nneg = rpn.get_targets(anchors, boxes)
+    assert int((lab[1] == 0).sum()) == 0 and float(bw[1].sum()) == 0 and int(lw[1].sum()) == 256      # second image: 256 negatives
+    props = rpn.get_bboxes([c.detach() for c in cls], [r.detach() for r in reg], metas)
+    results = roi.sample(props, boxes, labels)
+    assert results[1].pos_inds.numel() == 0 and results[1].neg_inds.numel() == min(64, props[1].shape[0])
+    lab, lw, bt, bw = roi.bbox_head.get_targets(results, roi.train_cfg)
+    n = lab.shape[0]
+    cs, bp = torch.randn(n, 9, requires_grad=True), torch.randn(n, 32, requires_grad=True)
+    from point_teacher_amd.core import bbox2roi
+    ls = roi.bbox_head.loss(cs, bp, bbox2roi([r.bboxes for r in results]), lab, lw, bt, bw)
+    assert torch.isfinite(ls['loss_cls']) and torch.isfinite(ls['loss_bbox'])
+    (ls['loss_cls'] + ls['loss_bbox']).backward()
+    # no annotation anywhere: the box loss is the empty sum
+    results = roi.sample(props, [empty, empty], [labels[1], labels[1]])
+    lab, lw, bt, bw = roi.bbox_head.get_targets(results, roi.train_cfg)
+    ls = roi.bbox_head.loss(torch.randn(lab.shape[0], 9), torch.randn(lab.shape[0], 32), None, lab, lw, bt, bw)
+    assert float(ls['loss_bbox']) == 0.0 and bool((lab == 8).all())
+    # inference with no proposals at all
+    out = roi.simple_test([torch.zeros(2, 256, 8, 8)] * 4, [torch.zeros((0, 5)), torch.zeros((0, 5))], metas)
+    assert all(d.shape == (0, 5) and l.shape == (0,) for d, l in out)
