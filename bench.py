@@ -56,7 +56,7 @@ def algorithmic_bytes(name, shapes):
         return shapes['n'] * 4 * shapes['streams']   # fp32 streams read + written per element (x, y, residual / g, y, gx, gres)
     if name == 'pt_ema_update':
         return shapes['n'] * 12             # read teacher+student, write teacher
-    if name == 'pt_sgd_step':
+    if name in ('pt_sgd_step', 'pt_sgd_step_groups'):
         return shapes['n'] * 20             # read p,g,m; write p,m
     if name == 'pt_sqnorm_partial':
         return shapes['n'] * 4
@@ -96,7 +96,7 @@ FAMILIES = {                                                    # op families fo
     'pt_roi_align': ('pt_roi_align_fwd', 'pt_roi_align_bwd'),
     'pt_roi_align_rotated': ('pt_roi_align_rotated_fwd', 'pt_roi_align_rotated_bwd'),
     'pt_affine_relu': ('pt_affine_relu_fwd', 'pt_affine_relu_bwd', 'pt_affine_relu_bwd_train'),
-    'pt_optimizer (ema + sqnorm + sgd)': ('pt_ema_update', 'pt_sqnorm_partial', 'pt_sgd_step'),
+    'pt_optimizer (ema + sqnorm + sgd)': ('pt_ema_update', 'pt_sqnorm_partial', 'pt_sgd_step', 'pt_sgd_step_groups'),
 }
 
 
@@ -226,8 +226,8 @@ def main():
                 shp = dict(n=a[3], streams=1 + (a[1] is not None) + (a[7] is not None) + (a[8] is not None))
             elif fn == 'pt_affine_relu_bwd_train':
                 shp = dict(n=a[4], streams=2 + (a[1] is not None) + (a[7] is not None) + (a[8] is not None))
-            elif fn in ('pt_ema_update', 'pt_sgd_step', 'pt_sqnorm_partial'):
-                shp = dict(n=a[2] if fn == 'pt_ema_update' else (a[3] if fn == 'pt_sgd_step' else a[1]))
+            elif fn in ('pt_ema_update', 'pt_sgd_step', 'pt_sgd_step_groups', 'pt_sqnorm_partial'):
+                shp = dict(n=a[2] if fn == 'pt_ema_update' else (a[3] if fn.startswith('pt_sgd_step') else a[1]))
             prof.setdefault(fn, []).append((e0, e1, shp))
             return r
         return orig_call(fn, *a)
@@ -367,6 +367,10 @@ def main():
             iteration=dict(flops=flops_iter, flops_reference=flops_ref, achieved_tflops=round(flops_iter * iters_s / 1e12, 2),
                            mfma_peak_tflops=peak / 1e12, frac=round(flops_iter * iters_s / peak, 4)),
             phase2=phase2,
+            # gradient exchange of the LAST timed step (N > 1): buckets, how many all-reduces were issued while backward was
+            # still running, payload per step; the never-used MIL stacks are in neither (runtime.FlatParams "dead")
+            exchange=(dict(trainer.exchange.stats, dead_bytes=4 * trainer.flat.n_dead, backend=dist.get_backend())
+                      if trainer.exchange is not None else dict(buckets=0, issued_during_backward=0, bytes=0, dead_bytes=4 * trainer.flat.n_dead)),
             custom_kernels_ms_per_step={k: round(v['total_ms'] / args.steps, 3) for k, v in sorted(kern.items())},
             loss=round(log_vars.get('loss', float('nan')), 4))
         print(json.dumps(line))

@@ -195,6 +195,43 @@ int pt_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n,
                 float bias_decay_mult, const float* sqnorm, float max_norm, int first_step,
                 void* stream);
 
+/* The same step under the full paramwise_cfg of mmcv's DefaultOptimizerConstructor (bias_lr_mult, bias_decay_mult,
+ * norm_decay_mult, dwconv_decay_mult, dcn_offset_lr_mult, custom_keys - e.g. configs/baselines/aitodv2_yolof_r50_1x.py:70-71:
+ * norm_decay_mult=0, custom_keys={'backbone': lr_mult 1/3}): the buffer is n_groups <= PT_MAX_PARAM_GROUPS contiguous
+ * segments, group g = [group_end[g-1], group_end[g]) with lr = lr*lr_mult[g], decay = weight_decay*decay_mult[g].
+ * group_end / lr_mult / decay_mult are [host] arrays of n_groups entries (copied into the launch); ends are multiples of 4,
+ * the last equals n.  Parameters that never receive a gradient (torch.optim.SGD skips `grad is None`: no decay, no momentum)
+ * are simply not part of the buffer. */
+#define PT_MAX_PARAM_GROUPS 8
+int pt_sgd_step_groups(float* param, const float* grad, float* momentum_buf, int64_t n,
+                       const int64_t* group_end, const float* lr_mult, const float* decay_mult,
+                       int n_groups, const float* lr, float momentum, float weight_decay,
+                       const float* sqnorm, float max_norm, int first_step, void* stream);
+
+/* ------------------------------------------------ fp32 GEMM on the bf16 matrix cores --
+ * The MIL FC stacks (dense_heads/fcos_head_p2b_ts.py:1202-1236, :1240-1256: `self.shared_fcs_reg/_bag[stage]` = Linear
+ * 12544 -> 1024 -> 1024 + ReLU over K RoIs, and their backward) are fp32 by the config's definition.  gfx950's fp32 MFMA runs at
+ * 1/16 of its bf16 rate; an fp32 value is exactly x0 + x1 + x2 with three bf16 terms, and the six leading cross products with
+ * fp32 accumulation reproduce the fp32 product to ~2^-26 (csrc/gemm_split.hip).
+ *
+ * pt_split_bf16x3: src[R, C] fp32 (row stride ld) -> three bf16 planes (planes + p * plane_stride; bf16 stored as uint16_t) of
+ * the GEMM operand  transpose == 0: rows = R, k = C      transpose != 0: rows = C, k = R
+ * in the BLOCKED layout [ceil(rows / 16)][ceil(k / 32)][16 rows][4 k-slots][8]: each 16 x 32 block is one contiguous KiB in
+ * the order the GEMM's LDS image wants it (k-slot XOR (row >> 2) & 3), zero padded; pt_split_bf16x3_plane_elems(rows, k) =
+ * elements of one plane.  The reduce dimension of an operand thus becomes block-contiguous whatever the layout of the fp32 tensor. */
+int64_t pt_split_bf16x3_plane_elems(int rows, int k);
+int pt_split_bf16x3(const float* src, int64_t ld, int R, int C, int transpose, uint16_t* planes,
+                    int64_t plane_stride, void* stream);
+/* c[M, N] (row stride ldc) = A[M, K] * B[N, K]^T (+ bias[N]) (ReLU if relu != 0) from the planes of pt_split_bf16x3 (A: rows M,
+ * k K; B: rows N, k K).  tile_rows = rows of the output tile (96, 128, ..., 256; 0 = pt_gemm_bf16x6_tile_rows(M, N), the height
+ * that fills 256 CUs best).  A torch.nn.Linear maps to it as
+ *   forward  y  = x W^T:   A = split(x),      B = split(W)          dgrad  dx = dy W:  A = split(dy),  B = split(W, transpose)
+ *   wgrad    dW = dy^T x:  A = split(dy, transpose), B = split(x, transpose). */
+int pt_gemm_bf16x6_tile_rows(int M, int N);
+int pt_gemm_bf16x6_nt(const uint16_t* a_planes, int64_t a_plane_stride, const uint16_t* b_planes,
+                      int64_t b_plane_stride, float* c, int64_t ldc, const float* bias, int M, int N,
+                      int K, int relu, int tile_rows, void* stream);
+
 /* Frozen BatchNorm (+ residual add) (+ ReLU) in one pass each way.  Every BatchNorm on the path
  * is in eval mode with a frozen affine (models/backbones/resnet.py:647-658, config
  * norm_cfg=dict(type='BN', requires_grad=False), norm_eval=True), i.e. y = x*scale[c] + shift[c]

@@ -1,0 +1,354 @@
+// fp32 GEMM on the bf16 matrix cores of gfx950: split-bf16 ("bf16x6") with fp32 accumulation.
+//
+// The MIL FC stacks of TS_P2BFCOSHead (dense_heads/fcos_head_p2b_ts.py:1202-1236, :1240-1256: Linear 12544 -> 1024 -> 1024 over
+// K = 5 000 ... 60 750 RoIs, forward + dgrad + wgrad) are fp32 by the config's definition (`force_fp32`).  gfx950 has no
+// TF32/xf32 path; its fp32 MFMA runs at 1/16 of the bf16 rate (157 vs 2 500 TFLOP/s).  Every fp32 value is the EXACT sum of
+// three bf16 terms x = x0 + x1 + x2 (8 + 8 + 8 significant bits, round-to-nearest at each step), so
+//     x * y = x0y0 + (x0y1 + x1y0) + (x0y2 + x1y1 + x2y0) + O(2^-26 |xy|)
+// and the six leading products on `v_mfma_f32_32x32x16_bf16` with the hardware's fp32 accumulation reproduce an fp32 product to
+// ~2^-26 - below the 2^-24 rounding of an fp32 fmaf chain - at 16 / 6 = 2.7x the fp32 matrix rate.
+//
+// Two kernels:
+//   split3_kernel / split3_t_kernel   fp32 [R, C] -> three bf16 planes [3][R][Cp] (or transposed [3][C][Rp]); the reduce dimension
+//                                     of every GEMM operand ends up contiguous and padded to 32 with zeros - HBM streaming.
+//   gemm_bf16x6_kernel<MB>            C[M, N] = A[M, K] * B[N, K]^T on the planes ("NT" form; forward, dgrad and wgrad of a Linear
+//                                     are all brought to it by the split kernel's transpose), optional bias + ReLU epilogue.
+//
+// GEMM structure (one 512-thread workgroup = 8 wavefronts per tile, one tile per CU at a time):
+//   tile 32*MB x 128 (MB = 3..8 chosen on the host so that the tile count fills 256 CUs), k-step 32;
+//   staging: `global_load_lds_dwordx4` straight into LDS (no VGPR round trip, no VALU), two stages, ONE barrier per k-step; the
+//     image of a stage is [6 planes][row][64 B], the 16-byte slot of a row XOR-swizzled with (row >> 2) & 3 - already in the
+//     planes' memory layout (the LDS side of an LDS-DMA is lane-linear) -, which makes every ds_read_b128 fragment read conflict-free;
+//   wave w computes the 32-column block (w & 3) of the tile for the k-half (w >> 2) of every k-step: 3*MB + 3 fragment reads feed
+//     6*MB MFMAs; the two k-halves are summed through LDS once, in the epilogue (two waves per SIMD hide each other's waits without a
+//     second tile in flight);
+//   blockIdx -> tile mapping is XCD-aware: the blocks of one XCD (b % 8) walk consecutive tiles of the column-fastest tile list,
+//     so the tiles that share an A row panel are in flight together behind the same L2.
+#include "pt_common.h"
+
+namespace pt {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+constexpr int GK = 32;              // k-step (bf16 elements): 64 bytes per row and plane
+constexpr int GBN = 128;            // tile columns
+constexpr int GTHREADS = 512;
+
+__device__ __forceinline__ unsigned bf16_rne_pair(float a, float b) {
+  // v_cvt_pk_bf16_f32: two fp32 -> packed bf16 (a in the low half), round to nearest even, NaN stays NaN
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  bf16x2_t v;
+  v[0] = (__bf16)a;
+  v[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, v);
+}
+
+// x -> (x0, x1, x2) for two values at once; planes receive the packed pairs
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+  p0 = bf16_rne_pair(a, b);
+  const float a1 = a - __uint_as_float(p0 << 16), b1 = b - __uint_as_float(p0 & 0xffff0000u);   // exact
+  p1 = bf16_rne_pair(a1, b1);
+  const float a2 = a1 - __uint_as_float(p1 << 16), b2 = b1 - __uint_as_float(p1 & 0xffff0000u); // exact
+  p2 = bf16_rne_pair(a2, b2);
+}
+
+// ---------------------------------------------------------------------------------------------- split --
+// Plane layout ("blocked"): [3 planes][RB = ceil(rows / 16)][KB = ceil(k / 32)][16 rows][4 slots][8 bf16] - every (16 rows x 32 k)
+// block is 1 KiB of CONTIGUOUS memory in exactly the order it will have in LDS, the 16-byte k-slot of a row XOR-swizzled with
+// (row >> 2) & 3 (conflict-free ds_read_b128 fragment reads).  One staging instruction of the GEMM (`global_load_lds_dwordx4`,
+// 1 KiB per wave) then reads 8 whole 128-byte lines; with row-major planes the same instruction touched 16 half lines 25 KB
+// apart and the L2 -> L1 traffic doubled.  Rows past the matrix and k past its width are zeros.
+__device__ __forceinline__ long block_off(long rb, long kb, long KB, int r16, int q) {      // in bf16 elements
+  return ((rb * KB + kb) << 9) + (r16 << 5) + ((q ^ ((r16 >> 2) & 3)) << 3);
+}
+
+// src [R, C] (row stride ld): rows = R, k = C.  One wavefront per block: 16 rows x 128 bytes read, 1 KiB written per plane.
+__global__ void __launch_bounds__(256)
+    split3_kernel(const float* __restrict__ src, long ld, int R, int C, int RB, int KB, uint16_t* __restrict__ dst, long plane) {
+  const int lane = threadIdx.x & 63, r16 = lane >> 2, q = lane & 3;
+  const long nblk = (long)RB * KB;
+  for (long blk = (long)blockIdx.x * 4 + (threadIdx.x >> 6); blk < nblk; blk += (long)gridDim.x * 4) {
+    const long rb = blk / KB, kb = blk - rb * KB;
+    const int r = (int)rb * 16 + r16, c = (int)kb * 32 + q * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (r < R) {
+      const float* s = src + (long)r * ld + c;
+      if (c + 8 <= C && ((((uintptr_t)s) & 15) == 0)) {
+        const float4 lo = *reinterpret_cast<const float4*>(s), hi = *reinterpret_cast<const float4*>(s + 4);
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (c + j < C) v[j] = s[j];
+      }
+    }
+    uint4 o0, o1, o2;
+    split_pair(v[0], v[1], o0.x, o1.x, o2.x);
+    split_pair(v[2], v[3], o0.y, o1.y, o2.y);
+    split_pair(v[4], v[5], o0.z, o1.z, o2.z);
+    split_pair(v[6], v[7], o0.w, o1.w, o2.w);
+    uint16_t* d = dst + block_off(rb, kb, KB, r16, q);
+    *reinterpret_cast<uint4*>(d) = o0;
+    *reinterpret_cast<uint4*>(d + plane) = o1;
+    *reinterpret_cast<uint4*>(d + 2 * plane) = o2;
+  }
+}
+
+// src [R, C] (row stride ld), transposed operand: rows = C, k = R.  64 x 64 source tiles through LDS: coalesced float4 reads
+// along C; the tile yields 4 row blocks x 2 k blocks, each written as one contiguous KiB per plane.
+__global__ void __launch_bounds__(256)
+    split3_t_kernel(const float* __restrict__ src, long ld, int R, int C, int RB, int KB, uint16_t* __restrict__ dst, long plane) {
+  __shared__ float tile[64][65];
+  const int tr = blockIdx.y * 64, tc = blockIdx.x * 64;
+  for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+    const int r = i >> 4, c4 = (i & 15) << 2;
+    const int gr = tr + r, gc = tc + c4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gr < R) {
+      const float* s = src + (long)gr * ld + gc;
+      if (gc + 4 <= C && ((((uintptr_t)s) & 15) == 0)) v = *reinterpret_cast<const float4*>(s);
+      else {
+        if (gc < C) v.x = s[0];
+        if (gc + 1 < C) v.y = s[1];
+        if (gc + 2 < C) v.z = s[2];
+        if (gc + 3 < C) v.w = s[3];
+      }
+    }
+    tile[r][c4] = v.x; tile[r][c4 + 1] = v.y; tile[r][c4 + 2] = v.z; tile[r][c4 + 3] = v.w;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 512; i += 256) {
+    const int blk = i >> 6, lane = i & 63, rbl = blk >> 1, kbl = blk & 1, r16 = lane >> 2, q = lane & 3;
+    const long rb = (tc >> 4) + rbl, kb = (tr >> 5) + kbl;
+    if (rb >= RB || kb >= KB) continue;
+    const int c = rbl * 16 + r16, r8 = kbl * 32 + q * 8;      // zeros beyond the matrix came in with the tile load
+    uint4 o0, o1, o2;
+    split_pair(tile[r8][c], tile[r8 + 1][c], o0.x, o1.x, o2.x);
+    split_pair(tile[r8 + 2][c], tile[r8 + 3][c], o0.y, o1.y, o2.y);
+    split_pair(tile[r8 + 4][c], tile[r8 + 5][c], o0.z, o1.z, o2.z);
+    split_pair(tile[r8 + 6][c], tile[r8 + 7][c], o0.w, o1.w, o2.w);
+    uint16_t* d = dst + block_off(rb, kb, KB, r16, q);
+    *reinterpret_cast<uint4*>(d) = o0;
+    *reinterpret_cast<uint4*>(d + plane) = o1;
+    *reinterpret_cast<uint4*>(d + 2 * plane) = o2;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------- GEMM --
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
+  // global_load_lds_dwordx4: 16 bytes per lane from a per-lane global address to (wave-uniform LDS base + lane * 16)
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int MB>
+__global__ void __launch_bounds__(GTHREADS)
+    gemm_bf16x6_kernel(const uint16_t* __restrict__ Ap, const uint16_t* __restrict__ Bp, float* __restrict__ C,
+                       const float* __restrict__ bias, int M, int N, int KB, long a_plane, long b_plane, long ldc, int relu,
+                       int tiles_n, int n_tiles) {
+  constexpr int BM = 32 * MB, ROWS = BM + GBN;
+  constexpr int STAGE = ROWS * 3 * 64;                 // bytes: A planes [3][BM][64] then B planes [3][128][64]
+  constexpr int NI = ROWS * 3 / 16;                    // staging instructions (one 1-KiB block each) per stage
+  constexpr int NJ = (NI + 7) / 8;                     // per wave
+  constexpr int PER = (NJ + MB - 1) / MB;              // staging instructions issued behind each row block's MFMAs
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+  // XCD-aware block -> tile (bijective for any tile count): blocks b, b + 8, ... share an XCD and take consecutive tiles
+  int tile;
+  {
+    const int b = blockIdx.x, q = n_tiles >> 3, r = n_tiles & 7, x = b & 7;
+    tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+  }
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * GBN;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+
+  // global source of every staging instruction this wave issues: one contiguous KiB block of the blocked planes per instruction
+  // (advances by one block = 1 KiB per k-step)
+  const int RBA = (M + 15) >> 4, RBN = (N + 15) >> 4;
+  const unsigned char* gsrc[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int i = w + 8 * j;                            // staging instruction = block index within the stage
+    gsrc[j] = nullptr;
+    if (i < NI) {
+      const bool isA = i < 3 * (BM / 16);
+      const int i2 = isA ? i : i - 3 * (BM / 16);
+      const int rbs = isA ? BM / 16 : GBN / 16;
+      const int p = i2 / rbs, rbi = i2 - p * rbs;
+      const int lim = isA ? RBA : RBN;
+      int rb = (isA ? m0 : n0) / 16 + rbi;
+      rb = rb < lim ? rb : lim - 1;                     // row blocks past the edge re-read the last one; their results are never stored
+      const uint16_t* base = isA ? Ap + p * a_plane : Bp + p * b_plane;
+      gsrc[j] = reinterpret_cast<const unsigned char*>(base + ((long)rb * KB << 9)) + lane * 16;
+    }
+  }
+  auto issue1 = [&](int j, int buf) {                   // one 1-KiB block of the next stage
+    if (j < NJ && w + 8 * j < NI) {                     // wave-uniform
+      glds16(gsrc[j], smem + buf * STAGE + (w + 8 * j) * 1024);
+      gsrc[j] += 1024;
+    }
+  };
+
+  f32x16_t acc[MB];
+#pragma unroll
+  for (int m = 0; m < MB; ++m)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+
+  const int nb = w & 3, kh = w >> 2;                    // column block, k-half
+  const int r = lane & 31, h = lane >> 5;
+  const int slot_phys = ((2 * kh + h) ^ ((r >> 2) & 3)) * 16;
+  const int a_off = r * 64 + slot_phys;                                  // + p * BM * 64 + mb * 32 * 64
+  const int b_off = 3 * BM * 64 + (nb * 32 + r) * 64 + slot_phys;        // + p * 128 * 64
+
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) issue1(j, 0);
+  for (int ks = 0; ks < KB; ++ks) {
+    __syncthreads();            // (emits s_waitcnt vmcnt(0)): stage ks has landed, every wave is done reading the other buffer
+    const bool more = ks + 1 < KB;
+    const int nbuf = (ks + 1) & 1;
+    const unsigned char* st = smem + (ks & 1) * STAGE;
+    const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(st + b_off);
+    const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(st + b_off + GBN * 64);
+    const bf16x8_t b2 = *reinterpret_cast<const bf16x8_t*>(st + b_off + 2 * GBN * 64);
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      const unsigned char* ap = st + a_off + m * 32 * 64;
+      const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(ap);
+      const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(ap + BM * 64);
+      const bf16x8_t a2 = *reinterpret_cast<const bf16x8_t*>(ap + 2 * BM * 64);
+      if (more) {               // the next stage's LDS-DMA is spread behind the MFMAs (issued in one burst after the barrier it
+#pragma unroll                  // held every wave's first MFMA back by ~7 x 60 cycles; measured +4 %)
+        for (int q = 0; q < PER; ++q) issue1(m * PER + q, nbuf);
+      }
+      // smallest terms first
+      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[m], 0, 0, 0);
+      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[m], 0, 0, 0);
+      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[m], 0, 0, 0);
+      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[m], 0, 0, 0);
+      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[m], 0, 0, 0);
+      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[m], 0, 0, 0);
+    }
+  }
+  __syncthreads();              // everyone is done with the staging buffers: they become the reduction scratch
+
+  // the two k-halves meet: waves 4..7 park their accumulators in LDS, waves 0..3 add them and store
+  float4* red = reinterpret_cast<float4*>(smem) + (size_t)nb * MB * 4 * 64;   // [nb][mb][reg4][lane]
+  if (kh == 1) {
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        red[(m * 4 + g) * 64 + lane] = make_float4(acc[m][4 * g], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]);
+  }
+  __syncthreads();
+  if (kh == 0) {
+    const int col = n0 + nb * 32 + r;
+    const float bv = (bias && col < N) ? bias[col] : 0.f;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 o = red[(m * 4 + g) * 64 + lane];
+        const float add[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = m0 + m * 32 + e + 8 * g + 4 * h;      // C/D map of the 32x32 MFMA: row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+          float v = acc[m][4 * g + e] + add[e] + bv;
+          if (relu) v = v > 0.f ? v : 0.f;
+          if (row < M && col < N) C[(long)row * ldc + col] = v;
+        }
+      }
+  }
+}
+
+template <int MB>
+static int launch_gemm(const uint16_t* Ap, const uint16_t* Bp, float* C, const float* bias, int M, int N, int KB, long a_plane,
+                       long b_plane, long ldc, int relu, hipStream_t s) {
+  constexpr int BM = 32 * MB;
+  constexpr int LDS = (BM + GBN) * 3 * 64 * 2;
+  static_assert(LDS <= 160 * 1024, "two stages must fit the CU's LDS");
+  static_assert(MB * 4 * 16 * 64 * 4 <= LDS, "reduction scratch must fit the staging buffers");
+  const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, GBN);
+  static bool once = false;
+  if (!once) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x6_kernel<MB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    once = true;
+  }
+  hipLaunchKernelGGL(gemm_bf16x6_kernel<MB>, dim3(tiles_m * tiles_n), dim3(GTHREADS), LDS, s, Ap, Bp, C, bias, M, N, KB, a_plane,
+                     b_plane, ldc, relu, tiles_n, tiles_m * tiles_n);
+  return 0;
+}
+
+}  // namespace pt
+
+using namespace pt;
+
+extern "C" int64_t pt_split_bf16x3_plane_elems(int rows, int k) {
+  return (int64_t)((rows + 15) / 16) * ((k + 31) / 32) * 512;
+}
+
+extern "C" int pt_split_bf16x3(const float* src, int64_t ld, int R, int C, int transpose, uint16_t* planes, int64_t plane_stride,
+                               void* stream) {
+  if (R == 0 || C == 0) return PT_OK;
+  PT_REQUIRE(src && planes && R > 0 && C > 0 && ld >= C, PT_EINVAL, "pt_split_bf16x3: bad argument");
+  const int rows = transpose ? C : R, k = transpose ? R : C;
+  const int RB = (rows + 15) / 16, KB = (k + 31) / 32;
+  PT_REQUIRE(plane_stride >= (int64_t)RB * KB * 512 && (plane_stride & 7) == 0 && (((uintptr_t)planes) & 15) == 0, PT_EINVAL,
+             "pt_split_bf16x3: plane_stride must cover pt_split_bf16x3_plane_elems(rows, k) and keep planes 16-byte aligned");
+  if (!transpose) {
+    const long nblk = (long)RB * KB;
+    int nb = cdiv(nblk, 4);
+    nb = nb > 16384 ? 16384 : nb;
+    hipLaunchKernelGGL(split3_kernel, dim3(nb), dim3(256), 0, as_stream(stream), src, (long)ld, R, C, RB, KB, planes, (long)plane_stride);
+  } else {
+    hipLaunchKernelGGL(split3_t_kernel, dim3(cdiv(C, 64), cdiv(R, 64)), dim3(256), 0, as_stream(stream), src, (long)ld, R, C, RB, KB,
+                       planes, (long)plane_stride);
+  }
+  PT_LAUNCH_CHECK("pt_split_bf16x3");
+  return PT_OK;
+}
+
+// Tile height for an [M, N] output: the MB in 3..8 with the least (waves of 256 tiles) x (tile rows); ties -> the larger tile
+// (fewer staged bytes per MFMA).
+extern "C" int pt_gemm_bf16x6_tile_rows(int M, int N) {
+  const long tn = cdiv(N, GBN);
+  int best = 8;
+  long best_cost = -1;
+  for (int mb = 8; mb >= 3; --mb) {
+    const long tiles = (long)cdiv(M, 32 * mb) * tn;
+    const long cost = ((tiles + 255) / 256) * mb;
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = mb; }
+  }
+  return 32 * best;
+}
+
+extern "C" int pt_gemm_bf16x6_nt(const uint16_t* a_planes, int64_t a_plane_stride, const uint16_t* b_planes, int64_t b_plane_stride,
+                                 float* c, int64_t ldc, const float* bias, int M, int N, int K, int relu, int tile_rows,
+                                 void* stream) {
+  if (M == 0 || N == 0) return PT_OK;
+  PT_REQUIRE(a_planes && b_planes && c && M > 0 && N > 0 && K > 0 && ldc >= N, PT_EINVAL, "pt_gemm_bf16x6_nt: bad argument");
+  const int Kp = (K + 31) / 32;                         // k blocks
+  PT_REQUIRE(a_plane_stride >= pt_split_bf16x3_plane_elems(M, K) && b_plane_stride >= pt_split_bf16x3_plane_elems(N, K), PT_EINVAL,
+             "pt_gemm_bf16x6_nt: plane strides too small for [M, K] / [N, K] blocked planes");
+  PT_REQUIRE(((((uintptr_t)a_planes) | ((uintptr_t)b_planes)) & 15) == 0 && (a_plane_stride & 7) == 0 && (b_plane_stride & 7) == 0, PT_EINVAL,
+             "pt_gemm_bf16x6_nt: planes must be 16-byte aligned");
+  if (tile_rows <= 0) tile_rows = pt_gemm_bf16x6_tile_rows(M, N);
+  PT_REQUIRE(tile_rows % 32 == 0 && tile_rows >= 96 && tile_rows <= 256, PT_EINVAL, "pt_gemm_bf16x6_nt: tile_rows in {96, 128, ..., 256}");
+  hipStream_t s = as_stream(stream);
+  int rc = 0;
+  switch (tile_rows / 32) {
+    case 3: rc = launch_gemm<3>(a_planes, b_planes, c, bias, M, N, Kp, a_plane_stride, b_plane_stride, ldc, relu, s); break;
+    case 4: rc = launch_gemm<4>(a_planes, b_planes, c, bias, M, N, Kp, a_plane_stride, b_plane_stride, ldc, relu, s); break;
+    case 5: rc = launch_gemm<5>(a_planes, b_planes, c, bias, M, N, Kp, a_plane_stride, b_plane_stride, ldc, relu, s); break;
+    case 6: rc = launch_gemm<6>(a_planes, b_planes, c, bias, M, N, Kp, a_plane_stride, b_plane_stride, ldc, relu, s); break;
+    case 7: rc = launch_gemm<7>(a_planes, b_planes, c, bias, M, N, Kp, a_plane_stride, b_plane_stride, ldc, relu, s); break;
+    default: rc = launch_gemm<8>(a_planes, b_planes, c, bias, M, N, Kp, a_plane_stride, b_plane_stride, ldc, relu, s); break;
+  }
+  PT_REQUIRE(rc == 0, rc, "pt_gemm_bf16x6_nt: hipFuncSetAttribute failed (%d)", rc);
+  PT_LAUNCH_CHECK("pt_gemm_bf16x6_nt");
+  return PT_OK;
+}

@@ -43,26 +43,54 @@ __global__ void __launch_bounds__(256) sqnorm_kernel(const float* __restrict__ g
   if (threadIdx.x == 0) partial[blockIdx.x] = acc;
 }
 
+// Parameter groups of mmcv's DefaultOptimizerConstructor (paramwise_cfg: bias_lr_mult / bias_decay_mult / norm_decay_mult /
+// dwconv_decay_mult / dcn_offset_lr_mult / custom_keys): the live trainable buffer is a sequence of <= PT_MAX_PARAM_GROUPS
+// contiguous, 16-byte aligned segments, each with its own (lr multiplier, decay multiplier).  The table travels by value.
+struct SgdGroups {
+  long end[PT_MAX_PARAM_GROUPS];      // exclusive end offsets, ascending; end[n-1] == n
+  float lr_mult[PT_MAX_PARAM_GROUPS];
+  float wd_mult[PT_MAX_PARAM_GROUPS];
+  int n;
+};
+
+__device__ __forceinline__ float sgd_one(float x, float g, float& m, float clip, float lri, float wdi, float mom, int first) {
+  float d = g * clip;
+  if (wdi != 0.f) d = d + wdi * x;
+  const float buf = first ? d : mom * m + d;
+  m = buf;
+  return x - lri * buf;
+}
+
 __global__ void __launch_bounds__(256)
-    sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, long n, long split,
-               const float* __restrict__ lr_p, float mom, float wd, float blr, float bwd,
-               const float* __restrict__ sqnorm, float max_norm, int first) {
+    sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, long n, SgdGroups grp,
+               const float* __restrict__ lr_p, float mom, float wd, const float* __restrict__ sqnorm, float max_norm, int first) {
   const float lr = lr_p[0];
   float clip = 1.f;
   if (max_norm > 0.f && sqnorm) {
     const float c = max_norm / (sqrtf(sqnorm[0]) + 1e-6f);  // torch.nn.utils.clip_grad_norm_
     clip = c < 1.f ? c : 1.f;
   }
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const bool bias = i >= split;
-    const float lri = bias ? lr * blr : lr;
-    const float wdi = bias ? wd * bwd : wd;
-    const float x = p[i];
-    float d = g[i] * clip;
-    if (wdi != 0.f) d = d + wdi * x;
-    const float buf = first ? d : mom * m[i] + d;
-    m[i] = buf;
-    p[i] = x - lri * buf;
+  // segments are multiples of 4 elements: a float4 never straddles two groups
+  const long n4 = n >> 2;
+  float4* p4 = reinterpret_cast<float4*>(p);
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  float4* m4 = reinterpret_cast<float4*>(m);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const long e = i << 2;
+    int k = 0;
+#pragma unroll
+    for (int j = 0; j < PT_MAX_PARAM_GROUPS - 1; ++j) k += (j < grp.n - 1 && e >= grp.end[j]) ? 1 : 0;
+    const float lri = lr * grp.lr_mult[k];
+    const float wdi = wd * grp.wd_mult[k];
+    float4 x = p4[i];
+    const float4 gg = g4[i];
+    float4 mm = m4[i];
+    x.x = sgd_one(x.x, gg.x, mm.x, clip, lri, wdi, mom, first);
+    x.y = sgd_one(x.y, gg.y, mm.y, clip, lri, wdi, mom, first);
+    x.z = sgd_one(x.z, gg.z, mm.z, clip, lri, wdi, mom, first);
+    x.w = sgd_one(x.w, gg.w, mm.w, clip, lri, wdi, mom, first);
+    m4[i] = mm;
+    p4[i] = x;
   }
 }
 
@@ -96,17 +124,52 @@ extern "C" int pt_sqnorm_partial(const float* g, int64_t n, float* partial, void
   return PT_OK;
 }
 
+static int sgd_launch(float* param, const float* grad, float* momentum_buf, int64_t n, const SgdGroups& grp, const float* lr,
+                      float momentum, float weight_decay, const float* sqnorm, float max_norm, int first_step, void* stream,
+                      const char* who) {
+  PT_REQUIRE((n & 3) == 0 && (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)momentum_buf) & 15) == 0, PT_EINVAL,
+             "pt_sgd_step: buffers must be 16-byte aligned and n a multiple of 4");
+  long prev = 0;
+  for (int j = 0; j < grp.n; ++j) {
+    PT_REQUIRE(grp.end[j] >= prev && (grp.end[j] & 3) == 0, PT_EINVAL, "pt_sgd_step: group ends must ascend in multiples of 4");
+    prev = grp.end[j];
+  }
+  PT_REQUIRE(prev == n, PT_EINVAL, "pt_sgd_step: the last group must end at n");
+  hipLaunchKernelGGL(sgd_kernel, dim3(stream_blocks(n >> 2)), dim3(256), 0, as_stream(stream), param, grad, momentum_buf,
+                     (long)n, grp, lr, momentum, weight_decay, sqnorm, max_norm, first_step);
+  PT_LAUNCH_CHECK(who);
+  return PT_OK;
+}
+
 extern "C" int pt_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, int64_t split,
                            const float* lr, float momentum, float weight_decay, float bias_lr_mult,
                            float bias_decay_mult, const float* sqnorm, float max_norm, int first_step, void* stream) {
   if (n == 0) return PT_OK;
   PT_REQUIRE(param && grad && momentum_buf && lr && n > 0 && split >= 0 && split <= n, PT_EINVAL,
              "pt_sgd_step: bad argument");
-  hipLaunchKernelGGL(sgd_kernel, dim3(stream_blocks(n)), dim3(256), 0, as_stream(stream), param, grad, momentum_buf,
-                     (long)n, (long)split, lr, momentum, weight_decay, bias_lr_mult, bias_decay_mult, sqnorm, max_norm,
-                     first_step);
-  PT_LAUNCH_CHECK("pt_sgd_step");
-  return PT_OK;
+  SgdGroups grp{};
+  grp.n = 2;
+  grp.end[0] = split; grp.lr_mult[0] = 1.f; grp.wd_mult[0] = 1.f;
+  grp.end[1] = n; grp.lr_mult[1] = bias_lr_mult; grp.wd_mult[1] = bias_decay_mult;
+  return sgd_launch(param, grad, momentum_buf, n, grp, lr, momentum, weight_decay, sqnorm, max_norm, first_step, stream,
+                    "pt_sgd_step");
+}
+
+extern "C" int pt_sgd_step_groups(float* param, const float* grad, float* momentum_buf, int64_t n, const int64_t* group_end,
+                                  const float* lr_mult, const float* decay_mult, int n_groups, const float* lr,
+                                  float momentum, float weight_decay, const float* sqnorm, float max_norm, int first_step,
+                                  void* stream) {
+  if (n == 0) return PT_OK;
+  PT_REQUIRE(param && grad && momentum_buf && lr && group_end && lr_mult && decay_mult && n > 0, PT_EINVAL,
+             "pt_sgd_step_groups: bad argument");
+  PT_REQUIRE(n_groups >= 1 && n_groups <= PT_MAX_PARAM_GROUPS, PT_ELIMIT, "pt_sgd_step_groups: 1 <= n_groups <= PT_MAX_PARAM_GROUPS (8)");
+  SgdGroups grp{};
+  grp.n = n_groups;
+  for (int j = 0; j < n_groups; ++j) {
+    grp.end[j] = group_end[j]; grp.lr_mult[j] = lr_mult[j]; grp.wd_mult[j] = decay_mult[j];
+  }
+  return sgd_launch(param, grad, momentum_buf, n, grp, lr, momentum, weight_decay, sqnorm, max_norm, first_step, stream,
+                    "pt_sgd_step_groups");
 }
 
 // ----------------------------------------------------------------------------------------------

@@ -312,15 +312,24 @@ class EpochBatches:
     after epoch (EpochBasedRunner.train: `data_loader.sampler.set_epoch(epoch)` then one pass)."""
 
     def __init__(self, loader, start_epoch=0):
-        self.loader, self.epoch, self._it = loader, int(start_epoch), None
+        self.loader, self.epoch, self._it, self._served = loader, int(start_epoch), None, 0
+
+    def next_epoch(self):
+        """The loader epoch a resumed run must start with: `epoch` only advances when the NEXT call finds the iterator empty,
+        so after the last batch of epoch e (where end-of-epoch checkpoints are written) it still reads e although e is used up
+        - resuming with it would replay e's shuffle and shift every later epoch by one."""
+        return self.epoch + 1 if (self._it is not None and self._served >= len(self.loader)) else self.epoch
 
     def __call__(self, iteration=None, batch_size=None):
         while True:
             if self._it is None:
                 self.loader.set_epoch(self.epoch)
                 self._it = iter(self.loader)
+                self._served = 0
             try:
-                return next(self._it)
+                b = next(self._it)
+                self._served += 1
+                return b
             except StopIteration:
                 self._it = None
                 self.epoch += 1

@@ -219,13 +219,22 @@ class TS_P2B_FCOS(BaseDetector):
         # hooks for tests: inject the random draws of one iteration
         self._inject = {}
         self._stem_shared = None          # decided at the first iteration (`_shared_stem`)
+        # ... and again after every route that can change frozen weights: any load_state_dict into this module or a child
+        # (pre-hook below), the Trainer's re-layouts, and once per epoch (`update_epoch`) for in-place edits nobody announced
+        self._register_load_state_dict_pre_hook(self._forget_stem_decision)
+        self.student.backbone._register_load_state_dict_pre_hook(self._forget_stem_decision)
+        self.teacher.backbone._register_load_state_dict_pre_hook(self._forget_stem_decision)
+        self.point_stamp = {}             # image key -> iteration of its last refinement (checkpoint merges keep the newest)
         self.teacher_stream = os.environ.get('PT_TEACHER_STREAM', '0') == '1'
         self._side_stream = None
 
     # the reference keeps count/point dictionaries as plain attributes, so they are lost on resume
     # (SURVEY section 5); persisting them is a documented deviation.
+    def _forget_stem_decision(self, *args, **kw):
+        self._stem_shared = None
+
     def get_extra_state(self):
-        return dict(count=self.count, epoch=self.epoch,
+        return dict(count=self.count, epoch=self.epoch, point_stamp=dict(self.point_stamp),
                     gt_bboxes_point={k: v.cpu() for k, v in self.gt_bboxes_point.items()},
                     refined_gt_bboxes_point={k: v.cpu() for k, v in self.refined_gt_bboxes_point.items()})
 
@@ -234,6 +243,7 @@ class TS_P2B_FCOS(BaseDetector):
             return
         dev = next(self.parameters()).device
         self.count, self.epoch = state.get('count', 0), state.get('epoch', 0)
+        self.point_stamp = dict(state.get('point_stamp', {}))
         self.gt_bboxes_point = {k: v.to(dev) for k, v in state.get('gt_bboxes_point', {}).items()}
         self.refined_gt_bboxes_point = {k: v.to(dev) for k, v in state.get('refined_gt_bboxes_point', {}).items()}
 
@@ -249,9 +259,9 @@ class TS_P2B_FCOS(BaseDetector):
         if self._stem_shared is None:
             ok = False
             sb = getattr(self.student, 'backbone', None)
-            if (self._flat is not None and getattr(self, '_flat_n_train', None) is not None and hasattr(sb, 'forward_stem')
+            if (self._flat is not None and getattr(self, '_flat_frozen_start', None) is not None and hasattr(sb, 'forward_stem')
                     and getattr(sb, 'frozen_stages', -1) >= 0 and os.environ.get('PT_SHARE_STEM', '1') != '0'):
-                n = self._flat_n_train
+                n = self._flat_frozen_start
                 ok = bool(torch.equal(self._flat[0][n:], self._flat[1][n:]))
                 ok = ok and all(torch.equal(a, b) for a, b in zip(self.teacher.backbone.buffers(), sb.buffers()))
             self._stem_shared = ok
@@ -286,7 +296,7 @@ class TS_P2B_FCOS(BaseDetector):
         """:254-257: over parameters() only (buffers untouched), at the START of the iteration."""
         with torch.no_grad():
             if self._flat is not None:
-                n = self._flat_n_train if self._shared_stem() else self._flat[0].numel()
+                n = self._flat_frozen_start if self._shared_stem() else self._flat[0].numel()
                 F.ema_update_(self._flat[0][:n], self._flat[1][:n], ema_decay)
             else:   # parameters not flattened yet (unit tests / CPU construction): per-tensor form
                 F.PARAM_EPOCH[0] += 1
@@ -299,6 +309,7 @@ class TS_P2B_FCOS(BaseDetector):
         if img_metas[0][self._epoch_key] in self.epoch_dict:
             self.epoch += 1
             self.epoch_dict = {}
+            self._stem_shared = None      # re-verified once per epoch (one comparison of the frozen segments)
         for i in range(num_img):
             self.epoch_dict[img_metas[i][self._epoch_key]] = 1
 
@@ -311,6 +322,7 @@ class TS_P2B_FCOS(BaseDetector):
             rc = (1 - self.lamda) * pc + self.lamda * oc
             out.append(rc)
             self.refined_gt_bboxes_point[img_metas[i]['ori_filename']] = rc
+            self.point_stamp[img_metas[i]['ori_filename']] = self.count
         return out
 
     def genrate_points(self, num_img, img, img_metas, gt_bboxes):

@@ -31,8 +31,49 @@ class _PinnedRing:
         self.words = words
         self.seg_words = words // self.SEG
         self.buf = None
-        self.pos = 0
+        self.pos = 0                     # invariant: 0 <= pos < words and pos is never a segment END (see `_turn`)
         self.events = [None] * self.SEG
+
+    # the three touch points with the device, separate so that the cursor logic can be driven without one (tests/test_host_logic.py)
+    def _alloc(self):
+        return torch.empty(self.words, dtype=torch.int32).pin_memory()
+
+    def _record(self, seg, stream):
+        ev = self.events[seg] or torch.cuda.Event()
+        ev.record(stream)                                  # covers every copy staged in the segment being left
+        self.events[seg] = ev
+
+    def _await(self, seg):
+        if self.events[seg] is not None:
+            self.events[seg].synchronize()                 # the previous lap's copies out of this segment have executed
+
+    def _turn(self, seg, stream):
+        """Leave segment `seg` (its copies are all enqueued: record the event that covers them) and enter the next one
+        (await the event of the previous lap).  -> the segment entered."""
+        self._record(seg, stream)
+        seg = (seg + 1) % self.SEG
+        self.pos = seg * self.seg_words
+        self._await(seg)
+        return seg
+
+    def _stage(self, arr, n, dtype, stream):
+        """Reserve n words, write `arr` there -> the staged view.  An upload that does not fit the rest of the current segment
+        starts the next one; an upload that ends EXACTLY on a segment end also turns the segment (after its copy is enqueued,
+        `_finish`): a cursor parked on a segment end - or on the end of the ring, where the slice is empty and the write
+        raises - would skip both the event of the segment left and the wait of the segment entered."""
+        seg = self.pos // self.seg_words
+        if self.pos - seg * self.seg_words + n > self.seg_words:
+            seg = self._turn(seg, stream)
+        view = self.buf[self.pos:self.pos + n]
+        self.pos += n
+        if dtype != torch.int32:
+            view = view.view(torch.float32)
+        view.numpy()[:] = arr.reshape(-1)
+        return view, seg
+
+    def _finish(self, seg, stream):
+        if self.pos == (seg + 1) * self.seg_words:          # exact fill: the copy of this upload is enqueued, turn now
+            self._turn(seg, stream)
 
     def upload(self, arr, device, dtype):
         np_dtype = np.int32 if dtype == torch.int32 else np.float32
@@ -46,22 +87,11 @@ class _PinnedRing:
             # torch's caching host allocator keeps the staging block alive until the stream has executed the copy
             return torch.from_numpy(arr).pin_memory().to(device, non_blocking=True)
         if self.buf is None:
-            self.buf = torch.empty(self.words, dtype=torch.int32).pin_memory()
-        seg = self.pos // self.seg_words
-        if self.pos - seg * self.seg_words + n > self.seg_words:
-            ev = self.events[seg] or torch.cuda.Event()
-            ev.record(stream)                              # covers every copy staged in the segment being left
-            self.events[seg] = ev
-            seg = (seg + 1) % self.SEG
-            self.pos = seg * self.seg_words
-            if self.events[seg] is not None:
-                self.events[seg].synchronize()             # the previous lap's copies out of this segment have executed
-        view = self.buf[self.pos:self.pos + n]
-        self.pos += n
-        if dtype != torch.int32:
-            view = view.view(torch.float32)
-        view.numpy()[:] = arr.reshape(-1)
-        return view.to(device, non_blocking=True).reshape(arr.shape)
+            self.buf = self._alloc()
+        view, seg = self._stage(arr, n, dtype, stream)
+        out = view.to(device, non_blocking=True).reshape(arr.shape)
+        self._finish(seg, stream)
+        return out
 
 
 _ring = _PinnedRing()
@@ -494,6 +524,106 @@ def sgd_step_(param, grad, mom, split, lr_t, momentum, weight_decay, bias_lr_mul
     hip.call('pt_sgd_step', param, grad, mom, param.numel(), int(split), lr_t, float(momentum), float(weight_decay),
              float(bias_lr_mult), float(bias_decay_mult), sqnorm, float(max_norm if max_norm else 0.0),
              int(bool(first_step)))
+
+
+def sgd_step_groups_(param, grad, mom, tables, lr_t, momentum, weight_decay, sqnorm, max_norm, first_step):
+    """pt_sgd_step_groups: `tables` = FlatParams.group_tables() ([host] ends, lr multipliers, decay multipliers, count)."""
+    PARAM_EPOCH[0] += 1
+    ends, lr_mult, wd_mult, n_groups = tables
+    hip.call('pt_sgd_step_groups', param, grad, mom, param.numel(), ends, lr_mult, wd_mult, int(n_groups), lr_t,
+             float(momentum), float(weight_decay), sqnorm, float(max_norm if max_norm else 0.0), int(bool(first_step)))
+
+
+# ------------------------------------------------------------- fp32 Linear on the bf16 matrix cores (bf16x6 split) --
+
+class SplitPlanes:
+    """Three bf16 planes of a GEMM operand [rows, k] in the blocked layout of pt_split_bf16x3."""
+    __slots__ = ('planes', 'rows', 'k')
+
+    def __init__(self, planes, rows, k):
+        self.planes, self.rows, self.k = planes, rows, k
+
+    def dense(self):
+        """-> fp32 [3, rows, k]: the three terms, un-blocked (tests)."""
+        RB, KB = (self.rows + 15) // 16, (self.k + 31) // 32
+        t = self.planes.view(3, RB, KB, 16, 4, 8).float()
+        r16 = torch.arange(16, device=t.device)
+        q = torch.arange(4, device=t.device)
+        phys = q[None, :] ^ ((r16[:, None] >> 2) & 3)                       # physical slot of logical slot q in row r16
+        t = torch.gather(t, 4, phys[None, None, None, :, :, None].expand(3, RB, KB, 16, 4, 8))
+        return t.permute(0, 1, 3, 2, 4, 5).reshape(3, RB * 16, KB * 32)
+
+
+def split_bf16x3(x, transpose=False):
+    """pt_split_bf16x3: fp32 [R, C] -> SplitPlanes of the operand [rows = R, k = C] (or [rows = C, k = R] when transposed)."""
+    assert x.dim() == 2 and x.dtype == f32 and x.stride(1) == 1
+    R, C = x.shape
+    rows, k = (C, R) if transpose else (R, C)
+    n = ((rows + 15) // 16) * ((k + 31) // 32) * 512
+    planes = torch.empty((3, n), dtype=torch.bfloat16, device=x.device)
+    hip.call('pt_split_bf16x3', x if x.is_contiguous() else x.data_ptr(), x.stride(0), R, C, int(transpose), planes, n)   # (a row-strided view travels as pointer + ld)
+    return SplitPlanes(planes, rows, k)
+
+
+def gemm_bf16x6_nt(a, b, bias=None, relu=False, out=None, tile_rows=0):
+    """pt_gemm_bf16x6_nt: [M, N] = A[M, K] B[N, K]^T (+ bias) (ReLU) from SplitPlanes a (rows M) and b (rows N)."""
+    assert a.k == b.k, (a.k, b.k)
+    M, N = a.rows, b.rows
+    c = out if out is not None else torch.empty((M, N), dtype=f32, device=a.planes.device)
+    hip.call('pt_gemm_bf16x6_nt', a.planes, a.planes.shape[1], b.planes, b.planes.shape[1], c, c.stride(0), bias, M, N, a.k,
+             int(bool(relu)), int(tile_rows))
+    return c
+
+
+_SPLIT_W_CACHE = {}      # id(weight) -> (PARAM_EPOCH, data_ptr, planes of W, planes of W^T or None)
+
+
+def _split_weight(w, transposed):
+    """The split planes of a weight change only when the parameters do (optimizer step / EMA / re-layout bump PARAM_EPOCH):
+    the stack is evaluated 2-3 times per iteration (boxes, negatives, both MIL branches' backward) on the same weights."""
+    key = id(w)
+    ent = _SPLIT_W_CACHE.get(key)
+    if ent is None or ent[0] != PARAM_EPOCH[0] or ent[1] != w.data_ptr():
+        ent = [PARAM_EPOCH[0], w.data_ptr(), None, None]
+        _SPLIT_W_CACHE[key] = ent
+    i = 3 if transposed else 2
+    if ent[i] is None:
+        ent[i] = split_bf16x3(w.detach(), transpose=transposed)
+    return ent[i]
+
+
+class _SplitLinear(torch.autograd.Function):
+    """y = [relu](x W^T + b) with fp32 operands and results, evaluated as six bf16 MFMA products per term with fp32
+    accumulation (csrc/gemm_split.hip).  Backward: dx = dy W, dW = dy^T x through the same NT kernel (the split kernel
+    transposes), db = column sums."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        xp = split_bf16x3(x)
+        y = gemm_bf16x6_nt(xp, _split_weight(w, False), b, relu)
+        ctx.relu = relu
+        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        gy = gy.contiguous()
+        if ctx.relu:
+            gy = gy * (y > 0)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = gemm_bf16x6_nt(split_bf16x3(gy), _split_weight(w, True))                       # [M, K] = gy[M, N] (W^T)[K, N]^T
+        if ctx.needs_input_grad[1]:
+            gw = gemm_bf16x6_nt(split_bf16x3(gy, transpose=True), split_bf16x3(x, transpose=True))   # [N, K] = gy^T[N, M] (x^T)[K, M]^T
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum(0)
+        return gx, gw, gb, None
+
+
+def split_linear(x, weight, bias=None, relu=False):
+    return _SplitLinear.apply(x.contiguous(), weight, bias, bool(relu))
 
 
 class _AffineReLU(torch.autograd.Function):

@@ -5,6 +5,8 @@ losses, RoIAlign, bag scoring and bag selection all run in libpt_hip.so; images 
 are processed in ONE launch per op and no method synchronises the host (the reference
 syncs on every `.nonzero()`, `len(pos_inds)`, `.item()` and `.tolist()`).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as TF
@@ -16,6 +18,8 @@ from .losses import diou_forward_masked
 from .nn_modules import ConvModule, Scale
 from .proposals import MIL_gen_proposals_from_cfg
 from .registry import HEADS, build_assigner, build_bbox_coder, build_loss, build_roi_extractor
+
+_SPLIT_GEMM = os.environ.get('PT_SPLIT_GEMM', '1') != '0'
 
 INF = 1e8
 
@@ -298,9 +302,19 @@ class TS_P2BFCOSHead(nn.Module):
         return -(((p - q) ** 2) * (q * (p + eps).log() + (1 - q) * (1 - p + eps).log()) * w).sum(dim=-1)
 
     # ----------------------------------------------------------------- MIL head --
+    SPLIT_GEMM_MIN_ROWS = 2048     # below it the tile count cannot fill 256 CUs and the library GEMM wins (profiles/r03/gemm_bf16x6_vs_library.txt)
+
     def _fc_stack(self, fcs, x):
+        """Linear + ReLU stack (:1202-1236, :1240-1256).  On the MI355X the fp32 products run on the bf16 matrix cores as six
+        split-bf16 MFMA products with fp32 accumulation (`functional.split_linear`, csrc/gemm_split.hip: error against float64
+        below the fp32 library kernel's, 1.4-1.6x its speed at K >= 5 000 RoIs); bias + ReLU are the GEMM's epilogue.
+        PT_SPLIT_GEMM=0: library GEMMs."""
+        use = x.is_cuda and x.dtype == torch.float32 and x.shape[0] >= self.SPLIT_GEMM_MIN_ROWS and _SPLIT_GEMM
         for fc in fcs:
-            x = TF.relu(fc(x), inplace=True)
+            if use:
+                x = F.split_linear(x, fc.weight, fc.bias, relu=True)
+            else:
+                x = TF.relu(fc(x), inplace=True)
         return x
 
     @staticmethod

@@ -29,9 +29,9 @@ def parse_header(path=HEADER_PATH):
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
     txt = re.sub(r'//[^\n]*', '', txt)
     protos = {}
-    for m in re.finditer(r'(const\s+char\s*\*|int)\s+(pt_\w+)\s*\(([^)]*)\)\s*;', txt):
+    for m in re.finditer(r'(const\s+char\s*\*|int64_t|int)\s+(pt_\w+)\s*\(([^)]*)\)\s*;', txt):
         ret, name, args = m.group(1), m.group(2), m.group(3)
-        restype = ctypes.c_char_p if 'char' in ret else ctypes.c_int
+        restype = ctypes.c_char_p if 'char' in ret else (ctypes.c_int64 if ret == 'int64_t' else ctypes.c_int)
         argl = []
         for a in [x.strip() for x in args.split(',') if x.strip() and x.strip() != 'void']:
             if '*' in a:
@@ -101,7 +101,7 @@ def call(fn, *args):
     if auto_stream:
         conv.append(torch.cuda.current_stream().cuda_stream)
     rc = getattr(_lib, fn)(*conv)
-    if restype is ctypes.c_int and fn not in ('pt_abi_version', 'pt_focal_nblocks', 'pt_sqnorm_nblocks', 'pt_affine_train_rows') and rc != 0:
+    if restype is ctypes.c_int and fn not in ('pt_abi_version', 'pt_focal_nblocks', 'pt_sqnorm_nblocks', 'pt_affine_train_rows', 'pt_gemm_bf16x6_tile_rows') and rc != 0:
         raise RuntimeError(f'{fn} failed (code {rc}): {last_error()}')
     return rc
 

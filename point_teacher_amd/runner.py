@@ -16,6 +16,37 @@ import torch
 import torch.distributed as dist
 
 
+def merge_point_states(parts):
+    """One extra-state dict out of every rank's: the DistributedSampler reshuffles every epoch, so the same image can sit in
+    several ranks' dictionaries with different ages - the entry with the NEWEST refinement stamp wins (`TS_P2B_FCOS.point_stamp`,
+    iteration of the last `update_points`; entries without a stamp are older than any with one; ties: lowest rank).  First-visit
+    points (`gt_bboxes_point`) are what `update_points` blends with: the earliest-stamped visit would be the reference's, but
+    the reference keeps them per process too, so they follow the refined entry's rank."""
+    merged = dict(parts[0])
+    best = {}
+    for r, part in enumerate(parts):
+        stamps = part.get('point_stamp', {})
+        for name in set(part.get('gt_bboxes_point', {})) | set(part.get('refined_gt_bboxes_point', {})):
+            st = stamps.get(name, -1)
+            if name not in best or st > best[name][0]:
+                best[name] = (st, r)
+    for k in ('gt_bboxes_point', 'refined_gt_bboxes_point'):
+        merged[k] = {}
+    merged['point_stamp'] = {}
+    for name, (st, r) in best.items():
+        for k in ('gt_bboxes_point', 'refined_gt_bboxes_point'):
+            if name in parts[r].get(k, {}):
+                merged[k][name] = parts[r][k][name]
+            else:                                        # e.g. refined on another rank only: take it from whoever has it
+                for part in parts:
+                    if name in part.get(k, {}):
+                        merged[k][name] = part[k][name]
+                        break
+        if st >= 0:
+            merged['point_stamp'][name] = st
+    return merged
+
+
 class Runner:
     def __init__(self, trainer, batches, work_dir, max_epochs, iters_per_epoch, log_interval=50, checkpoint_interval=1,
                  batch_size=2):
@@ -73,7 +104,8 @@ class Runner:
         if extra is not None:
             state['model']['_extra_state'] = extra
         state['meta'] = dict(epoch=self.epoch, iter=self.trainer.iter, time=time.strftime('%Y-%m-%d %H:%M:%S'),
-                             loader_epoch=getattr(self.batches, 'epoch', None))
+                             loader_epoch=(self.batches.next_epoch() if hasattr(self.batches, 'next_epoch')
+                                           else getattr(self.batches, 'epoch', None)))
         torch.save(state, path)
         latest = os.path.join(self.work_dir, 'latest.pth')
         if os.path.lexists(latest):
@@ -91,12 +123,7 @@ class Runner:
         mine = model.get_extra_state()
         parts = [None] * dist.get_world_size()
         dist.all_gather_object(parts, mine)
-        merged = dict(parts[0])
-        for k in ('gt_bboxes_point', 'refined_gt_bboxes_point'):
-            merged[k] = {}
-            for part in parts:
-                merged[k].update(part.get(k, {}))
-        return merged
+        return merge_point_states(parts)
 
     def resume(self, path):
         """--resume-from: model (incl. count / the point dictionaries of every rank), momentum, iteration, epoch, and the

@@ -6,9 +6,9 @@ DefaultOptimizerConstructor + MMDistributedDataParallel, driven by
 HBB_TOD/mmdet/apis/train.py:73-170 and the `optimizer*`/`lr_config` entries of
 configs/point_teacher/aitodv2_point_teacher_0%.py:212-223) with an MI355X-first layout:
 
-* every student parameter lives in ONE flat fp32 buffer `[trainable weights | trainable
-  biases | frozen]`, the teacher in a second buffer with the same order, gradients and
-  momentum in two more.  EMA, gradient norm and the SGD update are one streaming kernel each
+* every student parameter lives in ONE flat fp32 buffer `[parameter groups of the optimizer
+  (weights | biases | ...) | never-used | frozen]`, the teacher in a second buffer with the same
+  order, gradients and momentum of the live groups in two more.  EMA, gradient norm and the SGD update are one streaming kernel each
   (libpt_hip.so) instead of ~190 per-tensor launch pairs;
 * data parallel = one process per GPU; the flat gradient buffer is all-reduced over RCCL in a
   few large chunks on a side stream (xGMI is point-to-point: large messages, few of them).
@@ -25,42 +25,123 @@ import torch.distributed as dist
 from . import functional as F
 
 
-class FlatParams:
-    """Re-homes the parameters of `model.student` / `model.teacher` into flat buffers."""
+_NORMS = (torch.nn.modules.batchnorm._BatchNorm, torch.nn.GroupNorm, torch.nn.LayerNorm,
+          torch.nn.modules.instancenorm._InstanceNorm)
+MAX_GROUPS = 8                      # PT_MAX_PARAM_GROUPS of include/pt_hip.h
 
-    def __init__(self, model, channels_last=False):
+
+def param_multipliers(root, paramwise_cfg=None, prefix=''):
+    """{parameter name: (lr_mult, decay_mult)} by the rules of mmcv's DefaultOptimizerConstructor.add_params
+    (mmcv/runner/optimizer/default_constructor.py - the constructor every shipped `optimizer = dict(type='SGD', paramwise_cfg=...)`
+    selects; un-vendored, restated from the published source):
+      * `custom_keys`: the LONGEST key (ties: alphabetical) that is a substring of the full parameter name wins and sets
+        lr_mult / decay_mult (1 when absent); nothing else applies to that parameter
+        (configs/baselines/aitodv2_yolof_r50_1x.py:70-71: {'backbone': lr_mult 1/3});
+      * a parameter NAMED `bias` takes bias_lr_mult unless it belongs to a normalisation layer or to a deformable-convolution
+        module (incl. its `conv_offset` child); a Conv2d named `conv_offset` inside a DCN module takes dcn_offset_lr_mult (weight and bias);
+      * decay: norm layers x norm_decay_mult, else depth-wise convolutions x dwconv_decay_mult, else a `bias` outside DCN
+        modules x bias_decay_mult.
+    `prefix` is what the reference's names carry in front (the optimizer is built over the whole wrapper, apis/train.py:88:
+    'student.' for the teacher-student detectors) - custom keys see it."""
+    pw = dict(paramwise_cfg or {})
+    custom = pw.get('custom_keys', {}) or {}
+    keys = sorted(sorted(custom.keys()), key=len, reverse=True)
+    bias_lr, bias_wd = pw.get('bias_lr_mult', 1.), pw.get('bias_decay_mult', 1.)
+    norm_wd, dw_wd, dcn_lr = pw.get('norm_decay_mult', 1.), pw.get('dwconv_decay_mult', 1.), pw.get('dcn_offset_lr_mult', 1.)
+    from .nn_modules import DeformConv2dPack, ModulatedDeformConv2dPack
+    out = {}
+
+    def walk(module, mprefix, in_dcn):
+        is_norm = isinstance(module, _NORMS)
+        is_dw = isinstance(module, torch.nn.Conv2d) and module.in_channels == module.groups
+        in_dcn = in_dcn or isinstance(module, (DeformConv2dPack, ModulatedDeformConv2dPack))
+        for name, p in module.named_parameters(recurse=False):
+            full = f'{mprefix}.{name}' if mprefix else name
+            lr_m, wd_m = 1., 1.
+            for k in keys:
+                if k in prefix + full:
+                    lr_m, wd_m = custom[k].get('lr_mult', 1.), custom[k].get('decay_mult', 1.)
+                    break
+            else:
+                if name == 'bias' and not (is_norm or in_dcn):
+                    lr_m = bias_lr
+                if 'conv_offset' in mprefix and in_dcn and isinstance(module, torch.nn.Conv2d):
+                    lr_m = dcn_lr
+                if is_norm:
+                    wd_m = norm_wd
+                elif is_dw:
+                    wd_m = dw_wd
+                elif name == 'bias' and not in_dcn:
+                    wd_m = bias_wd
+            out[full] = (float(lr_m), float(wd_m))
+        for cname, child in module.named_children():
+            walk(child, f'{mprefix}.{cname}' if mprefix else cname, in_dcn)
+    walk(root, '', False)
+    return out
+
+
+class FlatParams:
+    """Re-homes the parameters of `model.student` / `model.teacher` into flat buffers
+
+        [ group 0 | group 1 | ... | dead | frozen ]           (every segment 16-byte aligned)
+
+    * group g = the live trainable parameters that share one (lr multiplier, decay multiplier) pair of the optimizer's
+      paramwise_cfg (`param_multipliers`); group 0 is the plain (1, 1) group - the "weights" -, bias_lr_mult=2 / bias_decay_mult=0
+      of the Point-Teacher configs makes group 1 the "biases".  Gradient and momentum buffers cover the groups only (`n_train`).
+    * dead = trainable parameters that have never received a gradient (`shared_fcs`, `shared_fcs_refine`, `fc_iou` of
+      TS_P2BFCOSHead are constructed, fcos_head_p2b_ts.py:147-181, and no forward reaches them: 27.8 M of the student's 88 M).
+      torch.optim.SGD skips a parameter whose `.grad is None` - no weight decay, no momentum - and DDP has nothing to reduce for
+      it; here they have no gradient / momentum storage, stay out of the gradient exchange and out of the fused clip+SGD launch.
+      They still follow the EMA (update_teacher_model runs over parameters()).  The set is discovered by the Trainer at the
+      first iteration (`relayout`); a dead parameter that later receives a gradient is revived the same way.
+    * frozen = requires_grad False."""
+
+    def __init__(self, model, channels_last=False, paramwise_cfg=None, dead=()):
         """channels_last=True stores 4-D (convolution) weights in [O,H,W,I] order inside the flat
         buffers and exposes them as channels_last-strided views, so MIOpen's NHWC kernels run
         without per-call layout transposes; the flat-buffer kernels are order-agnostic."""
         self.model = model
         self.channels_last = channels_last
+        self.paramwise_cfg = dict(paramwise_cfg) if paramwise_cfg is not None else dict(bias_lr_mult=1., bias_decay_mult=1.)
         # a plain detector (the supervised FCOS baseline, row N4) has no teacher: its own parameters are the "student"
         self.has_teacher = hasattr(model, 'student') and hasattr(model, 'teacher')
-        student = list((model.student if self.has_teacher else model).named_parameters())
+        self.root = model.student if self.has_teacher else model
+        self.mults = param_multipliers(self.root, self.paramwise_cfg, prefix='student.' if self.has_teacher else '')
+        self.student_flat = self.teacher_flat = self.grad_flat = self.mom_flat = None
+        self.slices = {}
+        self._build(frozenset(dead))
+
+    # ------------------------------------------------------------------------------------------------ layout --
+    def _build(self, dead):
+        model = self.model
+        student = list(self.root.named_parameters())
         teacher = dict(model.teacher.named_parameters()) if self.has_teacher else None
         assert teacher is None or [n for n, _ in student] == list(teacher.keys()), 'teacher/student parameter lists differ'
-
-        # mmcv DefaultOptimizerConstructor (optimizer/default_constructor.py): bias_lr_mult / bias_decay_mult apply to
-        # parameters NAMED 'bias' of every module EXCEPT normalisation layers; norm weights and biases keep lr x 1 and take
-        # weight_decay x norm_decay_mult (1 unless a config says otherwise) - i.e. they belong to the weights segment.
-        root = model.student if self.has_teacher else model
-        norm_owned = {id(p) for m in root.modules() if isinstance(m, (torch.nn.modules.batchnorm._BatchNorm, torch.nn.GroupNorm,
-                                                                    torch.nn.LayerNorm, torch.nn.modules.instancenorm._InstanceNorm))
-                      for p in m.parameters(recurse=False)}
-
-        def is_bias(name, p):
-            return (name.endswith('.bias') or name == 'bias') and id(p) not in norm_owned
-        weights = [(n, p) for n, p in student if p.requires_grad and not is_bias(n, p)]
-        biases = [(n, p) for n, p in student if p.requires_grad and is_bias(n, p)]
+        unknown = set(dead) - {n for n, p in student if p.requires_grad}
+        assert not unknown, f'dead parameters that are not trainable parameters of the model: {sorted(unknown)[:4]}'
+        keys = [(1.0, 1.0)]                                    # group 0 = the plain group, others in order of appearance
+        for n, p in student:
+            if p.requires_grad and n not in dead and self.mults[n] not in keys:
+                keys.append(self.mults[n])
+        assert len(keys) <= MAX_GROUPS, f'paramwise_cfg yields {len(keys)} (lr_mult, decay_mult) groups; the fused step holds {MAX_GROUPS}'
+        groups = [[(n, p) for n, p in student if p.requires_grad and n not in dead and self.mults[n] == k] for k in keys]
+        dead_l = [(n, p) for n, p in student if p.requires_grad and n in dead]
         frozen = [(n, p) for n, p in student if not p.requires_grad]
-        self.order = weights + biases + frozen
+        self.dead = frozenset(dead)
+        self.group_mults = keys
+        self.order = [e for g in groups for e in g] + dead_l + frozen
 
         def padded(entries):            # 16-byte aligned segments so every view is float4-friendly
             return sum((p.numel() + 3) // 4 * 4 for _, p in entries)
-        self.n_weights, self.n_biases, self.n_frozen = padded(weights), padded(biases), padded(frozen)
-        self.n_train = self.n_weights + self.n_biases
-        total = self.n_train + self.n_frozen
+        sizes = [padded(g) for g in groups]
+        self.group_ends = [sum(sizes[:i + 1]) for i in range(len(sizes))]
+        self.n_train = self.group_ends[-1]                                  # live trainable elements (gradient / momentum extent)
+        self.n_weights, self.n_biases = sizes[0], self.n_train - sizes[0]   # the two groups of the Point-Teacher configs
+        self.n_dead, self.n_frozen = padded(dead_l), padded(frozen)
+        self.frozen_start = self.n_train + self.n_dead
+        total = self.frozen_start + self.n_frozen
         dev = student[0][1].device
+        old = (self.student_flat, self.teacher_flat, self.grad_flat, self.mom_flat, dict(self.slices))
         self.student_flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.teacher_flat = torch.zeros(total, dtype=torch.float32, device=dev) if self.has_teacher else None
         self.grad_flat = torch.zeros(self.n_train, dtype=torch.float32, device=dev)
@@ -68,38 +149,64 @@ class FlatParams:
         self.numel = sum(p.numel() for _, p in self.order)
         off = 0
         self.slices = {}
-        self.train_params, self.grad_views = [], []
+        self.train_params, self.grad_views, self.dead_params = [], [], []
+        self._group_tables = None
         with torch.no_grad():
             for name, p in self.order:
                 n = p.numel()
                 t = teacher[name] if teacher is not None else None
-                if channels_last and p.dim() == 4:
+                if self.channels_last and p.dim() == 4:
                     O, I, KH, KW = p.shape
 
                     def view(buf):
                         return buf[off:off + n].view(O, KH, KW, I).permute(0, 3, 1, 2)
-                    view(self.student_flat).copy_(p.data)
-                    if t is not None:
-                        view(self.teacher_flat).copy_(t.data)
                 else:
                     def view(buf):
                         return buf[off:off + n].view(p.shape)
-                    self.student_flat[off:off + n].copy_(p.data.reshape(-1))
-                    if t is not None:
-                        self.teacher_flat[off:off + n].copy_(t.data.reshape(-1))
+                view(self.student_flat).copy_(p.data)
+                if t is not None:
+                    view(self.teacher_flat).copy_(t.data)
                 p.data = view(self.student_flat)
                 if t is not None:
                     t.data = view(self.teacher_flat)
-                if p.requires_grad:
+                if p.requires_grad and name not in dead:
+                    if old[2] is not None and name in old[4] and old[4][name][0] + n <= old[2].numel():
+                        o0 = old[4][name][0]                # a re-layout keeps gradient and momentum of parameters that stay live
+                        self.grad_flat[off:off + n].copy_(old[2][o0:o0 + n])
+                        self.mom_flat[off:off + n].copy_(old[3][o0:o0 + n])
                     p.grad = view(self.grad_flat)
                     self.train_params.append(p)
                     self.grad_views.append(p.grad)
+                elif p.requires_grad:
+                    p.grad = None
+                    self.dead_params.append((name, p))
                 self.slices[name] = (off, n)
                 off += (n + 3) // 4 * 4
+        self.name_of = {id(p): n for n, p in self.order}
         if self.has_teacher:
             model._flat = (self.teacher_flat, self.student_flat)
-            model._flat_n_train = self.n_train          # [n_train, total) = the frozen parameters
+            model._flat_frozen_start = self.frozen_start     # [frozen_start, total) = the frozen parameters
             model._stem_shared = None
+        F.PARAM_EPOCH[0] += 1                                 # cached views of parameter storage (fused BN affines) are stale
+
+    def relayout(self, dead):
+        """Move parameters between the live groups and the dead segment (values, gradients and momentum of parameters that
+        stay live are carried over; a revived parameter starts with zero gradient and momentum, as torch.optim.SGD creates
+        its momentum buffer at the first step that sees a gradient).  -> True if the layout changed."""
+        dead = frozenset(dead)
+        if dead == self.dead:
+            return False
+        self._build(dead)
+        return True
+
+    def group_tables(self):
+        """[host] arrays of pt_sgd_step_groups: ends, lr multipliers, decay multipliers."""
+        if self._group_tables is None:
+            import ctypes
+            ends = (ctypes.c_int64 * len(self.group_ends))(*self.group_ends)
+            self._group_tables = (ends, F.hip.host_floats([k[0] for k in self.group_mults]),
+                                  F.hip.host_floats([k[1] for k in self.group_mults]), len(self.group_ends))
+        return self._group_tables
 
     def zero_grad(self):
         self.grad_flat.zero_()
@@ -110,35 +217,54 @@ class FlatParams:
         for p in self.train_params:
             p.grad = None
 
-    def gather_grads(self):
+    def take_revived(self):
+        """Names of dead parameters autograd produced a gradient for in the backward that just ran (host-side knowledge:
+        `.grad` is no longer None - no synchronisation); their gradient tensors are dropped."""
+        out = []
+        for name, p in self.dead_params:
+            if p.grad is not None:
+                out.append(name)
+                p.grad = None
+        return out
+
+    def gather_grads(self, seen=None):
         """Copy the gradients autograd left in `.grad` into the flat buffer with multi-tensor copies (segments of
-        parameters that received none stay zero), then drop them."""
+        parameters that received none stay zero), then drop them.  `seen` (a set) collects the names that had one."""
         dst, src = [], []
         for p, v in zip(self.train_params, self.grad_views):
             if p.grad is not None:
                 dst.append(v)
                 src.append(p.grad)
+                if seen is not None:
+                    seen.add(self.name_of[id(p)])
         if dst:
             torch._foreach_copy_(dst, src)
         for p, v in zip(self.train_params, self.grad_views):
             p.grad = v
 
     def check_views(self):
-        """Autograd must have accumulated in place: every .grad still aliases the flat buffer."""
+        """Autograd must have accumulated in place: every live .grad still aliases the flat buffer, dead ones hold none."""
         base = self.grad_flat.data_ptr()
         for name, p in self.order:
-            if p.requires_grad:
+            if p.requires_grad and name not in self.dead:
                 off, n = self.slices[name]
                 if p.grad is None or p.grad.data_ptr() != base + 4 * off:
                     return False
+            elif p.requires_grad and p.grad is not None:
+                return False
         return True
 
 
 class BucketedGradExchange:
     """Mean of the flat gradient over the data-parallel ranks, OVERLAPPED with backward.
 
-    The trainable segment of the flat gradient buffer is cut into `n_buckets` contiguous ranges on parameter
-    boundaries.  A post-accumulate hook on every parameter counts arrivals; when the last gradient of a bucket
+    The live trainable segment of the flat gradient buffer is cut into contiguous buckets on parameter boundaries, never
+    across a parameter-group boundary (the bias group holds parameters of every depth of the network: mixed into a weight
+    bucket it would hold that bucket back until the first layers' biases arrive); groups below `small` elements are one
+    bucket each.  Dead parameters (FlatParams) are in no bucket: a bucket is complete when every one of ITS parameters has
+    fired, and with the never-used MIL FC stacks inside, the buckets of the head - the first to be needed - never completed
+    and every all-reduce went out after backward (round-2 verdict K1).
+    A post-accumulate hook on every parameter counts arrivals; when the last gradient of a bucket
     has been produced the bucket is copied into the flat buffer with one multi-tensor copy and its all-reduce
     (RCCL over xGMI; a few large messages, xGMI being point-to-point) is issued on a side stream while autograd
     keeps computing the earlier layers.  `finish()` flushes buckets whose parameters received no gradient in
@@ -149,42 +275,62 @@ class BucketedGradExchange:
     waits until every bucket ahead of it in that order has been issued, so two ranks on which gradients arrive in
     different orders, or on which a parameter receives no gradient at all (an empty image, a data-dependent branch),
     still enqueue the same sequence of equally sized all-reduces; `finish()` issues whatever is left in the same order
-    and asserts the sequence."""
+    and asserts the sequence.  `stats` = what the last iteration did (buckets, how many went out during backward, bytes)."""
 
-    def __init__(self, flat, n_buckets=6, device=None):
+    def __init__(self, flat, n_buckets=6, device=None, small=1 << 16):
         self.flat = flat
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         self.stream = torch.cuda.Stream(device=device) if (device is not None and device.type == 'cuda') else None
+        self.avg = None
+        if self.world > 1 and dist.get_backend() == 'nccl':
+            self.avg = dist.ReduceOp.AVG                    # RCCL divides inside the collective: one launch less per bucket
         total = flat.n_train
         target = max(total // max(int(n_buckets), 1), 1)
         self.buckets = []                      # [start, end, [(param, view)]]
-        cur, start, acc = [], 0, 0
+        group_of, g = [], 0
         off = 0
-        for p, v in zip(flat.train_params, flat.grad_views):
+        for p in flat.train_params:
+            while off >= flat.group_ends[g]:
+                g += 1
+            group_of.append(g)
+            off += (p.numel() + 3) // 4 * 4
+        gsize = [e - (flat.group_ends[i - 1] if i else 0) for i, e in enumerate(flat.group_ends)]
+        # the buckets that hold the FIRST layers complete last and their all-reduce has nothing left to hide behind: the first
+        # two buckets of a group are a quarter / half of the target size, so the exposed tail is small
+        cur, start, acc, off, k = [], 0, 0, 0, 0
+        for i, (p, v) in enumerate(zip(flat.train_params, flat.grad_views)):
             n = (p.numel() + 3) // 4 * 4
             cur.append((p, v))
             off += n
             acc += n
-            if acc >= target:
+            last_of_group = i + 1 == len(group_of) or group_of[i + 1] != group_of[i]
+            want = target // 4 if k == 0 else (target // 2 if k == 1 else target)
+            if last_of_group or (acc >= want and gsize[group_of[i]] > small):
                 self.buckets.append([start, off, cur])
-                cur, start, acc = [], off, 0
-        if cur:
-            self.buckets.append([start, off, cur])
-        assert off == total, (off, total)
+                cur, start, acc, k = [], off, 0, (0 if last_of_group else k + 1)
+        assert not cur and off == total, (off, total)
         self.bucket_of = {id(p): b for b, (_, _, ps) in enumerate(self.buckets) for p, _ in ps}
-        pos = {id(p): i for i, p in enumerate((flat.model.student if flat.has_teacher else flat.model).parameters())}
+        pos = {id(p): i for i, p in enumerate(flat.root.parameters())}
         first = [min(pos[id(p)] for p, _ in ps) for _, _, ps in self.buckets]
         self.issue_order = sorted(range(len(self.buckets)), key=lambda b: -first[b])
         self.left, self.done, self.active = [0] * len(self.buckets), [True] * len(self.buckets), False
         self.ready, self.next, self.issued = [False] * len(self.buckets), 0, []
-        for p in flat.train_params:
-            p.register_post_accumulate_grad_hook(self._on_grad)
+        self.seen = None
+        self.stats = dict(buckets=len(self.buckets), issued_during_backward=0, bytes=4 * total)
+        self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in flat.train_params]
 
-    def begin(self):
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+    def begin(self, seen=None):
         self.left = [len(ps) for _, _, ps in self.buckets]
         self.done = [False] * len(self.buckets)
         self.ready = [False] * len(self.buckets)
         self.next, self.issued = 0, []
+        self.seen = seen
+        self._in_backward = 0
         self.active = True
 
     def _on_grad(self, p):
@@ -200,6 +346,7 @@ class BucketedGradExchange:
         while self.next < len(self.issue_order) and self.ready[self.issue_order[self.next]]:
             self._flush(self.issue_order[self.next])
             self.next += 1
+            self._in_backward += 1
 
     def _flush(self, b):
         start, end, ps = self.buckets[b]
@@ -208,6 +355,8 @@ class BucketedGradExchange:
             if p.grad is not None:
                 dst.append(v)
                 src.append(p.grad)
+                if self.seen is not None:
+                    self.seen.add(self.flat.name_of[id(p)])
         if dst:
             with torch.no_grad():
                 torch._foreach_copy_(dst, src)
@@ -221,17 +370,22 @@ class BucketedGradExchange:
             else:
                 self.stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self.stream):
-                    g.div_(self.world)
-                    dist.all_reduce(g)
+                    if self.avg is not None:
+                        dist.all_reduce(g, op=self.avg)
+                    else:
+                        g.div_(self.world)
+                        dist.all_reduce(g)
         self.done[b] = True
         self.issued.append(b)
 
     def finish(self):
+        during = self._in_backward
         while self.next < len(self.issue_order):            # buckets still waiting for a gradient that never came, in order
             self._flush(self.issue_order[self.next])
             self.next += 1
         assert self.issued == self.issue_order, (self.issued, self.issue_order)
         self.active = False
+        self.stats = dict(buckets=len(self.buckets), issued_during_backward=during, bytes=4 * self.flat.n_train)
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
         for p, v in zip(self.flat.train_params, self.flat.grad_views):
@@ -298,14 +452,11 @@ class Trainer:
             # kernels).  MIOpen's NCHW bf16 path was measured 13 % away from a bf16-rounding oracle on the PSAGG
             # features (NHWC: 1.2 %, profiles/r02/bf16_accuracy.txt), so the layout is not left to the caller.
             channels_last = True
-        self.flat = FlatParams(model, channels_last=channels_last)
+        pw = optimizer_cfg.get('paramwise_cfg', {}) or {}
+        self.flat = FlatParams(model, channels_last=channels_last, paramwise_cfg=pw)
         self.channels_last = channels_last
         self.momentum = optimizer_cfg.get('momentum', 0.0)
         self.weight_decay = optimizer_cfg.get('weight_decay', 0.0)
-        pw = optimizer_cfg.get('paramwise_cfg', {}) or {}
-        self.bias_lr_mult, self.bias_decay_mult = pw.get('bias_lr_mult', 1.0), pw.get('bias_decay_mult', 1.0)
-        assert pw.get('norm_decay_mult', 1.0) == 1.0 and not pw.get('custom_keys'), \
-            'paramwise_cfg: only bias_lr_mult / bias_decay_mult are on the Point-Teacher path (norm parameters decay like weights)'
         clip = (optimizer_config or {}).get('grad_clip') or {}
         assert clip.get('norm_type', 2) == 2
         self.max_norm = float(clip.get('max_norm', 0.0))
@@ -319,7 +470,13 @@ class Trainer:
         self.iter = 0
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         # N > 1: bucketed exchange overlapped with backward; N == 1: nothing to exchange, one gather after backward
-        self.exchange = BucketedGradExchange(self.flat, max(grad_chunks, 1) + 2, dev) if self.world > 1 else None
+        self.n_buckets = max(grad_chunks, 1) + 2
+        self.exchange = BucketedGradExchange(self.flat, self.n_buckets, dev) if self.world > 1 else None
+        # Parameters that never receive a gradient (FlatParams "dead"): discovered at the first step, agreed between the ranks
+        # with one all-reduce of a bitmap, re-checked every `revive_interval` steps (N > 1; N == 1 sees a revival at once).
+        self.dead_known = False
+        self.revive_interval = 100
+        self._revived = set()
         # BASELINE configs[2] "bf16 backbone + fp32 head": autocast covers backbone / FPN / PSAGG only (Student_FCOS.extract_feat)
         self.autocast_dtype = autocast_dtype
         for m in model.modules():
@@ -349,26 +506,76 @@ class Trainer:
         if self.channels_last:
             data = dict(data, img=data['img'].contiguous(memory_format=torch.channels_last))
         out = self.model.train_step(data, None)     # reduced precision, if any, is scoped inside extract_feat
+        seen = set() if not self.dead_known else None
         if self.exchange is not None:
-            self.exchange.begin()
+            self.exchange.begin(seen)
             out['loss'].backward()
             self.exchange.finish()
         else:
             out['loss'].backward()
-            self.flat.gather_grads()
+            self.flat.gather_grads(seen)
+        self._settle_dead(seen)
         f = self.flat
         sq = F.grad_sqnorm(f.grad_flat) if self.max_norm > 0 else None
-        F.sgd_step_(f.student_flat[:f.n_train], f.grad_flat, f.mom_flat, f.n_weights, self.lr_t, self.momentum,
-                    self.weight_decay, self.bias_lr_mult, self.bias_decay_mult, sq, self.max_norm, self.iter == 0)
+        F.sgd_step_groups_(f.student_flat[:f.n_train], f.grad_flat, f.mom_flat, f.group_tables(), self.lr_t, self.momentum,
+                           self.weight_decay, sq, self.max_norm, self.iter == 0)
         self.iter += 1
         return out
 
+    # ------------------------------------------------------------------------------ never-used parameters --
+    def _agree(self, names, universe):
+        """Union over the ranks of a set of parameter names (one all-reduce of a bitmap + one read: only at the first step
+        and every `revive_interval` steps)."""
+        if self.world == 1:
+            return set(names)
+        bits = torch.zeros(len(universe), dtype=torch.int32)
+        for i, n in enumerate(universe):
+            if n in names:
+                bits[i] = 1
+        bits = bits.to(self.flat.student_flat.device)
+        dist.all_reduce(bits, op=dist.ReduceOp.MAX)
+        bits = bits.cpu()
+        return {n for i, n in enumerate(universe) if int(bits[i])}
+
+    def _settle_dead(self, seen):
+        """torch.optim.SGD skips parameters whose `.grad is None` and DDP reduces nothing for them: the parameters no backward
+        has ever reached (TS_P2BFCOSHead.shared_fcs / shared_fcs_refine / fc_iou: 31 % of the student) leave the live groups.
+        First step: dead = trainable parameters without a gradient on ANY rank.  Later: a dead parameter that received a
+        gradient is revived (N == 1: in the same step, before the update; N > 1: at the next agreement point, so that every
+        rank re-lays its buffers in the same step - its gradients of the steps in between are dropped, documented)."""
+        f = self.flat
+        trainable = [n for n, p in f.order if p.requires_grad]
+        if not self.dead_known:
+            live = self._agree(seen | set(f.take_revived()), trainable)
+            self.dead_known = True
+            self._relayout(set(trainable) - live)
+            return
+        self._revived.update(f.take_revived())
+        if self.world == 1:
+            if self._revived:
+                self._relayout(set(f.dead) - self._revived)
+                self._revived = set()
+        elif (self.iter + 1) % self.revive_interval == 0 and f.dead:
+            rev = self._agree(self._revived, sorted(f.dead))
+            self._revived = set()
+            if rev:
+                self._relayout(set(f.dead) - rev)
+
+    def _relayout(self, dead):
+        if self.flat.relayout(dead) and self.exchange is not None:
+            self.exchange.remove()
+            self.exchange = BucketedGradExchange(self.flat, self.n_buckets, self.flat.student_flat.device)
+
     def state_dict(self):
-        return dict(model=self.model.state_dict(), momentum=self.flat.mom_flat.clone(), iter=self.iter)
+        return dict(model=self.model.state_dict(), momentum=self.flat.mom_flat.clone(), iter=self.iter,
+                    dead=sorted(self.flat.dead), dead_known=self.dead_known)
 
     def load_state_dict(self, sd):
         self.model.load_state_dict(sd['model'])
         if hasattr(self.model, '_stem_shared'):
             self.model._stem_shared = None           # re-decided from the loaded state
+        # the flat momentum is stored in the layout of the run that wrote it: adopt its dead set first
+        self._relayout(set(sd.get('dead', ())))
+        self.dead_known = bool(sd.get('dead_known', False))
         self.flat.mom_flat.copy_(sd['momentum'])
         self.iter = sd['iter']

@@ -60,7 +60,20 @@ def _worker(rank, world, port, q):
             lv = out['log_vars'].materialize()
             assert all(v == v and abs(v) != float('inf') for v in lv.values()), (rank, it, lv)
             keys.append(sorted(lv))
-            assert tr.exchange.issued == tr.exchange.issue_order
+            assert it == 0 or tr.exchange.issued == tr.exchange.issue_order      # (step 0 ends with a freshly built exchange)
+            if it == 0:
+                # round-2 verdict K1 / P3: the never-used MIL stacks left the live segment at the first step, on both ranks
+                # alike (one bitmap all-reduce) - although rank 1 saw an image without objects
+                dead = sorted(tr.flat.dead)
+                assert tr.dead_known and len(dead) == 10, dead
+                assert all(n.split('.')[1] in ('shared_fcs', 'shared_fcs_refine', 'fc_iou') for n in dead)
+                assert tr.exchange.stats['bytes'] == 4 * tr.flat.n_train < 242e6
+                dead_before = torch.cat([tr.flat.student_flat[tr.flat.slices[n][0]:tr.flat.slices[n][0] + tr.flat.slices[n][1]] for n in dead]).clone()
+            else:
+                # ... and the REAL backward now completes buckets while it runs: all but the first layers' buckets go out
+                # before finish(), the first of them (MIL head) before the backbone's backward has produced anything
+                st = tr.exchange.stats
+                assert st['issued_during_backward'] >= max(st['buckets'] - 2, 4), st
         torch.cuda.synchronize()
         s, t = tr.flat.student_flat.cpu(), tr.flat.teacher_flat.cpu()
         both_s = [torch.empty_like(s) for _ in range(world)]
@@ -70,6 +83,11 @@ def _worker(rank, world, port, q):
         assert torch.equal(both_s[0], both_s[1]), float((both_s[0] - both_s[1]).abs().max())
         assert torch.equal(both_t[0], both_t[1])
         assert torch.isfinite(s).all() and keys[0] == keys[1] == keys[2]
+        dead_after = torch.cat([tr.flat.student_flat[tr.flat.slices[n][0]:tr.flat.slices[n][0] + tr.flat.slices[n][1]] for n in dead])
+        assert torch.equal(dead_after, dead_before)                   # no weight decay, no momentum: torch.optim.SGD skips `grad is None`
+        dlist = [None] * world
+        dist.all_gather_object(dlist, dead)
+        assert dlist[0] == dlist[1]
         klist = [None] * world
         dist.all_gather_object(klist, keys)
         assert klist[0] == klist[1]

@@ -1,0 +1,87 @@
+"""fp32 GEMM on the bf16 matrix cores (csrc/gemm_split.hip, `pt_split_bf16x3` + `pt_gemm_bf16x6_nt`): the MIL FC stacks
+(fcos_head_p2b_ts.py:1202-1236, :1240-1256) as six bf16 MFMA products per fp32 product with fp32 accumulation.
+Checked against a float64 reference; the bar is the fp32 library GEMM's own error on the same inputs (round-2 verdict, item 2)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _err(y, ref):
+    """max |y - ref| / (|a| @ |b|^T): error in units of the sum of the products' magnitudes - what an fp32 chain's bound is quoted in."""
+    return float(((y.double() - ref).abs() / _err.scale).max())
+
+
+def test_split_planes_sum_back_exactly():
+    """x0 + x1 + x2 == x bit for bit (8 + 8 + 8 significant bits, each step rounded to nearest); both orientations; padding is zero."""
+    from point_teacher_amd import functional as F
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device='cpu').manual_seed(0)
+    x = (torch.randn(70, 45, generator=g) * torch.logspace(-6, 6, 45)).to(dev)
+    x[3, 7] = 0.0
+    x[5, 9] = 1e-30
+    sp = F.split_bf16x3(x)
+    assert (sp.rows, sp.k) == (70, 45) and sp.planes.shape == (3, 5 * 2 * 512) and sp.planes.dtype == torch.bfloat16
+    p = sp.dense()                                                    # [3, 80, 64]: un-blocked, un-swizzled
+    s = p[0] + p[1] + p[2]                                            # exact in fp32: the terms do not overlap
+    assert torch.equal(s[:70, :45], x) and float(s[70:].abs().max()) == 0 and float(s[:, 45:].abs().max()) == 0
+    assert torch.equal(p[0][:70, :45], x.to(torch.bfloat16).float())  # the leading term is the round-to-nearest bf16 of x
+    st = F.split_bf16x3(x, transpose=True)
+    assert (st.rows, st.k) == (45, 70)
+    pt = st.dense()                                                   # [3, 48, 96]
+    s2 = pt[0] + pt[1] + pt[2]
+    assert torch.equal(s2[:45, :70], x.t()) and float(s2[45:].abs().max()) == 0 and float(s2[:, 70:].abs().max()) == 0
+    v = x[:, 3:40]                                                    # a strided view (row stride 45, unaligned start)
+    pv = F.split_bf16x3(v).dense()
+    assert torch.equal((pv[0] + pv[1] + pv[2])[:70, :37], v)
+
+
+@pytest.mark.parametrize('M,N,K', [(5000, 1024, 12544), (5000, 1024, 1024), (400, 1024, 12544), (1024, 12544, 5000), (333, 200, 96),
+                                   (97, 130, 40)])
+def test_gemm_matches_fp64_at_least_as_well_as_the_fp32_library(M, N, K):
+    from point_teacher_amd import functional as F
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device='cpu').manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(dev)
+    b = (torch.randn(N, K, generator=g) * 0.05).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    ref = a.double() @ b.double().t()
+    _err.scale = a.double().abs() @ b.double().abs().t()
+    y = F.gemm_bf16x6_nt(F.split_bf16x3(a), F.split_bf16x3(b))
+    lib = a @ b.t()
+    e_mine, e_lib = _err(y, ref), _err(lib, ref)
+    print(f'[{M}x{N}x{K}] bf16x6 {e_mine:.3e}  fp32 library {e_lib:.3e}  (units of sum |a||b|)')
+    assert e_mine <= max(e_lib, 2.0 ** -24), (e_mine, e_lib)
+    assert e_mine < 3e-7
+    # every tile height gives the same numbers up to the k-order inside a tile (none: the k loop is the same) -> identical
+    for rows in (96, 128, 160, 192, 224, 256):
+        y2 = F.gemm_bf16x6_nt(F.split_bf16x3(a), F.split_bf16x3(b), tile_rows=rows)
+        assert torch.equal(y2, y), rows
+    # epilogue: bias + ReLU
+    yb = F.gemm_bf16x6_nt(F.split_bf16x3(a), F.split_bf16x3(b), bias=bias, relu=True)
+    torch.testing.assert_close(yb, torch.relu(y + bias), rtol=0, atol=0)
+    # the transposed splits bring the other two products of a Linear to the same kernel
+    if M * N <= 6e6:
+        gy = torch.randn(M, N, generator=g).to(dev)
+        gx = F.gemm_bf16x6_nt(F.split_bf16x3(gy), F.split_bf16x3(b, transpose=True))            # gy @ b
+        rx = gy.double() @ b.double()
+        assert float((gx.double() - rx).abs().max() / rx.abs().max()) < 5e-6
+        gw = F.gemm_bf16x6_nt(F.split_bf16x3(gy, transpose=True), F.split_bf16x3(a, transpose=True))   # gy^T @ a
+        rw = gy.double().t() @ a.double()
+        assert float((gw.double() - rw).abs().max() / rw.abs().max()) < 5e-6
+
+
+def test_split_linear_autograd_matches_torch():
+    from point_teacher_amd import functional as F
+    dev = torch.device('cuda:0')
+    torch.manual_seed(3)
+    x = torch.randn(777, 12544, device=dev, requires_grad=True)
+    fc = torch.nn.Linear(12544, 1024).to(dev)
+    y = F.split_linear(x, fc.weight, fc.bias, relu=True)
+    ref = torch.relu(torch.nn.functional.linear(x.double(), fc.weight.double(), fc.bias.double()))
+    assert float((y.double() - ref).abs().max()) < 2e-5
+    gy = torch.randn_like(y)
+    gx, gw, gb = torch.autograd.grad(y, (x, fc.weight, fc.bias), gy)
+    rx, rw, rb = torch.autograd.grad(ref, (x, fc.weight, fc.bias), gy.double())
+    for mine, r in ((gx, rx), (gw, rw), (gb, rb)):
+        assert float((mine.double() - r).abs().max() / r.abs().max()) < 2e-6

@@ -150,6 +150,7 @@ def test_update_points_lamda_half_vs_reference_iteration():
     det = pta.registry.DETECTORS.get('TS_P2B_FCOS')
     m = det.__new__(det)                       # the method under test reads only these attributes
     m.lamda, m.gt_bboxes_point, m.refined_gt_bboxes_point = 0.5, {}, {}
+    m.count, m.point_stamp = 0, {}
     metas = [dict(ori_filename=f'g{i}.png') for i in range(2)]
     boxes = [G.t(f'in_gt_bboxes{i}').to(DEV) for i in range(2)]
     for i in range(2):

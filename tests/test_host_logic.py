@@ -95,3 +95,94 @@ def test_upload_helper_host_path():
     off, tot = Fn.make_offsets([2, 0, 5], 'cpu')
     assert off.tolist() == [0, 2, 2, 7] and tot == 7
     assert Fn._ring.seg_words * Fn._ring.SEG == Fn._ring.words
+
+
+def test_pinned_ring_cursor_exact_fills():
+    """an upload that ends exactly on a segment end - or on the end of the ring - used to park the cursor
+    there: no event for the segment left, no wait for the segment entered, and at the ring's end an empty slice (ValueError)
+    that broke every later upload.  The cursor logic is driven here without a device: events are a log."""
+    from point_teacher_amd.functional import _PinnedRing
+
+    class Ring(_PinnedRing):
+        SEG = 4
+
+        def __init__(self):
+            super().__init__(words=64)                      # 4 segments of 16 words
+            self.log = []
+            self.buf = torch.zeros(self.words, dtype=torch.int32)
+
+        def _record(self, seg, stream):
+            self.log.append(('record', seg))
+
+        def _await(self, seg):
+            self.log.append(('await', seg))
+
+        def put(self, n, dtype=torch.int32):
+            arr = np.arange(n, dtype=np.int32 if dtype == torch.int32 else np.float32) + 1
+            view, seg = self._stage(arr, n, dtype, None)
+            assert view.numel() == n and np.array_equal(view.numpy(), arr), (n, self.pos)
+            self._finish(seg, None)
+            assert 0 <= self.pos < self.words                 # never parked on the end of the ring
+            return seg
+
+    r = Ring()
+    assert r.put(10) == 0 and r.pos == 10 and r.log == []
+    assert r.put(6) == 0                                   # exact fill of segment 0: turned at once
+    assert r.pos == 16 and r.log == [('record', 0), ('await', 1)]
+    assert r.put(16, torch.float32) == 1 and r.pos == 32   # a whole segment in one upload
+    assert r.log[-2:] == [('record', 1), ('await', 2)]
+    r.put(9)
+    assert r.put(9) == 3 and r.pos == 48 + 9               # does not fit the rest of segment 2: segment 3
+    assert r.log[-2:] == [('record', 2), ('await', 3)]
+    assert r.put(7) == 3                                   # exact fill of the LAST segment: back to word 0, not parked on 64
+    assert r.pos == 0 and r.log[-2:] == [('record', 3), ('await', 0)]
+    for lap in range(3):                                   # many laps of mixed sizes incl. exact fills: never an empty slice,
+        for n in (1, 15, 16, 3, 13, 8, 8, 5, 11, 16, 2, 2, 12):
+            r.put(n)                                       # every byte written where the view says
+    records = [s for k, s in r.log if k == 'record']
+    awaits = [s for k, s in r.log if k == 'await']
+    assert awaits == [(s + 1) % 4 for s in records]        # every segment entered was awaited, every segment left recorded
+    assert all(b == (a + 1) % 4 for a, b in zip(records, records[1:]))     # segments are left in ring order, none skipped
+
+
+def test_point_state_merge_keeps_the_newest_refinement():
+    """the per-rank point dictionaries of a checkpoint are merged by refinement stamp, not by rank order."""
+    from point_teacher_amd.runner import merge_point_states
+    t = torch.tensor
+    r0 = dict(count=20, epoch=1, gt_bboxes_point={'a': t([1.]), 'b': t([2.])}, refined_gt_bboxes_point={'a': t([10.]), 'b': t([20.])},
+              point_stamp={'a': 17, 'b': 3})
+    r1 = dict(count=20, epoch=1, gt_bboxes_point={'b': t([2.5]), 'c': t([3.])}, refined_gt_bboxes_point={'b': t([25.]), 'c': t([30.])},
+              point_stamp={'b': 12, 'c': 5})
+    r2 = dict(count=20, epoch=1, gt_bboxes_point={'a': t([1.5]), 'd': t([4.])}, refined_gt_bboxes_point={'a': t([15.])}, point_stamp={'a': 9})
+    m = merge_point_states([r0, r1, r2])
+    assert m['count'] == 20 and set(m['refined_gt_bboxes_point']) == {'a', 'b', 'c'} and set(m['gt_bboxes_point']) == {'a', 'b', 'c', 'd'}
+    assert float(m['refined_gt_bboxes_point']['a']) == 10. and float(m['gt_bboxes_point']['a']) == 1.       # rank 0 refined it last (17 > 9)
+    assert float(m['refined_gt_bboxes_point']['b']) == 25. and float(m['gt_bboxes_point']['b']) == 2.5      # rank 1 (12 > 3): dict.update order would agree ...
+    m2 = merge_point_states([r1, r0, r2])
+    assert float(m2['refined_gt_bboxes_point']['b']) == 25. and float(m2['refined_gt_bboxes_point']['a']) == 10.   # ... but no longer decides
+    assert m['point_stamp'] == {'a': 17, 'b': 12, 'c': 5} and float(m['gt_bboxes_point']['d']) == 4.
+
+
+def test_epoch_batches_report_the_epoch_a_resume_must_start_with():
+    """after the last batch of loader epoch e an end-of-epoch checkpoint must store e + 1."""
+    from point_teacher_amd.datasets.loader import EpochBatches
+
+    class Loader:
+        def __init__(self):
+            self.epochs = []
+
+        def set_epoch(self, e):
+            self.epochs.append(e)
+
+        def __len__(self):
+            return 3
+
+        def __iter__(self):
+            e = self.epochs[-1]
+            return iter([(e, i) for i in range(3)])
+    b = EpochBatches(Loader())
+    assert b.next_epoch() == 0
+    assert [b() for _ in range(2)] == [(0, 0), (0, 1)] and b.next_epoch() == 0          # mid-epoch: the same epoch again
+    assert b() == (0, 2) and b.epoch == 0 and b.next_epoch() == 1                       # used up: the next one
+    resumed = EpochBatches(Loader(), start_epoch=b.next_epoch())
+    assert resumed() == b() == (1, 0)                                                   # the resumed run and the uninterrupted one agree

@@ -27,7 +27,7 @@ def test_norm_biases_are_not_bias_group():
             for p in self.frozen.parameters():
                 p.requires_grad = False
     net = Net()
-    flat = FlatParams(net)
+    flat = FlatParams(net, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.))
     seg = {}
     for name, _ in flat.order:
         off, n = flat.slices[name]
@@ -37,6 +37,80 @@ def test_norm_biases_are_not_bias_group():
     assert seg['bn.weight'] == 'weights' and seg['conv.weight'] == 'weights' and seg['fc.weight'] == 'weights'
     assert seg['frozen.weight'] == 'frozen' and seg['frozen.bias'] == 'frozen'
     assert flat.n_biases == 8 + 4
+    assert flat.group_mults == [(1., 1.), (2., 0.)] and flat.group_ends == [flat.n_weights, flat.n_train]
+
+
+def test_paramwise_cfg_of_the_yolof_baseline_and_dcn_rules():
+    """`paramwise_cfg=dict(norm_decay_mult=0., custom_keys={'backbone': dict(lr_mult=1. / 3)})`
+    (configs/baselines/aitodv2_yolof_r50_1x.py:70-71): a custom key wins over every other rule for the parameters whose name
+    contains it; norm layers elsewhere take decay x 0; every distinct (lr_mult, decay_mult) pair is one contiguous group of
+    the flat buffers.  DCN modules: their biases (and the conv_offset child's) take neither bias_lr_mult nor bias_decay_mult;
+    conv_offset takes dcn_offset_lr_mult (mmcv DefaultOptimizerConstructor `is_dcn_module`)."""
+    from point_teacher_amd.nn_modules import ModulatedDeformConv2dPack
+    from point_teacher_amd.runtime import FlatParams, param_multipliers
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, bias=True), torch.nn.BatchNorm2d(8))
+            self.neck = torch.nn.Sequential(torch.nn.Conv2d(8, 8, 3, bias=True), torch.nn.BatchNorm2d(8))
+            self.dw = torch.nn.Conv2d(8, 8, 3, groups=8, bias=False)
+            self.dcn = ModulatedDeformConv2dPack(8, 8, 3, padding=1)
+    net = Net()
+    pw = dict(norm_decay_mult=0., custom_keys={'backbone': dict(lr_mult=1. / 3)})
+    m = param_multipliers(net, pw)
+    third = float(1. / 3)
+    assert m['backbone.0.weight'] == m['backbone.0.bias'] == m['backbone.1.weight'] == (third, 1.)   # the key wins, decay x 1
+    assert m['neck.0.weight'] == (1., 1.) and m['neck.0.bias'] == (1., 1.)
+    assert m['neck.1.weight'] == m['neck.1.bias'] == (1., 0.)
+    flat = FlatParams(net, paramwise_cfg=pw)
+    assert flat.group_mults == [(1., 1.), (third, 1.), (1., 0.)]
+    for name, _ in flat.order:
+        off = flat.slices[name][0]
+        g = sum(off >= e for e in flat.group_ends)
+        assert flat.group_mults[g] == m[name], name
+    m2 = param_multipliers(net, dict(bias_lr_mult=2., bias_decay_mult=0., dwconv_decay_mult=0.5, dcn_offset_lr_mult=0.1))
+    assert m2['neck.0.bias'] == (2., 0.) and m2['dw.weight'] == (1., 0.5)
+    assert m2['dcn.bias'] == (1., 1.) and m2['dcn.weight'] == (1., 1.)
+    assert m2['dcn.conv_offset.weight'] == (0.1, 1.) and m2['dcn.conv_offset.bias'] == (0.1, 1.)
+    with pytest.raises(AssertionError, match='groups'):
+        FlatParams(net, paramwise_cfg=dict(custom_keys={f'backbone.{i}': dict(lr_mult=0.1 * (i + 1)) for i in range(2)} |
+                                           {f'neck.{i}': dict(lr_mult=0.01 * (i + 1)) for i in range(2)} |
+                                           {'dw': dict(lr_mult=5.), 'dcn.weight': dict(lr_mult=6.), 'dcn.bias': dict(lr_mult=7.),
+                                            'dcn.conv': dict(lr_mult=8.)}))
+
+
+def test_dead_segment_and_relayout():
+    """Trainable parameters without a gradient leave the live groups: they keep their values, have no gradient / momentum slot
+    (`grad is None`, what torch.optim.SGD skips), and come back - with their values - when revived."""
+    from point_teacher_amd.runtime import FlatParams
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 6), torch.nn.Linear(6, 7), torch.nn.Linear(7, 3))
+    for p in net[2].parameters():
+        p.requires_grad = False
+    before = {n: p.detach().clone() for n, p in net.named_parameters()}
+    flat = FlatParams(net, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.))
+    n_all = flat.n_train
+    flat.grad_flat.copy_(torch.arange(flat.n_train, dtype=torch.float32))
+    flat.mom_flat.copy_(-torch.arange(flat.n_train, dtype=torch.float32))
+    g0 = {n: p.grad.clone() for n, p in net.named_parameters() if p.requires_grad}
+    assert flat.relayout({'1.weight', '1.bias'}) and not flat.relayout({'1.weight', '1.bias'})
+    assert flat.n_train == n_all - 44 - 8 and flat.n_dead == 44 + 8 and flat.frozen_start == flat.n_train + flat.n_dead
+    assert net[1].weight.grad is None and net[1].bias.grad is None and flat.check_views()
+    for n, p in net.named_parameters():
+        assert torch.equal(p, before[n]), n                                             # values survive
+        off, k = flat.slices[n]
+        assert p.data_ptr() == flat.student_flat.data_ptr() + 4 * off
+        if p.requires_grad and n not in flat.dead:
+            assert torch.equal(p.grad, g0[n]) and torch.equal(flat.mom_flat[off:off + k], -g0[n].reshape(-1))   # carried over
+    assert [n for n, _ in flat.dead_params] == ['1.weight', '1.bias']
+    net[1].weight.grad = torch.ones_like(net[1].weight)                                 # autograd reached it after all
+    assert flat.take_revived() == ['1.weight'] and net[1].weight.grad is None
+    assert flat.relayout({'1.bias'}) and flat.n_dead == 8
+    off, k = flat.slices['1.weight']
+    assert off < flat.n_weights and float(flat.grad_flat[off:off + k].abs().sum()) == 0 and torch.equal(net[1].weight, before['1.weight'])
+    with pytest.raises(AssertionError, match='not trainable'):
+        flat.relayout({'2.weight'})
 
 
 def test_retinanet_baseline_config_groups():
@@ -47,7 +121,7 @@ def test_retinanet_baseline_config_groups():
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         model = pta.build_detector(cfg.model)
-    flat = FlatParams(model)
+    flat = FlatParams(model, paramwise_cfg=cfg.optimizer.paramwise_cfg)
     bn_bias = [n for n, p in model.named_parameters() if p.requires_grad and '.bn' in n and n.endswith('.bias')]
     assert bn_bias, 'this config trains BatchNorm affines'
     for n in bn_bias:

@@ -213,9 +213,17 @@ def test_full_size_iteration_properties():
     trainer = pta.Trainer(model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config, channels_last=True)
     data = SyntheticTiles(n=2, size=800, mean_objects=300, seed=1, device=dev)
     f = trainer.flat
-    t0, s0 = f.teacher_flat.clone(), f.student_flat.clone()
     batch = data.batch(0, 2)
-    trainer.step(batch)                                              # warm-up iteration (allocator, MIOpen)
+    before = {n: p.detach().clone() for n, p in model.student.named_parameters()}
+    trainer.step(batch)                 # warm-up iteration (allocator, MIOpen); the first step also settles the dead segment
+    dead = sorted(f.dead)
+    assert trainer.dead_known and len(dead) == 10 and all(n.split('.')[1] in ('shared_fcs', 'shared_fcs_refine', 'fc_iou') for n in dead)
+    assert f.n_dead * 4 > 110e6 and f.grad_flat.numel() == f.mom_flat.numel() == f.n_train and f.check_views()
+    for n in dead:                      # (0) round-2 verdict P3: never-used parameters are not decayed (torch.optim.SGD skips grad None)
+        assert torch.equal(dict(model.student.named_parameters())[n], before[n]), n
+    f.mom_flat.zero_()                  # so that the next step is a "first" step again: buf = 0.9*0 + d
+    t0, s0 = f.teacher_flat.clone(), f.student_flat.clone()
+    trainer.step(batch)
     t1, s1 = f.teacher_flat.clone(), f.student_flat.clone()
     torch.testing.assert_close(t1, t0 * 0.999 + s0 * (1 - 0.999), rtol=1e-6, atol=1e-8)        # (1) EMA ran BEFORE the update
     g = f.grad_flat.clone()
@@ -228,7 +236,8 @@ def test_full_size_iteration_properties():
     exp_b = s0[nw:f.n_train] - 2 * lr * (coef * g[nw:f.n_train])
     torch.testing.assert_close(s1[:nw], exp_w, rtol=1e-4, atol=1e-7)
     torch.testing.assert_close(s1[nw:f.n_train], exp_b, rtol=1e-4, atol=1e-7)
-    assert torch.equal(s1[f.n_train:], s0[f.n_train:])                                         # frozen segment untouched
+    assert torch.equal(s1[f.n_train:], s0[f.n_train:])                                         # dead and frozen segments untouched
+    assert f.frozen_start == f.n_train + f.n_dead
     # (2) gather path == autograd: rerun the same iteration by hand on the updated weights
     model._inject = dict(neg0=torch.rand(2, 4, 200, device=dev), aug=(['None', 'horizontal'], [1.0, 0.9]))
     f.zero_grad(); f.detach_grads()
@@ -239,7 +248,7 @@ def test_full_size_iteration_properties():
     f.gather_grads()
     unused = 0
     for n, p in f.order:
-        if not p.requires_grad:
+        if not p.requires_grad or n in f.dead:
             continue
         off, k = f.slices[n]
         seg = f.grad_flat[off:off + k]
@@ -249,7 +258,8 @@ def test_full_size_iteration_properties():
         else:
             ref = per_param[n].permute(0, 2, 3, 1).reshape(-1) if per_param[n].dim() == 4 else per_param[n].reshape(-1)
             assert torch.equal(seg, ref), n
-    assert unused >= 4 and f.check_views()            # shared_fcs / shared_fcs_refine / fc_iou never receive gradients
+    assert unused == 0 and f.check_views()            # shared_fcs / shared_fcs_refine / fc_iou are in the dead segment: every live parameter received a gradient
+    assert all(dict(model.student.named_parameters())[n].grad is None for n in dead)
     # (4) no host synchronisation inside a steady-state iteration
     torch.cuda.synchronize()
     torch.cuda.set_sync_debug_mode('error')
