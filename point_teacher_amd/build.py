@@ -14,8 +14,10 @@ SOURCES = ['assign.hip', 'losses.hip', 'roi_align.hip', 'mil.hip', 'optim.hip', 
            'image_prep.hip', 'glue.hip', 'gemm_split.hip']
 # -ffp-contract=off: index decisions (top-k, insider test) must see the same fp32 roundings
 # as the reference's un-fused torch ops; kernels that want FMA ask for it with fmaf().
+# -pragma-unroll-threshold: `#pragma unroll` over the 49 bins x 4 samples of a RoI must really unroll (49 per-channel values live in
+# registers; a partially unrolled loop indexes them dynamically and the whole array moves to scratch memory - measured 3x slower).
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-ffp-contract=off', '-Wall',
-         '-Wno-unused-function', '-Wno-unused-variable']
+         '-Wno-unused-function', '-Wno-unused-variable', '-mllvm', '-pragma-unroll-threshold=200000']
 
 
 def hipcc():

@@ -92,6 +92,11 @@ __global__ void __launch_bounds__(256)
     m4[i] = mm;
     p4[i] = x;
   }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {        // tail of a buffer whose length is not a multiple of 4: last group
+    const long i = (n4 << 2) + threadIdx.x;
+    const int k = grp.n - 1;
+    p[i] = sgd_one(p[i], g[i], m[i], clip, lr * grp.lr_mult[k], wd * grp.wd_mult[k], mom, first);
+  }
 }
 
 }  // namespace pt
@@ -127,15 +132,16 @@ extern "C" int pt_sqnorm_partial(const float* g, int64_t n, float* partial, void
 static int sgd_launch(float* param, const float* grad, float* momentum_buf, int64_t n, const SgdGroups& grp, const float* lr,
                       float momentum, float weight_decay, const float* sqnorm, float max_norm, int first_step, void* stream,
                       const char* who) {
-  PT_REQUIRE((n & 3) == 0 && (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)momentum_buf) & 15) == 0, PT_EINVAL,
-             "pt_sgd_step: buffers must be 16-byte aligned and n a multiple of 4");
+  PT_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)momentum_buf) & 15) == 0, PT_EINVAL,
+             "pt_sgd_step: buffers must be 16-byte aligned");
   long prev = 0;
   for (int j = 0; j < grp.n; ++j) {
-    PT_REQUIRE(grp.end[j] >= prev && (grp.end[j] & 3) == 0, PT_EINVAL, "pt_sgd_step: group ends must ascend in multiples of 4");
+    PT_REQUIRE(grp.end[j] >= prev && ((grp.end[j] & 3) == 0 || j == grp.n - 1), PT_EINVAL,
+               "pt_sgd_step: group ends must ascend; all but the last in multiples of 4");
     prev = grp.end[j];
   }
   PT_REQUIRE(prev == n, PT_EINVAL, "pt_sgd_step: the last group must end at n");
-  hipLaunchKernelGGL(sgd_kernel, dim3(stream_blocks(n >> 2)), dim3(256), 0, as_stream(stream), param, grad, momentum_buf,
+  hipLaunchKernelGGL(sgd_kernel, dim3(stream_blocks((n >> 2) + 1)), dim3(256), 0, as_stream(stream), param, grad, momentum_buf,
                      (long)n, grp, lr, momentum, weight_decay, sqnorm, max_norm, first_step);
   PT_LAUNCH_CHECK(who);
   return PT_OK;

@@ -453,6 +453,258 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---- r03: RoIAlignRotated as a small dense product per RoI ------------------------------------------------
+// Bilinear pooling is linear: out[bin][c] = sum_p Wt[p][bin] * feat[p][c] over the F footprint pixels of the RoI, with
+// Wt[p][bin] = the summed weights of the (<= 4 samples x 4 taps) of `bin` that land on pixel p, / count.  Wt is a [F <= 48][49]
+// matrix per RoI; building it costs 784 scalar read-modify-writes ONCE per RoI, by 49 lanes that own one column each (no atomics,
+// no sort).  After that every channel does F x 49 FMAs against broadcast ds_read_b128 rows of Wt:
+//   forward : each footprint pixel value is read ONCE per RoI and channel (a coalesced 256-byte row per wave, straight from
+//             L1 / L2 - nothing is staged), instead of 784 LDS reads + 392 tap reads per channel;
+//   backward: grad_feat[p][c] = sum_bin Wt[p][bin] * g[bin][c] with the 49 gradients of the channel in registers - ONE global
+//             atomic per footprint pixel and channel, no counting sort, no dependent LDS read-modify-write chains (the round-2
+//             backward spent 1.4 ms per 5 000 RoIs mostly in the sort's same-address LDS atomics and its serial prefix sum).
+// One 256-thread workgroup takes RR_GROUP = 4 consecutive RoIs: wave w builds the matrix of RoI w (the four builds run side by
+// side), then every wave owns 64 channels of each RoI in turn.  The [K, C, 7, 7] block is written / read through a wave-private
+// [32 channels][49] LDS tile: lane stride 49 words (conflict-free ds_write_b32 / ds_read_b32), 16-byte coalesced global accesses.
+// LDS 65 KB -> 2 workgroups per CU.  RoIs with a footprint above RR_FMAX pixels (the large synthetic rectangles of burn-in step 1)
+// keep their 196 samples' taps in the matrix's place and read / scatter per sample.
+constexpr int RR_GROUP = 4;
+constexpr int RR_WLD = 52;                         // row pitch of Wt in floats (49 bins, padded to 16-byte multiples)
+constexpr int RR_WT_FLOATS = RR_FMAX * RR_WLD;     // 2 496 floats = 9 984 B per RoI; >= 196 * 8 floats of per-sample taps
+static_assert(RR_WT_FLOATS >= RR_MAXS * 8, "the per-sample taps of a large RoI live in the matrix's place");
+
+struct RMeta {                                     // per RoI, wave-uniform
+  int F, y0, x0, nx, b;                            // F > 0: matrix path; F == 0: per-sample path; F < 0: nothing to do
+};
+
+// wave `w` of the workgroup prepares RoI k: geometry, footprint, Wt (or the per-sample taps)
+__device__ __forceinline__ void rroi_build(const float* __restrict__ roi, int B, int H, int W, float scale, int aligned, int clockwise,
+                                           float* __restrict__ wt, int* __restrict__ poff, RMeta* __restrict__ meta) {
+  const int lane = threadIdx.x & 63;
+  const RRoi g = rroi_geom(roi, 7, scale, 2, aligned, clockwise, B);
+  // lane = bin (< 49): its 2 x 2 samples
+  Tap4 q[4];
+  int ly0 = 1 << 30, lx0 = 1 << 30, ly1 = -1, lx1 = -1;
+  const int ph = lane / 7, pw = lane - ph * 7;
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    const int iy = s4 >> 1, ix = s4 & 1;
+    const float yy = g.start_h + ph * g.bin_h + (iy + .5f) * g.bin_h / 2.f;
+    const float xx = g.start_w + pw * g.bin_w + (ix + .5f) * g.bin_w / 2.f;
+    const float y = yy * g.cosv - xx * g.sinv + g.ch;
+    const float x = yy * g.sinv + xx * g.cosv + g.cw;
+    q[s4] = tap4(y, x, H, W);
+    if (lane >= RR_BINS) q[s4].valid = false;
+    if (q[s4].valid) {
+      ly0 = min(ly0, q[s4].y0); ly1 = max(ly1, q[s4].y1);
+      lx0 = min(lx0, q[s4].x0); lx1 = max(lx1, q[s4].x1);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ly0 = min(ly0, __shfl_xor(ly0, o, 64)); ly1 = max(ly1, __shfl_xor(ly1, o, 64));
+    lx0 = min(lx0, __shfl_xor(lx0, o, 64)); lx1 = max(lx1, __shfl_xor(lx1, o, 64));
+  }
+  const int nx = lx1 - lx0 + 1, ny = ly1 - ly0 + 1;
+  const int F = ly1 < 0 ? -1 : (nx * ny <= RR_FMAX ? nx * ny : 0);
+  if (lane == 0) { meta->F = F; meta->y0 = ly0; meta->x0 = lx0; meta->nx = nx; meta->b = g.b; }
+  const float inv = 1.f / g.count;
+  if (F > 0) {
+    for (int i = lane; i < F * (RR_WLD / 4); i += 64) reinterpret_cast<float4*>(wt)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < F) poff[lane] = (lane / nx) * W + lane % nx;
+    // (same wave: LDS operations execute in order, the zeros land before the adds below)
+    if (lane < RR_BINS) {
+      // This lane owns column `lane` of Wt.  Its 16 (pixel, weight) entries are merged IN REGISTERS first (the 2 x 2 samples of
+      // a bin revisit the same pixels), then each surviving entry is ONE plain store: a chain of 16 dependent LDS
+      // read-modify-writes per lane cost ~2 000 cycles per RoI.
+      int px[16];
+      float pw_[16];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int r0 = (q[s4].y0 - ly0) * nx - lx0, r1 = (q[s4].y1 - ly0) * nx - lx0;
+        const float m = q[s4].valid ? inv : 0.f;
+        px[4 * s4] = r0 + q[s4].x0; px[4 * s4 + 1] = r0 + q[s4].x1; px[4 * s4 + 2] = r1 + q[s4].x0; px[4 * s4 + 3] = r1 + q[s4].x1;
+        pw_[4 * s4] = q[s4].w1 * m; pw_[4 * s4 + 1] = q[s4].w2 * m; pw_[4 * s4 + 2] = q[s4].w3 * m; pw_[4 * s4 + 3] = q[s4].w4 * m;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int j = i + 1; j < 16; ++j) {                    // fold a later duplicate into the earlier entry
+          const bool same = px[j] == px[i];
+          pw_[i] += same ? pw_[j] : 0.f;
+          pw_[j] = same ? 0.f : pw_[j];
+        }
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (pw_[i] != 0.f) wt[px[i] * RR_WLD + lane] = pw_[i];
+    }
+  } else if (F == 0 && lane < RR_BINS) {           // per-sample taps: [bin][sample] x (4 offsets | 4 weights)
+    int* to = reinterpret_cast<int*>(wt);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int e = (lane * 4 + s4) * 8;
+      const float m = q[s4].valid ? inv : 0.f;
+      to[e] = q[s4].y0 * W + q[s4].x0; to[e + 1] = q[s4].y0 * W + q[s4].x1;
+      to[e + 2] = q[s4].y1 * W + q[s4].x0; to[e + 3] = q[s4].y1 * W + q[s4].x1;
+      wt[e + 4] = q[s4].w1 * m; wt[e + 5] = q[s4].w2 * m; wt[e + 6] = q[s4].w3 * m; wt[e + 7] = q[s4].w4 * m;
+    }
+  }
+}
+
+struct RGroupSmem {
+  float wt[RR_GROUP][RR_WT_FLOATS];
+  float tile[4][32 * RR_BINS];                      // wave-private transpose tiles
+  int off[RR_GROUP][RR_FMAX];                       // footprint pixel p -> (y * W + x) relative to the footprint's corner
+  RMeta meta[RR_GROUP];
+};
+
+__global__ void __launch_bounds__(256)
+    roi_align_rotated_fwd_mm(const float* __restrict__ feat, const float* __restrict__ rois, int B, int C, int H, int W, int K,
+                             float scale, int aligned, int clockwise, int group, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rr_smem[];
+  RGroupSmem& S = *reinterpret_cast<RGroupSmem*>(rr_smem);
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int k0 = blockIdx.x * group;
+  if (w < group && k0 + w < K) rroi_build(rois + (size_t)(k0 + w) * 6, B, H, W, scale, aligned, clockwise, S.wt[w], S.off[w], &S.meta[w]);
+  __syncthreads();
+  float* tile = S.tile[w];
+  for (int rr = 0; rr < group && k0 + rr < K; ++rr) {
+    const RMeta m = S.meta[rr];
+    const float* wt = S.wt[rr];
+    const float* fb = feat + (size_t)m.b * H * W * C;
+    for (int c0 = w * 64; c0 < C; c0 += 256) {               // this wave's 64 channels (C = 256: one pass)
+      const int c = c0 + lane;
+      const bool live = c < C;
+      float acc[RR_BINS];
+#pragma unroll
+      for (int bin = 0; bin < RR_BINS; ++bin) acc[bin] = 0.f;
+      if (m.F > 0) {
+        const float* px = fb + ((size_t)m.y0 * W + m.x0) * C + (live ? c : 0);
+        const int* po = S.off[rr];
+        for (int p0 = 0; p0 < m.F; p0 += 8) {                 // 8 footprint rows (256 B per wave each) in flight at a time
+          float fv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) fv[u] = (live && p0 + u < m.F) ? px[(size_t)po[p0 + u] * C] : 0.f;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if (p0 + u < m.F) {                               // wave-uniform
+              const float cur = fv[u];
+              const float4* row = reinterpret_cast<const float4*>(wt + (p0 + u) * RR_WLD);
+#pragma unroll
+              for (int j = 0; j < 12; ++j) {
+                const float4 w4 = row[j];
+                acc[4 * j] = fmaf(w4.x, cur, acc[4 * j]); acc[4 * j + 1] = fmaf(w4.y, cur, acc[4 * j + 1]);
+                acc[4 * j + 2] = fmaf(w4.z, cur, acc[4 * j + 2]); acc[4 * j + 3] = fmaf(w4.w, cur, acc[4 * j + 3]);
+              }
+              acc[48] = fmaf(wt[(p0 + u) * RR_WLD + 48], cur, acc[48]);
+            }
+          }
+        }
+      } else if (m.F == 0) {
+        const int* to = reinterpret_cast<const int*>(wt);
+        const float* fc = fb + (live ? c : 0);
+#pragma unroll
+        for (int bin = 0; bin < RR_BINS; ++bin) {
+          float a = 0.f;
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            const int e = (bin * 4 + s4) * 8;
+            const int4 o = *reinterpret_cast<const int4*>(to + e);
+            const float4 ww = *reinterpret_cast<const float4*>(wt + e + 4);
+            if (live) a += ww.x * fc[(size_t)o.x * C] + ww.y * fc[(size_t)o.y * C] + ww.z * fc[(size_t)o.z * C] + ww.w * fc[(size_t)o.w * C];
+          }
+          acc[bin] = a;
+        }
+      }
+      // [64 channels][49] -> global, 32 channels at a time through the wave's tile
+      const int cn = min(C - c0, 64);
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        if ((lane >> 5) == hh) {
+#pragma unroll
+          for (int bin = 0; bin < RR_BINS; ++bin) tile[(lane & 31) * RR_BINS + bin] = acc[bin];
+        }
+        const int nch = min(max(cn - 32 * hh, 0), 32);        // channels of this half that exist
+        float* ob = out + ((size_t)(k0 + rr) * C + c0 + 32 * hh) * RR_BINS;
+        const int n4 = nch * RR_BINS / 4, rem = nch * RR_BINS - n4 * 4;   // (nch = 32: 392 float4, no remainder)
+        for (int i = lane; i < n4; i += 64) reinterpret_cast<float4*>(ob)[i] = reinterpret_cast<const float4*>(tile)[i];
+        if (lane < rem) ob[n4 * 4 + lane] = tile[n4 * 4 + lane];
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    roi_align_rotated_bwd_mm(const float* __restrict__ gout, const float* __restrict__ rois, int B, int C, int H, int W, int K,
+                             float scale, int aligned, int clockwise, int group, float* __restrict__ gfeat) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rr_smem[];
+  RGroupSmem& S = *reinterpret_cast<RGroupSmem*>(rr_smem);
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int k0 = blockIdx.x * group;
+  if (w < group && k0 + w < K) rroi_build(rois + (size_t)(k0 + w) * 6, B, H, W, scale, aligned, clockwise, S.wt[w], S.off[w], &S.meta[w]);
+  __syncthreads();
+  float* tile = S.tile[w];
+  for (int rr = 0; rr < group && k0 + rr < K; ++rr) {
+    const RMeta m = S.meta[rr];
+    if (m.F < 0) continue;
+    const float* wt = S.wt[rr];
+    float* fb = gfeat + (size_t)m.b * H * W * C;
+    for (int c0 = w * 64; c0 < C; c0 += 256) {
+      const int c = c0 + lane;
+      const bool live = c < C;
+      const int cn = min(C - c0, 64);
+      float g[RR_BINS];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {                        // the 49 gradients of this lane's channel, through the tile
+        const int nch = min(max(cn - 32 * hh, 0), 32);
+        const float* gb = gout + ((size_t)(k0 + rr) * C + c0 + 32 * hh) * RR_BINS;
+        const int n4 = nch * RR_BINS / 4, rem = nch * RR_BINS - n4 * 4;
+        for (int i = lane; i < n4; i += 64) reinterpret_cast<float4*>(tile)[i] = reinterpret_cast<const float4*>(gb)[i];
+        if (lane < rem) tile[n4 * 4 + lane] = gb[n4 * 4 + lane];
+        if ((lane >> 5) == hh) {
+#pragma unroll
+          for (int bin = 0; bin < RR_BINS; ++bin) g[bin] = live ? tile[(lane & 31) * RR_BINS + bin] : 0.f;
+        }
+      }
+      if (m.F > 0) {
+        float* px = fb + ((size_t)m.y0 * W + m.x0) * C + (live ? c : 0);
+        const int* po = S.off[rr];
+        for (int p = 0; p < m.F; ++p) {
+          const float4* row = reinterpret_cast<const float4*>(wt + p * RR_WLD);
+          float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+          for (int j = 0; j < 12; ++j) {
+            const float4 w4 = row[j];
+            a0 = fmaf(w4.x, g[4 * j], a0); a1 = fmaf(w4.y, g[4 * j + 1], a1);
+            a2 = fmaf(w4.z, g[4 * j + 2], a2); a3 = fmaf(w4.w, g[4 * j + 3], a3);
+          }
+          const float a = (a0 + a1) + (a2 + a3) + wt[p * RR_WLD + 48] * g[48];
+          if (live && a != 0.f) atomicAdd(px + (size_t)po[p] * C, a);
+        }
+      } else {
+        const int* to = reinterpret_cast<const int*>(wt);
+        float* fc = fb + (live ? c : 0);
+#pragma unroll
+        for (int bin = 0; bin < RR_BINS; ++bin) {
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            const int e = (bin * 4 + s4) * 8;
+            const int4 o = *reinterpret_cast<const int4*>(to + e);
+            const float4 ww = *reinterpret_cast<const float4*>(wt + e + 4);
+            const float gv = g[bin];
+            if (live && gv != 0.f) {
+              if (ww.x != 0.f) atomicAdd(fc + (size_t)o.x * C, gv * ww.x);
+              if (ww.y != 0.f) atomicAdd(fc + (size_t)o.y * C, gv * ww.y);
+              if (ww.z != 0.f) atomicAdd(fc + (size_t)o.z * C, gv * ww.z);
+              if (ww.w != 0.f) atomicAdd(fc + (size_t)o.w * C, gv * ww.w);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
 }  // namespace pt
 
 using namespace pt;
@@ -489,7 +741,26 @@ static int rroi_launch(const char* fn, const float* src, const float* rois, int 
   hipStream_t s = as_stream(stream);
   const size_t fpb = (size_t)RR_FMAX * C * sizeof(float), tlb = (size_t)RR_BINS * (C + 1) * sizeof(float);
   const size_t lds = fpb > tlb ? fpb : tlb;
-  if (channels_last && out_size == 7 && sample_num == 2 &&
+  if (channels_last && out_size == 7 && sample_num == 2 && H * W < (1 << 24)) {
+    // r03: four RoIs per workgroup, one small dense product per RoI (config 5: out_size 7, sample_num 2)
+    static bool attr_mm[2] = {false, false};
+    const void* kf = BWD ? reinterpret_cast<const void*>(roi_align_rotated_bwd_mm) : reinterpret_cast<const void*>(roi_align_rotated_fwd_mm);
+    const size_t lds_mm = sizeof(RGroupSmem);
+    if (!attr_mm[BWD]) {
+      hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mm);
+      if (e != hipSuccess) { set_error("%s: LDS attribute: %s", fn, hipGetErrorString(e)); return (int)e; }
+      attr_mm[BWD] = true;
+    }
+    // four RoIs per workgroup (their matrices are built side by side) once that still leaves >= 2 workgroups per CU; a small
+    // batch (the 400 negatives: 70 x 70-pixel RoIs on the per-sample path) gets one workgroup per RoI
+    const int group = K >= 2048 ? RR_GROUP : 1;
+    if (BWD)
+      hipLaunchKernelGGL(roi_align_rotated_bwd_mm, dim3(cdiv(K, group)), dim3(256), lds_mm, s, src, rois, B, C, H, W, K, scale, aligned,
+                         clockwise, group, dst);
+    else
+      hipLaunchKernelGGL(roi_align_rotated_fwd_mm, dim3(cdiv(K, group)), dim3(256), lds_mm, s, src, rois, B, C, H, W, K, scale, aligned,
+                         clockwise, group, dst);
+  } else if (channels_last && out_size == 7 && sample_num == 2 &&
       lds + sizeof(RTaps) <= 150 * 1024) {
     // fast path: one workgroup per RoI, 49 bins x 4 samples (config 5: out_size 7, sample_num 2)
     static size_t attr[2] = {0, 0};

@@ -88,21 +88,16 @@ class COCO:
     def loadImgs(self, ids=[]):
         return [self.imgs[i] for i in ids] if isinstance(ids, (list, tuple)) else [self.imgs[ids]]
 
-    # snake-case aliases of api_wrappers/coco_api.py:24-41
-    def get_ann_ids(self, img_ids=[], cat_ids=[], area_rng=[], iscrowd=None):
-        return self.getAnnIds(img_ids, cat_ids, area_rng, iscrowd)
+    # mmdet's wrapper also answers to snake-case method AND keyword names (api_wrappers/coco_api.py:24-41): one adapter that
+    # renames the keywords, no second body per method
+    def _snake(method, **rename):
+        def call(self, *args, **kw):
+            return method(self, *args, **{rename.get(k, k): v for k, v in kw.items()})
+        call.__name__ = method.__name__
+        return call
 
-    def get_cat_ids(self, cat_names=[], sup_names=[], cat_ids=[]):
-        return self.getCatIds(cat_names, sup_names, cat_ids)
-
-    def get_img_ids(self, img_ids=[], cat_ids=[]):
-        return self.getImgIds(img_ids, cat_ids)
-
-    def load_anns(self, ids):
-        return self.loadAnns(ids)
-
-    def load_cats(self, ids):
-        return self.loadCats(ids)
-
-    def load_imgs(self, ids):
-        return self.loadImgs(ids)
+    get_ann_ids = _snake(getAnnIds, img_ids='imgIds', cat_ids='catIds', area_rng='areaRng')
+    get_cat_ids = _snake(getCatIds, cat_names='catNms', sup_names='supNms', cat_ids='catIds')
+    get_img_ids = _snake(getImgIds, img_ids='imgIds', cat_ids='catIds')
+    load_anns, load_cats, load_imgs = _snake(loadAnns), _snake(loadCats), _snake(loadImgs)
+    del _snake

@@ -170,33 +170,23 @@ class CocoDataset(CustomDataset):
         return valid_inds
 
     def _parse_ann_info(self, img_info, ann_info):
-        """coco.py:124-180"""
-        gt_bboxes, gt_labels, gt_bboxes_ignore, gt_masks_ann = [], [], [], []
-        for ann in ann_info:
-            if ann.get('ignore', False):
-                continue
-            x1, y1, w, h = ann['bbox']
-            inter_w = max(0, min(x1 + w, img_info['width']) - max(x1, 0))
-            inter_h = max(0, min(y1 + h, img_info['height']) - max(y1, 0))
-            if inter_w * inter_h == 0:
-                continue
-            if ann['area'] <= 0 or w < 1 or h < 1:
-                continue
-            if ann['category_id'] not in self.cat_ids:
-                continue
-            bbox = [x1, y1, x1 + w, y1 + h]
-            if ann.get('iscrowd', False):
-                gt_bboxes_ignore.append(bbox)
-            else:
-                gt_bboxes.append(bbox)
-                gt_labels.append(self.cat2label[ann['category_id']])
-                gt_masks_ann.append(ann.get('segmentation', None))
-        if gt_bboxes:
-            gt_bboxes, gt_labels = np.array(gt_bboxes, dtype=np.float32), np.array(gt_labels, dtype=np.int64)
-        else:
-            gt_bboxes, gt_labels = np.zeros((0, 4), dtype=np.float32), np.array([], dtype=np.int64)
-        gt_bboxes_ignore = np.array(gt_bboxes_ignore, dtype=np.float32) if gt_bboxes_ignore else np.zeros((0, 4), dtype=np.float32)
-        return dict(bboxes=gt_bboxes, labels=gt_labels, bboxes_ignore=gt_bboxes_ignore, masks=gt_masks_ann,
+        """coco.py:124-180 over the whole annotation table at once: an annotation survives when it is not flagged `ignore`, its
+        box overlaps the image, has a positive `area` and at least 1 px of width and height, and its category is one of the
+        dataset's; crowd boxes go to `bboxes_ignore`, the rest to `bboxes` / `labels` / `masks` (order preserved)."""
+        anns = [a for a in ann_info if not a.get('ignore', False)]
+        box = np.array([a['bbox'] for a in anns], dtype=np.float64).reshape(-1, 4)
+        x1, y1, w, h = box.T
+        overlap_w = np.clip(np.minimum(x1 + w, img_info['width']) - np.maximum(x1, 0), 0, None)
+        overlap_h = np.clip(np.minimum(y1 + h, img_info['height']) - np.maximum(y1, 0), 0, None)
+        keep = (overlap_w * overlap_h != 0) & (w >= 1) & (h >= 1)
+        keep &= np.array([a['area'] > 0 and a['category_id'] in self.cat2label for a in anns], dtype=bool).reshape(-1)
+        crowd = np.array([bool(a.get('iscrowd', False)) for a in anns], dtype=bool).reshape(-1)
+        xyxy = np.stack([x1, y1, x1 + w, y1 + h], 1).astype(np.float32)
+        real = np.flatnonzero(keep & ~crowd)
+        return dict(bboxes=xyxy[real].reshape(-1, 4),
+                    labels=np.array([self.cat2label[anns[i]['category_id']] for i in real], dtype=np.int64),
+                    bboxes_ignore=xyxy[keep & crowd].reshape(-1, 4),
+                    masks=[anns[i].get('segmentation', None) for i in real],
                     seg_map=img_info['filename'].replace('jpg', 'png'))
 
     @staticmethod

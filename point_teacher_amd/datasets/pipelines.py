@@ -400,15 +400,15 @@ class RResize(Resize):
         super().__init__(img_scale=img_scale, multiscale_mode=multiscale_mode, ratio_range=ratio_range, keep_ratio=True)
 
     def _resize_bboxes(self, results):
+        """Every (cx, cy, w, h, a) row times (w_scale, h_scale, g, g, 1), g = sqrt(w_scale * h_scale): ONE broadcast multiply per
+        field in the boxes' own dtype (the same float32 products, column by column, as mmrotate's transforms.py:36-46 forms with
+        three in-place column updates; pinned by tests/golden/pipeline_flow.npz)."""
+        w_scale, h_scale = results['scale_factor'][:2]
+        g = np.sqrt(w_scale * h_scale)
         for key in results.get('bbox_fields', []):
-            bboxes = results[key]
-            orig_shape = bboxes.shape
-            bboxes = bboxes.reshape((-1, 5))
-            w_scale, h_scale, _, _ = results['scale_factor']
-            bboxes[:, 0] *= w_scale
-            bboxes[:, 1] *= h_scale
-            bboxes[:, 2:4] *= np.sqrt(w_scale * h_scale)
-            results[key] = bboxes.reshape(orig_shape)
+            boxes = results[key]
+            factors = np.asarray([w_scale, h_scale, g, g, 1], dtype=boxes.dtype)
+            results[key] = (boxes.reshape(-1, 5) * factors).reshape(boxes.shape)
 
 
 @PIPELINES.register_module()
@@ -497,28 +497,28 @@ class RRandomFlip(RandomFlip):
         super().__init__(flip_ratio, direction)
 
     def bbox_flip(self, bboxes, img_shape, direction):
-        assert bboxes.shape[-1] % 5 == 0
-        orig_shape = bboxes.shape
-        bboxes = bboxes.reshape((-1, 5))
-        flipped = bboxes.copy()
-        if direction == 'horizontal':
-            flipped[:, 0] = img_shape[1] - bboxes[:, 0] - 1
-        elif direction == 'vertical':
-            flipped[:, 1] = img_shape[0] - bboxes[:, 1] - 1
-        elif direction == 'diagonal':
-            flipped[:, 0] = img_shape[1] - bboxes[:, 0] - 1
-            flipped[:, 1] = img_shape[0] - bboxes[:, 1] - 1
-            return flipped.reshape(orig_shape)
-        else:
+        """mmrotate transforms.py:75-96 as masks over the box table: which centre coordinates are mirrored is a property of the
+        direction, what happens to (w, h, a) a property of the angle version - 'oc': a -> pi/2 - a with w and h swapped, except
+        rows whose angle is exactly pi/2; otherwise a -> norm_angle(pi - a).  A diagonal flip leaves (w, h, a) alone."""
+        if bboxes.shape[-1] % 5:
+            raise AssertionError(bboxes.shape)
+        mirror = {'horizontal': (True, False), 'vertical': (False, True), 'diagonal': (True, True)}.get(direction)
+        if mirror is None:
             raise ValueError(f'Invalid flipping direction "{direction}"')
-        if self.version == 'oc':
-            rotated_flag = (bboxes[:, 4] != np.pi / 2)
-            flipped[rotated_flag, 4] = np.pi / 2 - bboxes[rotated_flag, 4]
-            flipped[rotated_flag, 2] = bboxes[rotated_flag, 3]
-            flipped[rotated_flag, 3] = bboxes[rotated_flag, 2]
-        else:
-            flipped[:, 4] = norm_angle(np.pi - bboxes[:, 4], self.version)
-        return flipped.reshape(orig_shape)
+        rows = bboxes.reshape(-1, 5)
+        out = rows.copy()
+        for col, (on, extent) in enumerate(zip(mirror, (img_shape[1], img_shape[0]))):
+            if on:
+                out[:, col] = extent - rows[:, col] - 1
+        if direction != 'diagonal':
+            if self.version == 'oc':
+                turn = rows[:, 4] != np.pi / 2
+                out[:, 4] = np.where(turn, np.pi / 2 - rows[:, 4], rows[:, 4])
+                out[:, 2] = np.where(turn, rows[:, 3], rows[:, 2])
+                out[:, 3] = np.where(turn, rows[:, 2], rows[:, 3])
+            else:
+                out[:, 4] = norm_angle(np.pi - rows[:, 4], self.version)
+        return out.reshape(bboxes.shape)
 
 
 @PIPELINES.register_module()

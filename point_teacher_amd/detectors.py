@@ -233,6 +233,19 @@ class TS_P2B_FCOS(BaseDetector):
     def _forget_stem_decision(self, *args, **kw):
         self._stem_shared = None
 
+    def _recheck_stem_async(self):
+        """Compare the frozen segments of teacher and student again WITHOUT stalling the host: the verdict lands in pinned
+        memory behind an event and is read by a later `_shared_stem()` once the event has completed."""
+        if not self._stem_shared or self._flat is None or not self._flat[0].is_cuda:
+            return
+        n = self._flat_frozen_start
+        differ = (self._flat[0][n:] != self._flat[1][n:]).any().to(torch.uint8)
+        host = torch.empty((), dtype=torch.uint8).pin_memory()
+        host.copy_(differ, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._stem_check = (ev, host)
+
     def get_extra_state(self):
         return dict(count=self.count, epoch=self.epoch, point_stamp=dict(self.point_stamp),
                     gt_bboxes_point={k: v.cpu() for k, v in self.gt_bboxes_point.items()},
@@ -256,6 +269,11 @@ class TS_P2B_FCOS(BaseDetector):
         models is bit-equal - the state of a run whose two detectors loaded the same pretrained backbone (the configs'
         init_cfg).  Then the EMA of the frozen segment is the identity and is skipped (alpha*t + (1-alpha)*t rounds away from
         t), and the stem of the clean images is evaluated once per iteration (`_student_inputs`).  PT_SHARE_STEM=0: off."""
+        chk = getattr(self, '_stem_check', None)
+        if chk is not None and chk[0].query():
+            self._stem_check = None
+            if int(chk[1]):
+                self._stem_shared = None      # the frozen weights diverged: decide again (and stop sharing)
         if self._stem_shared is None:
             ok = False
             sb = getattr(self.student, 'backbone', None)
@@ -309,7 +327,7 @@ class TS_P2B_FCOS(BaseDetector):
         if img_metas[0][self._epoch_key] in self.epoch_dict:
             self.epoch += 1
             self.epoch_dict = {}
-            self._stem_shared = None      # re-verified once per epoch (one comparison of the frozen segments)
+            self._recheck_stem_async()    # in-place edits of frozen weights nobody announced: re-verified once per epoch
         for i in range(num_img):
             self.epoch_dict[img_metas[i][self._epoch_key]] = 1
 

@@ -303,6 +303,29 @@ def test_ema_sgd_norm():
     pb, mb = R.sgd_momentum_step(p[split:], gr[split:], m[split:], 0.01, 0.9, 0.0, coef)
     close(pg, torch.cat([pw, pb]), rtol=1e-5, atol=1e-6)
     close(mg, torch.cat([mw, mb]), rtol=1e-5, atol=1e-6)
+    # pt_sgd_step_groups: the parameter groups of a full paramwise_cfg (configs/baselines/aitodv2_yolof_r50_1x.py:70-71:
+    # backbone lr x 1/3, norm decay x 0, plus a bias group) - four segments, the last one ending off a multiple of 4
+    import ctypes
+    from point_teacher_amd import hip
+    ends, lr_m, wd_m = [400_000, 700_000, 900_000, n], [1.0, 1.0 / 3, 1.0, 2.0], [1.0, 1.0, 0.0, 0.0]
+    pg, mg = cu(p).clone(), cu(m).clone()
+    tables = ((ctypes.c_int64 * 4)(*ends), hip.host_floats(lr_m), hip.host_floats(wd_m), 4)
+    f.sgd_step_groups_(pg, cu(gr), mg, tables, lr, 0.9, 1e-4, sq, 35.0, False)
+    exp_p, exp_m, lo = [], [], 0
+    for hi, a, b in zip(ends, lr_m, wd_m):
+        q, mm = R.sgd_momentum_step(p[lo:hi], gr[lo:hi], m[lo:hi], 0.005 * a, 0.9, 1e-4 * b, coef)
+        exp_p.append(q); exp_m.append(mm); lo = hi
+    close(pg, torch.cat(exp_p), rtol=1e-5, atol=1e-6)
+    close(mg, torch.cat(exp_m), rtol=1e-5, atol=1e-6)
+    # first step: the momentum buffer is created from the (clipped, decayed) gradient
+    pg, mg = cu(p).clone(), cu(m).clone()
+    f.sgd_step_groups_(pg, cu(gr), mg, tables, lr, 0.9, 1e-4, sq, 35.0, True)
+    q, mm = R.sgd_momentum_step(p[:400_000], gr[:400_000], torch.zeros(400_000), 0.005, 0.9, 1e-4, coef)
+    close(pg[:400_000], q, rtol=1e-5, atol=1e-6)
+    close(mg[:400_000], mm, rtol=1e-5, atol=1e-6)
+    with pytest.raises(RuntimeError, match='PT_MAX_PARAM_GROUPS'):
+        hip.call('pt_sgd_step_groups', pg, cu(gr), mg, n, (ctypes.c_int64 * 9)(*range(0, 36, 4)), hip.host_floats([1.0] * 9),
+                 hip.host_floats([1.0] * 9), 9, lr, 0.9, 1e-4, sq, 35.0, 0)
 
 
 def test_nms_and_rotated():

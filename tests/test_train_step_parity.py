@@ -270,7 +270,7 @@ def test_full_size_iteration_properties():
         torch.cuda.set_sync_debug_mode('default')
 
 
-@pytest.mark.parametrize('percent', [30, 100])
+@pytest.mark.parametrize('percent', [30, 60, 100])
 def test_full_size_noisy_point_configs(percent):
     """aitodv2_point_teacher_{30,100}% at BASELINE size (bs 2, 800x800, ~300 points/image): `_point_` > 0 (random initial
     points), lamda 0.5, U1 = 9 coarse boxes x U2 = 45 shaken boxes per object -> K = 2 x 75 x 405 = 60 750 RoIs per
