@@ -561,3 +561,64 @@ def test_full_size_vs_oracle(phase2):
     print({k: (round(float(lv[k]), 5), round(float(ref[k]), 5)) for k in ref})
     _check(lv, ref)
     _check_grads(model, ref['loss'], params, tol=3e-3)
+
+
+def test_full_size_bf16_backbone_properties():
+    """BASELINE configs[2] at its real size (round-2 verdict P2): bs 2, 800 x 800, ~300 points per image, bf16 backbone / FPN /
+    PSAGG under autocast + fp32 dense head, MIL head and losses, both phases through `Trainer.step`.  Size-independent
+    properties: the precision boundary sits where the config puts it (bf16 into the necks, fp32 into and out of the head, fp32 RoI
+    blocks and FC stacks), the loss dict keeps one finite key set, every key of an iteration is within 5 % of the SAME iteration
+    run in fp32 on the same weights / inputs / draws (bf16 keeps 8 significant bits; measured <= 1.5 %), the fp32 master weights
+    move and stay finite, and a steady-state iteration does not synchronise the host."""
+    from point_teacher_amd.synthetic import SyntheticTiles, benchmark_init_
+    import point_teacher_amd as pta
+    dev = torch.device('cuda:0')
+
+    def run(dtype):
+        torch.manual_seed(5)
+        cfg = pta.Config.fromfile(os.path.join(ROOT, 'point_teacher_amd', 'configs', 'point_teacher', 'aitodv2_point_teacher_0.py'))
+        cfg.model['burn_in_step'] = 0                                  # iteration 0 = phase 1, iterations 1, 2 = phase 2
+        model = pta.build_detector(cfg.model).to(dev)
+        benchmark_init_(model, phase2=True)
+        model.train()
+        tr = pta.Trainer(model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config, channels_last=True, autocast_dtype=dtype)
+        data = SyntheticTiles(n=2, size=800, mean_objects=300, seed=1, device=dev)
+        seen = {}
+        hooks = [model.student.backbone.layer3[0].conv1.register_forward_hook(lambda m, i, o: seen.__setitem__('backbone', o.dtype)),
+                 model.student.neck_agg.lateral_convs[0].register_forward_hook(lambda m, i, o: seen.__setitem__('psagg', o.dtype)),
+                 model.student.bbox_head.reg_convs[0].register_forward_hook(lambda m, i, o: seen.__setitem__('head', (i[0].dtype, o.dtype))),
+                 model.student.bbox_head.bbox_roi_extractor.register_forward_hook(lambda m, i, o: seen.__setitem__('roi', o.dtype)),
+                 model.student.bbox_head.fc_reg[0].register_forward_hook(lambda m, i, o: seen.__setitem__('fc', (i[0].dtype, o.dtype)))]
+        g = torch.Generator().manual_seed(17)
+        lvs = []
+        s0 = tr.flat.student_flat.clone()
+        for it in range(3):
+            model._inject = dict(neg0=torch.rand(2, 4, 200, generator=g).to(dev), aug=(['horizontal', 'None'], [0.9, 1.1]))
+            if it == 0:
+                model._inject['syn'] = [{k: v.to(dev) for k, v in _syn_draws(b.shape[0], 70 + i).items()}
+                                        for i, b in enumerate(data.batch(0, 2)['gt_bboxes'])]
+            if it == 2:
+                torch.cuda.synchronize()
+                torch.cuda.set_sync_debug_mode('error')
+            try:
+                out = tr.step(data.batch(0, 2))
+            finally:
+                torch.cuda.set_sync_debug_mode('default')
+            lvs.append(out['log_vars'].materialize())
+        for h in hooks:
+            h.remove()
+        assert torch.isfinite(tr.flat.student_flat).all() and not torch.equal(tr.flat.student_flat, s0)
+        assert tr.flat.student_flat.dtype == torch.float32 and tr.flat.grad_flat.dtype == torch.float32        # fp32 master weights
+        return seen, lvs
+
+    seen16, lv16 = run(torch.bfloat16)
+    assert seen16['backbone'] == torch.bfloat16 and seen16['psagg'] == torch.bfloat16
+    assert seen16['head'] == (torch.float32, torch.float32) and seen16['roi'] == torch.float32 and seen16['fc'] == (torch.float32, torch.float32)
+    seen32, lv32 = run(None)
+    assert seen32['backbone'] == torch.float32
+    for it, (a, b) in enumerate(zip(lv16, lv32)):
+        assert set(a) == set(b) and all(v == v and abs(v) != float('inf') for v in a.values()), (it, a)
+        if it == 0:          # same weights, inputs and draws: later iterations start from weights that already differ by an update
+            for k in a:
+                assert abs(a[k] - b[k]) <= 5e-2 * max(abs(b[k]), 1e-2), (it, k, a[k], b[k])
+    assert set(lv16[0]) == set(lv16[1]) == set(lv16[2])
