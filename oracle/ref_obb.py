@@ -380,7 +380,8 @@ def init_detector_state_obb(seed=0, num_stages=1):
         for fam in ('shared_fcs_bag', 'shared_fcs_reg'):
             lin(f'bbox_head.{fam}.{s}.0', 1024, 12544); lin(f'bbox_head.{fam}.{s}.1', 1024, 1024)
         lin(f'bbox_head.fc_cls.{s}', NUM_CLASSES, 1024); lin(f'bbox_head.fc_ins.{s}', NUM_CLASSES, 1024)
-        lin(f'bbox_head.fc_reg.{s}', 4, 1024, scale=0.01); lin(f'bbox_head.fc_iou.{s}', 1, 1024)
+        lin(f'bbox_head.fc_reg.{s}', 4, 1024, scale=0.01)
+        # (no fc_iou: the oriented head builds none, rotated_fcos_head_p2rb_ts.py:243-283)
     return sd
 
 

@@ -60,6 +60,8 @@ class TS_P2RBRotatedFCOSHead(TS_P2BFCOSHead):
     def _init_layers(self):
         """:217-241: the HBB layers + the angle branch."""
         super()._init_layers()
+        del self.fc_iou            # the oriented head builds no IoU branch (:243-283) - the HBB head does (fcos_head_p2b_ts.py:181) - so its
+        #                            checkpoints carry no `fc_iou.*` keys (found by building the reference's real head, oracle/gen_golden_obb_iter.py)
         self.conv_angle = nn.Conv2d(self.feat_channels, 1, 3, padding=1)
         if self.is_scale_angle:
             self.scale_angle = Scale(1.0)
