@@ -7,7 +7,7 @@ from . import hip                      # noqa: F401  (raises loudly when the HIP
 from . import functional               # noqa: F401
 from .registry import (BACKBONES, BBOX_ASSIGNERS, BBOX_CODERS, DETECTORS, HEADS, LOSSES, MATCH_COST, NECKS,  # noqa: F401
                        ROI_EXTRACTORS, Config, build_assigner, build_detector, build_from_cfg, build_loss)
-from . import core, losses, nn_modules, head, detectors, obb, obb_head, obb_detectors, datasets, fcos_baseline, retina_baseline, retina_student, faster_rcnn   # noqa: F401,E402  (populate the registries)
+from . import core, losses, nn_modules, head, detectors, obb, obb_head, obb_detectors, datasets, fcos_baseline, retina_baseline, retina_student, faster_rcnn, yolof_baseline   # noqa: F401,E402  (populate the registries)
 from . import ops                      # noqa: F401,E402  (the mmcv.ops signatures of the path)
 from .runtime import Trainer           # noqa: F401,E402
 

@@ -75,19 +75,29 @@ class ConvModule(nn.Module):
     norm layer follows" (mmcv/cnn/bricks/conv_module.py:113-116)."""
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, act=True, norm_cfg=None,
-                 conv_cfg=None):
+                 conv_cfg=None, dilation=1):
         super().__init__()
         if bias == 'auto':
             bias = norm_cfg is None
         conv_cls = _CONV_LAYERS[(conv_cfg or dict(type='Conv2d'))['type']]           # mmcv build_conv_layer
-        self.conv = conv_cls(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=bias)
+        self.conv = conv_cls(in_channels, out_channels, kernel_size, stride=stride, padding=padding, dilation=dilation, bias=bias)
         self.with_activation = act
         self.with_norm = norm_cfg is not None
+        self.gn = self.bn = None
         if self.with_norm:
-            assert norm_cfg['type'] == 'GN', 'GroupNorm is the only head norm on the Point-Teacher path'
-            self.gn = nn.GroupNorm(norm_cfg['num_groups'], out_channels)
-            for p in self.gn.parameters():
+            # GroupNorm on the Point-Teacher path; a trainable BatchNorm in TRAINING mode (batch statistics, running averages
+            # updated) in the YOLOF baseline's encoder and head (row N4): mmcv names the layer after its type, `.gn` / `.bn`
+            assert norm_cfg['type'] in ('GN', 'BN'), norm_cfg
+            if norm_cfg['type'] == 'GN':
+                self.gn = nn.GroupNorm(norm_cfg['num_groups'], out_channels)
+            else:
+                self.bn = nn.BatchNorm2d(out_channels)
+            for p in (self.gn or self.bn).parameters():
                 p.requires_grad = norm_cfg.get('requires_grad', True)
+            if self.gn is None:
+                del self.gn
+            else:
+                del self.bn
 
     def forward(self, x):
         c = self.conv
@@ -99,7 +109,7 @@ class ConvModule(nn.Module):
             return TF.relu(y + c.bias.view(1, -1, 1, 1), inplace=True)
         x = c(x)
         if self.with_norm:
-            x = self.gn(x)
+            x = self.gn(x) if hasattr(self, 'gn') else self.bn(x)
         return TF.relu(x, inplace=True) if self.with_activation else x
 
 
