@@ -60,8 +60,20 @@ def inputs(seed=37, B=2):
     return cls, obj, reg, boxes, labels, (H * 8, W * 8)
 
 
+def stable_topk(x, k, dim=-1, largest=True, sorted=True):
+    """`torch.topk` may return tied elements in any order, and the UniformAssigner's anchor costs tie STRUCTURALLY: the 8- and the
+    16-pixel anchor of one cell are equally far (L1 over cx, cy, w, h) from every box whose sides lie between 8 and 16 px.  The
+    order decides which of the duplicate writes of `assigned_gt_inds[indexes] = ...` comes last (uniform_assigner.py:113-131), so the
+    assignment is not a function of its inputs (CPU and GPU kernels disagree).  Served here by a stable top-k, lowest index first
+    among ties - one of the results torch may legally return, and the rule the oracle and the product implement."""
+    v, i = torch.sort(x, dim=dim, descending=largest, stable=True)
+    return v.narrow(dim, 0, k), i.narrow(dim, 0, k)
+
+
 def main():
     ag, ps, ua, yh = install()
+    ua.torch = types.SimpleNamespace(**{n: getattr(torch, n) for n in dir(torch) if not n.startswith('__')})
+    ua.torch.topk = stable_topk
     dc = L.ref('core.bbox.coder.delta_xywh_bbox_coder')
     fl = L.ref('models.losses.focal_loss')
     il = L.ref('models.losses.iou_loss')

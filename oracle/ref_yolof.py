@@ -1,4 +1,4 @@
-"""CPU ORACLE of the YOLOF baseline's training-side logic (groundwork, no product yet) - TEST INFRASTRUCTURE ONLY.
+"""CPU ORACLE of the YOLOF baseline's training-side logic (product: point_teacher_amd/yolof_baseline.py) - TEST INFRASTRUCTURE ONLY.
 
 Restates, in plain torch fp32 on the CPU, of /root/reference/HBB_TOD/mmdet:
   models/dense_heads/yolof_head.py forward_single :118-134 (implicit objectness), loss :136-222, get_targets :223-309,
@@ -51,8 +51,9 @@ def uniform_assign(pred, anchors, gts, gt_labels, pos_ignore_thr=0.15, neg_ignor
                     pos_pred=pred.new_zeros((0, 4)), target=pred.new_zeros((0, 4)))
     cost = torch.cdist(_cxcywh(pred), _cxcywh(gts), p=1)
     cost_a = torch.cdist(_cxcywh(anchors), _cxcywh(gts), p=1)
-    idx = torch.topk(cost, k=match_times, dim=0, largest=False)[1]
-    idx_a = torch.topk(cost_a, k=match_times, dim=0, largest=False)[1]
+    # stable top-k, lowest index first among ties: the anchor costs tie structurally (gen_golden_yolof.stable_topk)
+    idx = torch.sort(cost, dim=0, stable=True)[1][:match_times]
+    idx_a = torch.sort(cost_a, dim=0, stable=True)[1][:match_times]
     indexes = torch.cat((idx, idx_a), dim=1).reshape(-1)                    # row-major over [k, 2G]
     pred_ov = R.bbox_overlaps(pred, gts)
     anchor_ov = R.bbox_overlaps(anchors, gts)

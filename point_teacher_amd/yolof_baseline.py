@@ -112,8 +112,11 @@ class UniformAssigner:
         gt_c = _cxcywh(gt_bboxes)
         cost = torch.cdist(_cxcywh(bbox_pred.detach()), gt_c, p=1)
         cost_a = torch.cdist(_cxcywh(anchor), gt_c, p=1)
-        idx = torch.topk(cost, k=k, dim=0, largest=False)[1]                    # [k, G]
-        idx_a = torch.topk(cost_a, k=k, dim=0, largest=False)[1]
+        # Stable top-k, lowest index first among ties: the 8- and the 16-pixel anchor of one cell are EXACTLY equally far from every
+        # box whose sides lie between 8 and 16 px, `torch.topk` orders such ties differently on CPU and GPU, and the order decides
+        # which duplicate write below comes last (tests/golden/yolof_baseline.npz is generated under the same rule).
+        idx = torch.sort(cost, dim=0, stable=True)[1][:k]                       # [k, G]
+        idx_a = torch.sort(cost_a, dim=0, stable=True)[1][:k]
         indexes = torch.cat((idx, idx_a), dim=1).reshape(-1)                    # row-major over [k, 2 G]
         pred_ov = F.bbox_overlaps(bbox_pred.detach(), gt_bboxes)
         anchor_ov = F.bbox_overlaps(anchor, gt_bboxes)
