@@ -142,11 +142,20 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int MB>
+// CONV = true: the same product as an implicit GEMM of a 3 x 3, stride 1, pad 1 convolution over [B, H, W, Cin] activations (the
+// dense head's towers, anchor_free_head.py:198-219): row = output pixel, k = (tap, input channel).  The A operand is never
+// materialised: its planes are ROW-MAJOR [pixels + 1][Cin] (pt_split_bf16x3_rows; the extra row is zeros), and every lane of an A
+// staging instruction reads 16 bytes of the pixel shifted by the k-step's tap - or of the zero row where the tap leaves the image.
+// The LDS image, the fragment reads and the B (weight) side are those of the GEMM.
+struct ConvGeom {
+  int H, W, Cin, CB, P;             // CB = Cin / 32 k-blocks per tap; P = B * H * W pixels (the zero row is row P)
+};
+
+template <int MB, bool CONV>
 __global__ void __launch_bounds__(GTHREADS)
     gemm_bf16x6_kernel(const uint16_t* __restrict__ Ap, const uint16_t* __restrict__ Bp, float* __restrict__ C,
                        const float* __restrict__ bias, int M, int N, int KB, long a_plane, long b_plane, long ldc, int relu,
-                       int tiles_n, int n_tiles) {
+                       int tiles_n, int n_tiles, ConvGeom cg) {
   constexpr int BM = 32 * MB, ROWS = BM + GBN;
   constexpr int STAGE = ROWS * 3 * 64;                 // bytes: A planes [3][BM][64] then B planes [3][128][64]
   constexpr int NI = ROWS * 3 / 16;                    // staging instructions (one 1-KiB block each) per stage
@@ -168,10 +177,12 @@ __global__ void __launch_bounds__(GTHREADS)
   // (advances by one block = 1 KiB per k-step)
   const int RBA = (M + 15) >> 4, RBN = (N + 15) >> 4;
   const unsigned char* gsrc[NJ];
+  int cpix[NJ], cmask[NJ];                              // CONV: pixel of this lane's row, 9-bit "tap stays inside the image" mask
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int i = w + 8 * j;                            // staging instruction = block index within the stage
     gsrc[j] = nullptr;
+    cpix[j] = cmask[j] = 0;
     if (i < NI) {
       const bool isA = i < 3 * (BM / 16);
       const int i2 = isA ? i : i - 3 * (BM / 16);
@@ -181,13 +192,37 @@ __global__ void __launch_bounds__(GTHREADS)
       int rb = (isA ? m0 : n0) / 16 + rbi;
       rb = rb < lim ? rb : lim - 1;                     // row blocks past the edge re-read the last one; their results are never stored
       const uint16_t* base = isA ? Ap + p * a_plane : Bp + p * b_plane;
-      gsrc[j] = reinterpret_cast<const unsigned char*>(base + ((long)rb * KB << 9)) + lane * 16;
+      if (CONV && isA) {
+        const int rr = rbi * 16 + (lane >> 2), qd = lane & 3;            // row of the tile, physical 16-byte slot
+        const int sl = qd ^ ((rr >> 2) & 3);                             // logical k-slot that lands there
+        const int pix = m0 + rr;
+        const int x = pix % cg.W, y = (pix / cg.W) % cg.H;
+        int mask = 0;
+        if (pix < cg.P) {
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            mask |= (yy >= 0 && yy < cg.H && xx >= 0 && xx < cg.W) ? (1 << t) : 0;
+          }
+        }
+        cpix[j] = pix;
+        cmask[j] = mask;
+        gsrc[j] = reinterpret_cast<const unsigned char*>(base) + sl * 16;
+      } else {
+        gsrc[j] = reinterpret_cast<const unsigned char*>(base + ((long)rb * KB << 9)) + lane * 16;
+      }
     }
   }
-  auto issue1 = [&](int j, int buf) {                   // one 1-KiB block of the next stage
+  auto issue1 = [&](int j, int buf, int ksn) {          // one 1-KiB block of stage `ksn`
     if (j < NJ && w + 8 * j < NI) {                     // wave-uniform
-      glds16(gsrc[j], smem + buf * STAGE + (w + 8 * j) * 1024);
-      gsrc[j] += 1024;
+      if (CONV && w + 8 * j < 3 * (BM / 16)) {          // wave-uniform: an activation piece
+        const int tap = ksn / cg.CB, cb = ksn - tap * cg.CB;
+        const int pix = ((cmask[j] >> tap) & 1) ? cpix[j] + (tap / 3 - 1) * cg.W + (tap % 3 - 1) : cg.P;
+        glds16(gsrc[j] + ((long)pix * cg.Cin + cb * 32) * 2, smem + buf * STAGE + (w + 8 * j) * 1024);
+      } else {
+        glds16(gsrc[j], smem + buf * STAGE + (w + 8 * j) * 1024);
+        gsrc[j] += 1024;
+      }
     }
   };
 
@@ -204,7 +239,7 @@ __global__ void __launch_bounds__(GTHREADS)
   const int b_off = 3 * BM * 64 + (nb * 32 + r) * 64 + slot_phys;        // + p * 128 * 64
 
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) issue1(j, 0);
+  for (int j = 0; j < NJ; ++j) issue1(j, 0, 0);
   for (int ks = 0; ks < KB; ++ks) {
     __syncthreads();            // (emits s_waitcnt vmcnt(0)): stage ks has landed, every wave is done reading the other buffer
     const bool more = ks + 1 < KB;
@@ -221,7 +256,7 @@ __global__ void __launch_bounds__(GTHREADS)
       const bf16x8_t a2 = *reinterpret_cast<const bf16x8_t*>(ap + 2 * BM * 64);
       if (more) {               // the next stage's LDS-DMA is spread behind the MFMAs (issued in one burst after the barrier it
 #pragma unroll                  // held every wave's first MFMA back by ~7 x 60 cycles; measured +4 %)
-        for (int q = 0; q < PER; ++q) issue1(m * PER + q, nbuf);
+        for (int q = 0; q < PER; ++q) issue1(m * PER + q, nbuf, ks + 1);
       }
       // smallest terms first
       acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[m], 0, 0, 0);
@@ -264,9 +299,9 @@ __global__ void __launch_bounds__(GTHREADS)
   }
 }
 
-template <int MB>
+template <int MB, bool CONV>
 static int launch_gemm(const uint16_t* Ap, const uint16_t* Bp, float* C, const float* bias, int M, int N, int KB, long a_plane,
-                       long b_plane, long ldc, int relu, hipStream_t s) {
+                       long b_plane, long ldc, int relu, ConvGeom cg, hipStream_t s) {
   constexpr int BM = 32 * MB;
   constexpr int LDS = (BM + GBN) * 3 * 64 * 2;
   static_assert(LDS <= 160 * 1024, "two stages must fit the CU's LDS");
@@ -274,13 +309,50 @@ static int launch_gemm(const uint16_t* Ap, const uint16_t* Bp, float* C, const f
   const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, GBN);
   static bool once = false;
   if (!once) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x6_kernel<MB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x6_kernel<MB, CONV>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
     once = true;
   }
-  hipLaunchKernelGGL(gemm_bf16x6_kernel<MB>, dim3(tiles_m * tiles_n), dim3(GTHREADS), LDS, s, Ap, Bp, C, bias, M, N, KB, a_plane,
-                     b_plane, ldc, relu, tiles_n, tiles_m * tiles_n);
+  hipLaunchKernelGGL((gemm_bf16x6_kernel<MB, CONV>), dim3(tiles_m * tiles_n), dim3(GTHREADS), LDS, s, Ap, Bp, C, bias, M, N, KB, a_plane,
+                     b_plane, ldc, relu, tiles_n, tiles_m * tiles_n, cg);
   return 0;
+}
+
+template <bool CONV>
+static int launch_by_rows(int tile_rows, const uint16_t* Ap, const uint16_t* Bp, float* C, const float* bias, int M, int N, int KB,
+                          long a_plane, long b_plane, long ldc, int relu, ConvGeom cg, hipStream_t s) {
+  switch (tile_rows / 32) {
+    case 3: return launch_gemm<3, CONV>(Ap, Bp, C, bias, M, N, KB, a_plane, b_plane, ldc, relu, cg, s);
+    case 4: return launch_gemm<4, CONV>(Ap, Bp, C, bias, M, N, KB, a_plane, b_plane, ldc, relu, cg, s);
+    case 5: return launch_gemm<5, CONV>(Ap, Bp, C, bias, M, N, KB, a_plane, b_plane, ldc, relu, cg, s);
+    case 6: return launch_gemm<6, CONV>(Ap, Bp, C, bias, M, N, KB, a_plane, b_plane, ldc, relu, cg, s);
+    case 7: return launch_gemm<7, CONV>(Ap, Bp, C, bias, M, N, KB, a_plane, b_plane, ldc, relu, cg, s);
+    default: return launch_gemm<8, CONV>(Ap, Bp, C, bias, M, N, KB, a_plane, b_plane, ldc, relu, cg, s);
+  }
+}
+
+// fp32 [P, C] (row stride ld) -> ROW-MAJOR planes [3][(P + 1) * C]: row P is zeros (the padding every out-of-image tap reads)
+__global__ void __launch_bounds__(256)
+    split3_rows_kernel(const float* __restrict__ src, long ld, int P, int C, uint16_t* __restrict__ dst, long plane) {
+  const int c8 = C >> 3;
+  const long units = (long)(P + 1) * c8;
+  for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += (long)gridDim.x * blockDim.x) {
+    const long r = u / c8;
+    const int c = (int)(u - r * c8) << 3;
+    uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0, o2 = o0;
+    if (r < P) {
+      const float* sp = src + r * ld + c;
+      const float4 lo = *reinterpret_cast<const float4*>(sp), hi = *reinterpret_cast<const float4*>(sp + 4);
+      split_pair(lo.x, lo.y, o0.x, o1.x, o2.x);
+      split_pair(lo.z, lo.w, o0.y, o1.y, o2.y);
+      split_pair(hi.x, hi.y, o0.z, o1.z, o2.z);
+      split_pair(hi.z, hi.w, o0.w, o1.w, o2.w);
+    }
+    uint16_t* d = dst + r * C + c;
+    *reinterpret_cast<uint4*>(d) = o0;
+    *reinterpret_cast<uint4*>(d + plane) = o1;
+    *reinterpret_cast<uint4*>(d + 2 * plane) = o2;
+  }
 }
 
 }  // namespace pt
@@ -338,17 +410,42 @@ extern "C" int pt_gemm_bf16x6_nt(const uint16_t* a_planes, int64_t a_plane_strid
              "pt_gemm_bf16x6_nt: planes must be 16-byte aligned");
   if (tile_rows <= 0) tile_rows = pt_gemm_bf16x6_tile_rows(M, N);
   PT_REQUIRE(tile_rows % 32 == 0 && tile_rows >= 96 && tile_rows <= 256, PT_EINVAL, "pt_gemm_bf16x6_nt: tile_rows in {96, 128, ..., 256}");
-  hipStream_t s = as_stream(stream);
-  int rc = 0;
-  switch (tile_rows / 32) {
-    case 3: rc = launch_gemm<3>(a_planes, b_planes, c, bias, M, N, Kp, a_plane_stride, b_plane_stride, ldc, relu, s); break;
-    case 4: rc = launch_gemm<4>(a_planes, b_planes, c, bias, M, N, Kp, a_plane_stride, b_plane_stride, ldc, relu, s); break;
-    case 5: rc = launch_gemm<5>(a_planes, b_planes, c, bias, M, N, Kp, a_plane_stride, b_plane_stride, ldc, relu, s); break;
-    case 6: rc = launch_gemm<6>(a_planes, b_planes, c, bias, M, N, Kp, a_plane_stride, b_plane_stride, ldc, relu, s); break;
-    case 7: rc = launch_gemm<7>(a_planes, b_planes, c, bias, M, N, Kp, a_plane_stride, b_plane_stride, ldc, relu, s); break;
-    default: rc = launch_gemm<8>(a_planes, b_planes, c, bias, M, N, Kp, a_plane_stride, b_plane_stride, ldc, relu, s); break;
-  }
+  const int rc = launch_by_rows<false>(tile_rows, a_planes, b_planes, c, bias, M, N, Kp, a_plane_stride, b_plane_stride, ldc, relu,
+                                       ConvGeom{0, 0, 0, 0, 0}, as_stream(stream));
   PT_REQUIRE(rc == 0, rc, "pt_gemm_bf16x6_nt: hipFuncSetAttribute failed (%d)", rc);
   PT_LAUNCH_CHECK("pt_gemm_bf16x6_nt");
+  return PT_OK;
+}
+
+extern "C" int pt_split_bf16x3_rows(const float* src, int64_t ld, int P, int C, uint16_t* planes, int64_t plane_stride, void* stream) {
+  PT_REQUIRE(src && planes && P > 0 && C > 0 && (C & 7) == 0 && ld >= C && (ld & 3) == 0, PT_EINVAL, "pt_split_bf16x3_rows: bad argument (C, ld multiples of 8 / 4)");
+  PT_REQUIRE(plane_stride >= (int64_t)(P + 1) * C && (plane_stride & 7) == 0 && (((uintptr_t)planes) & 15) == 0 && (((uintptr_t)src) & 15) == 0,
+             PT_EINVAL, "pt_split_bf16x3_rows: plane_stride must cover (P + 1) * C, buffers 16-byte aligned");
+  const long units = (long)(P + 1) * (C >> 3);
+  int nb = cdiv(units, 256);
+  nb = nb > 16384 ? 16384 : nb;
+  hipLaunchKernelGGL(split3_rows_kernel, dim3(nb), dim3(256), 0, as_stream(stream), src, (long)ld, P, C, planes, (long)plane_stride);
+  PT_LAUNCH_CHECK("pt_split_bf16x3_rows");
+  return PT_OK;
+}
+
+extern "C" int pt_conv3x3_bf16x6_nhwc(const uint16_t* x_planes, int64_t x_plane_stride, const uint16_t* w_planes, int64_t w_plane_stride,
+                                      float* out, int64_t ldo, const float* bias, int B, int H, int W, int Cin, int Cout, int relu,
+                                      int tile_rows, void* stream) {
+  PT_REQUIRE(x_planes && w_planes && out && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && ldo >= Cout, PT_EINVAL, "pt_conv3x3_bf16x6_nhwc: bad argument");
+  PT_REQUIRE(Cin % 32 == 0, PT_EINVAL, "pt_conv3x3_bf16x6_nhwc: Cin must be a multiple of 32 (one k-step = 32 channels of one tap)");
+  const long P = (long)B * H * W;
+  PT_REQUIRE(P < (1L << 30), PT_ELIMIT, "pt_conv3x3_bf16x6_nhwc: B * H * W < 2^30");
+  PT_REQUIRE(x_plane_stride >= (P + 1) * Cin && w_plane_stride >= pt_split_bf16x3_plane_elems(Cout, 9 * Cin), PT_EINVAL,
+             "pt_conv3x3_bf16x6_nhwc: plane strides too small ([P + 1][Cin] row-major activations, blocked [Cout][9 Cin] weights)");
+  PT_REQUIRE(((((uintptr_t)x_planes) | ((uintptr_t)w_planes)) & 15) == 0 && (x_plane_stride & 7) == 0 && (w_plane_stride & 7) == 0, PT_EINVAL,
+             "pt_conv3x3_bf16x6_nhwc: planes must be 16-byte aligned");
+  if (tile_rows <= 0) tile_rows = pt_gemm_bf16x6_tile_rows((int)P, Cout);
+  PT_REQUIRE(tile_rows % 32 == 0 && tile_rows >= 96 && tile_rows <= 256, PT_EINVAL, "pt_conv3x3_bf16x6_nhwc: tile_rows in {96, 128, ..., 256}");
+  const ConvGeom cg{H, W, Cin, Cin / 32, (int)P};
+  const int rc = launch_by_rows<true>(tile_rows, x_planes, w_planes, out, bias, (int)P, Cout, 9 * (Cin / 32), x_plane_stride, w_plane_stride,
+                                      ldo, relu, cg, as_stream(stream));
+  PT_REQUIRE(rc == 0, rc, "pt_conv3x3_bf16x6_nhwc: hipFuncSetAttribute failed (%d)", rc);
+  PT_LAUNCH_CHECK("pt_conv3x3_bf16x6_nhwc");
   return PT_OK;
 }

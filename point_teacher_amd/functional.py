@@ -626,6 +626,82 @@ def split_linear(x, weight, bias=None, relu=False):
     return _SplitLinear.apply(x.contiguous(), weight, bias, bool(relu))
 
 
+# --------------------------------------------------- fp32 3x3 convolution on the bf16 matrix cores (implicit GEMM, bf16x6) --
+
+def _conv_weight_planes(w, dgrad):
+    """Split planes of a [O, I, 3, 3] weight as the [O, 9 I] matrix with k = (ky, kx, i) (forward; a channels_last weight IS
+    that matrix) or as w'[i, (2 - ky, 2 - kx), o] (input gradient); cached until the parameters change (PARAM_EPOCH)."""
+    key = (id(w), 'conv')
+    ent = _SPLIT_W_CACHE.get(key)
+    if ent is None or ent[0] != PARAM_EPOCH[0] or ent[1] != w.data_ptr():
+        ent = [PARAM_EPOCH[0], w.data_ptr(), None, None]
+        _SPLIT_W_CACHE[key] = ent
+    i = 3 if dgrad else 2
+    if ent[i] is None:
+        wd = w.detach()
+        O, I = wd.shape[:2]
+        m = (wd.flip(2, 3).permute(1, 2, 3, 0).reshape(I, 9 * O) if dgrad else wd.permute(0, 2, 3, 1).reshape(O, 9 * I))
+        ent[i] = split_bf16x3(m.contiguous())
+    return ent[i]
+
+
+def _conv3x3_planes(x_nhwc_rows, B, H, W, wp, bias, relu):
+    """x_nhwc_rows [B*H*W, Cin] fp32 contiguous -> [B*H*W, Cout] fp32 (pt_split_bf16x3_rows + pt_conv3x3_bf16x6_nhwc)."""
+    P, C = x_nhwc_rows.shape
+    n = (P + 1) * C
+    xp = torch.empty((3, n), dtype=torch.bfloat16, device=x_nhwc_rows.device)
+    hip.call('pt_split_bf16x3_rows', x_nhwc_rows, C, P, C, xp, n)
+    out = torch.empty((P, wp.rows), dtype=f32, device=x_nhwc_rows.device)
+    hip.call('pt_conv3x3_bf16x6_nhwc', xp, n, wp.planes, wp.planes.shape[1], out, wp.rows, bias, B, H, W, C, wp.rows, int(bool(relu)), 0)
+    return out
+
+
+class _SplitConv3x3(torch.autograd.Function):
+    """y = [relu](conv2d(x, w, b, stride 1, padding 1)) for channels_last fp32 tensors: forward and input gradient as implicit
+    GEMMs of six bf16 MFMA products per fp32 product with fp32 accumulation (csrc/gemm_split.hip, CONV variant; no im2col buffer);
+    the weight gradient stays with the library (its reduce dimension is the pixel index: another kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        B, C, H, W = x.shape
+        O = w.shape[0]
+        rows = x.permute(0, 2, 3, 1).reshape(B * H * W, C)                      # a view of a channels_last tensor
+        y = _conv3x3_planes(rows, B, H, W, _conv_weight_planes(w, False), b, relu).view(B, H, W, O).permute(0, 3, 1, 2)
+        ctx.relu, ctx.has_bias = relu, b is not None
+        ctx.save_for_backward(x, w, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        if ctx.relu:
+            gy = gy * (y > 0)
+        B, O, H, W = gy.shape
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            rows = gy.permute(0, 2, 3, 1).reshape(B * H * W, O)
+            gx = _conv3x3_planes(rows, B, H, W, _conv_weight_planes(w, True), None, False).view(B, H, W, w.shape[1]).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            gw = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum((0, 2, 3))
+        return gx, gw, gb, None
+
+
+def split_conv3x3_ok(x, conv):
+    """The tower shape: 3x3 / stride 1 / pad 1 / one group, Cin % 32 == 0, Cout % 128 == 0, channels_last fp32 on the device, enough
+    pixels to fill 256 CUs (below ~8 000 pixels the library's kernels win)."""
+    return (x.is_cuda and x.dtype == f32 and x.dim() == 4 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels % 32 == 0
+            and conv.out_channels % 128 == 0 and x.shape[0] * x.shape[2] * x.shape[3] >= 8192
+            and x.is_contiguous(memory_format=torch.channels_last) and not torch.is_autocast_enabled())
+
+
+def split_conv3x3(x, weight, bias=None, relu=False):
+    return _SplitConv3x3.apply(x, weight, bias, bool(relu))
+
+
 class _AffineReLU(torch.autograd.Function):
     """y = [relu](x*scale[c] + shift[c] [+ residual]) in place on x (x is a fresh conv output)."""
 

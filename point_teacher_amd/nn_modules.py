@@ -17,6 +17,9 @@ from . import functional as F
 from .registry import BACKBONES, NECKS, ROI_EXTRACTORS
 
 
+_SPLIT_CONV = os.environ.get('PT_SPLIT_CONV', '1') != '0'
+
+
 class ModulatedDeformConv2dPack(nn.Module):
     """mmcv.ops.ModulatedDeformConv2dPack (`conv_cfg=dict(type='DCNv2')`): a zero-initialised `conv_offset` predicts
     (dy, dx) offsets and a sigmoid mask per kernel tap, `pt_deform_*` does the sampling.  Parameter names as mmcv
@@ -101,6 +104,11 @@ class ConvModule(nn.Module):
 
     def forward(self, x):
         c = self.conv
+        if (_SPLIT_CONV and type(c) is nn.Conv2d and c.bias is not None and not self.with_norm and self.with_activation
+                and F.split_conv3x3_ok(x, c)):
+            # the dense head's tower convolutions (fp32 by the config): implicit GEMM on the bf16 matrix cores with split-bf16
+            # operands and fp32 accumulation, bias + ReLU in its epilogue (csrc/gemm_split.hip).  PT_SPLIT_CONV=0: library.
+            return F.split_conv3x3(x, c.weight, c.bias, True)
         if (type(c) is nn.Conv2d and c.bias is not None and not self.with_norm and self.with_activation and x.is_cuda
                 and not torch.is_autocast_enabled()):
             y = TF.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)

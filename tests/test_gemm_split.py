@@ -85,3 +85,42 @@ def test_split_linear_autograd_matches_torch():
     rx, rw, rb = torch.autograd.grad(ref, (x, fc.weight, fc.bias), gy.double())
     for mine, r in ((gx, rx), (gw, rw), (gb, rb)):
         assert float((mine.double() - r).abs().max() / r.abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [(2, 100, 100, 256, 256), (3, 37, 41, 64, 128), (6, 100, 100, 256, 256)])
+def test_conv3x3_bf16x6_matches_fp64_at_least_as_well_as_the_library(B, H, W, Cin, Cout):
+    """The tower shape (3x3, stride 1, pad 1, NHWC) as an implicit GEMM on the split-bf16 kernel: values against a float64
+    convolution (bar: the fp32 library kernel's error on the same inputs), the zero padding at every image border, bias + ReLU
+    epilogue, and the three gradients through the autograd Function (the weight gradient is the library's)."""
+    from point_teacher_amd import functional as F
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device='cpu').manual_seed(B * H + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    conv = torch.nn.Conv2d(Cin, Cout, 3, padding=1).to(dev).to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        conv.bias.normal_(0, 0.5)
+    y = F.split_conv3x3(x, conv.weight, conv.bias, relu=False)
+    assert y.shape == (B, Cout, H, W) and y.is_contiguous(memory_format=torch.channels_last)
+    ref = torch.nn.functional.conv2d(x.detach().double(), conv.weight.detach().double(), conv.bias.detach().double(), padding=1)
+    scale = torch.nn.functional.conv2d(x.detach().double().abs(), conv.weight.detach().double().abs(), None, padding=1) + conv.bias.detach().abs().double().view(1, -1, 1, 1)
+    lib = torch.nn.functional.conv2d(x.detach(), conv.weight.detach(), conv.bias.detach(), padding=1)
+    e_mine = float(((y.detach().double() - ref).abs() / scale).max())
+    e_lib = float(((lib.double() - ref).abs() / scale).max())
+    print(f'[{B}x{H}x{W} {Cin}->{Cout}] bf16x6 conv {e_mine:.3e}  fp32 library {e_lib:.3e}  (units of sum |x||w|)')
+    assert e_mine <= max(e_lib, 2.0 ** -23) and e_mine < 3e-7
+    # borders: the first / last rows and columns see zeros outside
+    for sl in ((slice(None), slice(None), 0), (slice(None), slice(None), H - 1), (slice(None), slice(None), slice(None), 0),
+               (slice(None), slice(None), slice(None), W - 1)):
+        assert float((y.detach().double()[sl] - ref[sl]).abs().max()) < 1e-4
+    yr = F.split_conv3x3(x, conv.weight, conv.bias, relu=True)
+    torch.testing.assert_close(yr.detach(), torch.relu(y.detach()), rtol=0, atol=0)
+    gy = torch.randn(B, Cout, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    gx, gw, gb = torch.autograd.grad(yr, (x, conv.weight, conv.bias), gy)
+    xr = x.detach().double().requires_grad_(True)
+    wr, br = conv.weight.detach().double().requires_grad_(True), conv.bias.detach().double().requires_grad_(True)
+    # (the ReLU mask of the kernel's own output: an element within one rounding of 0 may fall on either side of the kink, and the
+    # reference must differentiate the same piecewise-linear function)
+    mask = (yr.detach() > 0).double()
+    rx, rw, rb = torch.autograd.grad(torch.nn.functional.conv2d(xr, wr, br, padding=1), (xr, wr, br), gy.double() * mask)
+    for mine, r in ((gx, rx), (gw, rw), (gb, rb)):
+        assert float((mine.double() - r).abs().max() / r.abs().max()) < 5e-6
