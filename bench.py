@@ -392,9 +392,11 @@ def main():
             metric=f'train iters/sec ({args.size}x{args.size}, ~{args.objects} pts/img)', value=round(iters_s * world, 4), unit='iters/s',
             n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),
             higher_is_better=True, scaling='weak', vs_baseline=None,
-            # arithmetic type of the path; the MIL FC GEMMs form every fp32 product from six bf16 MFMA products with fp32
-            # accumulation (csrc/gemm_split.hip: error vs float64 below the fp32 library kernel's)
-            dtype=('f32' + (' (MIL FC GEMMs: bf16x6 split MFMA, fp32 accumulate)' if os.environ.get('PT_SPLIT_GEMM', '1') != '0' else ''))
+            # arithmetic type of the path; the MIL FC GEMMs and the dense head's 3x3 tower convolutions (forward, input gradient)
+            # form every fp32 product from six bf16 MFMA products with fp32 accumulation (csrc/gemm_split.hip: error vs float64
+            # below the fp32 library kernels')
+            dtype=('f32' + (' (MIL FC GEMMs' + (' + tower convolutions' if os.environ.get('PT_SPLIT_CONV', '1') != '0' else '')
+                            + ': bf16x6 split MFMA, fp32 accumulate)' if os.environ.get('PT_SPLIT_GEMM', '1') != '0' else ''))
             if args.dtype == 'fp32' else 'bf16', data='synthetic',
             config=dict(workload=(f'sodaa_fcos_pointteacher_1x (oriented) ' if obb else f'aitodv2_point_teacher_{args.percent}% ')
                                  + f'{"burn-in phase 1" if args.workload == "step1" else "phase 2 (MIL on)"}, '

@@ -304,11 +304,20 @@ int pt_box_iou_rotated(const float* a, const float* b, int M, int N, int aligned
 /* mmcv.ops.nms_rotated: dets[N,5] sorted by descending score; keep[N] uint8. N <= 32768. */
 int pt_nms_rotated_sorted(const float* dets, int N, float iou_thr, uint64_t* mask_ws,
                           uint8_t* keep, void* stream);
+/* The same for the images of a batch in ONE pair of launches (generate_black_paper runs one NMS per image,
+ * syn_images_generator_v2.py:667; each is a latency-bound serial scan): candidates of image i are rows
+ * [seg_off[i], seg_off[i+1]) of dets (each segment sorted by descending score), seg_off is a [host] array of n_seg + 1
+ * entries, n_seg <= 16, <= 8192 candidates per segment; mask_ws: sum_i n_i * ceil(n_i / 64) uint64. */
+int pt_nms_rotated_sorted_segments(const float* dets, const int32_t* seg_off, int n_seg, float iou_thr,
+                                   uint64_t* mask_ws, uint8_t* keep, void* stream);
 /* the 255-mask of generate_black_paper (syn_images_generator_v2.py:678-688): every pixel
  * inside or on the boundary of one of the quads[Q,8] (vertices truncated to int32 like
  * polygon.astype(np.int32)) with alive[q] != 0 is set to `value` in img[C,H,W]. */
 int pt_fill_quads(float* img, int C, int H, int W, const float* quads, const uint8_t* alive,
                   int Q, float value, void* stream);
+/* ... and for a whole batch: img [B, C, H, W]; quad q paints image img_of[q] (int32, device). */
+int pt_fill_quads_batch(float* img, int B, int C, int H, int W, const float* quads, const uint8_t* alive,
+                        const int32_t* img_of, int Q, float value, void* stream);
 
 /* ------------------------------------------------- oriented boxes (OBB variant) --
  * mmcv.ops.diff_iou_rotated_2d, call sites OBB_TOD/mmrotate/models/losses/rotated_iou_loss.py:47,90

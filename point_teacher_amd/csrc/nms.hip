@@ -111,10 +111,8 @@ __global__ void __launch_bounds__(64)
 }
 
 // ------------------------------------------------------------- quad fill -----
-__global__ void __launch_bounds__(256)
-    fill_quads_kernel(float* __restrict__ img, int C, int H, int W, const float* __restrict__ quads,
-                      const uint8_t* __restrict__ alive, float value) {
-  const int q = blockIdx.x;
+__device__ __forceinline__ void fill_one_quad(float* __restrict__ img, int C, int H, int W, const float* __restrict__ quads,
+                                              const uint8_t* __restrict__ alive, float value, int q) {
   if (alive && !alive[q]) return;
   long long vx[4], vy[4];
 #pragma unroll
@@ -148,6 +146,89 @@ __global__ void __launch_bounds__(256)
     if (in)
       for (int c = 0; c < C; ++c) img[((size_t)c * H + y) * W + x] = value;
   }
+}
+
+__global__ void __launch_bounds__(256)
+    fill_quads_kernel(float* __restrict__ img, int C, int H, int W, const float* __restrict__ quads,
+                      const uint8_t* __restrict__ alive, float value) {
+  fill_one_quad(img, C, H, W, quads, alive, value, blockIdx.x);
+}
+
+// ---- per-batch forms (r03): the step-1 generator runs one rotated NMS and one rasteriser pass per IMAGE of the batch; each is a
+// latency-bound serial scan (150 us for ~600 candidates), so the images' scans run side by side as workgroups of ONE launch.
+constexpr int NMS_MAXSEG = 16;
+struct NmsSegs {
+  int off[NMS_MAXSEG + 1];          // candidate offsets of the segments (images)
+  long ws[NMS_MAXSEG];              // word offset of each segment's bit matrix in the workspace
+  int n;
+};
+
+__global__ void __launch_bounds__(256)
+    nms_rotated_mask_seg_kernel(const float* __restrict__ boxes, NmsSegs sg, float thr, unsigned long long* __restrict__ mask) {
+  const int s = blockIdx.z, N = sg.off[s + 1] - sg.off[s];
+  const int cols = cdiv(N, 64);
+  const int rb = blockIdx.y, cb = blockIdx.x;
+  if (cb < rb || cb >= cols) return;
+  boxes += (size_t)sg.off[s] * 5;
+  mask += sg.ws[s];
+  __shared__ float cbox[64 * 5];
+  __shared__ unsigned long long part[4][64];
+  const int r = threadIdx.x & 63, q = threadIdx.x >> 6;
+  if (q == 0) {
+    const int j = cb * 64 + r;
+    if (j < N) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) cbox[r * 5 + k] = boxes[(size_t)j * 5 + k];
+    }
+  }
+  __syncthreads();
+  const int i = rb * 64 + r;
+  unsigned long long bits = 0ull;
+  if (i < N) {
+    float me[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) me[k] = boxes[(size_t)i * 5 + k];
+    const int nc = min(64, N - cb * 64);
+    const int lo = max(q * 16, (rb == cb) ? r + 1 : 0), hi = min(q * 16 + 16, nc);
+    for (int t = lo; t < hi; ++t)
+      if (rotated_iou(me, &cbox[t * 5]) > thr) bits |= 1ull << t;
+  }
+  part[q][r] = bits;
+  __syncthreads();
+  if (q == 0 && i < N) mask[(size_t)i * cols + cb] = part[0][r] | part[1][r] | part[2][r] | part[3][r];
+}
+
+__global__ void __launch_bounds__(64)
+    nms_scan_seg_kernel(const unsigned long long* __restrict__ mask, NmsSegs sg, uint8_t* __restrict__ keep) {
+  const int s = blockIdx.x, N = sg.off[s + 1] - sg.off[s];
+  mask += sg.ws[s];
+  keep += sg.off[s];
+  const int cols = cdiv(N, 64);
+  const int lane = threadIdx.x;
+  unsigned long long r[2] = {0ull, 0ull};                    // N <= 8192 per segment
+  for (int i = 0; i < N; ++i) {
+    const int wd = i >> 6;
+    const unsigned long long src = (wd >> 6) ? r[1] : r[0];
+    const unsigned lo = __shfl((unsigned)(src & 0xffffffffu), wd & 63, 64);
+    const unsigned hi = __shfl((unsigned)(src >> 32), wd & 63, 64);
+    const bool removed = ((((unsigned long long)hi << 32) | lo) >> (i & 63)) & 1ull;
+    if (lane == 0) keep[i] = removed ? 0 : 1;
+    if (!removed) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int c = lane + 64 * k;
+        if (c < cols && c >= wd) r[k] |= mask[(size_t)i * cols + c];
+      }
+    }
+  }
+}
+
+// quads of a whole batch: quad q belongs to image img_of[q]; img is [B, C, H, W]
+__global__ void __launch_bounds__(256)
+    fill_quads_batch_kernel(float* __restrict__ img, int C, int H, int W, const float* __restrict__ quads,
+                            const uint8_t* __restrict__ alive, const int32_t* __restrict__ img_of, float value) {
+  const int q = blockIdx.x;
+  fill_one_quad(img + (size_t)img_of[q] * C * H * W, C, H, W, quads, alive, value, q);
 }
 
 }  // namespace pt
@@ -202,5 +283,42 @@ extern "C" int pt_fill_quads(float* img, int C, int H, int W, const float* quads
   PT_REQUIRE(img && quads && C > 0 && H > 0 && W > 0 && Q > 0, PT_EINVAL, "pt_fill_quads: bad argument");
   hipLaunchKernelGGL(fill_quads_kernel, dim3(Q), dim3(256), 0, as_stream(stream), img, C, H, W, quads, alive, value);
   PT_LAUNCH_CHECK("pt_fill_quads");
+  return PT_OK;
+}
+
+extern "C" int pt_nms_rotated_sorted_segments(const float* dets, const int32_t* seg_off, int n_seg, float iou_thr, uint64_t* mask_ws,
+                                              uint8_t* keep, void* stream) {
+  PT_REQUIRE(seg_off && n_seg >= 1 && n_seg <= NMS_MAXSEG, PT_ELIMIT, "pt_nms_rotated_sorted_segments: 1 <= n_seg <= 16");
+  NmsSegs sg{};
+  sg.n = n_seg;
+  long words = 0;
+  int maxn = 0;
+  for (int i = 0; i < n_seg; ++i) {
+    const int n = seg_off[i + 1] - seg_off[i];
+    PT_REQUIRE(n >= 0 && n <= 8192, PT_ELIMIT, "pt_nms_rotated_sorted_segments: at most 8192 candidates per segment");
+    sg.off[i] = seg_off[i];
+    sg.ws[i] = words;
+    words += (long)n * cdiv(n, 64);
+    maxn = n > maxn ? n : maxn;
+  }
+  sg.off[n_seg] = seg_off[n_seg];
+  if (maxn == 0) return PT_OK;
+  PT_REQUIRE(dets && mask_ws && keep, PT_EINVAL, "pt_nms_rotated_sorted_segments: bad argument");
+  const int cols = cdiv(maxn, 64);
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(nms_rotated_mask_seg_kernel, dim3(cols, cols, n_seg), dim3(256), 0, s, dets, sg, iou_thr,
+                     reinterpret_cast<unsigned long long*>(mask_ws));
+  PT_LAUNCH_CHECK("pt_nms_rotated_sorted_segments");
+  hipLaunchKernelGGL(nms_scan_seg_kernel, dim3(n_seg), dim3(64), 0, s, reinterpret_cast<const unsigned long long*>(mask_ws), sg, keep);
+  PT_LAUNCH_CHECK("pt_nms_rotated_sorted_segments");
+  return PT_OK;
+}
+
+extern "C" int pt_fill_quads_batch(float* img, int B, int C, int H, int W, const float* quads, const uint8_t* alive,
+                                   const int32_t* img_of, int Q, float value, void* stream) {
+  if (Q == 0) return PT_OK;
+  PT_REQUIRE(img && quads && img_of && B > 0 && C > 0 && H > 0 && W > 0 && Q > 0, PT_EINVAL, "pt_fill_quads_batch: bad argument");
+  hipLaunchKernelGGL(fill_quads_batch_kernel, dim3(Q), dim3(256), 0, as_stream(stream), img, C, H, W, quads, alive, img_of, value);
+  PT_LAUNCH_CHECK("pt_fill_quads_batch");
   return PT_OK;
 }

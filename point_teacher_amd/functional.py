@@ -981,6 +981,27 @@ def nms_rotated_mask(dets_sorted, iou_threshold, keep_out=None):
     return keep_m
 
 
+def nms_rotated_mask_segments(dets_sorted, counts, iou_threshold, keep_out):
+    """pt_nms_rotated_sorted_segments: the candidates of every image of a batch (rows concatenated, each image's rows sorted by
+    descending score; `counts` = rows per image, host ints) in one pair of launches -> keep_out (uint8, pre-filled with ones)."""
+    import ctypes
+    off = [0]
+    for c in counts:
+        off.append(off[-1] + int(c))
+    words = sum(int(c) * ((int(c) + 63) // 64) for c in counts)
+    ws = torch.empty((max(words, 1),), dtype=torch.int64, device=dets_sorted.device)
+    hip.call('pt_nms_rotated_sorted_segments', _f(dets_sorted[:, :5]), (ctypes.c_int32 * len(off))(*off), len(counts),
+             float(iou_threshold), ws, keep_out)
+    return keep_out
+
+
+def fill_quads_batch_(imgs, quads, alive, img_of, value=255.0):
+    """imgs [B,C,H,W] float contiguous (in place); quads [Q,8]; alive uint8 [Q]; img_of int32 [Q]."""
+    B, C, H, W = imgs.shape
+    hip.call('pt_fill_quads_batch', imgs, B, C, H, W, _f(quads), alive.to(u8).contiguous(), img_of, quads.shape[0], float(value))
+    return imgs
+
+
 def fill_quads_(img, quads, alive, value=255.0):
     """img [C,H,W] float (in place); quads [Q,8]; alive uint8 [Q] or None."""
     C, H, W = img.shape

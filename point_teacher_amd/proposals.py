@@ -235,21 +235,19 @@ def generate_black_paper_batch(imgs, gt_bboxes, prior_size, dense_cls, imgsize, 
     order = torch.sort(key, stable=True)[1]
     sb, nms_in, polys, hull, pre = F.black_paper_sorted(table, order, exist, imgsize)
     keep = torch.ones_like(pre)
+    Ms = [2 * c + 10 for c in counts]
+    # one rotated NMS and one rasteriser pass for the whole batch (each image's serial scan is its own workgroup)
+    F.nms_rotated_mask_segments(nms_in, Ms, 0.05, keep)
+    alive_all = (keep & pre).bool()
+    img_of = F.upload_i32(np.repeat(np.arange(B, dtype=np.int32), Ms), dev)
+    if fill == 'max':          # device-side value: rasterise a 0/1 mask, then select (no host read of img.max())
+        mask = F.fill_quads_batch_(torch.zeros((B, 1, H, W), dtype=imgs[0].dtype, device=dev), polys, alive_all, img_of, 1.0)
+        syn = [torch.where(mask[i] == 1, imgs[i].max(), imgs[i]) for i in range(B)]
+    else:
+        syn = F.fill_quads_batch_(torch.stack([im.float() for im in imgs]).contiguous(), polys, alive_all, img_of, float(fill))
     out, t0 = [], 0
     for i in range(B):
-        M = 2 * counts[i] + 10
-        F.nms_rotated_mask(nms_in[t0:t0 + M], 0.05, keep_out=keep[t0:t0 + M])
-        t0 += M
-    alive_all = (keep & pre).bool()
-    t0 = 0
-    for i in range(B):
-        M = 2 * counts[i] + 10
-        alive, pl = alive_all[t0:t0 + M], polys[t0:t0 + M]
-        if fill == 'max':      # device-side value: rasterise a 0/1 mask, then select (no host read of img.max())
-            mask = F.fill_quads_(torch.zeros((1, H, W), dtype=imgs[i].dtype, device=dev), pl, alive, 1.0)
-            img_syn = torch.where(mask == 1, imgs[i].max(), imgs[i])
-        else:
-            img_syn = F.fill_quads_(imgs[i].clone().contiguous(), pl, alive, float(fill))
-        out.append((img_syn, sb[t0:t0 + M, :5].contiguous() if return_obb else hull[t0:t0 + M], alive))
+        M = Ms[i]
+        out.append((syn[i], sb[t0:t0 + M, :5].contiguous() if return_obb else hull[t0:t0 + M], alive_all[t0:t0 + M]))
         t0 += M
     return out
