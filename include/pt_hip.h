@@ -233,16 +233,21 @@ int pt_gemm_bf16x6_nt(const uint16_t* a_planes, int64_t a_plane_stride, const ui
                       int K, int relu, int tile_rows, void* stream);
 
 /* The 3 x 3, stride 1, pad 1 convolutions of the dense head's towers (anchor_free_head.py:198-219; fp32 by the config) as an
- * implicit GEMM on the same kernel: out[B*H*W, Cout] (NHWC, row stride ldo) = conv(x, w) (+ bias) (ReLU).
+ * implicit GEMM on the same kernel: out[B*H*W, Cout] (NHWC, row stride ldo) = conv(x, w) (* scale[Cout]) (+ bias[Cout]) (ReLU);
+ * scale / bias = the (scale, shift) of a frozen eval-mode BatchNorm behind the convolution (backbones/resnet.py:262-303) or NULL.
  *   x_planes: pt_split_bf16x3_rows of the [B*H*W, Cin] NHWC activations - ROW-MAJOR planes [3][(P + 1) * Cin], row P = zeros
  *             (what a tap outside the image reads); nothing like im2col is ever stored;
  *   w_planes: pt_split_bf16x3 (transpose == 0) of the [Cout, 9 * Cin] weight matrix, k = (ky, kx, cin) - a channels_last weight
  *             [Cout, Cin, 3, 3] is that matrix.  The input gradient is the same call on the output gradient with the weights
  *             w'[cin, (2 - ky, 2 - kx), cout]; the weight gradient stays with the library.  Cin % 32 == 0. */
-int pt_split_bf16x3_rows(const float* src, int64_t ld, int P, int C, uint16_t* planes, int64_t plane_stride, void* stream);
+/* pt_split_bf16x3_rows: optional backward preparation in the same pass - relu_of (the forward output [P, C]; the gradient is
+ * zeroed where it is <= 0), col_scale [C] (the frozen BatchNorm's scale), masked_out (fp32 [P, C]: the effective gradient the
+ * library's weight-gradient kernel reads); any of the three may be NULL. */
+int pt_split_bf16x3_rows(const float* src, int64_t ld, int P, int C, const float* relu_of, const float* col_scale,
+                         float* masked_out, uint16_t* planes, int64_t plane_stride, void* stream);
 int pt_conv3x3_bf16x6_nhwc(const uint16_t* x_planes, int64_t x_plane_stride, const uint16_t* w_planes, int64_t w_plane_stride,
-                           float* out, int64_t ldo, const float* bias, int B, int H, int W, int Cin, int Cout, int relu,
-                           int tile_rows, void* stream);
+                           float* out, int64_t ldo, const float* bias, const float* scale, int B, int H, int W, int Cin,
+                           int Cout, int relu, int tile_rows, void* stream);
 
 /* Frozen BatchNorm (+ residual add) (+ ReLU) in one pass each way.  Every BatchNorm on the path
  * is in eval mode with a frozen affine (models/backbones/resnet.py:647-658, config

@@ -154,8 +154,8 @@ struct ConvGeom {
 template <int MB, bool CONV>
 __global__ void __launch_bounds__(GTHREADS)
     gemm_bf16x6_kernel(const uint16_t* __restrict__ Ap, const uint16_t* __restrict__ Bp, float* __restrict__ C,
-                       const float* __restrict__ bias, int M, int N, int KB, long a_plane, long b_plane, long ldc, int relu,
-                       int tiles_n, int n_tiles, ConvGeom cg) {
+                       const float* __restrict__ bias, const float* __restrict__ scale, int M, int N, int KB, long a_plane, long b_plane,
+                       long ldc, int relu, int tiles_n, int n_tiles, ConvGeom cg) {
   constexpr int BM = 32 * MB, ROWS = BM + GBN;
   constexpr int STAGE = ROWS * 3 * 64;                 // bytes: A planes [3][BM][64] then B planes [3][128][64]
   constexpr int NI = ROWS * 3 / 16;                    // staging instructions (one 1-KiB block each) per stage
@@ -282,6 +282,7 @@ __global__ void __launch_bounds__(GTHREADS)
   if (kh == 0) {
     const int col = n0 + nb * 32 + r;
     const float bv = (bias && col < N) ? bias[col] : 0.f;
+    const float sv = (scale && col < N) ? scale[col] : 1.f;          // per-column scale: a frozen BatchNorm behind the convolution
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -291,7 +292,7 @@ __global__ void __launch_bounds__(GTHREADS)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int row = m0 + m * 32 + e + 8 * g + 4 * h;      // C/D map of the 32x32 MFMA: row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-          float v = acc[m][4 * g + e] + add[e] + bv;
+          float v = (acc[m][4 * g + e] + add[e]) * sv + bv;
           if (relu) v = v > 0.f ? v : 0.f;
           if (row < M && col < N) C[(long)row * ldc + col] = v;
         }
@@ -300,8 +301,8 @@ __global__ void __launch_bounds__(GTHREADS)
 }
 
 template <int MB, bool CONV>
-static int launch_gemm(const uint16_t* Ap, const uint16_t* Bp, float* C, const float* bias, int M, int N, int KB, long a_plane,
-                       long b_plane, long ldc, int relu, ConvGeom cg, hipStream_t s) {
+static int launch_gemm(const uint16_t* Ap, const uint16_t* Bp, float* C, const float* bias, const float* scale, int M, int N, int KB,
+                       long a_plane, long b_plane, long ldc, int relu, ConvGeom cg, hipStream_t s) {
   constexpr int BM = 32 * MB;
   constexpr int LDS = (BM + GBN) * 3 * 64 * 2;
   static_assert(LDS <= 160 * 1024, "two stages must fit the CU's LDS");
@@ -313,27 +314,31 @@ static int launch_gemm(const uint16_t* Ap, const uint16_t* Bp, float* C, const f
     if (e != hipSuccess) return (int)e;
     once = true;
   }
-  hipLaunchKernelGGL((gemm_bf16x6_kernel<MB, CONV>), dim3(tiles_m * tiles_n), dim3(GTHREADS), LDS, s, Ap, Bp, C, bias, M, N, KB, a_plane,
-                     b_plane, ldc, relu, tiles_n, tiles_m * tiles_n, cg);
+  hipLaunchKernelGGL((gemm_bf16x6_kernel<MB, CONV>), dim3(tiles_m * tiles_n), dim3(GTHREADS), LDS, s, Ap, Bp, C, bias, scale, M, N, KB,
+                     a_plane, b_plane, ldc, relu, tiles_n, tiles_m * tiles_n, cg);
   return 0;
 }
 
 template <bool CONV>
-static int launch_by_rows(int tile_rows, const uint16_t* Ap, const uint16_t* Bp, float* C, const float* bias, int M, int N, int KB,
-                          long a_plane, long b_plane, long ldc, int relu, ConvGeom cg, hipStream_t s) {
+static int launch_by_rows(int tile_rows, const uint16_t* Ap, const uint16_t* Bp, float* C, const float* bias, const float* scale, int M,
+                          int N, int KB, long a_plane, long b_plane, long ldc, int relu, ConvGeom cg, hipStream_t s) {
   switch (tile_rows / 32) {
-    case 3: return launch_gemm<3, CONV>(Ap, Bp, C, bias, M, N, KB, a_plane, b_plane, ldc, relu, cg, s);
-    case 4: return launch_gemm<4, CONV>(Ap, Bp, C, bias, M, N, KB, a_plane, b_plane, ldc, relu, cg, s);
-    case 5: return launch_gemm<5, CONV>(Ap, Bp, C, bias, M, N, KB, a_plane, b_plane, ldc, relu, cg, s);
-    case 6: return launch_gemm<6, CONV>(Ap, Bp, C, bias, M, N, KB, a_plane, b_plane, ldc, relu, cg, s);
-    case 7: return launch_gemm<7, CONV>(Ap, Bp, C, bias, M, N, KB, a_plane, b_plane, ldc, relu, cg, s);
-    default: return launch_gemm<8, CONV>(Ap, Bp, C, bias, M, N, KB, a_plane, b_plane, ldc, relu, cg, s);
+    case 3: return launch_gemm<3, CONV>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, s);
+    case 4: return launch_gemm<4, CONV>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, s);
+    case 5: return launch_gemm<5, CONV>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, s);
+    case 6: return launch_gemm<6, CONV>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, s);
+    case 7: return launch_gemm<7, CONV>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, s);
+    default: return launch_gemm<8, CONV>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, s);
   }
 }
 
-// fp32 [P, C] (row stride ld) -> ROW-MAJOR planes [3][(P + 1) * C]: row P is zeros (the padding every out-of-image tap reads)
+// fp32 [P, C] (row stride ld) -> ROW-MAJOR planes [3][(P + 1) * C]: row P is zeros (the padding every out-of-image tap reads).
+// Backward of conv -> (* scale) -> (+ shift) -> ReLU in the same pass: with `relu_of` (the forward output y) an element is zeroed
+// where y <= 0, with `col_scale` it is multiplied by scale[c]; `masked_out` (fp32 [P, C], may alias nothing) receives that
+// effective gradient for the library's weight-gradient kernel - one pass instead of mask, scale and split passes.
 __global__ void __launch_bounds__(256)
-    split3_rows_kernel(const float* __restrict__ src, long ld, int P, int C, uint16_t* __restrict__ dst, long plane) {
+    split3_rows_kernel(const float* __restrict__ src, long ld, int P, int C, const float* __restrict__ relu_of,
+                       const float* __restrict__ col_scale, float* __restrict__ masked_out, uint16_t* __restrict__ dst, long plane) {
   const int c8 = C >> 3;
   const long units = (long)(P + 1) * c8;
   for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += (long)gridDim.x * blockDim.x) {
@@ -342,7 +347,21 @@ __global__ void __launch_bounds__(256)
     uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0, o2 = o0;
     if (r < P) {
       const float* sp = src + r * ld + c;
-      const float4 lo = *reinterpret_cast<const float4*>(sp), hi = *reinterpret_cast<const float4*>(sp + 4);
+      float4 lo = *reinterpret_cast<const float4*>(sp), hi = *reinterpret_cast<const float4*>(sp + 4);
+      if (relu_of) {
+        const float4 ya = *reinterpret_cast<const float4*>(relu_of + r * C + c), yb = *reinterpret_cast<const float4*>(relu_of + r * C + c + 4);
+        lo.x = ya.x > 0.f ? lo.x : 0.f; lo.y = ya.y > 0.f ? lo.y : 0.f; lo.z = ya.z > 0.f ? lo.z : 0.f; lo.w = ya.w > 0.f ? lo.w : 0.f;
+        hi.x = yb.x > 0.f ? hi.x : 0.f; hi.y = yb.y > 0.f ? hi.y : 0.f; hi.z = yb.z > 0.f ? hi.z : 0.f; hi.w = yb.w > 0.f ? hi.w : 0.f;
+      }
+      if (col_scale) {
+        const float4 sa = *reinterpret_cast<const float4*>(col_scale + c), sb = *reinterpret_cast<const float4*>(col_scale + c + 4);
+        lo.x *= sa.x; lo.y *= sa.y; lo.z *= sa.z; lo.w *= sa.w;
+        hi.x *= sb.x; hi.y *= sb.y; hi.z *= sb.z; hi.w *= sb.w;
+      }
+      if (masked_out) {
+        *reinterpret_cast<float4*>(masked_out + r * C + c) = lo;
+        *reinterpret_cast<float4*>(masked_out + r * C + c + 4) = hi;
+      }
       split_pair(lo.x, lo.y, o0.x, o1.x, o2.x);
       split_pair(lo.z, lo.w, o0.y, o1.y, o2.y);
       split_pair(hi.x, hi.y, o0.z, o1.z, o2.z);
@@ -410,28 +429,32 @@ extern "C" int pt_gemm_bf16x6_nt(const uint16_t* a_planes, int64_t a_plane_strid
              "pt_gemm_bf16x6_nt: planes must be 16-byte aligned");
   if (tile_rows <= 0) tile_rows = pt_gemm_bf16x6_tile_rows(M, N);
   PT_REQUIRE(tile_rows % 32 == 0 && tile_rows >= 96 && tile_rows <= 256, PT_EINVAL, "pt_gemm_bf16x6_nt: tile_rows in {96, 128, ..., 256}");
-  const int rc = launch_by_rows<false>(tile_rows, a_planes, b_planes, c, bias, M, N, Kp, a_plane_stride, b_plane_stride, ldc, relu,
+  const int rc = launch_by_rows<false>(tile_rows, a_planes, b_planes, c, bias, nullptr, M, N, Kp, a_plane_stride, b_plane_stride, ldc, relu,
                                        ConvGeom{0, 0, 0, 0, 0}, as_stream(stream));
   PT_REQUIRE(rc == 0, rc, "pt_gemm_bf16x6_nt: hipFuncSetAttribute failed (%d)", rc);
   PT_LAUNCH_CHECK("pt_gemm_bf16x6_nt");
   return PT_OK;
 }
 
-extern "C" int pt_split_bf16x3_rows(const float* src, int64_t ld, int P, int C, uint16_t* planes, int64_t plane_stride, void* stream) {
+extern "C" int pt_split_bf16x3_rows(const float* src, int64_t ld, int P, int C, const float* relu_of, const float* col_scale,
+                                    float* masked_out, uint16_t* planes, int64_t plane_stride, void* stream) {
   PT_REQUIRE(src && planes && P > 0 && C > 0 && (C & 7) == 0 && ld >= C && (ld & 3) == 0, PT_EINVAL, "pt_split_bf16x3_rows: bad argument (C, ld multiples of 8 / 4)");
   PT_REQUIRE(plane_stride >= (int64_t)(P + 1) * C && (plane_stride & 7) == 0 && (((uintptr_t)planes) & 15) == 0 && (((uintptr_t)src) & 15) == 0,
              PT_EINVAL, "pt_split_bf16x3_rows: plane_stride must cover (P + 1) * C, buffers 16-byte aligned");
+  PT_REQUIRE(((((uintptr_t)relu_of) | ((uintptr_t)col_scale) | ((uintptr_t)masked_out)) & 15) == 0, PT_EINVAL,
+             "pt_split_bf16x3_rows: relu_of / col_scale / masked_out must be 16-byte aligned");
   const long units = (long)(P + 1) * (C >> 3);
   int nb = cdiv(units, 256);
   nb = nb > 16384 ? 16384 : nb;
-  hipLaunchKernelGGL(split3_rows_kernel, dim3(nb), dim3(256), 0, as_stream(stream), src, (long)ld, P, C, planes, (long)plane_stride);
+  hipLaunchKernelGGL(split3_rows_kernel, dim3(nb), dim3(256), 0, as_stream(stream), src, (long)ld, P, C, relu_of, col_scale, masked_out,
+                     planes, (long)plane_stride);
   PT_LAUNCH_CHECK("pt_split_bf16x3_rows");
   return PT_OK;
 }
 
 extern "C" int pt_conv3x3_bf16x6_nhwc(const uint16_t* x_planes, int64_t x_plane_stride, const uint16_t* w_planes, int64_t w_plane_stride,
-                                      float* out, int64_t ldo, const float* bias, int B, int H, int W, int Cin, int Cout, int relu,
-                                      int tile_rows, void* stream) {
+                                      float* out, int64_t ldo, const float* bias, const float* scale, int B, int H, int W, int Cin,
+                                      int Cout, int relu, int tile_rows, void* stream) {
   PT_REQUIRE(x_planes && w_planes && out && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && ldo >= Cout, PT_EINVAL, "pt_conv3x3_bf16x6_nhwc: bad argument");
   PT_REQUIRE(Cin % 32 == 0, PT_EINVAL, "pt_conv3x3_bf16x6_nhwc: Cin must be a multiple of 32 (one k-step = 32 channels of one tap)");
   const long P = (long)B * H * W;
@@ -443,7 +466,7 @@ extern "C" int pt_conv3x3_bf16x6_nhwc(const uint16_t* x_planes, int64_t x_plane_
   if (tile_rows <= 0) tile_rows = pt_gemm_bf16x6_tile_rows((int)P, Cout);
   PT_REQUIRE(tile_rows % 32 == 0 && tile_rows >= 96 && tile_rows <= 256, PT_EINVAL, "pt_conv3x3_bf16x6_nhwc: tile_rows in {96, 128, ..., 256}");
   const ConvGeom cg{H, W, Cin, Cin / 32, (int)P};
-  const int rc = launch_by_rows<true>(tile_rows, x_planes, w_planes, out, bias, (int)P, Cout, 9 * (Cin / 32), x_plane_stride, w_plane_stride,
+  const int rc = launch_by_rows<true>(tile_rows, x_planes, w_planes, out, bias, scale, (int)P, Cout, 9 * (Cin / 32), x_plane_stride, w_plane_stride,
                                       ldo, relu, cg, as_stream(stream));
   PT_REQUIRE(rc == 0, rc, "pt_conv3x3_bf16x6_nhwc: hipFuncSetAttribute failed (%d)", rc);
   PT_LAUNCH_CHECK("pt_conv3x3_bf16x6_nhwc");

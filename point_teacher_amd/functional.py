@@ -645,14 +645,15 @@ def _conv_weight_planes(w, dgrad):
     return ent[i]
 
 
-def _conv3x3_planes(x_nhwc_rows, B, H, W, wp, bias, relu):
-    """x_nhwc_rows [B*H*W, Cin] fp32 contiguous -> [B*H*W, Cout] fp32 (pt_split_bf16x3_rows + pt_conv3x3_bf16x6_nhwc)."""
+def _conv3x3_planes(x_nhwc_rows, B, H, W, wp, bias, relu, scale=None, relu_of=None, col_scale=None, masked_out=None):
+    """x_nhwc_rows [B*H*W, Cin] fp32 contiguous -> [B*H*W, Cout] fp32 (pt_split_bf16x3_rows + pt_conv3x3_bf16x6_nhwc).
+    relu_of / col_scale / masked_out: the backward preparation of pt_split_bf16x3_rows (ReLU mask, BatchNorm scale, fp32 copy)."""
     P, C = x_nhwc_rows.shape
     n = (P + 1) * C
     xp = torch.empty((3, n), dtype=torch.bfloat16, device=x_nhwc_rows.device)
-    hip.call('pt_split_bf16x3_rows', x_nhwc_rows, C, P, C, xp, n)
+    hip.call('pt_split_bf16x3_rows', x_nhwc_rows, C, P, C, relu_of, col_scale, masked_out, xp, n)
     out = torch.empty((P, wp.rows), dtype=f32, device=x_nhwc_rows.device)
-    hip.call('pt_conv3x3_bf16x6_nhwc', xp, n, wp.planes, wp.planes.shape[1], out, wp.rows, bias, B, H, W, C, wp.rows, int(bool(relu)), 0)
+    hip.call('pt_conv3x3_bf16x6_nhwc', xp, n, wp.planes, wp.planes.shape[1], out, wp.rows, bias, scale, B, H, W, C, wp.rows, int(bool(relu)), 0)
     return out
 
 
@@ -662,31 +663,41 @@ class _SplitConv3x3(torch.autograd.Function):
     the weight gradient stays with the library (its reduce dimension is the pixel index: another kernel)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu):
+    def forward(ctx, x, w, b, relu, scale):
         B, C, H, W = x.shape
         O = w.shape[0]
         rows = x.permute(0, 2, 3, 1).reshape(B * H * W, C)                      # a view of a channels_last tensor
-        y = _conv3x3_planes(rows, B, H, W, _conv_weight_planes(w, False), b, relu).view(B, H, W, O).permute(0, 3, 1, 2)
+        y = _conv3x3_planes(rows, B, H, W, _conv_weight_planes(w, False), b, relu, scale).view(B, H, W, O).permute(0, 3, 1, 2)
         ctx.relu, ctx.has_bias = relu, b is not None
-        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.save_for_backward(x, w, y if relu else None, scale)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, w, y = ctx.saved_tensors
+        x, w, y, scale = ctx.saved_tensors
         gy = gy.contiguous(memory_format=torch.channels_last)
-        if ctx.relu:
-            gy = gy * (y > 0)
         B, O, H, W = gy.shape
-        gx = gw = gb = None
+        P = B * H * W
+        rows = gy.permute(0, 2, 3, 1).reshape(P, O)
+        need_eff = ctx.relu or scale is not None
+        # ONE pass: ReLU mask (from y), BatchNorm scale, the fp32 effective gradient for the library's wgrad and the split planes
+        eff = torch.empty((P, O), dtype=f32, device=gy.device) if need_eff else rows
+        yrows = y.permute(0, 2, 3, 1).reshape(P, O) if ctx.relu else None
         if ctx.needs_input_grad[0]:
-            rows = gy.permute(0, 2, 3, 1).reshape(B * H * W, O)
-            gx = _conv3x3_planes(rows, B, H, W, _conv_weight_planes(w, True), None, False).view(B, H, W, w.shape[1]).permute(0, 3, 1, 2)
+            gx = _conv3x3_planes(rows, B, H, W, _conv_weight_planes(w, True), None, False, relu_of=yrows, col_scale=scale,
+                                 masked_out=eff if need_eff else None).view(B, H, W, w.shape[1]).permute(0, 3, 1, 2)
+        else:                                  # an input that takes no gradient (not on the training path): plain element-wise ops
+            gx = None
+            if need_eff:
+                eff = rows * (yrows > 0) if ctx.relu else rows
+                eff = eff * scale if scale is not None else eff
+        geff = eff.view(B, H, W, O).permute(0, 3, 1, 2)
+        gw = gb = None
         if ctx.needs_input_grad[1]:
-            gw = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+            gw = torch.ops.aten.convolution_backward(geff, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = gy.sum((0, 2, 3))
-        return gx, gw, gb, None
+            gb = eff.sum(0)                   # (only without a scale: a frozen BatchNorm's shift takes no gradient)
+        return gx, gw, gb, None, None
 
 
 def split_conv3x3_ok(x, conv):
@@ -698,8 +709,9 @@ def split_conv3x3_ok(x, conv):
             and x.is_contiguous(memory_format=torch.channels_last) and not torch.is_autocast_enabled())
 
 
-def split_conv3x3(x, weight, bias=None, relu=False):
-    return _SplitConv3x3.apply(x, weight, bias, bool(relu))
+def split_conv3x3(x, weight, bias=None, relu=False, scale=None):
+    """[relu](conv2d(x, weight, padding 1) * scale[o] + bias[o]); scale / bias may be the (scale, shift) of a frozen BatchNorm."""
+    return _SplitConv3x3.apply(x, weight, bias, bool(relu), scale)
 
 
 class _AffineReLU(torch.autograd.Function):

@@ -109,6 +109,9 @@ class ConvModule(nn.Module):
             # the dense head's tower convolutions (fp32 by the config): implicit GEMM on the bf16 matrix cores with split-bf16
             # operands and fp32 accumulation, bias + ReLU in its epilogue (csrc/gemm_split.hip).  PT_SPLIT_CONV=0: library.
             return F.split_conv3x3(x, c.weight, c.bias, True)
+        if (_SPLIT_CONV and type(c) is nn.Conv2d and c.bias is not None and not self.with_norm and not self.with_activation
+                and F.split_conv3x3_ok(x, c)):
+            return F.split_conv3x3(x, c.weight, c.bias, False)             # FPN output convolutions (no activation)
         if (type(c) is nn.Conv2d and c.bias is not None and not self.with_norm and self.with_activation and x.is_cuda
                 and not torch.is_autocast_enabled()):
             y = TF.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
@@ -234,6 +237,12 @@ def conv_bn(x, conv, bn, relu, residual=None):
     with a frozen affine (norm_eval=True, requires_grad=False, resnet.py:647-658), i.e. a
     per-channel affine map; BN, the residual add and the ReLU then run as ONE pass over the
     activation in each direction (pt_affine_relu_fwd/bwd) instead of three."""
+    if (_SPLIT_CONV and residual is None and type(conv) is nn.Conv2d and conv.bias is None and not bn.training
+            and not bn.weight.requires_grad and getattr(bn, 'fuse_epilogue', True) and F.split_conv3x3_ok(x, conv)):
+        # the 3x3 convolution of a bottleneck with its frozen BatchNorm and ReLU as the epilogue of the implicit GEMM on the bf16
+        # matrix cores (split-bf16 operands, fp32 accumulation): no separate pass over the activation at all
+        sc, sh = _bn_affine(bn)
+        return F.split_conv3x3(x, conv.weight, sh, relu, scale=sc)
     y = conv(x)
     fused = (not bn.training and not bn.weight.requires_grad and y.dtype == torch.float32 and y.is_cuda
              and getattr(bn, 'fuse_epilogue', True) and y.numel() % 4 == 0

@@ -124,3 +124,36 @@ def test_conv3x3_bf16x6_matches_fp64_at_least_as_well_as_the_library(B, H, W, Ci
     rx, rw, rb = torch.autograd.grad(torch.nn.functional.conv2d(xr, wr, br, padding=1), (xr, wr, br), gy.double() * mask)
     for mine, r in ((gx, rx), (gw, rw), (gb, rb)):
         assert float((mine.double() - r).abs().max() / r.abs().max()) < 5e-6
+
+
+def test_conv3x3_bf16x6_with_frozen_batchnorm_epilogue():
+    """conv -> frozen eval-mode BatchNorm -> ReLU (a ResNet bottleneck's conv2 / bn2, backbones/resnet.py:262-303) with the
+    BatchNorm's (scale, shift) as the implicit GEMM's epilogue, through `nn_modules.conv_bn`: values and the gradients of the
+    input and the weight against torch in float64."""
+    from point_teacher_amd import nn_modules as NM
+    dev = torch.device('cuda:0')
+    torch.manual_seed(4)
+    conv = torch.nn.Conv2d(128, 128, 3, padding=1, bias=False).to(dev).to(memory_format=torch.channels_last)
+    bn = torch.nn.BatchNorm2d(128).to(dev).eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3); bn.running_mean.normal_(0, 0.2); bn.running_var.uniform_(0.5, 2.0)
+    for p in bn.parameters():
+        p.requires_grad = False
+    x = torch.randn(2, 128, 70, 72, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    calls = []
+    orig = NM.F.split_conv3x3
+    NM.F.split_conv3x3 = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        y = NM.conv_bn(x, conv, bn, relu=True)
+    finally:
+        NM.F.split_conv3x3 = orig
+    assert calls, 'the bottleneck shape did not take the implicit-GEMM path'
+    xr, wr = x.detach().double().requires_grad_(True), conv.weight.detach().double().requires_grad_(True)
+    sc = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).double()
+    pre = torch.nn.functional.conv2d(xr, wr, None, padding=1) * sc.view(1, -1, 1, 1) + (bn.bias - bn.running_mean * sc.float()).double().view(1, -1, 1, 1)
+    assert float((y.detach().double() - torch.relu(pre)).abs().max()) < 2e-5
+    gy = torch.randn_like(y)
+    gx, gw = torch.autograd.grad(y, (x, conv.weight), gy)
+    rx, rw = torch.autograd.grad(pre, (xr, wr), gy.double() * (y.detach() > 0).double())
+    for mine, r in ((gx, rx), (gw, rw)):
+        assert float((mine.double() - r).abs().max() / r.abs().max()) < 5e-6

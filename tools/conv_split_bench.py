@@ -38,7 +38,7 @@ for B in (2, 4, 6):
     rows = x.permute(0, 2, 3, 1).reshape(-1, C)
     n = (rows.shape[0] + 1) * C
     xp = torch.empty((3, n), dtype=torch.bfloat16, device=dev)
-    t_split = timed(lambda: F.hip.call('pt_split_bf16x3_rows', rows, C, rows.shape[0], C, xp, n))
+    t_split = timed(lambda: F.hip.call('pt_split_bf16x3_rows', rows, C, rows.shape[0], C, None, None, None, xp, n))
     t_lib_d = timed(lambda: torch.ops.aten.convolution_backward(gy, x, conv.weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False]))
     wp = F._conv_weight_planes(conv.weight, True)
     grows = gy.permute(0, 2, 3, 1).reshape(-1, O)
