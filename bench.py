@@ -94,6 +94,17 @@ def iteration_flops(workload, cfg_model, batch, size, objects, executed=True):
     return 2.0 * (conv + mil)
 
 
+def algorithmic_flops(name, shapes):
+    """fp32-equivalent FLOPs of the matrix kernels (2 M N K); the kernels execute 6 bf16 MFMA products per fp32 product."""
+    if name == 'pt_gemm_bf16x6_nt':
+        return 2.0 * shapes['M'] * shapes['N'] * shapes['K']
+    if name == 'pt_conv3x3_bf16x6_nhwc':
+        return 2.0 * shapes['P'] * shapes['Cout'] * 9 * shapes['Cin']
+    return None
+
+
+MFMA_FAMILY = ('pt_bf16x6 (gemm + conv3x3)', ('pt_gemm_bf16x6_nt', 'pt_conv3x3_bf16x6_nhwc'))
+
 FAMILIES = {                                                    # op families for the roofline line
     'pt_roi_align': ('pt_roi_align_fwd', 'pt_roi_align_bwd'),
     'pt_roi_align_rotated': ('pt_roi_align_rotated_fwd', 'pt_roi_align_rotated_bwd'),
@@ -228,6 +239,10 @@ def main():
                 shp = dict(n=a[3], streams=1 + (a[1] is not None) + (a[7] is not None) + (a[8] is not None))
             elif fn == 'pt_affine_relu_bwd_train':
                 shp = dict(n=a[4], streams=2 + (a[1] is not None) + (a[7] is not None) + (a[8] is not None))
+            elif fn == 'pt_gemm_bf16x6_nt':
+                shp = dict(M=a[7], N=a[8], K=a[9])
+            elif fn == 'pt_conv3x3_bf16x6_nhwc':
+                shp = dict(P=a[8] * a[9] * a[10], Cin=a[11], Cout=a[12])
             elif fn in ('pt_ema_update', 'pt_sgd_step', 'pt_sgd_step_groups', 'pt_sqnorm_partial'):
                 shp = dict(n=a[2] if fn == 'pt_ema_update' else (a[3] if fn.startswith('pt_sgd_step') else a[1]))
             prof.setdefault(fn, []).append((e0, e1, shp))
@@ -281,23 +296,30 @@ def main():
     for fn, evs in prof.items():
         ms = [e0.elapsed_time(e1) for e0, e1, _ in evs]
         byts = [algorithmic_bytes(fn, s) if s else None for _, _, s in evs]
-        kern[fn] = dict(calls=len(ms), total_ms=sum(ms), bytes=sum(b for b in byts if b) if all(b for b in byts) else None)
+        fl = [algorithmic_flops(fn, s) if s else None for _, _, s in evs]
+        kern[fn] = dict(calls=len(ms), total_ms=sum(ms), bytes=sum(b for b in byts if b) if all(b for b in byts) else None,
+                        flops=sum(f for f in fl if f) if all(f for f in fl) else None)
     fam = {}
     for name, members in FAMILIES.items():
         ks = [kern[m] for m in members if m in kern and kern[m]['bytes']]
         if ks:
             fam[name] = dict(calls=sum(k['calls'] for k in ks), total_ms=sum(k['total_ms'] for k in ks), bytes=sum(k['bytes'] for k in ks))
+    # the matrix kernels of the path (fp32 products as six bf16 MFMA products): MFMA-bound, priced against the dense bf16 peak
+    mk = [kern[m] for m in MFMA_FAMILY[1] if m in kern and kern[m].get('flops')]
+    mfma = dict(calls=sum(k['calls'] for k in mk), total_ms=sum(k['total_ms'] for k in mk), flops=sum(k['flops'] for k in mk)) if mk else None
     dom = args.roofline_kernel if args.roofline_kernel != 'auto' else max(fam, key=lambda k: fam[k]['total_ms'])
-    d = fam[dom]
+    if args.roofline_kernel == 'auto' and mfma and mfma['total_ms'] > fam[dom]['total_ms']:
+        dom = MFMA_FAMILY[0]
+    d = fam[dom] if dom in fam else mfma
     # HIP-event pairs include ~5 us of event overhead per launch (event_pair_overhead_us); `achieved` keeps it in
     # (conservative); rocprofv3's bare kernel time is shorter by about that much per launch
-    achieved = d['bytes'] / (d['total_ms'] * 1e-3) / 1e9
+    achieved = d['bytes'] / (d['total_ms'] * 1e-3) / 1e9 if 'bytes' in d else None
     # HBM bytes from PMC passes: only when profiles/r02/pmc_traffic.json was taken with THIS kernel source (sha256 of the
     # .hip file) and this workload; otherwise null (never a number measured on other code)
     traffic = None
     try:
         import hashlib
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02', 'pmc_traffic.json')))
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r03', 'pmc_traffic.json')))
         ent = pmc.get(('obb_' if obb else '') + args.workload + ('_bf16' if args.dtype == 'bf16' else ''), {}).get(dom)
         if ent:
             src = os.path.join(ROOT, 'point_teacher_amd', 'csrc', ent['source'])
@@ -305,12 +327,25 @@ def main():
                 traffic = ent['traffic_bytes_per_launch']
     except Exception:
         pass
-    roofline = dict(bound='hbm', kernel=dom, achieved=round(achieved, 1), peak=8000.0, unit='GB/s',
-                    frac=round(achieved / 8000.0, 4), traffic=traffic,
-                    avg_launch_us=round(d['total_ms'] / d['calls'] * 1e3, 2), event_pair_overhead_us=round(event_overhead_us, 2),
-                    launches=d['calls'], bytes_per_launch=int(d['bytes'] / d['calls']),
-                    families={k: dict(ms_per_step=round(v['total_ms'] / args.steps, 3),
-                                      achieved_GBps=round(v['bytes'] / (v['total_ms'] * 1e-3) / 1e9, 1)) for k, v in sorted(fam.items())})
+    fams = {k: dict(ms_per_step=round(v['total_ms'] / args.steps, 3), achieved_GBps=round(v['bytes'] / (v['total_ms'] * 1e-3) / 1e9, 1))
+            for k, v in sorted(fam.items())}
+    if mfma:
+        ex = 6.0 * mfma['flops'] / (mfma['total_ms'] * 1e-3) / 1e12
+        fams[MFMA_FAMILY[0]] = dict(ms_per_step=round(mfma['total_ms'] / args.steps, 3), executed_bf16_TFLOPs=round(ex, 1),
+                                    fp32_equivalent_TFLOPs=round(ex / 6.0, 1))
+    if dom == MFMA_FAMILY[0]:
+        # achieved = EXECUTED bf16 FLOPs (6 MFMA products per fp32 product) / HIP-event time, peak = dense bf16 MFMA (guide);
+        # the fp32 work it replaces (2 M N K) runs at achieved / 6 against a 157.3 TFLOP/s fp32 matrix peak
+        ex = 6.0 * mfma['flops'] / (mfma['total_ms'] * 1e-3) / 1e12
+        roofline = dict(bound='mfma', kernel=dom, achieved=round(ex, 1), peak=2500.0, unit='TFLOP/s', frac=round(ex / 2500.0, 4),
+                        traffic=traffic, fp32_equivalent_tflops=round(ex / 6.0, 1), fp32_mfma_peak_tflops=157.3,
+                        avg_launch_us=round(mfma['total_ms'] / mfma['calls'] * 1e3, 2), event_pair_overhead_us=round(event_overhead_us, 2),
+                        launches=mfma['calls'], flops_per_launch=int(6.0 * mfma['flops'] / mfma['calls']), families=fams)
+    else:
+        roofline = dict(bound='hbm', kernel=dom, achieved=round(achieved, 1), peak=8000.0, unit='GB/s',
+                        frac=round(achieved / 8000.0, 4), traffic=traffic,
+                        avg_launch_us=round(d['total_ms'] / d['calls'] * 1e3, 2), event_pair_overhead_us=round(event_overhead_us, 2),
+                        launches=d['calls'], bytes_per_launch=int(d['bytes'] / d['calls']), families=fams)
 
     # ---- the steady-state phase as well (94 % of a 12-epoch run is phase 2): same model, phase switch flipped ----
     phase2 = None

@@ -19,7 +19,9 @@ FAMILY = {'roi_align7_fwd': ('pt_roi_align', 'roi_align.hip'), 'roi_align7_bwd':
           'affine_relu_fwd_kernel': ('pt_affine_relu', 'optim.hip'), 'affine_relu_bwd_kernel': ('pt_affine_relu', 'optim.hip'),
           'affine_relu_fwd_bf16_kernel': ('pt_affine_relu', 'optim.hip'), 'affine_relu_bwd_bf16_kernel': ('pt_affine_relu', 'optim.hip'),
           'ema_kernel': ('pt_optimizer (ema + sqnorm + sgd)', 'optim.hip'), 'sgd_kernel': ('pt_optimizer (ema + sqnorm + sgd)', 'optim.hip'),
-          'sqnorm_kernel': ('pt_optimizer (ema + sqnorm + sgd)', 'optim.hip')}
+          'sqnorm_kernel': ('pt_optimizer (ema + sqnorm + sgd)', 'optim.hip'),
+          'gemm_bf16x6_kernel': ('pt_bf16x6 (gemm + conv3x3)', 'gemm_split.hip'),
+          'roi_align_rotated_fwd_mm': ('pt_roi_align_rotated', 'rotated.hip'), 'roi_align_rotated_bwd_mm': ('pt_roi_align_rotated', 'rotated.hip')}
 
 
 def read(path):
@@ -35,7 +37,7 @@ def read(path):
 
 
 tag, key = sys.argv[1], sys.argv[2]
-out_path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, 'profiles', 'r02', 'pmc_traffic.json')
+out_path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, 'profiles', 'r03', 'pmc_traffic.json')
 fetch = read(os.path.join(ROOT, 'gpurun_out', f'pmc_{tag}_FETCH_SIZE.txt'))
 write = read(os.path.join(ROOT, 'gpurun_out', f'pmc_{tag}_WRITE_SIZE.txt'))
 fam = {}
