@@ -5,7 +5,7 @@
 // TF32/xf32 path; its fp32 MFMA runs at 1/16 of the bf16 rate (157 vs 2 500 TFLOP/s).  Every fp32 value is the EXACT sum of
 // three bf16 terms x = x0 + x1 + x2 (8 + 8 + 8 significant bits, round-to-nearest at each step), so
 //     x * y = x0y0 + (x0y1 + x1y0) + (x0y2 + x1y1 + x2y0) + O(2^-26 |xy|)
-// and the six leading products on `v_mfma_f32_32x32x16_bf16` with the hardware's fp32 accumulation reproduce an fp32 product to
+// and the six leading products on `v_mfma_f32_16x16x32_bf16` with the hardware's fp32 accumulation reproduce an fp32 product to
 // ~2^-26 - below the 2^-24 rounding of an fp32 fmaf chain - at 16 / 6 = 2.7x the fp32 matrix rate.
 //
 // Two kernels:
@@ -17,11 +17,15 @@
 // GEMM structure (one 512-thread workgroup = 8 wavefronts per tile, one tile per CU at a time):
 //   tile 32*MB x 128 (MB = 3..8 chosen on the host so that the tile count fills 256 CUs), k-step 32;
 //   staging: `global_load_lds_dwordx4` straight into LDS (no VGPR round trip, no VALU), two stages, ONE barrier per k-step; the
-//     image of a stage is [6 planes][row][64 B], the 16-byte slot of a row XOR-swizzled with (row >> 2) & 3 - already in the
-//     planes' memory layout (the LDS side of an LDS-DMA is lane-linear) -, which makes every ds_read_b128 fragment read conflict-free;
-//   wave w computes the 32-column block (w & 3) of the tile for the k-half (w >> 2) of every k-step: 3*MB + 3 fragment reads feed
-//     6*MB MFMAs; the two k-halves are summed through LDS once, in the epilogue (two waves per SIMD hide each other's waits without a
-//     second tile in flight);
+//     image of a stage is [6 planes][row][64 B], the 16-byte slot of a row XOR-swizzled (slot_swz) - already in the planes' memory
+//     layout (the LDS side of an LDS-DMA is lane-linear) -, which makes every ds_read_b128 fragment read conflict-free;
+//   `v_mfma_f32_16x16x32_bf16`: one MFMA spans the 32-deep k-step; the waves split the tile as 2 row groups x 4 column blocks
+//     (16*MB rows x 32 columns each); 3*MB + 6 fragment reads feed 12*MB MFMAs per wave and k-step; the leading product a0*b0 and
+//     the five correction products keep separate accumulators (error vs float64 1.1 - 1.6e-7 of sum|a||b|; the fp32 library
+//     kernels: 2.9 - 3.9e-7).  The 32x32x16 form (4 column blocks x 2 k-halves summed through LDS) measured 6 - 17 % slower at
+//     1.6 - 2.1e-7 (profiles/r03/mfma_shape_ab.txt): the guide's observation that the chip sustains a higher clock on this shape;
+//   epilogue: the tile leaves through LDS ([BM][132] fp32) as whole 512-byte row segments of 16-byte stores, with the
+//     per-column scale / bias / ReLU of the caller (Linear bias, frozen BatchNorm);
 //   blockIdx -> tile mapping is XCD-aware: the blocks of one XCD (b % 8) walk consecutive tiles of the column-fastest tile list,
 //     so the tiles that share an A row panel are in flight together behind the same L2.
 #include "pt_common.h"
@@ -29,7 +33,6 @@
 namespace pt {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
 constexpr int GK = 32;              // k-step (bf16 elements): 64 bytes per row and plane
 constexpr int GBN = 128;            // tile columns
@@ -59,8 +62,16 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsig
 // (row >> 2) & 3 (conflict-free ds_read_b128 fragment reads).  One staging instruction of the GEMM (`global_load_lds_dwordx4`,
 // 1 KiB per wave) then reads 8 whole 128-byte lines; with row-major planes the same instruction touched 16 half lines 25 KB
 // apart and the L2 -> L1 traffic doubled.  Rows past the matrix and k past its width are zeros.
+// XOR mask of the 16-byte k-slot of row `r`: f((r >> 2) & 3) with f = (0, 2, 3, 1).  With it every ds_read_b128 lane group
+// (16 lanes) of BOTH fragment patterns - 32 rows x 2 slots (v_mfma 32x32x16) and 16 rows x 4 slots (16x16x32) - touches 16
+// distinct 16-byte slots of the 256-byte bank row.
+__host__ __device__ __forceinline__ int slot_swz(int r) {
+  const int g = (r >> 2) & 3;
+  return (((g ^ (g >> 1)) & 1) << 1) | (g >> 1);
+}
+
 __device__ __forceinline__ long block_off(long rb, long kb, long KB, int r16, int q) {      // in bf16 elements
-  return ((rb * KB + kb) << 9) + (r16 << 5) + ((q ^ ((r16 >> 2) & 3)) << 3);
+  return ((rb * KB + kb) << 9) + (r16 << 5) + ((q ^ slot_swz(r16)) << 3);
 }
 
 // src [R, C] (row stride ld): rows = R, k = C.  One wavefront per block: 16 rows x 128 bytes read, 1 KiB written per plane.
@@ -151,6 +162,8 @@ struct ConvGeom {
   int H, W, Cin, CB, P;             // CB = Cin / 32 k-blocks per tap; P = B * H * W pixels (the zero row is row P)
 };
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
 template <int MB, bool CONV>
 __global__ void __launch_bounds__(GTHREADS)
     gemm_bf16x6_kernel(const uint16_t* __restrict__ Ap, const uint16_t* __restrict__ Bp, float* __restrict__ C,
@@ -194,7 +207,7 @@ __global__ void __launch_bounds__(GTHREADS)
       const uint16_t* base = isA ? Ap + p * a_plane : Bp + p * b_plane;
       if (CONV && isA) {
         const int rr = rbi * 16 + (lane >> 2), qd = lane & 3;            // row of the tile, physical 16-byte slot
-        const int sl = qd ^ ((rr >> 2) & 3);                             // logical k-slot that lands there
+        const int sl = qd ^ slot_swz(rr);                                // logical k-slot that lands there
         const int pix = m0 + rr;
         const int x = pix % cg.W, y = (pix / cg.W) % cg.H;
         int mask = 0;
@@ -226,77 +239,89 @@ __global__ void __launch_bounds__(GTHREADS)
     }
   };
 
-  f32x16_t acc[MB];
+  // v_mfma_f32_16x16x32_bf16: one MFMA spans the whole 32-deep k-step, so the eight waves split the tile as 2 row groups x 4
+  // column blocks (16 * MB rows x 32 columns each: balanced for every MB, no k-halves to sum afterwards).  A fragment = one
+  // 16 x 32 block of the LDS image (lane l: row l & 15, k-slot l >> 4).
+  const int nb = w & 3, rg = w >> 2;
+  const int r16 = lane & 15, sq = lane >> 4;
+  const int phys = (sq ^ slot_swz(r16)) * 16;
+  const int a_off = (rg * MB * 16 + r16) * 64 + phys;                  // + p * BM * 64 + i * 16 * 64
+  const int b_off = 3 * BM * 64 + (nb * 32 + r16) * 64 + phys;         // + p * 128 * 64 + c * 16 * 64
+  // Two accumulators per output tile: the leading product a0 b0 and the five correction products (2^-8 ... 2^-16 of it).  Every
+  // MFMA rounds the running fp32 sum once; kept apart, the long chain of corrections rounds at ITS magnitude and the leading
+  // chain is 6x shorter - the error against float64 drops below the 32x32x16 form's (which sums two k-halves) again.
+  f32x4_t acc[MB][2], cor[MB][2];
 #pragma unroll
-  for (int m = 0; m < MB; ++m)
+  for (int i = 0; i < MB; ++i)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
-
-  const int nb = w & 3, kh = w >> 2;                    // column block, k-half
-  const int r = lane & 31, h = lane >> 5;
-  const int slot_phys = ((2 * kh + h) ^ ((r >> 2) & 3)) * 16;
-  const int a_off = r * 64 + slot_phys;                                  // + p * BM * 64 + mb * 32 * 64
-  const int b_off = 3 * BM * 64 + (nb * 32 + r) * 64 + slot_phys;        // + p * 128 * 64
-
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][c][e] = cor[i][c][e] = 0.f;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) issue1(j, 0, 0);
   for (int ks = 0; ks < KB; ++ks) {
-    __syncthreads();            // (emits s_waitcnt vmcnt(0)): stage ks has landed, every wave is done reading the other buffer
+    __syncthreads();          // (emits s_waitcnt vmcnt(0)): stage ks has landed, every wave is done reading the other buffer
     const bool more = ks + 1 < KB;
     const int nbuf = (ks + 1) & 1;
     const unsigned char* st = smem + (ks & 1) * STAGE;
-    const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(st + b_off);
-    const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(st + b_off + GBN * 64);
-    const bf16x8_t b2 = *reinterpret_cast<const bf16x8_t*>(st + b_off + 2 * GBN * 64);
+    bf16x8_t b[2][3];
 #pragma unroll
-    for (int m = 0; m < MB; ++m) {
-      const unsigned char* ap = st + a_off + m * 32 * 64;
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) b[c][p] = *reinterpret_cast<const bf16x8_t*>(st + b_off + p * GBN * 64 + c * 16 * 64);
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+      const unsigned char* ap = st + a_off + i * 16 * 64;
       const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(ap);
       const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(ap + BM * 64);
       const bf16x8_t a2 = *reinterpret_cast<const bf16x8_t*>(ap + 2 * BM * 64);
-      if (more) {               // the next stage's LDS-DMA is spread behind the MFMAs (issued in one burst after the barrier it
-#pragma unroll                  // held every wave's first MFMA back by ~7 x 60 cycles; measured +4 %)
-        for (int q = 0; q < PER; ++q) issue1(m * PER + q, nbuf, ks + 1);
+      if (more) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) issue1(i * PER + q, nbuf, ks + 1);
       }
-      // smallest terms first
-      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[m], 0, 0, 0);
-      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[m], 0, 0, 0);
-      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[m], 0, 0, 0);
-      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[m], 0, 0, 0);
-      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[m], 0, 0, 0);
-      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[m], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {                     // smallest terms first
+        cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b[c][0], cor[i][c], 0, 0, 0);
+        cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b[c][1], cor[i][c], 0, 0, 0);
+        cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[c][2], cor[i][c], 0, 0, 0);
+        cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b[c][0], cor[i][c], 0, 0, 0);
+        cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[c][1], cor[i][c], 0, 0, 0);
+        acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[c][0], acc[i][c], 0, 0, 0);
+      }
     }
   }
-  __syncthreads();              // everyone is done with the staging buffers: they become the reduction scratch
-
-  // the two k-halves meet: waves 4..7 park their accumulators in LDS, waves 0..3 add them and store
-  float4* red = reinterpret_cast<float4*>(smem) + (size_t)nb * MB * 4 * 64;   // [nb][mb][reg4][lane]
-  if (kh == 1) {
+  __syncthreads();            // everyone is done with the staging buffers: they become the output tile [BM][132] (fp32)
+  constexpr int TLD = GBN + 4;
+  float* otile = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int m = 0; m < MB; ++m)
+  for (int i = 0; i < MB; ++i)
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        red[(m * 4 + g) * 64 + lane] = make_float4(acc[m][4 * g], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]);
-  }
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)         // C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+        otile[(rg * MB * 16 + i * 16 + sq * 4 + e) * TLD + nb * 32 + c * 16 + r16] = acc[i][c][e] + cor[i][c][e];
   __syncthreads();
-  if (kh == 0) {
-    const int col = n0 + nb * 32 + r;
-    const float bv = (bias && col < N) ? bias[col] : 0.f;
-    const float sv = (scale && col < N) ? scale[col] : 1.f;          // per-column scale: a frozen BatchNorm behind the convolution
+  // whole rows of the tile leave as 16-byte stores: 32 lanes = one 512-byte row segment
+  for (int idx = threadIdx.x; idx < BM * (GBN / 4); idx += GTHREADS) {
+    const int row = idx >> 5, c4 = (idx & 31) << 2;
+    const int grow = m0 + row, gcol = n0 + c4;
+    if (grow >= M || gcol >= N) continue;
+    float4 v = *reinterpret_cast<const float4*>(otile + row * TLD + c4);
+    float o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int m = 0; m < MB; ++m)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 o = red[(m * 4 + g) * 64 + lane];
-        const float add[4] = {o.x, o.y, o.z, o.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int row = m0 + m * 32 + e + 8 * g + 4 * h;      // C/D map of the 32x32 MFMA: row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-          float v = (acc[m][4 * g + e] + add[e]) * sv + bv;
-          if (relu) v = v > 0.f ? v : 0.f;
-          if (row < M && col < N) C[(long)row * ldc + col] = v;
-        }
+    for (int e = 0; e < 4; ++e) {
+      if (gcol + e < N) {
+        if (scale) o[e] *= scale[gcol + e];
+        if (bias) o[e] += bias[gcol + e];
+        if (relu) o[e] = o[e] > 0.f ? o[e] : 0.f;
       }
+    }
+    float* dst = C + (long)grow * ldc + gcol;
+    if (gcol + 4 <= N && ((((uintptr_t)dst) & 15) == 0)) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    else
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (gcol + e < N) dst[e] = o[e];
   }
 }
 
@@ -306,7 +331,7 @@ static int launch_gemm(const uint16_t* Ap, const uint16_t* Bp, float* C, const f
   constexpr int BM = 32 * MB;
   constexpr int LDS = (BM + GBN) * 3 * 64 * 2;
   static_assert(LDS <= 160 * 1024, "two stages must fit the CU's LDS");
-  static_assert(MB * 4 * 16 * 64 * 4 <= LDS, "reduction scratch must fit the staging buffers");
+  static_assert(BM * (GBN + 4) * 4 <= LDS, "the output tile must fit the staging buffers");
   const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, GBN);
   static bool once = false;
   if (!once) {

@@ -549,7 +549,9 @@ class SplitPlanes:
         t = self.planes.view(3, RB, KB, 16, 4, 8).float()
         r16 = torch.arange(16, device=t.device)
         q = torch.arange(4, device=t.device)
-        phys = q[None, :] ^ ((r16[:, None] >> 2) & 3)                       # physical slot of logical slot q in row r16
+        g = (r16 >> 2) & 3
+        f = (((g ^ (g >> 1)) & 1) << 1) | (g >> 1)                           # slot_swz of csrc/gemm_split.hip: f = (0, 2, 3, 1)
+        phys = q[None, :] ^ f[:, None]                                       # physical slot of logical slot q in row r16
         t = torch.gather(t, 4, phys[None, None, None, :, :, None].expand(3, RB, KB, 16, 4, 8))
         return t.permute(0, 1, 3, 2, 4, 5).reshape(3, RB * 16, KB * 32)
 
