@@ -98,12 +98,12 @@ def algorithmic_flops(name, shapes):
     """fp32-equivalent FLOPs of the matrix kernels (2 M N K); the kernels execute 6 bf16 MFMA products per fp32 product."""
     if name == 'pt_gemm_bf16x6_nt':
         return 2.0 * shapes['M'] * shapes['N'] * shapes['K']
-    if name == 'pt_conv3x3_bf16x6_nhwc':
+    if name in ('pt_conv3x3_bf16x6_nhwc', 'pt_conv3x3_wgrad_bf16x6_nhwc'):
         return 2.0 * shapes['P'] * shapes['Cout'] * 9 * shapes['Cin']
     return None
 
 
-MFMA_FAMILY = ('pt_bf16x6 (gemm + conv3x3)', ('pt_gemm_bf16x6_nt', 'pt_conv3x3_bf16x6_nhwc'))
+MFMA_FAMILY = ('pt_bf16x6 (gemm + conv3x3)', ('pt_gemm_bf16x6_nt', 'pt_conv3x3_bf16x6_nhwc', 'pt_conv3x3_wgrad_bf16x6_nhwc'))
 
 FAMILIES = {                                                    # op families for the roofline line
     'pt_roi_align': ('pt_roi_align_fwd', 'pt_roi_align_bwd'),
@@ -243,6 +243,8 @@ def main():
                 shp = dict(M=a[7], N=a[8], K=a[9])
             elif fn == 'pt_conv3x3_bf16x6_nhwc':
                 shp = dict(P=a[8] * a[9] * a[10], Cin=a[11], Cout=a[12])
+            elif fn == 'pt_conv3x3_wgrad_bf16x6_nhwc':       # (includes its fixed-order reduction of the pixel chunks)
+                shp = dict(P=a[7] * a[8] * a[9], Cin=a[10], Cout=a[11])
             elif fn in ('pt_ema_update', 'pt_sgd_step', 'pt_sgd_step_groups', 'pt_sqnorm_partial'):
                 shp = dict(n=a[2] if fn == 'pt_ema_update' else (a[3] if fn.startswith('pt_sgd_step') else a[1]))
             prof.setdefault(fn, []).append((e0, e1, shp))
@@ -407,7 +409,7 @@ def main():
             cpu_baseline = dict(value=None, unit='iters/s', cores=None, kind='port',
                                 sample='not timed for the oriented variant (its oracle, oracle/ref_obb.py, loops over RoIs '
                                        'in python); the CPU leg is reported on the default hbb workload')
-        elif not args.no_cpu_baseline and world == 1:
+        elif not args.no_cpu_baseline and args.cpu_baseline_iters > 0 and world == 1:
             try:
                 from oracle import ref_model
                 cpu_baseline = ref_model.cpu_baseline(args.workload, args.batch, args.size, args.objects,

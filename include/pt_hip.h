@@ -239,7 +239,7 @@ int pt_gemm_bf16x6_nt(const uint16_t* a_planes, int64_t a_plane_stride, const ui
  *             (what a tap outside the image reads); nothing like im2col is ever stored;
  *   w_planes: pt_split_bf16x3 (transpose == 0) of the [Cout, 9 * Cin] weight matrix, k = (ky, kx, cin) - a channels_last weight
  *             [Cout, Cin, 3, 3] is that matrix.  The input gradient is the same call on the output gradient with the weights
- *             w'[cin, (2 - ky, 2 - kx), cout]; the weight gradient stays with the library.  Cin % 32 == 0. */
+ *             w'[cin, (2 - ky, 2 - kx), cout]; the weight gradient is pt_conv3x3_wgrad_bf16x6_nhwc.  Cin % 32 == 0. */
 /* pt_split_bf16x3_rows: optional backward preparation in the same pass - relu_of (the forward output [P, C]; the gradient is
  * zeroed where it is <= 0), col_scale [C] (the frozen BatchNorm's scale), masked_out (fp32 [P, C]: the effective gradient the
  * library's weight-gradient kernel reads); any of the three may be NULL. */
@@ -248,6 +248,19 @@ int pt_split_bf16x3_rows(const float* src, int64_t ld, int P, int C, const float
 int pt_conv3x3_bf16x6_nhwc(const uint16_t* x_planes, int64_t x_plane_stride, const uint16_t* w_planes, int64_t w_plane_stride,
                            float* out, int64_t ldo, const float* bias, const float* scale, int B, int H, int W, int Cin,
                            int Cout, int relu, int tile_rows, void* stream);
+
+/* Weight gradient of the same convolution (replaces the convolution_backward the towers' autograd reaches from
+ * anchor_free_head.py:198-219): dw[Cout][3][3][Cin] (the memory of a channels_last [Cout, Cin, 3, 3] weight)
+ *   = sum over pixels p of gy[p][cout] * x[p + (ky - 1) * W + (kx - 1)][cin]   (taps outside the image contribute nothing).
+ * gy_planes / x_planes: pt_split_bf16x3_rows planes of the [B*H*W, Cout] output gradient (the ones the input gradient used) and of
+ * the [B*H*W, Cin] activations (the ones the forward used) - the pixel index is their row index; the kernel reads both
+ * column-wise out of LDS (ds_read_b64_tr_b16), nothing is transposed in memory.  The pixels are cut into `splits` chunks
+ * (0 = pt_conv3x3_wgrad_bf16x6_splits); partial sums go to `workspace` (>= splits * Cout * 9 * Cin floats) and are added in a
+ * fixed order: deterministic, no atomics.  Cin % 128 == 0, Cout % 128 == 0. */
+int pt_conv3x3_wgrad_bf16x6_splits(int B, int H, int W, int Cin, int Cout);
+int pt_conv3x3_wgrad_bf16x6_nhwc(const uint16_t* gy_planes, int64_t gy_plane_stride, const uint16_t* x_planes,
+                                 int64_t x_plane_stride, float* dw, float* workspace, int64_t workspace_elems, int B,
+                                 int H, int W, int Cin, int Cout, int splits, void* stream);
 
 /* Frozen BatchNorm (+ residual add) (+ ReLU) in one pass each way.  Every BatchNorm on the path
  * is in eval mode with a frozen affine (models/backbones/resnet.py:647-658, config

@@ -399,6 +399,189 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+
+// ------------------------------------------------------------------------------------ conv3x3 weight gradient --
+// dW[o][tap][c] = sum_p gy[p][o] * x[p + shift(tap)][c]  (3 x 3, stride 1, pad 1; anchor_free_head.py:198-219 backward).
+// The reduce dimension is the PIXEL index - the ROW index of both row-major plane sets (the output-gradient planes the input
+// gradient already made, the activation planes the forward made): nothing is transposed or re-split.  A stage is a set of
+// [32 pixels][128 columns] bf16 images (256-byte rows, 16-byte chunk XOR-swizzled with ((row & 3) << 2) | ((row >> 2) & 3)), written by
+// `global_load_lds_dwordx4` (the activation rows shifted by the tile's tap, the zero row where the tap leaves the image) and read
+// COLUMN-wise by `ds_read_b64_tr_b16`: two transposed reads = the 8 consecutive k of one MFMA operand lane; every read is
+// bank-conflict free on this image.  Tile = all BM = 32 MB output channels x 128 columns of one tap; the pixels are cut into
+// `S` chunks (grid = S x tiles) whose partial tiles go to a workspace and are summed in a fixed order (deterministic; no atomics,
+// no zero fill).  Same MFMA schedule, accumulator pair and LDS-staged epilogue as gemm_bf16x6_kernel.
+struct WgradGeom {
+  int H, W, C, O, P;
+  int KBT, KS;                      // k-steps (32 pixels) in total / per chunk
+  int tiles_m, tiles_n;
+};
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* lo, const unsigned char* hi) {
+  const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)lo);
+  const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)hi);
+  const s16x8_t v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <int MB>
+__global__ void __launch_bounds__(GTHREADS)
+    wgrad3x3_bf16x6_kernel(const uint16_t* __restrict__ Gp, const uint16_t* __restrict__ Xp, float* __restrict__ part, long g_plane,
+                           long x_plane, WgradGeom wg, int n_items) {
+  constexpr int BM = 32 * MB, IMG_A = BM / 128, NIMG = IMG_A + 1;
+  constexpr int IMG = 32 * 256;                        // bytes of one image
+  constexpr int STAGE = NIMG * 3 * IMG;                // [image][plane][32 rows][256 B]; images 0 .. IMG_A-1: gy, image IMG_A: x
+  static_assert(BM % 128 == 0, "whole 128-column images");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+  int item;                                            // XCD-aware: the blocks of one XCD walk consecutive (chunk, tile) items
+  {
+    const int b = blockIdx.x, q = n_items >> 3, r = n_items & 7, x = b & 7;
+    item = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+  }
+  const int per = wg.tiles_m * wg.tiles_n;
+  const int s = item / per, t = item - s * per;
+  const int tm = t / wg.tiles_n, tn = t - tm * wg.tiles_n;
+  const int m0 = tm * BM, n0 = tn * GBN;
+  const int tap = n0 / wg.C, c0 = n0 - tap * wg.C;
+  const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+
+  // staging: wave w owns rows 4w .. 4w+3 (one KiB) of every image; lane = (row, physical chunk)
+  const int srow = 4 * w + (lane >> 4);
+  const int lc = (lane & 15) ^ (((srow & 3) << 2) | ((srow >> 2) & 3));       // logical chunk that lands in this lane's slot
+  const int k_begin = s * wg.KS, k_end = min(wg.KBT, k_begin + wg.KS);
+  int pix = k_begin * 32 + srow;
+  int px = pix % wg.W, py = (pix / wg.W) % wg.H;
+  const uint16_t* ga = Gp + m0 + lc * 8;
+  const uint16_t* xb = Xp + c0 + lc * 8;
+  long arow = 0, brow = 0;
+  auto next_rows = [&]() {                             // rows of the stage at `pix`, then advance one k-step
+    arow = (long)(pix < wg.P ? pix : wg.P) * wg.O;
+    const int yy = py + dy, xx = px + dx;
+    const bool ok = pix < wg.P && yy >= 0 && yy < wg.H && xx >= 0 && xx < wg.W;
+    brow = (long)(ok ? pix + dy * wg.W + dx : wg.P) * wg.C;
+    pix += 32;
+    px += 32;
+    while (px >= wg.W) { px -= wg.W; ++py; }
+    while (py >= wg.H) py -= wg.H;
+  };
+  auto issue = [&](int img, int buf) {                 // the three planes of one image
+    unsigned char* dst = smem + buf * STAGE + img * 3 * IMG + w * 1024;
+    const uint16_t* src = img < IMG_A ? ga + arow + img * 128 : xb + brow;
+    const long plane = img < IMG_A ? g_plane : x_plane;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) glds16(src + p * plane, dst + p * IMG);
+  };
+
+  // fragments: lane 16 g + 4 q + p2 supplies row 8 g + q (+ 4 for the second read), 8-byte half p2 & 1 of chunk c0 + (p2 >> 1)
+  const int nb = w & 3, rg = w >> 2;
+  const int g4 = lane >> 4, q4 = (lane >> 2) & 3, p2 = lane & 3;
+  int a_off[MB][2], b_off[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = 8 * g4 + q4 + 4 * h;
+    const int X = (q4 << 2) | ((2 * g4 + h) & 3);
+    const int base = 256 * row + 8 * (p2 & 1);
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+      const int blk = rg * MB + i;                     // 16-channel block of the tile
+      a_off[i][h] = (blk >> 3) * 3 * IMG + base + 16 * ((2 * (blk & 7) + (p2 >> 1)) ^ X);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) b_off[c][h] = IMG_A * 3 * IMG + base + 16 * ((nb * 4 + c * 2 + (p2 >> 1)) ^ X);
+  }
+
+  f32x4_t acc[MB][2], cor[MB][2];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][c][e] = cor[i][c][e] = 0.f;
+  if (k_begin < k_end) {
+    next_rows();
+#pragma unroll
+    for (int img = 0; img < NIMG; ++img) issue(img, 0);
+  }
+  for (int ks = k_begin; ks < k_end; ++ks) {
+    __syncthreads();          // the stage has landed (s_waitcnt vmcnt(0)) and every wave has left the other buffer
+    const bool more = ks + 1 < k_end;
+    const int cur = (ks - k_begin) & 1;
+    const unsigned char* st = smem + cur * STAGE;
+    if (more) next_rows();
+    bf16x8_t b[2][3];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) b[c][p] = tr_frag(st + b_off[c][0] + p * IMG, st + b_off[c][1] + p * IMG);
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+      const bf16x8_t a0 = tr_frag(st + a_off[i][0], st + a_off[i][1]);
+      const bf16x8_t a1 = tr_frag(st + a_off[i][0] + IMG, st + a_off[i][1] + IMG);
+      const bf16x8_t a2 = tr_frag(st + a_off[i][0] + 2 * IMG, st + a_off[i][1] + 2 * IMG);
+      if (more && i < NIMG) issue(i, cur ^ 1);         // wave-uniform
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {                     // smallest terms first
+        cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b[c][0], cor[i][c], 0, 0, 0);
+        cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b[c][1], cor[i][c], 0, 0, 0);
+        cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[c][2], cor[i][c], 0, 0, 0);
+        cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b[c][0], cor[i][c], 0, 0, 0);
+        cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[c][1], cor[i][c], 0, 0, 0);
+        acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[c][0], acc[i][c], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();            // the staging buffers become the output tile [BM][132] (fp32)
+  constexpr int TLD = GBN + 4;
+  float* otile = reinterpret_cast<float*>(smem);
+  const int r16 = lane & 15, sq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        otile[(rg * MB * 16 + i * 16 + sq * 4 + e) * TLD + nb * 32 + c * 16 + r16] = acc[i][c][e] + cor[i][c][e];
+  __syncthreads();
+  const long ldp = 9L * wg.C;
+  float* dst = part + ((long)s * wg.O + m0) * ldp + n0;
+  for (int idx = threadIdx.x; idx < BM * (GBN / 4); idx += GTHREADS) {
+    const int row = idx >> 5, c4 = (idx & 31) << 2;
+    *reinterpret_cast<float4*>(dst + row * ldp + c4) = *reinterpret_cast<const float4*>(otile + row * TLD + c4);
+  }
+}
+
+// out[i] = sum_s part[s][i] in the order s = 0, 1, ... (n4 = elements / 4)
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float4* __restrict__ part, int S, long n4, float4* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 a = part[i];
+  for (int s = 1; s < S; ++s) {
+    const float4 v = part[(long)s * n4 + i];
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  out[i] = a;
+}
+
+template <int MB>
+static int launch_wgrad(const uint16_t* Gp, const uint16_t* Xp, float* part, long g_plane, long x_plane, WgradGeom wg, int S, hipStream_t s) {
+  constexpr int LDS = (32 * MB / 128 + 1) * 3 * 8192 * 2;
+  static_assert(LDS <= 160 * 1024, "two stages must fit the CU's LDS");
+  static_assert(32 * MB * (GBN + 4) * 4 <= LDS, "the output tile must fit the staging buffers");
+  static bool once = false;
+  if (!once) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_bf16x6_kernel<MB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    once = true;
+  }
+  const int n_items = S * wg.tiles_m * wg.tiles_n;
+  hipLaunchKernelGGL((wgrad3x3_bf16x6_kernel<MB>), dim3(n_items), dim3(GTHREADS), LDS, s, Gp, Xp, part, g_plane, x_plane, wg, n_items);
+  return 0;
+}
+
 }  // namespace pt
 
 using namespace pt;
@@ -495,5 +678,48 @@ extern "C" int pt_conv3x3_bf16x6_nhwc(const uint16_t* x_planes, int64_t x_plane_
                                       ldo, relu, cg, as_stream(stream));
   PT_REQUIRE(rc == 0, rc, "pt_conv3x3_bf16x6_nhwc: hipFuncSetAttribute failed (%d)", rc);
   PT_LAUNCH_CHECK("pt_conv3x3_bf16x6_nhwc");
+  return PT_OK;
+}
+
+
+// Pixel chunks of the weight gradient: about two workgroups per CU, at least 16 k-steps (512 pixels) each.
+extern "C" int pt_conv3x3_wgrad_bf16x6_splits(int B, int H, int W, int Cin, int Cout) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  const long P = (long)B * H * W;
+  const int kbt = (int)((P + 31) / 32);
+  const int bm = Cout % 256 == 0 ? 256 : 128;
+  const int per = (Cout / bm) * (9 * Cin / GBN);
+  int S = (512 + per / 2) / (per > 0 ? per : 1);
+  const int cap = kbt / 16;
+  if (S > cap) S = cap;
+  return S < 1 ? 1 : S;
+}
+
+extern "C" int pt_conv3x3_wgrad_bf16x6_nhwc(const uint16_t* gy_planes, int64_t gy_plane_stride, const uint16_t* x_planes,
+                                            int64_t x_plane_stride, float* dw, float* workspace, int64_t workspace_elems, int B, int H,
+                                            int W, int Cin, int Cout, int splits, void* stream) {
+  PT_REQUIRE(gy_planes && x_planes && dw && workspace && B > 0 && H > 0 && W > 0, PT_EINVAL, "pt_conv3x3_wgrad_bf16x6_nhwc: bad argument");
+  PT_REQUIRE(Cin > 0 && Cin % 128 == 0 && Cout > 0 && Cout % 128 == 0, PT_EINVAL,
+             "pt_conv3x3_wgrad_bf16x6_nhwc: Cin and Cout must be multiples of 128 (a tile = 128 channels of one tap x 128 or 256 outputs)");
+  const long P = (long)B * H * W;
+  PT_REQUIRE(P < (1L << 30), PT_ELIMIT, "pt_conv3x3_wgrad_bf16x6_nhwc: B * H * W < 2^30");
+  PT_REQUIRE(gy_plane_stride >= (P + 1) * Cout && x_plane_stride >= (P + 1) * Cin, PT_EINVAL,
+             "pt_conv3x3_wgrad_bf16x6_nhwc: plane strides too small (row-major [P + 1][C] planes with a zero last row)");
+  PT_REQUIRE(((((uintptr_t)gy_planes) | ((uintptr_t)x_planes) | ((uintptr_t)dw) | ((uintptr_t)workspace)) & 15) == 0 &&
+                 (gy_plane_stride & 7) == 0 && (x_plane_stride & 7) == 0, PT_EINVAL, "pt_conv3x3_wgrad_bf16x6_nhwc: buffers must be 16-byte aligned");
+  const int kbt = (int)((P + 31) / 32);
+  int S = splits > 0 ? splits : pt_conv3x3_wgrad_bf16x6_splits(B, H, W, Cin, Cout);
+  if (S > kbt) S = kbt;
+  const long n = (long)Cout * 9 * Cin;
+  PT_REQUIRE(workspace_elems >= (int64_t)S * n, PT_EINVAL, "pt_conv3x3_wgrad_bf16x6_nhwc: workspace must hold splits * Cout * 9 * Cin floats");
+  const int bm = Cout % 256 == 0 ? 256 : 128;
+  WgradGeom wg{H, W, Cin, Cout, (int)P, kbt, (kbt + S - 1) / S, Cout / bm, 9 * Cin / GBN};
+  const int rc = bm == 256 ? launch_wgrad<8>(gy_planes, x_planes, workspace, gy_plane_stride, x_plane_stride, wg, S, as_stream(stream))
+                           : launch_wgrad<4>(gy_planes, x_planes, workspace, gy_plane_stride, x_plane_stride, wg, S, as_stream(stream));
+  PT_REQUIRE(rc == 0, rc, "pt_conv3x3_wgrad_bf16x6_nhwc: hipFuncSetAttribute failed (%d)", rc);
+  PT_LAUNCH_CHECK("pt_conv3x3_wgrad_bf16x6_nhwc");
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, as_stream(stream), reinterpret_cast<const float4*>(workspace),
+                     S, n / 4, reinterpret_cast<float4*>(dw));
+  PT_LAUNCH_CHECK("pt_conv3x3_wgrad_bf16x6_nhwc (reduce)");
   return PT_OK;
 }

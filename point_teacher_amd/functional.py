@@ -5,6 +5,8 @@ fallback.  Batched inputs follow the C ABI convention: per-image ground truths a
 concatenated and described by an int32 offsets tensor `off[B+1]` on the device.
 """
 import numpy as np
+import os
+
 import torch
 
 from . import hip
@@ -577,6 +579,7 @@ def gemm_bf16x6_nt(a, b, bias=None, relu=False, out=None, tile_rows=0):
     return c
 
 
+_SPLIT_WGRAD = os.environ.get('PT_SPLIT_WGRAD', '1') != '0'      # 0: the 3x3 convolutions' weight gradient stays with the library
 _SPLIT_W_CACHE = {}      # id(weight) -> (PARAM_EPOCH, data_ptr, planes of W, planes of W^T or None)
 
 
@@ -647,57 +650,90 @@ def _conv_weight_planes(w, dgrad):
     return ent[i]
 
 
-def _conv3x3_planes(x_nhwc_rows, B, H, W, wp, bias, relu, scale=None, relu_of=None, col_scale=None, masked_out=None):
-    """x_nhwc_rows [B*H*W, Cin] fp32 contiguous -> [B*H*W, Cout] fp32 (pt_split_bf16x3_rows + pt_conv3x3_bf16x6_nhwc).
-    relu_of / col_scale / masked_out: the backward preparation of pt_split_bf16x3_rows (ReLU mask, BatchNorm scale, fp32 copy)."""
+def _split_rows(x_nhwc_rows, relu_of=None, col_scale=None, masked_out=None):
+    """[P, C] fp32 contiguous -> ROW-MAJOR bf16 planes [3, (P + 1) * C] (row P = zeros), pt_split_bf16x3_rows.
+    relu_of / col_scale / masked_out: its backward preparation (ReLU mask, BatchNorm scale, fp32 copy of the effective gradient)."""
     P, C = x_nhwc_rows.shape
     n = (P + 1) * C
     xp = torch.empty((3, n), dtype=torch.bfloat16, device=x_nhwc_rows.device)
     hip.call('pt_split_bf16x3_rows', x_nhwc_rows, C, P, C, relu_of, col_scale, masked_out, xp, n)
-    out = torch.empty((P, wp.rows), dtype=f32, device=x_nhwc_rows.device)
-    hip.call('pt_conv3x3_bf16x6_nhwc', xp, n, wp.planes, wp.planes.shape[1], out, wp.rows, bias, scale, B, H, W, C, wp.rows, int(bool(relu)), 0)
+    return xp
+
+
+def _conv3x3_from_planes(xp, P, C, B, H, W, wp, bias, relu, scale=None):
+    """planes of [B*H*W, Cin] -> [B*H*W, Cout] fp32 (pt_conv3x3_bf16x6_nhwc)."""
+    out = torch.empty((P, wp.rows), dtype=f32, device=xp.device)
+    hip.call('pt_conv3x3_bf16x6_nhwc', xp, xp.shape[1], wp.planes, wp.planes.shape[1], out, wp.rows, bias, scale, B, H, W, C, wp.rows,
+             int(bool(relu)), 0)
     return out
 
 
+def conv3x3_wgrad_ok(Cin, Cout):
+    return Cin % 128 == 0 and Cout % 128 == 0
+
+
+def _conv3x3_wgrad(gp, xp, B, H, W, Cin, Cout):
+    """planes of the output gradient [P, Cout] and of the activations [P, Cin] -> the weight gradient as a channels_last
+    [Cout, Cin, 3, 3] tensor (pt_conv3x3_wgrad_bf16x6_nhwc: split over pixel chunks, summed in a fixed order)."""
+    S = hip.call('pt_conv3x3_wgrad_bf16x6_splits', B, H, W, Cin, Cout)
+    n = Cout * 9 * Cin
+    ws = torch.empty((S * n,), dtype=f32, device=gp.device)
+    dw = torch.empty((Cout, 3, 3, Cin), dtype=f32, device=gp.device)
+    hip.call('pt_conv3x3_wgrad_bf16x6_nhwc', gp, gp.shape[1], xp, xp.shape[1], dw, ws, S * n, B, H, W, Cin, Cout, S)
+    return dw.permute(0, 3, 1, 2)
+
+
 class _SplitConv3x3(torch.autograd.Function):
-    """y = [relu](conv2d(x, w, b, stride 1, padding 1)) for channels_last fp32 tensors: forward and input gradient as implicit
-    GEMMs of six bf16 MFMA products per fp32 product with fp32 accumulation (csrc/gemm_split.hip, CONV variant; no im2col buffer);
-    the weight gradient stays with the library (its reduce dimension is the pixel index: another kernel)."""
+    """y = [relu](conv2d(x, w, b, stride 1, padding 1)) for channels_last fp32 tensors: forward, input gradient and weight
+    gradient as implicit GEMMs of six bf16 MFMA products per fp32 product with fp32 accumulation (csrc/gemm_split.hip; no im2col
+    buffer).  The forward's activation planes are kept for the weight gradient (its reduce dimension is their row index); shapes
+    the weight-gradient kernel does not take (channels not multiples of 128) fall back to the library for that one product."""
 
     @staticmethod
     def forward(ctx, x, w, b, relu, scale):
         B, C, H, W = x.shape
         O = w.shape[0]
         rows = x.permute(0, 2, 3, 1).reshape(B * H * W, C)                      # a view of a channels_last tensor
-        y = _conv3x3_planes(rows, B, H, W, _conv_weight_planes(w, False), b, relu, scale).view(B, H, W, O).permute(0, 3, 1, 2)
+        xp = _split_rows(rows)
+        y = _conv3x3_from_planes(xp, B * H * W, C, B, H, W, _conv_weight_planes(w, False), b, relu, scale).view(B, H, W, O).permute(0, 3, 1, 2)
         ctx.relu, ctx.has_bias = relu, b is not None
-        ctx.save_for_backward(x, w, y if relu else None, scale)
+        ctx.own_wgrad = bool(_SPLIT_WGRAD and conv3x3_wgrad_ok(C, O))
+        keep = w.requires_grad and ctx.own_wgrad
+        ctx.save_for_backward(None if keep else x, w, y if relu else None, scale, xp if keep else None)
+        ctx.xshape = (B, C, H, W)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, w, y, scale = ctx.saved_tensors
+        x, w, y, scale, xp = ctx.saved_tensors
         gy = gy.contiguous(memory_format=torch.channels_last)
         B, O, H, W = gy.shape
+        C = ctx.xshape[1]
         P = B * H * W
         rows = gy.permute(0, 2, 3, 1).reshape(P, O)
-        need_eff = ctx.relu or scale is not None
-        # ONE pass: ReLU mask (from y), BatchNorm scale, the fp32 effective gradient for the library's wgrad and the split planes
-        eff = torch.empty((P, O), dtype=f32, device=gy.device) if need_eff else rows
+        need_w = ctx.needs_input_grad[1]
+        own = need_w and xp is not None
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        masked = ctx.relu or scale is not None
+        # the fp32 effective gradient (ReLU mask, BatchNorm scale) is only written for a consumer outside the planes
+        need_eff = masked and (need_b or (need_w and not own))
+        eff = torch.empty((P, O), dtype=f32, device=gy.device) if need_eff else (None if masked else rows)
         yrows = y.permute(0, 2, 3, 1).reshape(P, O) if ctx.relu else None
-        if ctx.needs_input_grad[0]:
-            gx = _conv3x3_planes(rows, B, H, W, _conv_weight_planes(w, True), None, False, relu_of=yrows, col_scale=scale,
-                                 masked_out=eff if need_eff else None).view(B, H, W, w.shape[1]).permute(0, 3, 1, 2)
-        else:                                  # an input that takes no gradient (not on the training path): plain element-wise ops
-            gx = None
-            if need_eff:
-                eff = rows * (yrows > 0) if ctx.relu else rows
-                eff = eff * scale if scale is not None else eff
-        geff = eff.view(B, H, W, O).permute(0, 3, 1, 2)
-        gw = gb = None
-        if ctx.needs_input_grad[1]:
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0] or own:
+            # ONE pass: ReLU mask (from y), BatchNorm scale, [the fp32 effective gradient] and the split planes
+            gp = _split_rows(rows, relu_of=yrows, col_scale=scale, masked_out=eff if need_eff else None)
+            if ctx.needs_input_grad[0]:
+                gx = _conv3x3_from_planes(gp, P, O, B, H, W, _conv_weight_planes(w, True), None, False).view(B, H, W, C).permute(0, 3, 1, 2)
+            if own:
+                gw = _conv3x3_wgrad(gp, xp, B, H, W, C, O)
+        elif need_eff:                         # an input that takes no gradient (not on the training path): plain element-wise ops
+            e = rows * (yrows > 0) if ctx.relu else rows
+            eff = e * scale if scale is not None else e
+        if need_w and not own:
+            geff = eff.view(B, H, W, O).permute(0, 3, 1, 2)
             gw = torch.ops.aten.convolution_backward(geff, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if need_b:
             gb = eff.sum(0)                   # (only without a scale: a frozen BatchNorm's shift takes no gradient)
         return gx, gw, gb, None, None
 

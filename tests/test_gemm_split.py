@@ -91,7 +91,8 @@ def test_split_linear_autograd_matches_torch():
 def test_conv3x3_bf16x6_matches_fp64_at_least_as_well_as_the_library(B, H, W, Cin, Cout):
     """The tower shape (3x3, stride 1, pad 1, NHWC) as an implicit GEMM on the split-bf16 kernel: values against a float64
     convolution (bar: the fp32 library kernel's error on the same inputs), the zero padding at every image border, bias + ReLU
-    epilogue, and the three gradients through the autograd Function (the weight gradient is the library's)."""
+    epilogue, and the three gradients through the autograd Function (the weight gradient: pt_conv3x3_wgrad_bf16x6_nhwc where
+    both channel counts are multiples of 128, else the library's)."""
     from point_teacher_amd import functional as F
     dev = torch.device('cuda:0')
     g = torch.Generator(device='cpu').manual_seed(B * H + Cin)
@@ -157,3 +158,38 @@ def test_conv3x3_bf16x6_with_frozen_batchnorm_epilogue():
     rx, rw = torch.autograd.grad(pre, (xr, wr), gy.double() * (y.detach() > 0).double())
     for mine, r in ((gx, rx), (gw, rw)):
         assert float((mine.double() - r).abs().max() / r.abs().max()) < 5e-6
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [(2, 100, 100, 256, 256), (1, 37, 41, 128, 256), (2, 20, 17, 256, 128), (6, 100, 100, 128, 128)])
+def test_conv3x3_wgrad_bf16x6_matches_fp64_at_least_as_well_as_the_library(B, H, W, Cin, Cout):
+    """dW[o, c, ky, kx] = sum_p gy[p, o] x[p + shift, c] with the pixel index as the reduce dimension (transposed LDS reads of the
+    row-major planes): against float64 in units of sum |gy||x| (bar: the fp32 library kernel), borders of every image, pixel
+    counts that are not multiples of the 32-pixel k-step, rows narrower than a k-step, any number of pixel chunks, and bit-identical
+    repeats (fixed summation order, no atomics)."""
+    from point_teacher_amd import functional as F
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device='cpu').manual_seed(B * H + Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(B, Cout, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    w = torch.zeros(Cout, Cin, 3, 3, device=dev).contiguous(memory_format=torch.channels_last)
+    P = B * H * W
+    xp = F._split_rows(x.permute(0, 2, 3, 1).reshape(P, Cin))
+    gp = F._split_rows(gy.permute(0, 2, 3, 1).reshape(P, Cout))
+    dw = F._conv3x3_wgrad(gp, xp, B, H, W, Cin, Cout)
+    assert dw.shape == (Cout, Cin, 3, 3) and dw.is_contiguous(memory_format=torch.channels_last)
+    ref = torch.ops.aten.convolution_backward(gy.double(), x.double(), w.double(), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    scale = torch.ops.aten.convolution_backward(gy.double().abs(), x.double().abs(), w.double(), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                [False, True, False])[1]
+    lib = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    e_mine = float(((dw.double() - ref).abs() / scale).max())
+    e_lib = float(((lib.double() - ref).abs() / scale).max())
+    print(f'[{B}x{H}x{W} {Cin}->{Cout}] bf16x6 wgrad {e_mine:.3e}  fp32 library {e_lib:.3e}  (units of sum |gy||x|)')
+    assert e_mine <= max(e_lib, 2.0 ** -23) and e_mine < 3e-7
+    assert float((dw.double() - ref).abs().max() / ref.abs().max()) < 5e-6
+    assert torch.equal(F._conv3x3_wgrad(gp, xp, B, H, W, Cin, Cout), dw)
+    n = Cout * 9 * Cin
+    for S in (1, 3, 8):
+        ws = torch.empty((S * n,), device=dev)
+        d2 = torch.empty((Cout, 3, 3, Cin), device=dev)
+        F.hip.call('pt_conv3x3_wgrad_bf16x6_nhwc', gp, gp.shape[1], xp, xp.shape[1], d2, ws, S * n, B, H, W, Cin, Cout, S)
+        assert float((d2.permute(0, 3, 1, 2).double() - ref).abs().max() / ref.abs().max()) < 5e-6, S

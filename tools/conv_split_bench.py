@@ -1,4 +1,4 @@
-"""bf16x6 implicit-GEMM 3x3 convolution vs the library (MIOpen) on the dense head's tower shape, forward and input gradient:
+"""bf16x6 implicit-GEMM 3x3 convolution vs the library (MIOpen) on the dense head's tower shape, forward, input gradient and weight gradient:
 time (HIP events, median of 20).  python tools/conv_split_bench.py > profiles/r03/conv_bf16x6_vs_library.txt"""
 import os
 import statistics
@@ -25,7 +25,7 @@ def timed(fn, n=20):
 
 
 dev = torch.device('cuda:0')
-print('shape | library fwd ms (TF) | bf16x6 fwd ms incl. split (TF) [split alone] | library dgrad ms | bf16x6 dgrad ms incl. split')
+print('shape | library fwd ms (TF) | bf16x6 fwd ms incl. split (TF) [split alone] | library dgrad ms | bf16x6 dgrad ms incl. split | library wgrad ms | bf16x6 wgrad ms (TF)')
 for B in (2, 4, 6):
     H = W = 100
     C = O = 256
@@ -42,6 +42,8 @@ for B in (2, 4, 6):
     t_lib_d = timed(lambda: torch.ops.aten.convolution_backward(gy, x, conv.weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False]))
     wp = F._conv_weight_planes(conv.weight, True)
     grows = gy.permute(0, 2, 3, 1).reshape(-1, O)
-    t_mine_d = timed(lambda: F._conv3x3_planes(grows, B, H, W, wp, None, False))
+    t_mine_d = timed(lambda: F._conv3x3_from_planes(F._split_rows(grows), grows.shape[0], O, B, H, W, wp, None, False))
+    gp, xq = F._split_rows(grows), F._split_rows(rows)
+    t_mine_w = timed(lambda: F._conv3x3_wgrad(gp, xq, B, H, W, C, O))
     t_lib_w = timed(lambda: torch.ops.aten.convolution_backward(gy, x, conv.weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False]))
-    print(f'B={B} 100x100 256->256 | {t_lib:.3f} ({fl / t_lib / 1e9:.0f}) | {t_mine:.3f} ({fl / t_mine / 1e9:.0f}) [{t_split:.3f}] | {t_lib_d:.3f} | {t_mine_d:.3f} | library wgrad {t_lib_w:.3f}', flush=True)
+    print(f'B={B} 100x100 256->256 | {t_lib:.3f} ({fl / t_lib / 1e9:.0f}) | {t_mine:.3f} ({fl / t_mine / 1e9:.0f}) [{t_split:.3f}] | {t_lib_d:.3f} | {t_mine_d:.3f} | library wgrad {t_lib_w:.3f} | bf16x6 wgrad (planes reused) {t_mine_w:.3f} ({fl / t_mine_w / 1e9:.0f})', flush=True)

@@ -21,6 +21,7 @@ FAMILY = {'roi_align7_fwd': ('pt_roi_align', 'roi_align.hip'), 'roi_align7_bwd':
           'ema_kernel': ('pt_optimizer (ema + sqnorm + sgd)', 'optim.hip'), 'sgd_kernel': ('pt_optimizer (ema + sqnorm + sgd)', 'optim.hip'),
           'sqnorm_kernel': ('pt_optimizer (ema + sqnorm + sgd)', 'optim.hip'),
           'gemm_bf16x6_kernel': ('pt_bf16x6 (gemm + conv3x3)', 'gemm_split.hip'),
+          'wgrad3x3_bf16x6_kernel': ('pt_bf16x6 (gemm + conv3x3)', 'gemm_split.hip'),
           'roi_align_rotated_fwd_mm': ('pt_roi_align_rotated', 'rotated.hip'), 'roi_align_rotated_bwd_mm': ('pt_roi_align_rotated', 'rotated.hip')}
 
 
