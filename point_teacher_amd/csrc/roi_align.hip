@@ -16,6 +16,11 @@
 //   B  any RoI up to 104x104 feature pixels: separable per-axis weights (one thread per (axis, bin), no
 //      atomics) in LDS, (g+1)^2 pixel reads per bin instead of 4 g^2 taps; the backward issues ONE f32
 //      atomic per footprint pixel and channel (256 contiguous bytes per wave instruction);
+//   R  (backward only) a run of 2..5 members whose own extents are <= 48 pixels per axis: the members' gradient blocks
+//      (a 64-channel slice each) and all their axis weights sit in LDS together, a wavefront walks the rows of the UNION of
+//      the footprints and adds the members' contributions in registers before the one atomic per union pixel - the 25
+//      members of a bag are concentric, so a run's union is barely larger than its largest member (phase 1's synthetic
+//      boxes: 3.9x fewer atomic adds at run length 5, profiles/r03/roi_stats_step1.txt);
 //   C  larger RoIs: direct per-sample taps (correct, slow, never seen in training).
 // Other out_sizes keep the generic one-workgroup-per-RoI kernels (roi_align_fwd_cl / _bwd_cl).
 #include "pt_common.h"
@@ -350,6 +355,131 @@ __device__ __forceinline__ void tile_load(float* __restrict__ tile, const float*
   }
 }
 
+// Path R: up to RN members of one run whose UNION spans <= RU pixels per axis.
+constexpr int RN = 5;    // members held together
+constexpr int RU = 48;   // largest per-axis extent (feature pixels) of the union
+constexpr int RC = 64;   // channels per workgroup (one wavefront-wide slice)
+
+struct RunRowsLds {
+  float wx[RN][RU + 2][8];      // [member][pixel - union x0][bin]; zero outside the member (and for absent members)
+  float wy[RN][RU + 2][8];      // [member][pixel - union y0][bin], divided by the sample count
+  int lo[RN][2][NB], hi[RN][2][NB];
+  int ext[RN][4];               // ox, nx, oy, ny per member (n <= 0: the member samples nothing inside the map)
+  int u[4];                     // union of the members' footprints: x0, nx, y0, ny
+  int b[RN];
+  int ok;
+};
+
+// Set-up for members [k0, k0 + m): bands, extents, union, weights relative to the union's origin; R.ok (block-uniform after the
+// final barrier) says whether the sub-run qualifies (union <= RU per axis, one image).  Mirrors roi_setup member by member.
+__device__ void rows_setup(const float* __restrict__ rois, int k0, int m, int B, int H, int W, float scale, int sampling_ratio,
+                           int aligned, RunRowsLds& R) {
+  const int t = threadIdx.x;
+  const int r = t / (2 * NB), a = (t / NB) & 1, p = t % NB;
+  const bool mine = t < m * 2 * NB;
+  RoiGeom g;
+  float start = 0.f, bin = 0.f;
+  int grid = 0, L = 1;
+  if (mine) {
+    g = roi_geom(rois + (size_t)(k0 + r) * 5, NB, scale, sampling_ratio, aligned, B);
+    start = a ? g.start_h : g.start_w; bin = a ? g.bin_h : g.bin_w;
+    grid = a ? g.grid_h : g.grid_w; L = a ? H : W;
+    int lo = 1 << 30, hi = -1;
+    for (int i = 0; i < grid; ++i) {
+      int l, h; float fl; bool valid;
+      small_tap(start + p * bin + (i + .5f) * bin / (float)grid, L, l, h, fl, valid);
+      if (!valid) continue;
+      lo = min(lo, l); hi = max(hi, h);
+    }
+    R.lo[r][a][p] = lo; R.hi[r][a][p] = hi;
+    if (a == 0 && p == 0) R.b[r] = g.b;
+  }
+  for (int i = t; i < RN * (RU + 2) * 8; i += blockDim.x) { (&R.wx[0][0][0])[i] = 0.f; (&R.wy[0][0][0])[i] = 0.f; }
+  __syncthreads();
+  if (mine && p == 0) {
+    int o = 1 << 30, e = -1;
+    for (int q = 0; q < NB; ++q)
+      if (R.hi[r][a][q] >= R.lo[r][a][q]) { o = min(o, R.lo[r][a][q]); e = max(e, R.hi[r][a][q]); }
+    R.ext[r][2 * a] = o; R.ext[r][2 * a + 1] = e >= o ? e - o + 1 : 0;
+  }
+  __syncthreads();
+  if (t == 0) {
+    int x0 = 1 << 30, x1 = -1, y0 = 1 << 30, y1 = -1, ok = 1;
+    for (int q = 0; q < m; ++q) {
+      if (R.b[q] != R.b[0]) ok = 0;
+      if (R.ext[q][1] > 0 && R.ext[q][3] > 0) {
+        x0 = min(x0, R.ext[q][0]); x1 = max(x1, R.ext[q][0] + R.ext[q][1] - 1);
+        y0 = min(y0, R.ext[q][2]); y1 = max(y1, R.ext[q][2] + R.ext[q][3] - 1);
+      }
+    }
+    const int nx = x1 >= x0 ? x1 - x0 + 1 : 0, ny = y1 >= y0 ? y1 - y0 + 1 : 0;
+    R.u[0] = x0; R.u[1] = nx; R.u[2] = y0; R.u[3] = ny;
+    R.ok = ok && nx <= RU && ny <= RU;
+  }
+  __syncthreads();
+  if (R.ok && mine && R.ext[r][1] > 0 && R.ext[r][3] > 0) {   // column p of axis a of member r belongs to this thread alone
+    float (*w)[8] = a ? R.wy[r] : R.wx[r];
+    const int o = a ? R.u[2] : R.u[0];
+    for (int i = 0; i < grid; ++i) {
+      int l, h; float fl; bool valid;
+      small_tap(start + p * bin + (i + .5f) * bin / (float)grid, L, l, h, fl, valid);
+      if (!valid) continue;
+      w[l - o][p] += 1.f - fl;
+      w[h - o][p] += fl;
+    }
+    if (a) for (int q = R.lo[r][1][p]; q <= R.hi[r][1][p]; ++q) w[q - o][p] = w[q - o][p] / g.inv_count;
+  }
+  __syncthreads();
+}
+
+// Path R for one 64-channel slice: tiles[m][64][49] in LDS, wavefront w takes the union's rows w, w + 4, ...; a row's pixels go
+// two at a time with every member's weights loaded unconditionally (zeros outside a member): no branches in the pixel loop.
+__device__ void rows_path(const float* __restrict__ gout, int k0, int m, int C, int H, int W, int c0, float* __restrict__ tiles,
+                          const RunRowsLds& R, float* __restrict__ gfeat) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int r = 0; r < m; ++r) tile_load(tiles + r * RC * 49, gout + ((size_t)(k0 + r) * C + c0) * 49, RC * 49);
+  __syncthreads();
+  const int x0 = R.u[0], nx = R.u[1], y0 = R.u[2], ny = R.u[3];
+  float* fb = gfeat + ((size_t)R.b[0] * H * W + x0) * C + c0 + lane;
+  for (int py = wv; py < ny; py += 4) {
+    float s7[RN][NB];
+#pragma unroll
+    for (int r = 0; r < RN; ++r) {
+#pragma unroll
+      for (int pw = 0; pw < NB; ++pw) s7[r][pw] = 0.f;
+      if (r < m) {                                                                     // wave-uniform
+        const float* my = tiles + (r * RC + lane) * 49;
+        const float4 ya = *reinterpret_cast<const float4*>(&R.wy[r][py][0]);
+        const float4 yb = *reinterpret_cast<const float4*>(&R.wy[r][py][4]);
+        const float wy[NB] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z};
+#pragma unroll
+        for (int ph = 0; ph < NB; ++ph) {
+          if (__builtin_amdgcn_readfirstlane(__float_as_uint(wy[ph])) != 0u) {       // a row meets one or two bins of a large RoI
+#pragma unroll
+            for (int pw = 0; pw < NB; ++pw) s7[r][pw] = fmaf(wy[ph], my[ph * NB + pw], s7[r][pw]);
+          }
+        }
+      }
+    }
+    float* row = fb + (size_t)(y0 + py) * W * C;
+    for (int px = 0; px < nx; px += 2) {                                               // wx has two zero rows of padding
+      float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+      for (int r = 0; r < RN; ++r) {
+        const float4 a0 = *reinterpret_cast<const float4*>(&R.wx[r][px][0]);
+        const float4 b0 = *reinterpret_cast<const float4*>(&R.wx[r][px][4]);
+        const float4 a1 = *reinterpret_cast<const float4*>(&R.wx[r][px + 1][0]);
+        const float4 b1 = *reinterpret_cast<const float4*>(&R.wx[r][px + 1][4]);
+        v0 += a0.x * s7[r][0] + a0.y * s7[r][1] + a0.z * s7[r][2] + a0.w * s7[r][3] + b0.x * s7[r][4] + b0.y * s7[r][5] + b0.z * s7[r][6];
+        v1 += a1.x * s7[r][0] + a1.y * s7[r][1] + a1.z * s7[r][2] + a1.w * s7[r][3] + b1.x * s7[r][4] + b1.y * s7[r][5] + b1.z * s7[r][6];
+      }
+      if (v0 != 0.f) atomicAdd(&row[(size_t)px * C], v0);
+      if (v1 != 0.f && px + 1 < nx) atomicAdd(&row[(size_t)(px + 1) * C], v1);
+    }
+  }
+  __syncthreads();                                       // the tiles are reloaded for the next slice / sub-run
+}
+
 __global__ void __launch_bounds__(256)
     roi_align7_fwd(const float* __restrict__ feat, const float* __restrict__ rois, int B, int C, int H, int W, int K,
                    int gs, float scale, int sampling_ratio, int aligned, float* __restrict__ out, int tile_bytes) {
@@ -497,127 +627,163 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// Backward of ONE member on path B (separable weights, one atomic per footprint pixel and channel) or C (direct taps).  The
+// caller's workgroups share a path-B member by footprint rows (rows phase, phase + step, ...: a 60 x 60 member is 3 600 serial
+// atomics per thread otherwise - the launch's tail); path C belongs to phase 0 alone.
+__device__ void member_bc(const float* __restrict__ gout, const float* __restrict__ rois, int k, int B, int C, int H, int W,
+                          float scale, int sampling_ratio, int aligned, float* __restrict__ tile, Roi7Lds& S,
+                          float* __restrict__ gfeat, int phase, int step) {
+  const RoiGeom g = roi_geom(rois + (size_t)k * 5, NB, scale, sampling_ratio, aligned, B);
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    const int nc = min(256, C - c0), c = c0 + threadIdx.x;
+    const bool act = (int)threadIdx.x < nc;
+    const float* my = tile + threadIdx.x * 49;
+    tile_load(tile, gout + ((size_t)k * C + c0) * 49, nc * 49);
+    roi_setup(g, H, W, S);                                          // its barriers also publish the tile
+    const int ox = S.ext[0], nx = S.ext[1], oy = S.ext[2], ny = S.ext[3];
+    if (act && nx > 0 && ny > 0) {
+      float* fb = gfeat + (size_t)g.b * H * W * C + c;
+      if (nx <= MAXE && ny <= MAXE) {                               // path B
+        float gv[49];
+#pragma unroll
+        for (int i = 0; i < 49; ++i) gv[i] = my[i];
+        for (int py = phase; py < ny; py += step) {
+          const float4 ya = *reinterpret_cast<const float4*>(&S.w.b.wy[py][0]);
+          const float4 yb = *reinterpret_cast<const float4*>(&S.w.b.wy[py][4]);
+          const float wy[NB] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z};
+          float s7[NB];
+#pragma unroll
+          for (int pw = 0; pw < NB; ++pw) {
+            float t = 0.f;
+#pragma unroll
+            for (int ph = 0; ph < NB; ++ph) t = fmaf(wy[ph], gv[ph * NB + pw], t);
+            s7[pw] = t;
+          }
+          float* row = fb + ((size_t)(oy + py) * W + ox) * C;
+          for (int px = 0; px < nx; px += 2) {                      // two pixels per trip: the weight reads overlap
+            const int p1 = min(px + 1, MAXE - 1);
+            const float4 wa = *reinterpret_cast<const float4*>(&S.w.b.wx[px][0]);
+            const float4 wb = *reinterpret_cast<const float4*>(&S.w.b.wx[px][4]);
+            const float4 wc = *reinterpret_cast<const float4*>(&S.w.b.wx[p1][0]);
+            const float4 wd = *reinterpret_cast<const float4*>(&S.w.b.wx[p1][4]);
+            const float v0 = wa.x * s7[0] + wa.y * s7[1] + wa.z * s7[2] + wa.w * s7[3] + wb.x * s7[4] + wb.y * s7[5] +
+                             wb.z * s7[6];
+            const float v1 = wc.x * s7[0] + wc.y * s7[1] + wc.z * s7[2] + wc.w * s7[3] + wd.x * s7[4] + wd.y * s7[5] +
+                             wd.z * s7[6];
+            if (v0 != 0.f) atomicAdd(&row[(size_t)px * C], v0);
+            if (v1 != 0.f && px + 1 < nx) atomicAdd(&row[(size_t)(px + 1) * C], v1);
+          }
+        }
+      } else if (phase == 0) {                                      // path C: direct taps
+        for (int ph = 0; ph < NB; ++ph)
+          for (int pw = 0; pw < NB; ++pw) {
+            const float gvv = my[ph * NB + pw] / g.inv_count;
+            for (int iy = 0; iy < g.grid_h; ++iy) {
+              const float y = g.start_h + ph * g.bin_h + (iy + .5f) * g.bin_h / (float)g.grid_h;
+              for (int ix = 0; ix < g.grid_w; ++ix) {
+                const float x = g.start_w + pw * g.bin_w + (ix + .5f) * g.bin_w / (float)g.grid_w;
+                const Bilin q = bilin(y, x, H, W);
+                if (q.valid) {
+                  atomicAdd(&fb[((size_t)q.y0 * W + q.x0) * C], gvv * q.w1);
+                  atomicAdd(&fb[((size_t)q.y0 * W + q.x1) * C], gvv * q.w2);
+                  atomicAdd(&fb[((size_t)q.y1 * W + q.x0) * C], gvv * q.w3);
+                  atomicAdd(&fb[((size_t)q.y1 * W + q.x1) * C], gvv * q.w4);
+                }
+              }
+            }
+          }
+      }
+    }
+    __syncthreads();                                                // the tile is reloaded for the next slice / RoI
+  }
+}
+
 __global__ void __launch_bounds__(256)
     roi_align7_bwd(const float* __restrict__ gout, const float* __restrict__ rois, int B, int C, int H, int W, int K,
                    int gs, float scale, int sampling_ratio, int aligned, float* __restrict__ gfeat, int tile_bytes) {
-  // grid (runs, gs): a run whose taps fit the register footprint is reduced by its workgroup y == 0 alone (one atomic
-  // pass for the whole run); in any other run workgroup y takes member y, so large RoIs - whose cost is their
-  // footprint's worth of atomics - are spread over gs times as many workgroups instead of queueing in one.
+  // grid (runs, max(gs, C / 64)): a run whose taps fit the register footprint (path A) is reduced by its workgroup y == 0 alone
+  // (one atomic pass for the whole run).  Any other run is cut into sub-runs of up to RN members: where the members qualify
+  // (path R) workgroup y takes the 64-channel slices y, y + gridDim.y, ... and adds the members in registers before the atomics
+  // of the union's pixels; otherwise every workgroup of the run takes its share of each member's footprint rows on path B, so
+  // large RoIs - whose cost is their footprint's worth of atomics - are spread over workgroups instead of queueing in one.
   extern __shared__ __align__(16) unsigned char smem[];
   float* tile = reinterpret_cast<float*>(smem);
   Roi7Lds& S = *reinterpret_cast<Roi7Lds*>(smem + tile_bytes);
   const int k0 = blockIdx.x * gs, n = min(gs, K - k0);
-  const int y = blockIdx.y;
-  if (y >= n) return;
+  const int y = blockIdx.y, gy = gridDim.y;
   run_setup(rois, k0, n, B, H, W, scale, sampling_ratio, aligned, S, y == 0);
   const bool path_a = S.ub[5] != 0;
-  if (path_a && y != 0) return;
-  const int r_lo = path_a ? 0 : y, r_hi = path_a ? n : y + 1;
+  if (!path_a) {
+    // rows_setup gives every workgroup of the run the same answer (it depends on the RoIs alone)
+    RunRowsLds& R = *reinterpret_cast<RunRowsLds*>(smem + RN * RC * 49 * 4);
+    for (int r0 = 0; r0 < n; r0 += RN) {
+      const int m = min(RN, n - r0);
+      bool rows = m >= 2 && (C % RC) == 0;
+      if (rows) {
+        __syncthreads();                                            // S / the tile are dead: R aliases them
+        rows_setup(rois, k0 + r0, m, B, H, W, scale, sampling_ratio, aligned, R);
+        rows = R.ok != 0;
+      }
+      if (rows) {
+        if (R.u[1] > 0 && R.u[3] > 0)
+          for (int sl = y; sl < C / RC; sl += gy) rows_path(gout, k0 + r0, m, C, H, W, sl * RC, tile, R, gfeat);
+      } else {
+        __syncthreads();
+        for (int r = r0; r < r0 + m; ++r)
+          member_bc(gout, rois, k0 + r, B, C, H, W, scale, sampling_ratio, aligned, tile, S, gfeat, y, gy);
+      }
+    }
+    return;
+  }
+  if (y != 0) return;
   const int ux = S.ub[0], uy = S.ub[1], ub = S.ub[4];
   for (int c0 = 0; c0 < C; c0 += 256) {
     const int nc = min(256, C - c0), c = c0 + threadIdx.x;
     const bool act = (int)threadIdx.x < nc;
     const float* my = tile + threadIdx.x * 49;
-    if (path_a) {
-      float acc[SF][SF];
+    float acc[SF][SF];
 #pragma unroll
-      for (int y = 0; y < SF; ++y)
+    for (int y = 0; y < SF; ++y)
 #pragma unroll
-        for (int x = 0; x < SF; ++x) acc[y][x] = 0.f;
-      for (int r = 0; r < n; ++r) {
-        tile_load(tile, gout + ((size_t)(k0 + r) * C + c0) * 49, nc * 49);
-        __syncthreads();
-        if (act) {
-          float Sy[SF][NB];
-#pragma unroll
-          for (int y = 0; y < SF; ++y)
-#pragma unroll
-            for (int pw = 0; pw < NB; ++pw) Sy[y][pw] = 0.f;
-#pragma unroll
-          for (int ph = 0; ph < NB; ++ph)
-#pragma unroll
-            for (int pw = 0; pw < NB; ++pw) {
-              const float gv = my[ph * NB + pw];
-#pragma unroll
-              for (int y = 0; y < SF; ++y) Sy[y][pw] = fmaf(S.w.a.ay[r][ph][y], gv, Sy[y][pw]);
-            }
-#pragma unroll
-          for (int y = 0; y < SF; ++y)
-#pragma unroll
-            for (int x = 0; x < SF; ++x) {
-              float v = acc[y][x];
-#pragma unroll
-              for (int pw = 0; pw < NB; ++pw) v = fmaf(S.w.a.ax[r][pw][x], Sy[y][pw], v);
-              acc[y][x] = v;
-            }
-        }
-        __syncthreads();
-      }
+      for (int x = 0; x < SF; ++x) acc[y][x] = 0.f;
+    for (int r = 0; r < n; ++r) {
+      tile_load(tile, gout + ((size_t)(k0 + r) * C + c0) * 49, nc * 49);
+      __syncthreads();
       if (act) {
+        float Sy[SF][NB];
+#pragma unroll
+        for (int y = 0; y < SF; ++y)
+#pragma unroll
+          for (int pw = 0; pw < NB; ++pw) Sy[y][pw] = 0.f;
+#pragma unroll
+        for (int ph = 0; ph < NB; ++ph)
+#pragma unroll
+          for (int pw = 0; pw < NB; ++pw) {
+            const float gv = my[ph * NB + pw];
+#pragma unroll
+            for (int y = 0; y < SF; ++y) Sy[y][pw] = fmaf(S.w.a.ay[r][ph][y], gv, Sy[y][pw]);
+          }
 #pragma unroll
         for (int y = 0; y < SF; ++y)
 #pragma unroll
           for (int x = 0; x < SF; ++x) {
-            const float v = acc[y][x];
-            if (v != 0.f && uy + y < H && ux + x < W)
-              atomicAdd(&gfeat[(((size_t)ub * H + uy + y) * W + ux + x) * C + c], v);
+            float v = acc[y][x];
+#pragma unroll
+            for (int pw = 0; pw < NB; ++pw) v = fmaf(S.w.a.ax[r][pw][x], Sy[y][pw], v);
+            acc[y][x] = v;
           }
       }
-    } else {
-      for (int r = r_lo; r < r_hi; ++r) {
-        const RoiGeom g = roi_geom(rois + (size_t)(k0 + r) * 5, NB, scale, sampling_ratio, aligned, B);
-        tile_load(tile, gout + ((size_t)(k0 + r) * C + c0) * 49, nc * 49);
-        roi_setup(g, H, W, S);                                          // its barriers also publish the tile
-        const int ox = S.ext[0], nx = S.ext[1], oy = S.ext[2], ny = S.ext[3];
-        if (act && nx > 0 && ny > 0) {
-          float* fb = gfeat + (size_t)g.b * H * W * C + c;
-          if (nx <= MAXE && ny <= MAXE) {                               // path B
-            float gv[49];
+      __syncthreads();
+    }
+    if (act) {
 #pragma unroll
-            for (int i = 0; i < 49; ++i) gv[i] = my[i];
-            for (int py = 0; py < ny; ++py) {
-              const float4 ya = *reinterpret_cast<const float4*>(&S.w.b.wy[py][0]);
-              const float4 yb = *reinterpret_cast<const float4*>(&S.w.b.wy[py][4]);
-              const float wy[NB] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z};
-              float s7[NB];
+      for (int y = 0; y < SF; ++y)
 #pragma unroll
-              for (int pw = 0; pw < NB; ++pw) {
-                float t = 0.f;
-#pragma unroll
-                for (int ph = 0; ph < NB; ++ph) t = fmaf(wy[ph], gv[ph * NB + pw], t);
-                s7[pw] = t;
-              }
-              float* row = fb + ((size_t)(oy + py) * W + ox) * C;
-              for (int px = 0; px < nx; ++px) {
-                const float4 wa = *reinterpret_cast<const float4*>(&S.w.b.wx[px][0]);
-                const float4 wb = *reinterpret_cast<const float4*>(&S.w.b.wx[px][4]);
-                const float v = wa.x * s7[0] + wa.y * s7[1] + wa.z * s7[2] + wa.w * s7[3] + wb.x * s7[4] + wb.y * s7[5] +
-                                wb.z * s7[6];
-                if (v != 0.f) atomicAdd(&row[(size_t)px * C], v);
-              }
-            }
-          } else {                                                      // path C: direct taps
-            for (int ph = 0; ph < NB; ++ph)
-              for (int pw = 0; pw < NB; ++pw) {
-                const float gvv = my[ph * NB + pw] / g.inv_count;
-                for (int iy = 0; iy < g.grid_h; ++iy) {
-                  const float y = g.start_h + ph * g.bin_h + (iy + .5f) * g.bin_h / (float)g.grid_h;
-                  for (int ix = 0; ix < g.grid_w; ++ix) {
-                    const float x = g.start_w + pw * g.bin_w + (ix + .5f) * g.bin_w / (float)g.grid_w;
-                    const Bilin q = bilin(y, x, H, W);
-                    if (q.valid) {
-                      atomicAdd(&fb[((size_t)q.y0 * W + q.x0) * C], gvv * q.w1);
-                      atomicAdd(&fb[((size_t)q.y0 * W + q.x1) * C], gvv * q.w2);
-                      atomicAdd(&fb[((size_t)q.y1 * W + q.x0) * C], gvv * q.w3);
-                      atomicAdd(&fb[((size_t)q.y1 * W + q.x1) * C], gvv * q.w4);
-                    }
-                  }
-                }
-              }
-          }
+        for (int x = 0; x < SF; ++x) {
+          const float v = acc[y][x];
+          if (v != 0.f && uy + y < H && ux + x < W)
+            atomicAdd(&gfeat[(((size_t)ub * H + uy + y) * W + ux + x) * C + c], v);
         }
-        __syncthreads();                                                // the tile is reloaded for the next RoI
-      }
     }
   }
 }
@@ -695,13 +861,17 @@ static int roi_check(const char* fn, const void* a, const void* rois, const void
 // set once per process through a thread-safe function-local static.
 static constexpr int ROI7_TILE_BYTES = 256 * 49 * 4;
 static constexpr int ROI7_LDS = ROI7_TILE_BYTES + (int)((sizeof(pt::Roi7Lds) + 15) / 16 * 16);
+// backward: the larger of that and path R's [RN][64][49] tiles + RunRowsLds (both under 80 KiB: two workgroups per CU)
+static constexpr int ROI7_ROWS_LDS = pt::RN * pt::RC * 49 * 4 + (int)((sizeof(pt::RunRowsLds) + 15) / 16 * 16);
+static constexpr int ROI7_BWD_LDS = ROI7_ROWS_LDS > ROI7_LDS ? ROI7_ROWS_LDS : ROI7_LDS;
+static_assert(ROI7_BWD_LDS <= 80 * 1024, "two backward workgroups per CU");
 static hipError_t roi7_attr() {
   static const hipError_t rc = [] {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align7_fwd),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, ROI7_LDS);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align7_bwd), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               ROI7_LDS);
+                               ROI7_BWD_LDS);
   }();
   return rc;
 }
@@ -769,8 +939,11 @@ extern "C" int pt_roi_align_bwd(const float* grad_out, const float* rois, int B,
     hipError_t e = roi7_attr();
     if (e != hipSuccess) { set_error("pt_roi_align_bwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
     const int gs = run_length(group, K, 512);
-    hipLaunchKernelGGL(roi_align7_bwd, dim3(cdiv(K, gs), gs), dim3(256), ROI7_LDS, s, grad_out, rois, B, C, H, W, K, gs,
-                       spatial_scale, sampling_ratio, aligned, grad_feat, ROI7_TILE_BYTES);
+    const int slices = (C % pt::RC) == 0 ? C / pt::RC : 1;
+    // (dealing the runs of one bag apart in dispatch order - so that their atomics do not queue on the same pixels - was tried:
+    // the large-bag launch gained 12 %, the launches of tiny bags lost 20 %: kept adjacent)
+    hipLaunchKernelGGL(roi_align7_bwd, dim3(cdiv(K, gs), gs > slices ? gs : slices), dim3(256), ROI7_BWD_LDS, s, grad_out, rois, B, C,
+                       H, W, K, gs, spatial_scale, sampling_ratio, aligned, grad_feat, ROI7_TILE_BYTES);
   } else if (channels_last) {
     const size_t lds = (size_t)(C + 1) * out_size * out_size * sizeof(float);
     hipError_t e = roi_generic_attr();

@@ -416,6 +416,48 @@ def test_roi_align_bag_fast_path():
     close(out1, out, rtol=1e-5, atol=1e-5)
 
 
+def test_roi_align_backward_run_union_path():
+    """Enough bags (K / 5 >= 512) for runs of 5: a run whose members span 6 ... 48 feature pixels takes the backward's path R
+    (roi_align.hip: the members' blocks and weights together in LDS, one atomic per pixel of the footprints' UNION, 64-channel
+    slices); tiny bags stay on the register path, members beyond 48 pixels and a bag spanning two images fall back member by
+    member - all inside one launch.  Checked against the oracle's autograd on a channel subset (the op is channel-wise) and, on
+    every channel, against the same op with group = 1 (per-RoI paths, themselves checked against the oracle above)."""
+    f = F()
+    gen = torch.Generator().manual_seed(77)
+    B, C, H, W = 2, 128, 60, 60
+    n, U = 108, 25
+    feat = torch.randn(B, C, H, W, generator=gen)
+    c = torch.rand(n, 2, generator=gen) * 400 + 40
+    wh = torch.exp(torch.randn(n, 2, generator=gen) * 0.5 + np.log(11.))
+    wh[:30] = torch.rand(30, 2, generator=gen) * 290 + 60            # 7 ... 44 feature pixels: path R
+    wh[30] = torch.tensor([450., 120.])                              # one axis beyond 48 pixels: its run falls back
+    wh[31] = torch.tensor([20., 300.])
+    c[32] = torch.tensor([3.0, 470.0]); wh[32] = torch.tensor([150., 180.])   # clamped at two borders
+    base = torch.cat([c - wh / 2, c + wh / 2], 1)
+    props, _ = R.fine_proposals(base, [1.0, 1.2, 1.3, 0.8, 0.7], None, 4, (480, 480))
+    bi = (torch.arange(n).repeat_interleave(U) % 2).float()[:, None]
+    bi[5 * U + 7] = 1 - bi[5 * U + 7]                                # a large bag with one member in the other image
+    rois = torch.cat([bi, props], 1)
+    K = rois.shape[0]
+    assert K // 5 >= 512
+    wgt = torch.randn(K, C, 7, 7, generator=gen)
+    fg = cu(feat).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    out = f.roi_align(fg, cu(rois), 7, 0.125, 0, True, U)
+    (out * cu(wgt)).sum().backward()
+    g25 = fg.grad.clone()
+    fg.grad = None
+    out1 = f.roi_align(fg, cu(rois), 7, 0.125, 0, True, 1)
+    (out1 * cu(wgt)).sum().backward()
+    close(out, out1, rtol=1e-5, atol=1e-5)
+    close(g25, fg.grad, rtol=1e-4, atol=5e-4)
+    sub = [0, 63, 64, 127]                                            # both 64-channel slices
+    fr = feat[:, sub].clone().requires_grad_(True)
+    out_ref = R.roi_align(fr, rois, 7, 0.125)
+    (out_ref * wgt[:, sub]).sum().backward()
+    close(out[:, sub], out_ref, rtol=1e-4, atol=2e-5)
+    close(g25[:, sub], fr.grad, rtol=1e-4, atol=5e-4)
+
+
 @pytest.mark.parametrize('C,H,W,group,out_size,sr', [(320, 24, 24, 45, 7, 0),      # two channel blocks (256 + 64); runs of 15
                                                        (6, 24, 24, 25, 7, 0),        # 6*49 floats: not a multiple of 4 -> scalar tile copies
                                                        (16, 120, 120, 7, 7, 0),      # map large enough for a > 104-pixel RoI: direct path C

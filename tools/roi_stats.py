@@ -35,7 +35,7 @@ def spy(fn, *a):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); r = orig(fn, *a); e1.record()
         # fwd: (feat, rois, B, C, H, W, K, out, scale, sr, aligned, cl, group, out)   bwd: (g, rois, B, C, H, W, K, out, scale, ...)
-        rec.append((fn, a[1].clone(), float(a[8]), int(a[12]), e0, e1))
+        rec.append((fn, a[1].clone(), float(a[8]), int(a[12]), e0, e1, a))
         return r
     return orig(fn, *a)
 
@@ -57,7 +57,7 @@ def extent(lo, hi, L=100):
     return a.astype(np.int64), b.astype(np.int64)
 
 
-for fn, rois, scale, group, e0, e1 in rec:
+for fn, rois, scale, group, e0, e1, args in rec:
     r = rois.cpu().numpy().astype(np.float64)
     K = r.shape[0]
     x0, x1 = extent(r[:, 1] * scale - 0.5, r[:, 3] * scale - 0.5)
@@ -69,6 +69,9 @@ for fn, rois, scale, group, e0, e1 in rec:
             f'{np.quantile(np.maximum(nx, ny), .9):.0f} max {np.maximum(nx, ny).max()}')
     print(line)
     if fn.endswith('bwd'):
+        side1 = np.maximum(nx, ny)
+        print('      share of the per-RoI pixel adds by RoI side: ' + ' '.join(
+            f'<= {b}: {F[side1 <= b].sum() / max(F.sum(), 1) * 100:.0f}%' for b in (5, 8, 12, 16, 24, 32, 48, 64, 104)))
         for gs in (1, 5, 9, 15, 25, 45):
             if group % gs or K % gs:
                 continue
@@ -79,3 +82,39 @@ for fn, rois, scale, group, e0, e1 in rec:
             print(f'      run {gs:2d}: per-RoI pixel adds {F.sum():8d}  run-union adds {(ux * uy).sum():8d}  union side median '
                   f'{np.median(side):.0f} p90 {np.quantile(side, .9):.0f} max {side.max()}  runs with side <= s: '
                   + ' '.join(f'{s}:{v * 100:.0f}%' for s, v in fits.items()))
+
+
+# ---- replay of the heaviest backward call with classes of RoIs replaced by a 1-pixel box at the bag's centre: which class costs the time
+heavy = max((r for r in rec if r[0].endswith('bwd')), key=lambda r: r[4].elapsed_time(r[5]))
+fn, rois, scale, group, _, _, args = heavy
+r = rois.cpu().numpy().astype(np.float64)
+x0, x1 = extent(r[:, 1] * scale - 0.5, r[:, 3] * scale - 0.5)
+y0, y1 = extent(r[:, 2] * scale - 0.5, r[:, 4] * scale - 0.5)
+side = torch.from_numpy(np.maximum(x1 - x0 + 1, y1 - y0 + 1)).to(dev)
+cx, cy = (rois[:, 1] + rois[:, 3]) / 2, (rois[:, 2] + rois[:, 4]) / 2
+tiny = torch.stack([rois[:, 0], cx - 2, cy - 2, cx + 2, cy + 2], 1)
+
+
+def replay(keep, label):
+    rr = torch.where(keep[:, None], rois, tiny).contiguous()
+    a = list(args)
+    a[1] = rr
+    a[-1] = torch.zeros_like(args[-1])
+    for _ in range(3):
+        orig(fn, *a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        orig(fn, *a)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f'replay {label:34s} kept {int(keep.sum()):5d} RoIs  {e0.elapsed_time(e1) * 100:8.1f} us')
+
+
+replay(side > 0, 'all')
+replay(side <= 5, 'side <= 5 only')
+replay(side <= 16, 'side <= 16 only')
+replay(side <= 32, 'side <= 32 only')
+replay(side <= 48, 'side <= 48 only')
+replay(side > 48, 'side > 48 only')
+replay((side > 16) & (side <= 48), '16 < side <= 48 only')
