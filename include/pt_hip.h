@@ -262,6 +262,21 @@ int pt_conv3x3_wgrad_bf16x6_nhwc(const uint16_t* gy_planes, int64_t gy_plane_str
                                  int64_t x_plane_stride, float* dw, float* workspace, int64_t workspace_elems, int B,
                                  int H, int W, int Cin, int Cout, int splits, void* stream);
 
+/* GroupNorm (+ ReLU) on channels_last activations x[N, HW, C] (replaces torch.nn.GroupNorm behind the tower convolutions of the
+ * oriented head: mmcv ConvModule with norm_cfg=dict(type='GN', num_groups=32), OBB_TOD/mmrotate/models/dense_heads/
+ * rotated_fcos_head.py via rotated_anchor_free_head.py _init_cls_convs / _init_reg_convs):
+ *   y = (x - mean[n, g]) * rstd[n, g] * gamma[c] + beta[c]   (ReLU if relu != 0),  statistics over the H*W * C/G elements of a
+ * group (biased variance, float64 accumulation), mean / rstd [N, G] saved for the backward.
+ * bwd: dy = grad_y * (y > 0) when y != NULL (the fused ReLU) else grad_y;  grad_x, grad_gamma[C], grad_beta[C] are written.
+ * workspace: pt_group_norm_cl_workspace_bytes(N, HW, C, G) bytes, 16-byte aligned.  Fixed-order reductions: deterministic.
+ * C % 4 == 0, (C / G) % 4 == 0, C / 4 divides 256, C / G divides 256, G <= 64. */
+int64_t pt_group_norm_cl_workspace_bytes(int N, int HW, int C, int G);
+int pt_group_norm_cl_fwd(const float* x, const float* gamma, const float* beta, int N, int HW, int C, int G, float eps,
+                         int relu, float* y, float* mean, float* rstd, void* workspace, void* stream);
+int pt_group_norm_cl_bwd(const float* grad_y, const float* x, const float* y, const float* gamma, const float* mean,
+                         const float* rstd, int N, int HW, int C, int G, float* grad_x, float* grad_gamma,
+                         float* grad_beta, void* workspace, void* stream);
+
 /* Frozen BatchNorm (+ residual add) (+ ReLU) in one pass each way.  Every BatchNorm on the path
  * is in eval mode with a frozen affine (models/backbones/resnet.py:647-658, config
  * norm_cfg=dict(type='BN', requires_grad=False), norm_eval=True), i.e. y = x*scale[c] + shift[c]

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libpt_hip.so')
 SOURCES = ['assign.hip', 'losses.hip', 'roi_align.hip', 'mil.hip', 'optim.hip', 'nms.hip', 'rotated.hip', 'deform.hip', 'cocoeval.hip',
-           'image_prep.hip', 'glue.hip', 'gemm_split.hip']
+           'image_prep.hip', 'glue.hip', 'gemm_split.hip', 'group_norm.hip']
 # -ffp-contract=off: index decisions (top-k, insider test) must see the same fp32 roundings
 # as the reference's un-fused torch ops; kernels that want FMA ask for it with fmaf().
 # -pragma-unroll-threshold: `#pragma unroll` over the 49 bins x 4 samples of a RoI must really unroll (49 per-channel values live in

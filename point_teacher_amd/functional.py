@@ -752,6 +752,50 @@ def split_conv3x3(x, weight, bias=None, relu=False, scale=None):
     return _SplitConv3x3.apply(x, weight, bias, bool(relu), scale)
 
 
+class _GroupNormCL(torch.autograd.Function):
+    """y = [relu](group_norm(x, G, gamma, beta, eps)) for a channels_last fp32 [N, C, H, W] tensor, staying channels_last
+    (csrc/group_norm.hip: two launches forward, three backward, no layout copies; fixed-order reductions)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, G, eps, relu):
+        N, C, H, W = x.shape
+        xr = x.permute(0, 2, 3, 1)                                             # [N, H, W, C] view of the channels_last memory
+        y = torch.empty_like(xr)
+        mean = torch.empty((N, G), dtype=f32, device=x.device)
+        rstd = torch.empty((N, G), dtype=f32, device=x.device)
+        ws = torch.empty((hip.call('pt_group_norm_cl_workspace_bytes', N, H * W, C, G) + 15) // 16 * 2, dtype=torch.float64, device=x.device)
+        hip.call('pt_group_norm_cl_fwd', xr, gamma, beta, N, H * W, C, G, float(eps), int(relu), y, mean, rstd, ws)
+        ctx.save_for_backward(x, gamma, mean, rstd, y if relu else None)
+        ctx.G = G
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma, mean, rstd, y = ctx.saved_tensors
+        N, C, H, W = x.shape
+        G = ctx.G
+        gy = gy.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+        gx = torch.empty_like(gy)
+        gg, gb = torch.empty_like(gamma), torch.empty_like(gamma)
+        ws = torch.empty((hip.call('pt_group_norm_cl_workspace_bytes', N, H * W, C, G) + 15) // 16 * 2, dtype=torch.float64, device=x.device)
+        hip.call('pt_group_norm_cl_bwd', gy, x.permute(0, 2, 3, 1), y, gamma, mean, rstd, N, H * W, C, G, gx, gg, gb, ws)
+        return gx.permute(0, 3, 1, 2), gg, gb, None, None, None
+
+
+def group_norm_cl_ok(x, gn):
+    """channels_last fp32 on the device, a shape the kernels take (C / 4 divides 256, groups of a multiple of 4 channels that divide
+    256, at most 64 groups), both affine parameters present and training together."""
+    C, G = gn.num_channels, gn.num_groups
+    return (x.is_cuda and x.dtype == f32 and x.dim() == 4 and gn.affine and C % 4 == 0 and C <= 1024 and 256 % (C // 4) == 0
+            and C % G == 0 and (C // G) % 4 == 0 and 256 % (C // G) == 0 and G <= 64 and x.shape[0] * x.shape[2] * x.shape[3] > 0
+            and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous() and not torch.is_autocast_enabled())
+
+
+def group_norm_cl(x, gn, relu=False):
+    """torch.nn.GroupNorm `gn` (+ ReLU) on a channels_last activation; the result stays channels_last."""
+    return _GroupNormCL.apply(x, gn.weight, gn.bias, int(gn.num_groups), float(gn.eps), bool(relu))
+
+
 class _AffineReLU(torch.autograd.Function):
     """y = [relu](x*scale[c] + shift[c] [+ residual]) in place on x (x is a fresh conv output)."""
 

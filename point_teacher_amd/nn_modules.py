@@ -18,6 +18,7 @@ from .registry import BACKBONES, NECKS, ROI_EXTRACTORS
 
 
 _SPLIT_CONV = os.environ.get('PT_SPLIT_CONV', '1') != '0'
+_GN_CL = os.environ.get('PT_GN_CL', '1') != '0'
 
 
 class ModulatedDeformConv2dPack(nn.Module):
@@ -118,8 +119,15 @@ class ConvModule(nn.Module):
             if F.bias_relu_ok(y, c.bias):
                 return F.bias_relu_(y, c.bias, True)          # bias + ReLU in one pass; backward: grad_x + bias gradient in one
             return TF.relu(y + c.bias.view(1, -1, 1, 1), inplace=True)
-        x = c(x)
+        if _SPLIT_CONV and type(c) is nn.Conv2d and c.bias is None and self.with_norm and F.split_conv3x3_ok(x, c):
+            x = F.split_conv3x3(x, c.weight, None, False)     # towers with GroupNorm (config 5): the convolution alone, then the norm
+        else:
+            x = c(x)
         if self.with_norm:
+            if hasattr(self, 'gn') and _GN_CL and F.group_norm_cl_ok(x, self.gn):
+                # GroupNorm + ReLU on the channels_last activation itself (csrc/group_norm.hip): no NCHW round trip, and the next
+                # tower convolution still sees channels_last.  PT_GN_CL=0: torch.nn.GroupNorm.
+                return F.group_norm_cl(x, self.gn, self.with_activation)
             x = self.gn(x) if hasattr(self, 'gn') else self.bn(x)
         return TF.relu(x, inplace=True) if self.with_activation else x
 
@@ -243,7 +251,12 @@ def conv_bn(x, conv, bn, relu, residual=None):
         # matrix cores (split-bf16 operands, fp32 accumulation): no separate pass over the activation at all
         sc, sh = _bn_affine(bn)
         return F.split_conv3x3(x, conv.weight, sh, relu, scale=sc)
-    y = conv(x)
+    if _SPLIT_CONV and type(conv) is nn.Conv2d and conv.bias is None and F.split_conv3x3_ok(x, conv):
+        # a BatchNorm that is not a frozen affine map (config 5: eval-mode statistics, trainable affine): the convolution alone on
+        # the bf16 matrix cores, the norm by the passes below
+        y = F.split_conv3x3(x, conv.weight, None, False)
+    else:
+        y = conv(x)
     fused = (not bn.training and not bn.weight.requires_grad and y.dtype == torch.float32 and y.is_cuda
              and getattr(bn, 'fuse_epilogue', True) and y.numel() % 4 == 0
              and (y.shape[1] % 4 == 0 if (y.is_contiguous(memory_format=torch.channels_last) and not y.is_contiguous())

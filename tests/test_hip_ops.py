@@ -864,3 +864,39 @@ def test_obb_building_blocks():
     dets, labels = obb.multiclass_nms_rotated(cu(tgt), cu(scores), 0.3, dict(iou_thr=0.1), 50)
     assert dets.shape[1] == 6 and dets.shape[0] == labels.shape[0] <= 50
     assert bool((dets[:-1, 5] >= dets[1:, 5]).all())
+
+
+@pytest.mark.parametrize('N,C,H,W,G,relu', [(2, 256, 150, 150, 32, True), (3, 64, 37, 41, 16, False), (1, 128, 9, 7, 32, True),
+                                            (2, 512, 20, 20, 32, True)])
+def test_group_norm_channels_last(N, C, H, W, G, relu):
+    """pt_group_norm_cl_* == torch.nn.GroupNorm (+ ReLU) on a channels_last activation (the oriented head's tower norm): values and
+    the three gradients against float64 torch, an input far from zero mean (the variance is accumulated in float64), pixel counts
+    that are not multiples of the 256-pixel chunk, bit-identical repeats, and the result stays channels_last."""
+    from point_teacher_amd import functional as PF
+    gen = torch.Generator().manual_seed(N * C + H)
+    x = (torch.randn(N, C, H, W, generator=gen) * 2.0 + 30.0 * torch.randn(1, C, 1, 1, generator=gen)).to(DEV)
+    x = x.contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gn = torch.nn.GroupNorm(G, C).to(DEV)
+    with torch.no_grad():
+        gn.weight.uniform_(0.5, 1.5, generator=None); gn.bias.normal_(0, 0.3)
+    assert PF.group_norm_cl_ok(x, gn)
+    y = PF.group_norm_cl(x, gn, relu)
+    assert y.shape == x.shape and y.is_contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(N, C, H, W, generator=gen).to(DEV).contiguous(memory_format=torch.channels_last)
+    gx, gw, gb = torch.autograd.grad(y, (x, gn.weight, gn.bias), gy)
+    xr = x.detach().double().requires_grad_(True)
+    wr, br = gn.weight.detach().double().requires_grad_(True), gn.bias.detach().double().requires_grad_(True)
+    pre = torch.nn.functional.group_norm(xr, G, wr, br, gn.eps)
+    ref = torch.relu(pre) if relu else pre
+    assert float((y.detach().double() - ref).abs().max()) < 2e-5
+    mask = (y.detach() > 0).double() if relu else 1.0               # the kernel's own kink (an element within rounding of 0)
+    rx, rw, rb = torch.autograd.grad(pre, (xr, wr, br), gy.double() * mask)
+    for mine, r, tol in ((gx, rx, 2e-5), (gw, rw, 2e-5), (gb, rb, 2e-5)):
+        assert float((mine.double() - r).abs().max() / r.abs().max()) < tol
+    lib = gn(x.detach())
+    e_mine = float((y.detach().double() - ref).abs().max())
+    e_lib = float(((torch.relu(lib) if relu else lib).double() - ref).abs().max())
+    print(f'[{N}x{C}x{H}x{W} G={G}] group norm error vs float64: own {e_mine:.2e}, torch fp32 {e_lib:.2e}')
+    y2 = PF.group_norm_cl(x, gn, relu)
+    g2 = torch.autograd.grad(y2, (x, gn.weight, gn.bias), gy)
+    assert torch.equal(y2, y) and all(torch.equal(a, b) for a, b in zip(g2, (gx, gw, gb)))
