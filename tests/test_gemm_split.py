@@ -193,3 +193,26 @@ def test_conv3x3_wgrad_bf16x6_matches_fp64_at_least_as_well_as_the_library(B, H,
         d2 = torch.empty((Cout, 3, 3, Cin), device=dev)
         F.hip.call('pt_conv3x3_wgrad_bf16x6_nhwc', gp, gp.shape[1], xp, xp.shape[1], d2, ws, S * n, B, H, W, Cin, Cout, S)
         assert float((d2.permute(0, 3, 1, 2).double() - ref).abs().max() / ref.abs().max()) < 5e-6, S
+
+
+def test_conv3x3_weight_gradient_library_fallback_agrees():
+    """PT_SPLIT_WGRAD=0 (or channel counts that are not multiples of 128) keeps the library's weight gradient behind the same
+    autograd Function: both routes give the same three gradients, with and without the fused ReLU / BatchNorm scale."""
+    from point_teacher_amd import functional as F
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device='cpu').manual_seed(11)
+    x = torch.randn(2, 128, 70, 66, generator=g).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    conv = torch.nn.Conv2d(128, 256, 3, padding=1).to(dev).to(memory_format=torch.channels_last)
+    scale = (torch.rand(256, generator=g) + 0.5).to(dev)
+    gy = torch.randn(2, 256, 70, 66, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    res = {}
+    for own in (True, False):
+        F._SPLIT_WGRAD = own
+        try:
+            y1 = F.split_conv3x3(x, conv.weight, conv.bias, relu=True)
+            y2 = F.split_conv3x3(x, conv.weight, conv.bias, relu=True, scale=scale)
+            res[own] = (torch.autograd.grad(y1, (x, conv.weight, conv.bias), gy), torch.autograd.grad(y2, (x, conv.weight), gy))
+        finally:
+            F._SPLIT_WGRAD = True
+    for a, b in zip(res[True][0] + res[True][1], res[False][0] + res[False][1]):
+        assert float((a - b).abs().max()) <= 5e-6 * float(b.abs().max())

@@ -900,3 +900,28 @@ def test_group_norm_channels_last(N, C, H, W, G, relu):
     y2 = PF.group_norm_cl(x, gn, relu)
     g2 = torch.autograd.grad(y2, (x, gn.weight, gn.bias), gy)
     assert torch.equal(y2, y) and all(torch.equal(a, b) for a, b in zip(g2, (gx, gw, gb)))
+
+
+def test_conv_module_group_norm_routes_agree():
+    """mmcv-style ConvModule(conv -> GroupNorm(32) -> ReLU) of the oriented head's towers: the channels_last GroupNorm kernels (and
+    the split convolution they keep reachable) against the torch.nn.GroupNorm route (PT_GN_CL=0), values and all gradients; the
+    output of the own route stays channels_last."""
+    from point_teacher_amd import nn_modules as NM
+    torch.manual_seed(5)
+    m = NM.ConvModule(256, 256, 3, padding=1, bias='auto', norm_cfg=dict(type='GN', num_groups=32, requires_grad=True)).to(DEV).to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        m.gn.weight.uniform_(0.5, 1.5); m.gn.bias.normal_(0, 0.2)
+    x = torch.randn(2, 256, 96, 100, device=DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gy = torch.randn(2, 256, 96, 100, device=DEV).contiguous(memory_format=torch.channels_last)
+    res = {}
+    for own in (True, False):
+        NM._GN_CL = own
+        try:
+            y = m(x)
+            res[own] = (y.detach(), torch.autograd.grad(y, [x] + list(m.parameters()), gy))
+        finally:
+            NM._GN_CL = True
+    assert res[True][0].is_contiguous(memory_format=torch.channels_last)
+    assert float((res[True][0] - res[False][0]).abs().max()) < 2e-5
+    for a, b in zip(res[True][1], res[False][1]):
+        assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-7
