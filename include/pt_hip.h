@@ -263,8 +263,9 @@ int pt_conv3x3_wgrad_bf16x6_nhwc(const uint16_t* gy_planes, int64_t gy_plane_str
                                  int H, int W, int Cin, int Cout, int splits, void* stream);
 
 /* GroupNorm (+ ReLU) on channels_last activations x[N, HW, C] (replaces torch.nn.GroupNorm behind the tower convolutions of the
- * oriented head: mmcv ConvModule with norm_cfg=dict(type='GN', num_groups=32), OBB_TOD/mmrotate/models/dense_heads/
- * rotated_fcos_head.py via rotated_anchor_free_head.py _init_cls_convs / _init_reg_convs):
+ * oriented head: mmcv ConvModule with norm_cfg=dict(type='GN', num_groups=32) - the default of
+ * OBB_TOD/mmrotate/models/dense_heads/rotated_fcos_head_p2rb_ts.py:135, built by mmdet's AnchorFreeHead._init_cls_convs /
+ * _init_reg_convs, HBB_TOD/mmdet/models/dense_heads/anchor_free_head.py:86-135):
  *   y = (x - mean[n, g]) * rstd[n, g] * gamma[c] + beta[c]   (ReLU if relu != 0),  statistics over the H*W * C/G elements of a
  * group (biased variance, float64 accumulation), mean / rstd [N, G] saved for the backward.
  * bwd: dy = grad_y * (y > 0) when y != NULL (the fused ReLU) else grad_y;  grad_x, grad_gamma[C], grad_beta[C] are written.

@@ -1,7 +1,8 @@
 // GroupNorm (+ ReLU) on channels_last activations for gfx950.
 //
-// The oriented config's dense head (OBB_TOD/mmrotate/models/dense_heads/rotated_fcos_head.py towers through mmcv's ConvModule
-// with norm_cfg=dict(type='GN', num_groups=32)) normalises every tower convolution's output with torch.nn.GroupNorm.  The
+// The oriented config's dense head (OBB_TOD/mmrotate/models/dense_heads/rotated_fcos_head_p2rb_ts.py:135: norm_cfg=dict(type='GN',
+// num_groups=32); towers = mmcv ConvModules built by mmdet's AnchorFreeHead, anchor_free_head.py:86-135) normalises every tower
+// convolution's output with torch.nn.GroupNorm.  The
 // library's kernels want NCHW: on the channels_last training layout every call paid two layout copies each way, handed the next
 // tower convolution an NCHW tensor (so that one fell back to the library as well) and ran ~6 launches.  Here the activation stays
 // [N, H*W, C] end to end:
