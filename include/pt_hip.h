@@ -278,6 +278,22 @@ int pt_group_norm_cl_bwd(const float* grad_y, const float* x, const float* y, co
                          const float* rstd, int N, int HW, int C, int G, float* grad_x, float* grad_gamma,
                          float* grad_beta, void* workspace, void* stream);
 
+/* The weight planes of many 3 x 3 convolutions in ONE launch (the weights change once per iteration: one launch instead of a split
+ * - and, for the input-gradient form, a flip and a copy - per weight and form).  `items`: DEVICE array; every item = a channels_last
+ * fp32 weight [Cout][3][3][Cin] (Cin % 32 == 0, Cout % 32 == 0), 16-byte aligned planes of pt_split_bf16x3_plane_elems(rows, k)
+ * elements each (plane stride `plane`), and the form: mode 0 = rows Cout, k = (ky, kx, cin) - what pt_conv3x3_bf16x6_nhwc's forward
+ * takes; mode 1 = rows cin, k = (2 - ky, 2 - kx, cout) - its input gradient.  first_block = number of 16 x 32 blocks of the items
+ * before this one (blocks of an item = ceil(rows / 16) * (9 * cols / 32)); total_blocks = their sum over all items. */
+typedef struct {
+  const float* w;
+  uint16_t* dst;
+  int64_t plane;
+  int32_t O, I;
+  int32_t mode;
+  int32_t first_block;
+} pt_conv_weight_item;
+int pt_conv_weight_planes_batch(const pt_conv_weight_item* items, int n_items, int total_blocks, void* stream);
+
 /* Frozen BatchNorm (+ residual add) (+ ReLU) in one pass each way.  Every BatchNorm on the path
  * is in eval mode with a frozen affine (models/backbones/resnet.py:647-658, config
  * norm_cfg=dict(type='BN', requires_grad=False), norm_eval=True), i.e. y = x*scale[c] + shift[c]

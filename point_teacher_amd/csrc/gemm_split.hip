@@ -146,6 +146,58 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// The weight planes of MANY 3 x 3 convolutions in ONE launch.  The weights change once per iteration (SGD step, EMA), every
+// split convolution needs the planes of [Cout][9 Cin] (forward) and / or of w'[cin][(2 - ky, 2 - kx), cout] (input gradient): one
+// split launch per weight and form (plus a flip and a copy for the second form) were ~100 launch-bound kernels per iteration.
+// items[i] (device memory, pt_conv_weight_item in the header): a channels_last fp32 weight [Cout][3][3][Cin], the destination planes
+// and the form; one wavefront per 16 x 32 block of the blocked plane layout, the item found by a scan of the block prefix.
+struct ConvWItem {
+  const float* w;
+  uint16_t* dst;
+  long plane;                       // plane stride in elements
+  int O, I;
+  int mode;                         // 0: rows = Cout, k = (tap, cin);  1: rows = cin, k = (flipped tap, cout)
+  int first_block;
+};
+
+__global__ void __launch_bounds__(256)
+    conv_weight_planes_kernel(const ConvWItem* __restrict__ items, int n_items, int total_blocks) {
+  const int lane = threadIdx.x & 63, r16 = lane >> 2, q = lane & 3;
+  const int gb = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (gb >= total_blocks) return;
+  int it = 0;
+  for (int i = 1; i < n_items; ++i)
+    if (gb >= items[i].first_block) it = i;
+  const ConvWItem e = items[it];
+  const int rows = e.mode ? e.I : e.O, kdim = 9 * (e.mode ? e.O : e.I);
+  const int KB = kdim >> 5;
+  const int blk = gb - e.first_block;
+  const int rb = blk / KB, kb = blk - rb * KB;
+  const int r = rb * 16 + r16, kk = kb * 32 + q * 8;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (r < rows) {
+    if (e.mode == 0) {
+      const float* sp = e.w + (long)r * kdim + kk;
+      const float4 lo = *reinterpret_cast<const float4*>(sp), hi = *reinterpret_cast<const float4*>(sp + 4);
+      v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    } else {
+      const int tapf = kk / e.O, o = kk - tapf * e.O;        // (8 - tapf) = the tap flipped in both directions
+      const float* sp = e.w + ((long)o * 9 + (8 - tapf)) * e.I + r;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = sp[(long)j * 9 * e.I];
+    }
+  }
+  uint4 o0, o1, o2;
+  split_pair(v[0], v[1], o0.x, o1.x, o2.x);
+  split_pair(v[2], v[3], o0.y, o1.y, o2.y);
+  split_pair(v[4], v[5], o0.z, o1.z, o2.z);
+  split_pair(v[6], v[7], o0.w, o1.w, o2.w);
+  uint16_t* d = e.dst + block_off(rb, kb, KB, r16, q);
+  *reinterpret_cast<uint4*>(d) = o0;
+  *reinterpret_cast<uint4*>(d + e.plane) = o1;
+  *reinterpret_cast<uint4*>(d + 2 * e.plane) = o2;
+}
+
 // ----------------------------------------------------------------------------------------------- GEMM --
 __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
   // global_load_lds_dwordx4: 16 bytes per lane from a per-lane global address to (wave-uniform LDS base + lane * 16)
@@ -721,5 +773,17 @@ extern "C" int pt_conv3x3_wgrad_bf16x6_nhwc(const uint16_t* gy_planes, int64_t g
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, as_stream(stream), reinterpret_cast<const float4*>(workspace),
                      S, n / 4, reinterpret_cast<float4*>(dw));
   PT_LAUNCH_CHECK("pt_conv3x3_wgrad_bf16x6_nhwc (reduce)");
+  return PT_OK;
+}
+
+
+static_assert(sizeof(pt::ConvWItem) == sizeof(pt_conv_weight_item), "the header's item layout");
+
+extern "C" int pt_conv_weight_planes_batch(const pt_conv_weight_item* items, int n_items, int total_blocks, void* stream) {
+  if (n_items == 0 || total_blocks == 0) return PT_OK;
+  PT_REQUIRE(items && n_items > 0 && n_items <= 256 && total_blocks > 0, PT_EINVAL, "pt_conv_weight_planes_batch: bad argument (1 .. 256 items)");
+  hipLaunchKernelGGL(conv_weight_planes_kernel, dim3(cdiv(total_blocks, 4)), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const ConvWItem*>(items), n_items, total_blocks);
+  PT_LAUNCH_CHECK("pt_conv_weight_planes_batch");
   return PT_OK;
 }

@@ -633,9 +633,76 @@ def split_linear(x, weight, bias=None, relu=False):
 
 # --------------------------------------------------- fp32 3x3 convolution on the bf16 matrix cores (implicit GEMM, bf16x6) --
 
+class _ConvWeightPlanes:
+    """All 3x3 convolution weights' split planes, refreshed by ONE launch per parameter epoch (pt_conv_weight_planes_batch).
+    A (weight, form) pair registers itself at its first use; from then on the first request after the parameters changed
+    (optimizer step / EMA bump PARAM_EPOCH) re-splits every registered pair at once - the student's and the teacher's weights,
+    forward and input-gradient forms - instead of one split (and, for the second form, a flip and a copy) per weight and form."""
+
+    def __init__(self):
+        self.ent = {}            # (id(w), mode) -> [weakref(w), data_ptr, SplitPlanes]
+        self.table = None        # (device uint8 tensor of pt_conv_weight_item, n_items, total_blocks)
+        self.epoch = -1
+
+    @staticmethod
+    def ok(w):
+        O, I = w.shape[:2]
+        return (w.is_cuda and w.dtype == f32 and w.dim() == 4 and w.shape[2:] == (3, 3) and I % 32 == 0 and O % 32 == 0
+                and w.permute(0, 2, 3, 1).is_contiguous())
+
+    def _build_table(self):
+        import weakref  # noqa: F401
+        rec = np.zeros(len(self.ent), dtype=np.dtype([('w', '<u8'), ('dst', '<u8'), ('plane', '<i8'), ('O', '<i4'), ('I', '<i4'),
+                                                       ('mode', '<i4'), ('first', '<i4')]))
+        first = 0
+        dev = None
+        for i, ((_, mode), (ref, ptr, sp)) in enumerate(self.ent.items()):
+            w = ref()
+            O, I = w.shape[:2]
+            rows, k = (I, 9 * O) if mode else (O, 9 * I)
+            rec[i] = (ptr, sp.planes.data_ptr(), sp.planes.shape[1], O, I, mode, first)
+            first += ((rows + 15) // 16) * (k // 32)
+            dev = w.device
+        self.table = (torch.from_numpy(rec.view(np.uint8)).to(dev), len(self.ent), first)
+
+    def get(self, w, dgrad):
+        import weakref
+        mode = int(bool(dgrad))
+        key = (id(w), mode)
+        e = self.ent.get(key)
+        if e is not None and (e[0]() is not w or e[1] != w.data_ptr()):
+            e = None                                            # the id was reused, or the storage moved (re-layout of the flat buffer)
+        if e is None:
+            # drop entries whose weight is gone or moved, then register this pair with planes of its own
+            self.ent = {k: v for k, v in self.ent.items() if v[0]() is not None and v[0]().data_ptr() == v[1] and k != key}
+            O, I = w.shape[:2]
+            rows, k = (I, 9 * O) if mode else (O, 9 * I)
+            n = ((rows + 15) // 16) * ((k + 31) // 32) * 512
+            sp = SplitPlanes(torch.empty((3, n), dtype=torch.bfloat16, device=w.device), rows, k)
+            self.ent[key] = [weakref.ref(w), w.data_ptr(), sp]
+            self.table = None
+            self.epoch = -1
+        if self.epoch != PARAM_EPOCH[0] or self.table is None:
+            if any(v[0]() is None or v[0]().data_ptr() != v[1] for v in self.ent.values()):
+                self.ent = {k: v for k, v in self.ent.items() if v[0]() is not None and v[0]().data_ptr() == v[1]}
+                self.table = None
+            if self.table is None:
+                self._build_table()
+            tab, n_items, blocks = self.table
+            hip.call('pt_conv_weight_planes_batch', tab, n_items, blocks)
+            self.epoch = PARAM_EPOCH[0]
+        return self.ent[key][2]
+
+
+_CONV_W = _ConvWeightPlanes()
+
+
 def _conv_weight_planes(w, dgrad):
     """Split planes of a [O, I, 3, 3] weight as the [O, 9 I] matrix with k = (ky, kx, i) (forward; a channels_last weight IS
-    that matrix) or as w'[i, (2 - ky, 2 - kx), o] (input gradient); cached until the parameters change (PARAM_EPOCH)."""
+    that matrix) or as w'[i, (2 - ky, 2 - kx), o] (input gradient); cached until the parameters change (PARAM_EPOCH).  Channels_last
+    weights go through the batched refresh (_ConvWeightPlanes); any other layout is split on its own."""
+    if _ConvWeightPlanes.ok(w):
+        return _CONV_W.get(w, dgrad)
     key = (id(w), 'conv')
     ent = _SPLIT_W_CACHE.get(key)
     if ent is None or ent[0] != PARAM_EPOCH[0] or ent[1] != w.data_ptr():

@@ -216,3 +216,48 @@ def test_conv3x3_weight_gradient_library_fallback_agrees():
             F._SPLIT_WGRAD = True
     for a, b in zip(res[True][0] + res[True][1], res[False][0] + res[False][1]):
         assert float((a - b).abs().max()) <= 5e-6 * float(b.abs().max())
+
+
+def test_conv_weight_planes_are_refreshed_in_one_launch_per_parameter_epoch():
+    """Channels_last 3x3 weights register with the batched plane cache: both forms of every registered weight equal the planes of
+    the per-weight split, they follow the weights after PARAM_EPOCH moves (and only then), a freed weight drops out, and a weight
+    in another layout takes the per-weight path."""
+    from point_teacher_amd import functional as F
+    dev = torch.device('cuda:0')
+    torch.manual_seed(2)
+    ws = [torch.randn(o, i, 3, 3, device=dev).contiguous(memory_format=torch.channels_last) for o, i in ((256, 256), (128, 64), (512, 128))]
+
+    def expect(w, dgrad):
+        O, I = w.shape[:2]
+        m = (w.flip(2, 3).permute(1, 2, 3, 0).reshape(I, 9 * O) if dgrad else w.permute(0, 2, 3, 1).reshape(O, 9 * I))
+        return F.split_bf16x3(m.contiguous())
+
+    F.PARAM_EPOCH[0] += 1
+    for w in ws:
+        for dgrad in (False, True):
+            got, ref = F._conv_weight_planes(w, dgrad), expect(w, dgrad)
+            assert (got.rows, got.k) == (ref.rows, ref.k) and torch.equal(got.planes, ref.planes)
+    calls = []
+    orig = F.hip.call
+    F.hip.call = lambda fn, *a: (calls.append(fn), orig(fn, *a))[1]
+    try:
+        with torch.no_grad():
+            for w in ws:
+                w.mul_(1.5)
+        stale = F._conv_weight_planes(ws[0], False)                    # same epoch: the cached planes, no launch
+        assert not calls and not torch.equal(stale.planes, expect(ws[0], False).planes)
+        F.PARAM_EPOCH[0] += 1
+        for w in ws:
+            for dgrad in (False, True):
+                assert torch.equal(F._conv_weight_planes(w, dgrad).planes, expect(w, dgrad).planes)
+        assert calls.count('pt_conv_weight_planes_batch') == 1       # ONE launch for the six (weight, form) pairs
+    finally:
+        F.hip.call = orig
+    n = len(F._CONV_W.ent)
+    del ws[2], w
+    F.PARAM_EPOCH[0] += 1
+    F._conv_weight_planes(ws[0], True)
+    assert len(F._CONV_W.ent) == n - 2
+    plain = torch.randn(128, 64, 3, 3, device=dev)                    # NCHW-contiguous: per-weight path
+    assert not F._ConvWeightPlanes.ok(plain)
+    assert torch.equal(F._conv_weight_planes(plain, True).planes, expect(plain, True).planes)
