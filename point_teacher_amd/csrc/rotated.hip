@@ -473,13 +473,21 @@ constexpr int RR_WLD = 52;                         // row pitch of Wt in floats 
 constexpr int RR_WT_FLOATS = RR_FMAX * RR_WLD;     // 2 496 floats = 9 984 B per RoI; >= 196 * 8 floats of per-sample taps
 static_assert(RR_WT_FLOATS >= RR_MAXS * 8, "the per-sample taps of a large RoI live in the matrix's place");
 
+// Backward only: a footprint of 49 ... RR_CSRMAX pixels keeps the <= 784 (pixel, bin, weight) entries of the RoI SORTED BY PIXEL in
+// the matrix's place (counting sort inside the building wavefront: per-pixel counts by LDS atomics, a wave-wide prefix sum, a
+// scatter): every channel then adds its entries pixel by pixel and issues ONE atomic per touched pixel instead of four per sample
+// (784 per channel and RoI) - phase 1's synthetic bags have footprints of 64 (median) ... 224 (p90) pixels.
+constexpr int RR_CSRMAX = 448;                     // 64 lanes x 7 pixels of the prefix sum
+static_assert(RR_WT_FLOATS >= (RR_CSRMAX + 1) + RR_CSRMAX + 2 * RR_MAXS * 4, "start | cursor | (bin, weight) entries fit the matrix area");
+
 struct RMeta {                                     // per RoI, wave-uniform
-  int F, y0, x0, nx, b;                            // F > 0: matrix path; F == 0: per-sample path; F < 0: nothing to do
+  int F, y0, x0, nx, b;                            // F > 0: matrix path; F == 0: per-sample path; F == -1: nothing to do;
+  int Fc;                                          // F == -2: pixel-sorted entries over Fc = nx * ny footprint pixels
 };
 
 // wave `w` of the workgroup prepares RoI k: geometry, footprint, Wt (or the per-sample taps)
 __device__ __forceinline__ void rroi_build(const float* __restrict__ roi, int B, int H, int W, float scale, int aligned, int clockwise,
-                                           float* __restrict__ wt, int* __restrict__ poff, RMeta* __restrict__ meta) {
+                                           float* __restrict__ wt, int* __restrict__ poff, RMeta* __restrict__ meta, bool csr = false) {
   const int lane = threadIdx.x & 63;
   const RRoi g = rroi_geom(roi, 7, scale, 2, aligned, clockwise, B);
   // lane = bin (< 49): its 2 x 2 samples
@@ -506,38 +514,80 @@ __device__ __forceinline__ void rroi_build(const float* __restrict__ roi, int B,
     lx0 = min(lx0, __shfl_xor(lx0, o, 64)); lx1 = max(lx1, __shfl_xor(lx1, o, 64));
   }
   const int nx = lx1 - lx0 + 1, ny = ly1 - ly0 + 1;
-  const int F = ly1 < 0 ? -1 : (nx * ny <= RR_FMAX ? nx * ny : 0);
-  if (lane == 0) { meta->F = F; meta->y0 = ly0; meta->x0 = lx0; meta->nx = nx; meta->b = g.b; }
+  int F = ly1 < 0 ? -1 : (nx * ny <= RR_FMAX ? nx * ny : 0);
+  if (csr && F == 0 && nx * ny <= RR_CSRMAX) F = -2;
+  if (lane == 0) { meta->F = F; meta->y0 = ly0; meta->x0 = lx0; meta->nx = nx; meta->b = g.b; meta->Fc = nx * ny; }
   const float inv = 1.f / g.count;
+  // This lane (= bin) owns 16 (pixel, weight) entries, merged IN REGISTERS first (the 2 x 2 samples of a bin revisit the same pixels)
+  int px[16];
+  float pw_[16];
+  if (F > 0 || F == -2) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int r0 = (q[s4].y0 - ly0) * nx - lx0, r1 = (q[s4].y1 - ly0) * nx - lx0;
+      const float m = (q[s4].valid && lane < RR_BINS) ? inv : 0.f;
+      px[4 * s4] = r0 + q[s4].x0; px[4 * s4 + 1] = r0 + q[s4].x1; px[4 * s4 + 2] = r1 + q[s4].x0; px[4 * s4 + 3] = r1 + q[s4].x1;
+      pw_[4 * s4] = q[s4].w1 * m; pw_[4 * s4 + 1] = q[s4].w2 * m; pw_[4 * s4 + 2] = q[s4].w3 * m; pw_[4 * s4 + 3] = q[s4].w4 * m;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int j = i + 1; j < 16; ++j) {                      // fold a later duplicate into the earlier entry
+        const bool same = px[j] == px[i];
+        pw_[i] += same ? pw_[j] : 0.f;
+        pw_[j] = same ? 0.f : pw_[j];
+      }
+  }
   if (F > 0) {
     for (int i = lane; i < F * (RR_WLD / 4); i += 64) reinterpret_cast<float4*>(wt)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (lane < F) poff[lane] = (lane / nx) * W + lane % nx;
-    // (same wave: LDS operations execute in order, the zeros land before the adds below)
+    // (same wave: LDS operations execute in order, the zeros land before the stores below.)  Each surviving entry is ONE plain
+    // store into this lane's column of Wt: a chain of 16 dependent LDS read-modify-writes per lane cost ~2 000 cycles per RoI.
     if (lane < RR_BINS) {
-      // This lane owns column `lane` of Wt.  Its 16 (pixel, weight) entries are merged IN REGISTERS first (the 2 x 2 samples of
-      // a bin revisit the same pixels), then each surviving entry is ONE plain store: a chain of 16 dependent LDS
-      // read-modify-writes per lane cost ~2 000 cycles per RoI.
-      int px[16];
-      float pw_[16];
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const int r0 = (q[s4].y0 - ly0) * nx - lx0, r1 = (q[s4].y1 - ly0) * nx - lx0;
-        const float m = q[s4].valid ? inv : 0.f;
-        px[4 * s4] = r0 + q[s4].x0; px[4 * s4 + 1] = r0 + q[s4].x1; px[4 * s4 + 2] = r1 + q[s4].x0; px[4 * s4 + 3] = r1 + q[s4].x1;
-        pw_[4 * s4] = q[s4].w1 * m; pw_[4 * s4 + 1] = q[s4].w2 * m; pw_[4 * s4 + 2] = q[s4].w3 * m; pw_[4 * s4 + 3] = q[s4].w4 * m;
-      }
-#pragma unroll
-      for (int i = 0; i < 16; ++i)
-#pragma unroll
-        for (int j = i + 1; j < 16; ++j) {                    // fold a later duplicate into the earlier entry
-          const bool same = px[j] == px[i];
-          pw_[i] += same ? pw_[j] : 0.f;
-          pw_[j] = same ? 0.f : pw_[j];
-        }
 #pragma unroll
       for (int i = 0; i < 16; ++i)
         if (pw_[i] != 0.f) wt[px[i] * RR_WLD + lane] = pw_[i];
     }
+  } else if (F == -2) {                            // counting sort of the entries by pixel: start[Fc + 1] | cursor[Fc] | (bin, weight)[<= 784]
+    const int Fc = nx * ny;
+    int* start = reinterpret_cast<int*>(wt);
+    int* cur = start + (RR_CSRMAX + 1);
+    int* ent = cur + RR_CSRMAX;
+    for (int i = lane; i < Fc; i += 64) { start[i] = 0; cur[i] = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (pw_[i] != 0.f) atomicAdd(&start[px[i]], 1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    int cnt[7], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int idx = 7 * lane + j;
+      cnt[j] = idx < Fc ? start[idx] : 0;
+      sum += cnt[j];
+    }
+    int incl = sum;                                  // inclusive wave scan
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    int run = incl - sum;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int idx = 7 * lane + j;
+      if (idx < Fc) start[idx] = run;
+      run += cnt[j];
+    }
+    if (lane == 63) start[Fc] = incl;                // the total (lane 63's pixels 441 .. 447 end at or before Fc)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (pw_[i] != 0.f) {
+        const int pos = start[px[i]] + atomicAdd(&cur[px[i]], 1);
+        ent[2 * pos] = lane;
+        ent[2 * pos + 1] = __float_as_int(pw_[i]);
+      }
   } else if (F == 0 && lane < RR_BINS) {           // per-sample taps: [bin][sample] x (4 offsets | 4 weights)
     int* to = reinterpret_cast<int*>(wt);
 #pragma unroll
@@ -641,18 +691,33 @@ __global__ void __launch_bounds__(256)
   RGroupSmem& S = *reinterpret_cast<RGroupSmem*>(rr_smem);
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int k0 = blockIdx.x * group;
-  if (w < group && k0 + w < K) rroi_build(rois + (size_t)(k0 + w) * 6, B, H, W, scale, aligned, clockwise, S.wt[w], S.off[w], &S.meta[w]);
+  if (w < group && k0 + w < K) rroi_build(rois + (size_t)(k0 + w) * 6, B, H, W, scale, aligned, clockwise, S.wt[w], S.off[w], &S.meta[w], true);
   __syncthreads();
   float* tile = S.tile[w];
   for (int rr = 0; rr < group && k0 + rr < K; ++rr) {
     const RMeta m = S.meta[rr];
-    if (m.F < 0) continue;
+    if (m.F == -1) continue;
     const float* wt = S.wt[rr];
     float* fb = gfeat + (size_t)m.b * H * W * C;
     for (int c0 = w * 64; c0 < C; c0 += 256) {
       const int c = c0 + lane;
       const bool live = c < C;
       const int cn = min(C - c0, 64);
+      if (m.F == -2) {                                        // pixel-sorted entries: one atomic per touched footprint pixel
+        const int* start = reinterpret_cast<const int*>(S.wt[rr]);
+        const int* ent = start + (RR_CSRMAX + 1) + RR_CSRMAX;
+        const float* gl = gout + ((size_t)(k0 + rr) * C + (live ? c : 0)) * RR_BINS;   // this lane's 49 gradients (cache resident)
+        float* px = gfeat + (size_t)m.b * H * W * C + ((size_t)m.y0 * W + m.x0) * C + (live ? c : 0);
+        int x = 0, rowoff = 0;
+        for (int p = 0; p < m.Fc; ++p) {
+          const int e0 = start[p], e1 = start[p + 1];
+          float a = 0.f;
+          for (int e = e0; e < e1; ++e) a = fmaf(__int_as_float(ent[2 * e + 1]), gl[ent[2 * e]], a);
+          if (live && e1 > e0 && a != 0.f) atomicAdd(px + (size_t)(rowoff + x) * C, a);
+          if (++x == m.nx) { x = 0; rowoff += W; }
+        }
+        continue;
+      }
       float g[RR_BINS];
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {                        // the 49 gradients of this lane's channel, through the tile

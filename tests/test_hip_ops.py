@@ -925,3 +925,35 @@ def test_conv_module_group_norm_routes_agree():
     assert float((res[True][0] - res[False][0]).abs().max()) < 2e-5
     for a, b in zip(res[True][1], res[False][1]):
         assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-7
+
+
+def test_roi_align_rotated_backward_pixel_sorted_path():
+    """2 100 RoIs (groups of four per workgroup) of 0.5 ... 19 feature pixels per side at every angle: footprints of 9 ... ~700 pixels,
+    i.e. all three backward routes of pt_roi_align_rotated_bwd in one launch - the small dense product (<= 48 px), the pixel-sorted
+    entries (49 ... 448 px: one atomic per touched pixel) and the per-sample taps beyond.  Forward and backward against the oracle's
+    autograd on a channel subset (the op is channel-wise), all 256 channels against each other through linearity."""
+    f = F()
+    gen = torch.Generator().manual_seed(47)
+    B, C, H, W = 2, 256, 60, 60
+    K = 2100
+    feat = torch.randn(B, C, H, W, generator=gen)
+    rois = torch.cat([torch.randint(0, B, (K, 1), generator=gen).float(), torch.rand(K, 2, generator=gen) * 400 + 40,
+                      torch.rand(K, 2, generator=gen) * 150 + 4, (torch.rand(K, 1, generator=gen) - 0.5) * np.pi], 1)
+    rois[5, 1:3] = torch.tensor([-90., -90.])                         # outside the map
+    rois[6, 1:5] = torch.tensor([2., 477., 120., 90.])                # a medium footprint clipped by two borders
+    wgt = torch.randn(K, C, 7, 7, generator=gen)
+    fg = cu(feat).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    out = f.roi_align_rotated(fg, cu(rois), 7, 0.125, 2, True, True)
+    (out * cu(wgt)).sum().backward()
+    sub = [0, 31, 64, 255]
+    fr = feat[:, sub].clone().requires_grad_(True)
+    ref = R.roi_align_rotated(fr, rois, 7, 0.125, 2, True, True)
+    (ref * wgt[:, sub]).sum().backward()
+    close(out[:, sub], ref, atol=2e-5)
+    close(fg.grad[:, sub], fr.grad, rtol=1e-4, atol=5e-4)
+    # every channel does the same arithmetic: the gradient of channel c for the upstream gradient of channel 0 equals channel 0's
+    g0 = fg.grad[:, 0].clone()
+    fg.grad = None
+    w2 = cu(wgt[:, :1]).expand(-1, C, -1, -1).contiguous()
+    (f.roi_align_rotated(fg, cu(rois), 7, 0.125, 2, True, True) * w2).sum().backward()
+    close(fg.grad, g0[:, None].expand(-1, C, -1, -1), rtol=1e-4, atol=5e-4)
