@@ -486,8 +486,9 @@ struct RMeta {                                     // per RoI, wave-uniform
 };
 
 // wave `w` of the workgroup prepares RoI k: geometry, footprint, Wt (or the per-sample taps)
+template <bool CSR = false>
 __device__ __forceinline__ void rroi_build(const float* __restrict__ roi, int B, int H, int W, float scale, int aligned, int clockwise,
-                                           float* __restrict__ wt, int* __restrict__ poff, RMeta* __restrict__ meta, bool csr = false) {
+                                           float* __restrict__ wt, int* __restrict__ poff, RMeta* __restrict__ meta) {
   const int lane = threadIdx.x & 63;
   const RRoi g = rroi_geom(roi, 7, scale, 2, aligned, clockwise, B);
   // lane = bin (< 49): its 2 x 2 samples
@@ -515,13 +516,13 @@ __device__ __forceinline__ void rroi_build(const float* __restrict__ roi, int B,
   }
   const int nx = lx1 - lx0 + 1, ny = ly1 - ly0 + 1;
   int F = ly1 < 0 ? -1 : (nx * ny <= RR_FMAX ? nx * ny : 0);
-  if (csr && F == 0 && nx * ny <= RR_CSRMAX) F = -2;
+  if (CSR && F == 0 && nx * ny <= RR_CSRMAX) F = -2;
   if (lane == 0) { meta->F = F; meta->y0 = ly0; meta->x0 = lx0; meta->nx = nx; meta->b = g.b; meta->Fc = nx * ny; }
   const float inv = 1.f / g.count;
   // This lane (= bin) owns 16 (pixel, weight) entries, merged IN REGISTERS first (the 2 x 2 samples of a bin revisit the same pixels)
   int px[16];
   float pw_[16];
-  if (F > 0 || F == -2) {
+  if (F > 0 || (CSR && F == -2)) {
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
       const int r0 = (q[s4].y0 - ly0) * nx - lx0, r1 = (q[s4].y1 - ly0) * nx - lx0;
@@ -548,7 +549,7 @@ __device__ __forceinline__ void rroi_build(const float* __restrict__ roi, int B,
       for (int i = 0; i < 16; ++i)
         if (pw_[i] != 0.f) wt[px[i] * RR_WLD + lane] = pw_[i];
     }
-  } else if (F == -2) {                            // counting sort of the entries by pixel: start[Fc + 1] | cursor[Fc] | (bin, weight)[<= 784]
+  } else if (CSR && F == -2) {                     // counting sort of the entries by pixel: start[Fc + 1] | cursor[Fc] | (bin, weight)[<= 784]
     const int Fc = nx * ny;
     int* start = reinterpret_cast<int*>(wt);
     int* cur = start + (RR_CSRMAX + 1);
@@ -684,6 +685,10 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// CSR: the instantiation for bags (K >= 2 048: four RoIs per workgroup) carries the pixel-sorted route; the one for small batches
+// (the 400 negatives: footprints of thousands of pixels, always on the per-sample route) does not - with the extra route compiled
+// in, the per-sample route of that launch measured 40 % slower (register allocation / scheduling of the whole kernel).
+template <bool CSR>
 __global__ void __launch_bounds__(256)
     roi_align_rotated_bwd_mm(const float* __restrict__ gout, const float* __restrict__ rois, int B, int C, int H, int W, int K,
                              float scale, int aligned, int clockwise, int group, float* __restrict__ gfeat) {
@@ -691,7 +696,7 @@ __global__ void __launch_bounds__(256)
   RGroupSmem& S = *reinterpret_cast<RGroupSmem*>(rr_smem);
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int k0 = blockIdx.x * group;
-  if (w < group && k0 + w < K) rroi_build(rois + (size_t)(k0 + w) * 6, B, H, W, scale, aligned, clockwise, S.wt[w], S.off[w], &S.meta[w], true);
+  if (w < group && k0 + w < K) rroi_build<CSR>(rois + (size_t)(k0 + w) * 6, B, H, W, scale, aligned, clockwise, S.wt[w], S.off[w], &S.meta[w]);
   __syncthreads();
   float* tile = S.tile[w];
   for (int rr = 0; rr < group && k0 + rr < K; ++rr) {
@@ -703,7 +708,7 @@ __global__ void __launch_bounds__(256)
       const int c = c0 + lane;
       const bool live = c < C;
       const int cn = min(C - c0, 64);
-      if (m.F == -2) {                                        // pixel-sorted entries: one atomic per touched footprint pixel
+      if (CSR && m.F == -2) {                                 // pixel-sorted entries: one atomic per touched footprint pixel
         const int* start = reinterpret_cast<const int*>(S.wt[rr]);
         const int* ent = start + (RR_CSRMAX + 1) + RR_CSRMAX;
         const float* gl = gout + ((size_t)(k0 + rr) * C + (live ? c : 0)) * RR_BINS;   // this lane's 49 gradients (cache resident)
@@ -808,20 +813,26 @@ static int rroi_launch(const char* fn, const float* src, const float* rois, int 
   const size_t lds = fpb > tlb ? fpb : tlb;
   if (channels_last && out_size == 7 && sample_num == 2 && H * W < (1 << 24)) {
     // r03: four RoIs per workgroup, one small dense product per RoI (config 5: out_size 7, sample_num 2)
-    static bool attr_mm[2] = {false, false};
-    const void* kf = BWD ? reinterpret_cast<const void*>(roi_align_rotated_bwd_mm) : reinterpret_cast<const void*>(roi_align_rotated_fwd_mm);
-    const size_t lds_mm = sizeof(RGroupSmem);
-    if (!attr_mm[BWD]) {
-      hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mm);
-      if (e != hipSuccess) { set_error("%s: LDS attribute: %s", fn, hipGetErrorString(e)); return (int)e; }
-      attr_mm[BWD] = true;
-    }
     // four RoIs per workgroup (their matrices are built side by side) once that still leaves >= 2 workgroups per CU; a small
     // batch (the 400 negatives: 70 x 70-pixel RoIs on the per-sample path) gets one workgroup per RoI
     const int group = K >= 2048 ? RR_GROUP : 1;
-    if (BWD)
-      hipLaunchKernelGGL(roi_align_rotated_bwd_mm, dim3(cdiv(K, group)), dim3(256), lds_mm, s, src, rois, B, C, H, W, K, scale, aligned,
-                         clockwise, group, dst);
+    static bool attr_mm[3] = {false, false, false};
+    const int which = BWD ? (group > 1 ? 2 : 1) : 0;
+    const void* kf = which == 2 ? reinterpret_cast<const void*>(roi_align_rotated_bwd_mm<true>)
+                   : which == 1 ? reinterpret_cast<const void*>(roi_align_rotated_bwd_mm<false>)
+                                : reinterpret_cast<const void*>(roi_align_rotated_fwd_mm);
+    const size_t lds_mm = sizeof(RGroupSmem);
+    if (!attr_mm[which]) {
+      hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mm);
+      if (e != hipSuccess) { set_error("%s: LDS attribute: %s", fn, hipGetErrorString(e)); return (int)e; }
+      attr_mm[which] = true;
+    }
+    if (which == 2)
+      hipLaunchKernelGGL(roi_align_rotated_bwd_mm<true>, dim3(cdiv(K, group)), dim3(256), lds_mm, s, src, rois, B, C, H, W, K, scale,
+                         aligned, clockwise, group, dst);
+    else if (which == 1)
+      hipLaunchKernelGGL(roi_align_rotated_bwd_mm<false>, dim3(cdiv(K, group)), dim3(256), lds_mm, s, src, rois, B, C, H, W, K, scale,
+                         aligned, clockwise, group, dst);
     else
       hipLaunchKernelGGL(roi_align_rotated_fwd_mm, dim3(cdiv(K, group)), dim3(256), lds_mm, s, src, rois, B, C, H, W, K, scale, aligned,
                          clockwise, group, dst);
