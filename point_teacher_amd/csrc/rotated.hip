@@ -477,7 +477,11 @@ static_assert(RR_WT_FLOATS >= RR_MAXS * 8, "the per-sample taps of a large RoI l
 // the matrix's place (counting sort inside the building wavefront: per-pixel counts by LDS atomics, a wave-wide prefix sum, a
 // scatter): every channel then adds its entries pixel by pixel and issues ONE atomic per touched pixel instead of four per sample
 // (784 per channel and RoI) - phase 1's synthetic bags have footprints of 64 (median) ... 224 (p90) pixels.
-constexpr int RR_CSRMAX = 448;                     // 64 lanes x 7 pixels of the prefix sum
+constexpr int RR_CSRMAX = 448;                     // 64 lanes x 7 pixels of the prefix sum (capacity of the layout)
+// Used up to RR_CSRUSE pixels (>= 6 entries per pixel): the route trades 784 fire-and-forget atomics for a chain of 784 dependent
+// (LDS entry -> cached gradient -> FMA) steps, which only pays while the launch is bound by the atomic rate.  With the cap at 448
+// phase 1's launch went 2.55 -> 1.30 ms but the benchmark's phase 2 (fewer, larger bags) lost 1.3 ms / iteration.
+constexpr int RR_CSRUSE = 128;
 static_assert(RR_WT_FLOATS >= (RR_CSRMAX + 1) + RR_CSRMAX + 2 * RR_MAXS * 4, "start | cursor | (bin, weight) entries fit the matrix area");
 
 struct RMeta {                                     // per RoI, wave-uniform
@@ -516,7 +520,7 @@ __device__ __forceinline__ void rroi_build(const float* __restrict__ roi, int B,
   }
   const int nx = lx1 - lx0 + 1, ny = ly1 - ly0 + 1;
   int F = ly1 < 0 ? -1 : (nx * ny <= RR_FMAX ? nx * ny : 0);
-  if (CSR && F == 0 && nx * ny <= RR_CSRMAX) F = -2;
+  if (CSR && F == 0 && nx * ny <= RR_CSRUSE) F = -2;
   if (lane == 0) { meta->F = F; meta->y0 = ly0; meta->x0 = lx0; meta->nx = nx; meta->b = g.b; meta->Fc = nx * ny; }
   const float inv = 1.f / g.count;
   // This lane (= bin) owns 16 (pixel, weight) entries, merged IN REGISTERS first (the 2 x 2 samples of a bin revisit the same pixels)
