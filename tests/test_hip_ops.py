@@ -930,7 +930,7 @@ def test_conv_module_group_norm_routes_agree():
 def test_roi_align_rotated_backward_pixel_sorted_path():
     """2 100 RoIs (groups of four per workgroup) of 0.5 ... 19 feature pixels per side at every angle: footprints of 9 ... ~700 pixels,
     i.e. all three backward routes of pt_roi_align_rotated_bwd in one launch - the small dense product (<= 48 px), the pixel-sorted
-    entries (49 ... 448 px: one atomic per touched pixel) and the per-sample taps beyond.  Forward and backward against the oracle's
+    entries (49 ... 128 px: one atomic per touched pixel) and the per-sample taps beyond.  Forward and backward against the oracle's
     autograd on a channel subset (the op is channel-wise), all 256 channels against each other through linearity."""
     f = F()
     gen = torch.Generator().manual_seed(47)
