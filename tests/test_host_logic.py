@@ -186,3 +186,18 @@ def test_epoch_batches_report_the_epoch_a_resume_must_start_with():
     assert b() == (0, 2) and b.epoch == 0 and b.next_epoch() == 1                       # used up: the next one
     resumed = EpochBatches(Loader(), start_epoch=b.next_epoch())
     assert resumed() == b() == (1, 0)                                                   # the resumed run and the uninterrupted one agree
+
+
+def test_bench_matrix_family_accounting():
+    """bench.py prices the matrix family by the EXECUTED bf16 FLOPs: 2 M N K per GEMM launch, 2 P Cout 9 Cin per convolution
+    launch - forward / input gradient and the weight gradient alike - and the three entry points form one family."""
+    import bench
+    assert bench.algorithmic_flops('pt_gemm_bf16x6_nt', dict(M=5000, N=1024, K=12544)) == 2.0 * 5000 * 1024 * 12544
+    conv = dict(P=2 * 100 * 100, Cin=256, Cout=256)
+    assert bench.algorithmic_flops('pt_conv3x3_bf16x6_nhwc', conv) == 2.0 * 20000 * 256 * 9 * 256
+    assert bench.algorithmic_flops('pt_conv3x3_wgrad_bf16x6_nhwc', conv) == bench.algorithmic_flops('pt_conv3x3_bf16x6_nhwc', conv)
+    assert bench.algorithmic_flops('pt_roi_align_fwd', dict(K=1)) is None
+    assert set(bench.MFMA_FAMILY[1]) == {'pt_gemm_bf16x6_nt', 'pt_conv3x3_bf16x6_nhwc', 'pt_conv3x3_wgrad_bf16x6_nhwc'}
+    import point_teacher_amd.hip as hip
+    for fn in bench.MFMA_FAMILY[1] + tuple(m for ms in bench.FAMILIES.values() for m in ms):
+        assert fn in hip.PROTOS, fn                                # every entry point the roofline names exists in the header
