@@ -262,6 +262,77 @@ int pt_conv3x3_wgrad_bf16x6_nhwc(const uint16_t* gy_planes, int64_t gy_plane_str
                                  int64_t x_plane_stride, float* dw, float* workspace, int64_t workspace_elems, int B,
                                  int H, int W, int Cin, int Cout, int splits, void* stream);
 
+/* ---------------------------------------------- plane-native convolutions (ABI 4) --
+ * The same implicit GEMM for every convolution of the trunk: the Bottlenecks' 1 x 1 / 3 x 3 convolutions with their frozen BatchNorm,
+ * identity add and ReLU (backbones/resnet.py:262-303; `caffe` style puts the stride on conv1, :153-158), FPN's laterals and output
+ * convolutions (necks/fpn.py:151-202), PSAGG's 1 x 1 convolutions (necks/ps_fpn.py:56-75) and the dense head's towers
+ * (anchor_free_head.py:198-219) - and for their input gradients (the same call on the output gradient with mode-1 weight planes).
+ * Activations travel between layers as ROW-MAJOR split planes [3][(pixels + 1) * C] (x = x0 + x1 + x2 exactly, last row zeros) so
+ * that no layer re-splits its input and no fp32 copy of an intermediate activation is written:
+ *   acc[p][o]  = sum over taps, cin of x[(y * stride - pad + ky, x * stride - pad + kx)][cin] * w[o][ky][kx][cin]     (zero outside)
+ *   v          = acc * scale[o] + shift[o]  (+ res_planes[p][o] summed)  (+ res_f32[p][o])     -> ReLU when relu != 0
+ *   v          = 0 where mask_planes' plane 0 is <= 0   (the ReLU mask of the tensor whose gradient is being formed)
+ *   out_f32[p][o] = v   and / or   out_planes = split(v) (row M = zeros).
+ * scatter_stride == 2: output row (b, y, x) is written to row (b * scatter_H + 2 y) * scatter_W + 2 x of mask / out_f32 / out_planes -
+ * the input gradient of a stride-2 1 x 1 convolution computed on the coarse grid and placed into a buffer the caller zeroed
+ * (res_* stay indexed by the coarse row).  Every pointer of the epilogue may be NULL; at least one output is required.
+ * w_planes: blocked planes of [Cout][KH * KW * Cin] (pt_conv_weight_planes_batch / pt_split_bf16x3).  Cin % 32 == 0, Cout % 8 == 0.
+ * [host] struct; device pointers inside. */
+typedef struct {
+  int32_t B, Hs, Ws, Cin, Cout, KH, KW, stride, pad;
+  int32_t relu;
+  const uint16_t* x_planes;
+  int64_t x_plane_stride;
+  const uint16_t* w_planes;
+  int64_t w_plane_stride;
+  const float* scale;
+  const float* shift;
+  const uint16_t* res_planes;
+  int64_t res_plane_stride;
+  const float* res_f32;
+  const uint16_t* mask_planes;
+  float* out_f32;
+  uint16_t* out_planes;
+  int64_t out_plane_stride;
+  int32_t scatter_stride, scatter_H, scatter_W;
+  int32_t tile_rows;
+} pt_conv_desc;
+int pt_conv_bf16x6(const pt_conv_desc* desc, void* stream);
+
+/* Weight (and bias) gradient of the same convolutions: dw[Cout][KH][KW][Cin] (+)= row_scale[o] * sum over output pixels p of
+ * gy[p][o] * x[src(p, tap)][cin]; dbias[o] (+)= sum_p gy[p][o] (formed by the same launch: one more MFMA operand of ones, no extra
+ * pass).  gy_planes: row-major planes of the [B*Ho*Wo, Cout] output gradient (what the input-gradient call read), x_planes: of the
+ * [B*Hs*Ws, Cin] activations (what the forward read).  accumulate != 0: added to dw / dbias (a parameter's gradient buffer) instead
+ * of stored.  workspace >= splits * (Cout * KH * KW * Cin [+ Cout]) floats; fixed-order reduction: deterministic, no atomics.
+ * Cin % 128 == 0, Cout % 128 == 0.  [host] struct; device pointers inside. */
+typedef struct {
+  int32_t B, Hs, Ws, Cin, Cout, KH, KW, stride, pad;
+  int32_t accumulate;
+  const uint16_t* gy_planes;
+  int64_t gy_plane_stride;
+  const uint16_t* x_planes;
+  int64_t x_plane_stride;
+  float* dw;
+  float* dbias;
+  const float* row_scale;
+  float* workspace;
+  int64_t workspace_elems;
+  int32_t splits;
+  int32_t reserved;
+} pt_conv_wgrad_desc;
+int pt_conv_wgrad_bf16x6_splits(int B, int Ho, int Wo, int KH, int KW, int Cin, int Cout);
+int pt_conv_wgrad_bf16x6(const pt_conv_wgrad_desc* desc, void* stream);
+
+/* fp32 NHWC [B, Hs, Ws, C] (pixel stride ld) -> row-major planes of the pixels (y * stride, x * stride): [3][(B * Ho * Wo + 1) * C],
+ * Ho = (Hs - 1) / stride + 1.  stride 2 = the pixels layer2's first Bottleneck reads from the frozen layer1 (resnet.py:153-158). */
+int pt_split_bf16x3_gather(const float* src, int64_t ld, int B, int Hs, int Ws, int C, int stride, uint16_t* planes,
+                           int64_t plane_stride, void* stream);
+/* out = split(m * (a + b + c)) element-wise on row-major planes (n elements per plane, n % 8 == 0): a, b planes (b may be NULL),
+ * c fp32 (may be NULL), m = (mask's plane 0 > 0) or 1 when mask == NULL; out (planes) and / or out_f32.  The gradient of an
+ * activation with several consumers (a stage output feeding the next stage and an FPN lateral), or planes -> fp32. */
+int pt_planes_combine(const uint16_t* a, int64_t a_plane_stride, const uint16_t* b, int64_t b_plane_stride, const float* c,
+                      const uint16_t* mask, int64_t n, uint16_t* out, int64_t out_plane_stride, float* out_f32, void* stream);
+
 /* GroupNorm (+ ReLU) on channels_last activations x[N, HW, C] (replaces torch.nn.GroupNorm behind the tower convolutions of the
  * oriented head: mmcv ConvModule with norm_cfg=dict(type='GN', num_groups=32) - the default of
  * OBB_TOD/mmrotate/models/dense_heads/rotated_fcos_head_p2rb_ts.py:135, built by mmdet's AnchorFreeHead._init_cls_convs /
@@ -278,12 +349,15 @@ int pt_group_norm_cl_bwd(const float* grad_y, const float* x, const float* y, co
                          const float* rstd, int N, int HW, int C, int G, float* grad_x, float* grad_gamma,
                          float* grad_beta, void* workspace, void* stream);
 
-/* The weight planes of many 3 x 3 convolutions in ONE launch (the weights change once per iteration: one launch instead of a split
- * - and, for the input-gradient form, a flip and a copy - per weight and form).  `items`: DEVICE array; every item = a channels_last
- * fp32 weight [Cout][3][3][Cin] (Cin % 32 == 0, Cout % 32 == 0), 16-byte aligned planes of pt_split_bf16x3_plane_elems(rows, k)
- * elements each (plane stride `plane`), and the form: mode 0 = rows Cout, k = (ky, kx, cin) - what pt_conv3x3_bf16x6_nhwc's forward
- * takes; mode 1 = rows cin, k = (2 - ky, 2 - kx, cout) - its input gradient.  first_block = number of 16 x 32 blocks of the items
- * before this one (blocks of an item = ceil(rows / 16) * (9 * cols / 32)); total_blocks = their sum over all items. */
+/* The weight planes of many convolutions (1 x 1 and 3 x 3) in ONE launch (the weights change once per iteration: one launch instead
+ * of a split - and, for the input-gradient form, a flip and a copy - per weight and form).  `items`: DEVICE array; every item = a
+ * channels_last fp32 weight [Cout][KH][KW][Cin] (taps = KH * KW = 1 or 9; Cin % 32 == 0, Cout % 32 == 0), 16-byte aligned planes of
+ * pt_split_bf16x3_plane_elems(rows, k) elements each (plane stride `plane`), and the form: mode 0 = rows Cout, k = (ky, kx, cin) - what
+ * pt_conv_bf16x6's forward takes; mode 1 = rows cin, k = (KH - 1 - ky, KW - 1 - kx, cout) - its input gradient.  scale (NULL or
+ * [Cout], device): w[o] * scale[o] is what gets split - the scale of the frozen BatchNorm behind the convolution folded into the
+ * input-gradient weights (backbones/resnet.py:262-303: dx = (g * scale) W = g (diag(scale) W)).  first_block = number of 16 x 32 blocks
+ * of the items before this one (blocks of an item = ceil(rows / 16) * (taps * cols / 32)); total_blocks = their sum over all items.
+ * ABI 4: the item grew `taps` and `scale`. */
 typedef struct {
   const float* w;
   uint16_t* dst;
@@ -291,6 +365,9 @@ typedef struct {
   int32_t O, I;
   int32_t mode;
   int32_t first_block;
+  int32_t taps;
+  int32_t reserved;
+  const float* scale;
 } pt_conv_weight_item;
 int pt_conv_weight_planes_batch(const pt_conv_weight_item* items, int n_items, int total_blocks, void* stream);
 

@@ -146,11 +146,12 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// The weight planes of MANY 3 x 3 convolutions in ONE launch.  The weights change once per iteration (SGD step, EMA), every
-// split convolution needs the planes of [Cout][9 Cin] (forward) and / or of w'[cin][(2 - ky, 2 - kx), cout] (input gradient): one
-// split launch per weight and form (plus a flip and a copy for the second form) were ~100 launch-bound kernels per iteration.
-// items[i] (device memory, pt_conv_weight_item in the header): a channels_last fp32 weight [Cout][3][3][Cin], the destination planes
-// and the form; one wavefront per 16 x 32 block of the blocked plane layout, the item found by a scan of the block prefix.
+// The weight planes of MANY convolutions (1 x 1 and 3 x 3) in ONE launch.  The weights change once per iteration (SGD step, EMA),
+// every split convolution needs the planes of [Cout][taps Cin] (forward) and / or of w'[cin][(flipped tap), cout] (input gradient):
+// one split launch per weight and form (plus a flip and a copy for the second form) were ~100 launch-bound kernels per iteration.
+// items[i] (device memory, pt_conv_weight_item in the header): a channels_last fp32 weight [Cout][KH][KW][Cin], the destination
+// planes, the form and an optional per-output-channel scale folded into the weights; one wavefront per 16 x 32 block of the blocked
+// plane layout, the item found by a binary search of the block prefix.
 struct ConvWItem {
   const float* w;
   uint16_t* dst;
@@ -158,6 +159,10 @@ struct ConvWItem {
   int O, I;
   int mode;                         // 0: rows = Cout, k = (tap, cin);  1: rows = cin, k = (flipped tap, cout)
   int first_block;
+  int taps;                         // KH * KW (1 or 9)
+  int pad_;
+  const float* scale;               // NULL or [Cout]: w[o] * scale[o] is split (the frozen BatchNorm's scale folded into the
+                                    // input-gradient weights: dx = (g * scale) W = g (diag(scale) W))
 };
 
 __global__ void __launch_bounds__(256)
@@ -165,11 +170,14 @@ __global__ void __launch_bounds__(256)
   const int lane = threadIdx.x & 63, r16 = lane >> 2, q = lane & 3;
   const int gb = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (gb >= total_blocks) return;
-  int it = 0;
-  for (int i = 1; i < n_items; ++i)
-    if (gb >= items[i].first_block) it = i;
+  int it = 0, hi = n_items - 1;                                // the last item whose first block is <= gb
+  while (it < hi) {
+    const int mid = (it + hi + 1) >> 1;
+    if (gb >= items[mid].first_block) it = mid; else hi = mid - 1;
+  }
   const ConvWItem e = items[it];
-  const int rows = e.mode ? e.I : e.O, kdim = 9 * (e.mode ? e.O : e.I);
+  const int T = e.taps;
+  const int rows = e.mode ? e.I : e.O, kdim = T * (e.mode ? e.O : e.I);
   const int KB = kdim >> 5;
   const int blk = gb - e.first_block;
   const int rb = blk / KB, kb = blk - rb * KB;
@@ -180,11 +188,20 @@ __global__ void __launch_bounds__(256)
       const float* sp = e.w + (long)r * kdim + kk;
       const float4 lo = *reinterpret_cast<const float4*>(sp), hi = *reinterpret_cast<const float4*>(sp + 4);
       v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-    } else {
-      const int tapf = kk / e.O, o = kk - tapf * e.O;        // (8 - tapf) = the tap flipped in both directions
-      const float* sp = e.w + ((long)o * 9 + (8 - tapf)) * e.I + r;
+      if (e.scale) {
+        const float sc = e.scale[r];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = sp[(long)j * 9 * e.I];
+        for (int j = 0; j < 8; ++j) v[j] *= sc;
+      }
+    } else {
+      const int tapf = kk / e.O, o = kk - tapf * e.O;        // (T - 1 - tapf) = the tap flipped in both directions
+      const float* sp = e.w + ((long)o * T + (T - 1 - tapf)) * e.I + r;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = sp[(long)j * T * e.I];
+      if (e.scale) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= e.scale[o + j];
+      }
     }
   }
   uint4 o0, o1, o2;
@@ -205,22 +222,59 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// CONV = true: the same product as an implicit GEMM of a 3 x 3, stride 1, pad 1 convolution over [B, H, W, Cin] activations (the
-// dense head's towers, anchor_free_head.py:198-219): row = output pixel, k = (tap, input channel).  The A operand is never
-// materialised: its planes are ROW-MAJOR [pixels + 1][Cin] (pt_split_bf16x3_rows; the extra row is zeros), and every lane of an A
-// staging instruction reads 16 bytes of the pixel shifted by the k-step's tap - or of the zero row where the tap leaves the image.
-// The LDS image, the fragment reads and the B (weight) side are those of the GEMM.
+// CONV = true: the same product as an implicit GEMM of a KH x KW convolution (1 x 1 or 3 x 3, stride 1 or 2) over [B, Hs, Ws, Cin]
+// activations (the dense head's towers, anchor_free_head.py:198-219; the Bottlenecks of backbones/resnet.py:262-303; the laterals
+// and output convolutions of necks/fpn.py:151-202 and necks/ps_fpn.py:56-75): row = output pixel, k = (tap, input channel).  The A
+// operand is never materialised: its planes are ROW-MAJOR [Ps + 1][Cin] (the extra row is zeros), and every lane of an A staging
+// instruction reads 16 bytes of the source pixel of its output pixel under the k-step's tap - or of the zero row where the tap
+// leaves the image.  The LDS image, the fragment reads and the B (weight) side are those of the GEMM.
 struct ConvGeom {
-  int H, W, Cin, CB, P;             // CB = Cin / 32 k-blocks per tap; P = B * H * W pixels (the zero row is row P)
+  int Hs, Ws, Ho, Wo;               // source grid (rows of the A planes) / output grid (rows of the product)
+  int Cin, CB;                      // CB = Cin / 32 k-blocks per tap
+  int KW, taps;                     // taps = KH * KW
+  int stride, pad;                  // source pixel of output (y, x) under tap (ky, kx): (y * stride - pad + ky, x * stride - pad + kx)
+  int Ps;                           // B * Hs * Ws: the zero row of the A planes
+};
+
+// What happens to a finished tile (CONV kernels): v = acc * scale[col] + shift[col] (+ residual) -> ReLU -> mask -> fp32 and / or
+// planes.  Every pointer may be NULL.
+struct ConvEpi {
+  const float* scale;               // [N]
+  const float* shift;               // [N]
+  const uint16_t* res_planes;       // row-major planes [M][N] (x0 + x1 + x2 is added): the Bottleneck's identity, or the gradient
+  long res_plane;                   //   that by-passes a convolution on the identity path
+  const float* res_f32;             // fp32 [M][N] added (a down-sampled identity; a gradient accumulated by an earlier launch)
+  const uint16_t* mask_planes;      // plane 0 of row-major planes [rows_out][N]: the result is zeroed where it is <= 0 (the ReLU of
+                                    //   the tensor whose gradient this launch produces)
+  float* out_f32;                   // fp32 [rows_out][N] (row stride ldc)
+  long ldc;
+  uint16_t* out_planes;             // row-major planes [rows_out + 1][N]
+  long out_plane;
+  int relu;
+  int zero_row;                     // >= 0: this row of out_planes is written with zeros (by the last row tile)
+  int sc_stride, sc_Ho, sc_Wo, sc_H, sc_W;   // sc_stride != 0: output row (b, y, x) of [sc_Ho, sc_Wo] leaves as row
+                                    //   (b * sc_H + y * sc_stride) * sc_W + x * sc_stride of mask / out (a stride-2 1 x 1 input gradient)
 };
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned h) { return __uint_as_float(h << 16); }
+
+// the 8 values of three packed-bf16 quads summed: x = (x0 + x1) + x2 is exact for planes made by split_pair
+__device__ __forceinline__ void planes_sum8(const uint4 a, const uint4 b, const uint4 c, float* o) {
+  const unsigned pa[4] = {a.x, a.y, a.z, a.w}, pb[4] = {b.x, b.y, b.z, b.w}, pc[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    o[2 * j] = (__uint_as_float(pa[j] << 16) + __uint_as_float(pb[j] << 16)) + __uint_as_float(pc[j] << 16);
+    o[2 * j + 1] = (__uint_as_float(pa[j] & 0xffff0000u) + __uint_as_float(pb[j] & 0xffff0000u)) + __uint_as_float(pc[j] & 0xffff0000u);
+  }
+}
 
 template <int MB, bool CONV>
 __global__ void __launch_bounds__(GTHREADS)
     gemm_bf16x6_kernel(const uint16_t* __restrict__ Ap, const uint16_t* __restrict__ Bp, float* __restrict__ C,
                        const float* __restrict__ bias, const float* __restrict__ scale, int M, int N, int KB, long a_plane, long b_plane,
-                       long ldc, int relu, int tiles_n, int n_tiles, ConvGeom cg) {
+                       long ldc, int relu, int tiles_n, int n_tiles, ConvGeom cg, ConvEpi ep) {
   constexpr int BM = 32 * MB, ROWS = BM + GBN;
   constexpr int STAGE = ROWS * 3 * 64;                 // bytes: A planes [3][BM][64] then B planes [3][128][64]
   constexpr int NI = ROWS * 3 / 16;                    // staging instructions (one 1-KiB block each) per stage
@@ -242,7 +296,7 @@ __global__ void __launch_bounds__(GTHREADS)
   // (advances by one block = 1 KiB per k-step)
   const int RBA = (M + 15) >> 4, RBN = (N + 15) >> 4;
   const unsigned char* gsrc[NJ];
-  int cpix[NJ], cmask[NJ];                              // CONV: pixel of this lane's row, 9-bit "tap stays inside the image" mask
+  int cpix[NJ], cmask[NJ];                              // CONV: source pixel of this lane's row under tap (0, 0), "tap stays inside" mask
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int i = w + 8 * j;                            // staging instruction = block index within the stage
@@ -261,16 +315,17 @@ __global__ void __launch_bounds__(GTHREADS)
         const int rr = rbi * 16 + (lane >> 2), qd = lane & 3;            // row of the tile, physical 16-byte slot
         const int sl = qd ^ slot_swz(rr);                                // logical k-slot that lands there
         const int pix = m0 + rr;
-        const int x = pix % cg.W, y = (pix / cg.W) % cg.H;
+        const int x = pix % cg.Wo, yq = pix / cg.Wo;
+        const int y = yq % cg.Ho, bi = yq / cg.Ho;
+        const int yb = y * cg.stride - cg.pad, xb = x * cg.stride - cg.pad;
         int mask = 0;
-        if (pix < cg.P) {
-#pragma unroll
-          for (int t = 0; t < 9; ++t) {
-            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-            mask |= (yy >= 0 && yy < cg.H && xx >= 0 && xx < cg.W) ? (1 << t) : 0;
+        if (pix < M) {
+          for (int t = 0; t < cg.taps; ++t) {
+            const int yy = yb + t / cg.KW, xx = xb + t % cg.KW;
+            mask |= (yy >= 0 && yy < cg.Hs && xx >= 0 && xx < cg.Ws) ? (1 << t) : 0;
           }
         }
-        cpix[j] = pix;
+        cpix[j] = (bi * cg.Hs + yb) * cg.Ws + xb;
         cmask[j] = mask;
         gsrc[j] = reinterpret_cast<const unsigned char*>(base) + sl * 16;
       } else {
@@ -278,15 +333,26 @@ __global__ void __launch_bounds__(GTHREADS)
       }
     }
   }
-  auto issue1 = [&](int j, int buf, int ksn) {          // one 1-KiB block of stage `ksn`
+  // (tap, channel block) of the stage that is issued next: wave-uniform counters instead of divisions per k-step
+  int s_tap = 0, s_cb = 0, s_off = 0, s_kx = 0;         // s_off = ky * Ws + kx of s_tap
+  auto issue1 = [&](int j, int buf) {                   // one 1-KiB block of the next stage
     if (j < NJ && w + 8 * j < NI) {                     // wave-uniform
       if (CONV && w + 8 * j < 3 * (BM / 16)) {          // wave-uniform: an activation piece
-        const int tap = ksn / cg.CB, cb = ksn - tap * cg.CB;
-        const int pix = ((cmask[j] >> tap) & 1) ? cpix[j] + (tap / 3 - 1) * cg.W + (tap % 3 - 1) : cg.P;
-        glds16(gsrc[j] + ((long)pix * cg.Cin + cb * 32) * 2, smem + buf * STAGE + (w + 8 * j) * 1024);
+        const int pix = ((cmask[j] >> s_tap) & 1) ? cpix[j] + s_off : cg.Ps;
+        glds16(gsrc[j] + ((long)pix * cg.Cin + s_cb * 32) * 2, smem + buf * STAGE + (w + 8 * j) * 1024);
       } else {
         glds16(gsrc[j], smem + buf * STAGE + (w + 8 * j) * 1024);
         gsrc[j] += 1024;
+      }
+    }
+  };
+  auto next_stage = [&]() {                             // advance the counters once every piece of a stage has been issued
+    if (CONV) {
+      if (++s_cb == cg.CB) {
+        s_cb = 0;
+        ++s_tap;
+        ++s_off;
+        if (++s_kx == cg.KW) { s_kx = 0; s_off += cg.Ws - cg.KW; }
       }
     }
   };
@@ -310,7 +376,8 @@ __global__ void __launch_bounds__(GTHREADS)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[i][c][e] = cor[i][c][e] = 0.f;
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) issue1(j, 0, 0);
+  for (int j = 0; j < NJ; ++j) issue1(j, 0);
+  next_stage();
   for (int ks = 0; ks < KB; ++ks) {
     __syncthreads();          // (emits s_waitcnt vmcnt(0)): stage ks has landed, every wave is done reading the other buffer
     const bool more = ks + 1 < KB;
@@ -329,7 +396,7 @@ __global__ void __launch_bounds__(GTHREADS)
       const bf16x8_t a2 = *reinterpret_cast<const bf16x8_t*>(ap + 2 * BM * 64);
       if (more) {
 #pragma unroll
-        for (int q = 0; q < PER; ++q) issue1(i * PER + q, nbuf, ks + 1);
+        for (int q = 0; q < PER; ++q) issue1(i * PER + q, nbuf);
       }
 #pragma unroll
       for (int c = 0; c < 2; ++c) {                     // smallest terms first
@@ -341,6 +408,7 @@ __global__ void __launch_bounds__(GTHREADS)
         acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[c][0], acc[i][c], 0, 0, 0);
       }
     }
+    next_stage();
   }
   __syncthreads();            // everyone is done with the staging buffers: they become the output tile [BM][132] (fp32)
   constexpr int TLD = GBN + 4;
@@ -353,33 +421,107 @@ __global__ void __launch_bounds__(GTHREADS)
       for (int e = 0; e < 4; ++e)         // C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
         otile[(rg * MB * 16 + i * 16 + sq * 4 + e) * TLD + nb * 32 + c * 16 + r16] = acc[i][c][e] + cor[i][c][e];
   __syncthreads();
-  // whole rows of the tile leave as 16-byte stores: 32 lanes = one 512-byte row segment
-  for (int idx = threadIdx.x; idx < BM * (GBN / 4); idx += GTHREADS) {
-    const int row = idx >> 5, c4 = (idx & 31) << 2;
-    const int grow = m0 + row, gcol = n0 + c4;
-    if (grow >= M || gcol >= N) continue;
-    float4 v = *reinterpret_cast<const float4*>(otile + row * TLD + c4);
-    float o[4] = {v.x, v.y, v.z, v.w};
+  if constexpr (!CONV) {
+    // whole rows of the tile leave as 16-byte stores: 32 lanes = one 512-byte row segment
+    for (int idx = threadIdx.x; idx < BM * (GBN / 4); idx += GTHREADS) {
+      const int row = idx >> 5, c4 = (idx & 31) << 2;
+      const int grow = m0 + row, gcol = n0 + c4;
+      if (grow >= M || gcol >= N) continue;
+      float4 v = *reinterpret_cast<const float4*>(otile + row * TLD + c4);
+      float o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (gcol + e < N) {
-        if (scale) o[e] *= scale[gcol + e];
-        if (bias) o[e] += bias[gcol + e];
-        if (relu) o[e] = o[e] > 0.f ? o[e] : 0.f;
+      for (int e = 0; e < 4; ++e) {
+        if (gcol + e < N) {
+          if (scale) o[e] *= scale[gcol + e];
+          if (bias) o[e] += bias[gcol + e];
+          if (relu) o[e] = o[e] > 0.f ? o[e] : 0.f;
+        }
+      }
+      float* dst = C + (long)grow * ldc + gcol;
+      if (gcol + 4 <= N && ((((uintptr_t)dst) & 15) == 0)) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+      else
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (gcol + e < N) dst[e] = o[e];
+    }
+  } else {
+    // 8 columns per thread (N % 8 == 0): 16 lanes = one 512-byte row segment of fp32, 256 bytes of every plane
+    for (int idx = threadIdx.x; idx < BM * (GBN / 8); idx += GTHREADS) {
+      const int row = idx >> 4, c8 = (idx & 15) << 3;
+      const int grow = m0 + row, gcol = n0 + c8;
+      if (grow >= M || gcol >= N) continue;
+      const float4 va = *reinterpret_cast<const float4*>(otile + row * TLD + c8), vb = *reinterpret_cast<const float4*>(otile + row * TLD + c8 + 4);
+      float o[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+      if (ep.scale) {
+        const float4 sa = *reinterpret_cast<const float4*>(ep.scale + gcol), sb = *reinterpret_cast<const float4*>(ep.scale + gcol + 4);
+        o[0] *= sa.x; o[1] *= sa.y; o[2] *= sa.z; o[3] *= sa.w; o[4] *= sb.x; o[5] *= sb.y; o[6] *= sb.z; o[7] *= sb.w;
+      }
+      if (ep.shift) {
+        const float4 sa = *reinterpret_cast<const float4*>(ep.shift + gcol), sb = *reinterpret_cast<const float4*>(ep.shift + gcol + 4);
+        o[0] += sa.x; o[1] += sa.y; o[2] += sa.z; o[3] += sa.w; o[4] += sb.x; o[5] += sb.y; o[6] += sb.z; o[7] += sb.w;
+      }
+      const long rin = (long)grow * N + gcol;
+      if (ep.res_planes) {
+        float r[8];
+        planes_sum8(*reinterpret_cast<const uint4*>(ep.res_planes + rin), *reinterpret_cast<const uint4*>(ep.res_planes + ep.res_plane + rin),
+                    *reinterpret_cast<const uint4*>(ep.res_planes + 2 * ep.res_plane + rin), r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += r[e];
+      }
+      if (ep.res_f32) {
+        const float4 ra = *reinterpret_cast<const float4*>(ep.res_f32 + rin), rb2 = *reinterpret_cast<const float4*>(ep.res_f32 + rin + 4);
+        o[0] += ra.x; o[1] += ra.y; o[2] += ra.z; o[3] += ra.w; o[4] += rb2.x; o[5] += rb2.y; o[6] += rb2.z; o[7] += rb2.w;
+      }
+      if (ep.relu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
+      }
+      long orow = grow;
+      if (ep.sc_stride) {
+        const int x = grow % ep.sc_Wo, yq = grow / ep.sc_Wo;
+        const int y = yq % ep.sc_Ho, bi = yq / ep.sc_Ho;
+        orow = ((long)bi * ep.sc_H + y * ep.sc_stride) * ep.sc_W + x * ep.sc_stride;
+      }
+      const long rout = orow * N + gcol;
+      if (ep.mask_planes) {
+        const uint4 mk = *reinterpret_cast<const uint4*>(ep.mask_planes + rout);
+        const unsigned mm[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                   // bf16 > 0: sign clear and not zero
+          if (!((mm[j] & 0x7fffu) != 0 && (mm[j] & 0x8000u) == 0)) o[2 * j] = 0.f;
+          if (!((mm[j] & 0x7fff0000u) != 0 && (mm[j] & 0x80000000u) == 0)) o[2 * j + 1] = 0.f;
+        }
+      }
+      if (ep.out_f32) {
+        float* dst = ep.out_f32 + orow * ep.ldc + gcol;
+        *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+      }
+      if (ep.out_planes) {
+        uint4 p0, p1, p2;
+        split_pair(o[0], o[1], p0.x, p1.x, p2.x);
+        split_pair(o[2], o[3], p0.y, p1.y, p2.y);
+        split_pair(o[4], o[5], p0.z, p1.z, p2.z);
+        split_pair(o[6], o[7], p0.w, p1.w, p2.w);
+        uint16_t* d = ep.out_planes + rout;
+        *reinterpret_cast<uint4*>(d) = p0;
+        *reinterpret_cast<uint4*>(d + ep.out_plane) = p1;
+        *reinterpret_cast<uint4*>(d + 2 * ep.out_plane) = p2;
       }
     }
-    float* dst = C + (long)grow * ldc + gcol;
-    if (gcol + 4 <= N && ((((uintptr_t)dst) & 15) == 0)) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-    else
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (gcol + e < N) dst[e] = o[e];
+    if (ep.out_planes && ep.zero_row >= 0 && m0 + BM >= M && threadIdx.x < 16 && n0 + threadIdx.x * 8 < N) {
+      uint16_t* d = ep.out_planes + (long)ep.zero_row * N + n0 + threadIdx.x * 8;
+      const uint4 z = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(d) = z;
+      *reinterpret_cast<uint4*>(d + ep.out_plane) = z;
+      *reinterpret_cast<uint4*>(d + 2 * ep.out_plane) = z;
+    }
   }
 }
 
 template <int MB, bool CONV>
 static int launch_gemm(const uint16_t* Ap, const uint16_t* Bp, float* C, const float* bias, const float* scale, int M, int N, int KB,
-                       long a_plane, long b_plane, long ldc, int relu, ConvGeom cg, hipStream_t s) {
+                       long a_plane, long b_plane, long ldc, int relu, ConvGeom cg, ConvEpi ep, hipStream_t s) {
   constexpr int BM = 32 * MB;
   constexpr int LDS = (BM + GBN) * 3 * 64 * 2;
   static_assert(LDS <= 160 * 1024, "two stages must fit the CU's LDS");
@@ -392,20 +534,20 @@ static int launch_gemm(const uint16_t* Ap, const uint16_t* Bp, float* C, const f
     once = true;
   }
   hipLaunchKernelGGL((gemm_bf16x6_kernel<MB, CONV>), dim3(tiles_m * tiles_n), dim3(GTHREADS), LDS, s, Ap, Bp, C, bias, scale, M, N, KB,
-                     a_plane, b_plane, ldc, relu, tiles_n, tiles_m * tiles_n, cg);
+                     a_plane, b_plane, ldc, relu, tiles_n, tiles_m * tiles_n, cg, ep);
   return 0;
 }
 
 template <bool CONV>
 static int launch_by_rows(int tile_rows, const uint16_t* Ap, const uint16_t* Bp, float* C, const float* bias, const float* scale, int M,
-                          int N, int KB, long a_plane, long b_plane, long ldc, int relu, ConvGeom cg, hipStream_t s) {
+                          int N, int KB, long a_plane, long b_plane, long ldc, int relu, ConvGeom cg, ConvEpi ep, hipStream_t s) {
   switch (tile_rows / 32) {
-    case 3: return launch_gemm<3, CONV>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, s);
-    case 4: return launch_gemm<4, CONV>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, s);
-    case 5: return launch_gemm<5, CONV>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, s);
-    case 6: return launch_gemm<6, CONV>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, s);
-    case 7: return launch_gemm<7, CONV>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, s);
-    default: return launch_gemm<8, CONV>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, s);
+    case 3: return launch_gemm<3, CONV>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
+    case 4: return launch_gemm<4, CONV>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
+    case 5: return launch_gemm<5, CONV>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
+    case 6: return launch_gemm<6, CONV>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
+    case 7: return launch_gemm<7, CONV>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
+    default: return launch_gemm<8, CONV>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
   }
 }
 
@@ -452,20 +594,25 @@ __global__ void __launch_bounds__(256)
 }
 
 
-// ------------------------------------------------------------------------------------ conv3x3 weight gradient --
-// dW[o][tap][c] = sum_p gy[p][o] * x[p + shift(tap)][c]  (3 x 3, stride 1, pad 1; anchor_free_head.py:198-219 backward).
-// The reduce dimension is the PIXEL index - the ROW index of both row-major plane sets (the output-gradient planes the input
-// gradient already made, the activation planes the forward made): nothing is transposed or re-split.  A stage is a set of
-// [32 pixels][128 columns] bf16 images (256-byte rows, 16-byte chunk XOR-swizzled with ((row & 3) << 2) | ((row >> 2) & 3)), written by
-// `global_load_lds_dwordx4` (the activation rows shifted by the tile's tap, the zero row where the tap leaves the image) and read
+// ------------------------------------------------------------------------------------ convolution weight gradient --
+// dW[o][tap][c] = sum_p gy[p][o] * x[src(p, tap)][c]  (1 x 1 or 3 x 3, stride 1 or 2; anchor_free_head.py:198-219 and
+// backbones/resnet.py:262-303 backward).  The reduce dimension is the OUTPUT PIXEL index - the row index of the output-gradient planes
+// and (through the tap's shift / the stride) of the activation planes the forward read: nothing is transposed or re-split.  A
+// stage is a set of [32 pixels][128 columns] bf16 images (256-byte rows, 16-byte chunk XOR-swizzled with ((row & 3) << 2) | ((row >> 2) & 3)),
+// written by `global_load_lds_dwordx4` (the activation rows of the tile's tap, the zero row where the tap leaves the image) and read
 // COLUMN-wise by `ds_read_b64_tr_b16`: two transposed reads = the 8 consecutive k of one MFMA operand lane; every read is
 // bank-conflict free on this image.  Tile = all BM = 32 MB output channels x 128 columns of one tap; the pixels are cut into
 // `S` chunks (grid = S x tiles) whose partial tiles go to a workspace and are summed in a fixed order (deterministic; no atomics,
 // no zero fill).  Same MFMA schedule, accumulator pair and LDS-staged epilogue as gemm_bf16x6_kernel.
+// Bias gradient (column sums of gy) for free: the tiles of the first column block multiply their gy fragments with a constant
+// all-ones operand (three more MFMAs per row block, dealt over the four column waves) - every column of that product is the sum.
 struct WgradGeom {
-  int H, W, C, O, P;
+  int Hs, Ws, Ho, Wo, C, O;         // source grid (x planes) / output grid (gy planes), channels in / out
+  int KW, taps, stride, pad;
+  int P, Ps;                        // B * Ho * Wo, B * Hs * Ws: the zero rows of the two plane sets
   int KBT, KS;                      // k-steps (32 pixels) in total / per chunk
   int tiles_m, tiles_n;
+  int want_bias;
 };
 
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
@@ -480,8 +627,8 @@ __device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* lo, const unsig
 
 template <int MB>
 __global__ void __launch_bounds__(GTHREADS)
-    wgrad3x3_bf16x6_kernel(const uint16_t* __restrict__ Gp, const uint16_t* __restrict__ Xp, float* __restrict__ part, long g_plane,
-                           long x_plane, WgradGeom wg, int n_items) {
+    wgrad_bf16x6_kernel(const uint16_t* __restrict__ Gp, const uint16_t* __restrict__ Xp, float* __restrict__ part,
+                        float* __restrict__ part_bias, long g_plane, long x_plane, WgradGeom wg, int n_items) {
   constexpr int BM = 32 * MB, IMG_A = BM / 128, NIMG = IMG_A + 1;
   constexpr int IMG = 32 * 256;                        // bytes of one image
   constexpr int STAGE = NIMG * 3 * IMG;                // [image][plane][32 rows][256 B]; images 0 .. IMG_A-1: gy, image IMG_A: x
@@ -498,27 +645,29 @@ __global__ void __launch_bounds__(GTHREADS)
   const int tm = t / wg.tiles_n, tn = t - tm * wg.tiles_n;
   const int m0 = tm * BM, n0 = tn * GBN;
   const int tap = n0 / wg.C, c0 = n0 - tap * wg.C;
-  const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+  const int ky = tap / wg.KW, kx = tap - ky * wg.KW;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool bias_tile = wg.want_bias && tn == 0;      // block-uniform
 
   // staging: wave w owns rows 4w .. 4w+3 (one KiB) of every image; lane = (row, physical chunk)
   const int srow = 4 * w + (lane >> 4);
   const int lc = (lane & 15) ^ (((srow & 3) << 2) | ((srow >> 2) & 3));       // logical chunk that lands in this lane's slot
   const int k_begin = s * wg.KS, k_end = min(wg.KBT, k_begin + wg.KS);
   int pix = k_begin * 32 + srow;
-  int px = pix % wg.W, py = (pix / wg.W) % wg.H;
+  int px = pix % wg.Wo, py = (pix / wg.Wo) % wg.Ho;
+  int sbase = (pix / (wg.Wo * wg.Ho)) * wg.Hs * wg.Ws;                        // first source pixel of the image `pix` lies in
   const uint16_t* ga = Gp + m0 + lc * 8;
   const uint16_t* xb = Xp + c0 + lc * 8;
   long arow = 0, brow = 0;
   auto next_rows = [&]() {                             // rows of the stage at `pix`, then advance one k-step
     arow = (long)(pix < wg.P ? pix : wg.P) * wg.O;
-    const int yy = py + dy, xx = px + dx;
-    const bool ok = pix < wg.P && yy >= 0 && yy < wg.H && xx >= 0 && xx < wg.W;
-    brow = (long)(ok ? pix + dy * wg.W + dx : wg.P) * wg.C;
+    const int yy = py * wg.stride - wg.pad + ky, xx = px * wg.stride - wg.pad + kx;
+    const bool ok = pix < wg.P && yy >= 0 && yy < wg.Hs && xx >= 0 && xx < wg.Ws;
+    brow = (long)(ok ? sbase + yy * wg.Ws + xx : wg.Ps) * wg.C;
     pix += 32;
     px += 32;
-    while (px >= wg.W) { px -= wg.W; ++py; }
-    while (py >= wg.H) py -= wg.H;
+    while (px >= wg.Wo) { px -= wg.Wo; ++py; }
+    while (py >= wg.Ho) { py -= wg.Ho; sbase += wg.Hs * wg.Ws; }
   };
   auto issue = [&](int img, int buf) {                 // the three planes of one image
     unsigned char* dst = smem + buf * STAGE + img * 3 * IMG + w * 1024;
@@ -547,12 +696,21 @@ __global__ void __launch_bounds__(GTHREADS)
   }
 
   f32x4_t acc[MB][2], cor[MB][2];
+  constexpr int NBS = (MB + 3) / 4;                    // row blocks whose bias sums this wave forms (i % 4 == nb)
+  f32x4_t bsum[NBS];
 #pragma unroll
   for (int i = 0; i < MB; ++i)
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[i][c][e] = cor[i][c][e] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NBS; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bsum[i][e] = 0.f;
+  bf16x8_t ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
   if (k_begin < k_end) {
     next_rows();
 #pragma unroll
@@ -584,6 +742,11 @@ __global__ void __launch_bounds__(GTHREADS)
         cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[c][1], cor[i][c], 0, 0, 0);
         acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[c][0], acc[i][c], 0, 0, 0);
       }
+      if (bias_tile && (i & 3) == nb) {                 // wave-uniform
+        bsum[i >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, ones, bsum[i >> 2], 0, 0, 0);
+        bsum[i >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, ones, bsum[i >> 2], 0, 0, 0);
+        bsum[i >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, ones, bsum[i >> 2], 0, 0, 0);
+      }
     }
   }
   __syncthreads();            // the staging buffers become the output tile [BM][132] (fp32)
@@ -597,8 +760,15 @@ __global__ void __launch_bounds__(GTHREADS)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         otile[(rg * MB * 16 + i * 16 + sq * 4 + e) * TLD + nb * 32 + c * 16 + r16] = acc[i][c][e] + cor[i][c][e];
+  if (bias_tile && r16 == 0) {                          // column 0 of the all-equal columns: rows sq * 4 + e of row block i
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+      if ((i & 3) == nb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part_bias[(long)s * wg.O + m0 + rg * MB * 16 + i * 16 + sq * 4 + e] = bsum[i >> 2][e];
+  }
   __syncthreads();
-  const long ldp = 9L * wg.C;
+  const long ldp = (long)wg.taps * wg.C;
   float* dst = part + ((long)s * wg.O + m0) * ldp + n0;
   for (int idx = threadIdx.x; idx < BM * (GBN / 4); idx += GTHREADS) {
     const int row = idx >> 5, c4 = (idx & 31) << 2;
@@ -606,32 +776,135 @@ __global__ void __launch_bounds__(GTHREADS)
   }
 }
 
-// out[i] = sum_s part[s][i] in the order s = 0, 1, ... (n4 = elements / 4)
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float4* __restrict__ part, int S, long n4, float4* __restrict__ out) {
+// out[i] (+)= row_scale[row(i)] * sum_s part[s][i] in the order s = 0, 1, ... (n4 = elements / 4, ld4 = elements of a row / 4);
+// the items past n4 reduce the bias partials [S][O] the same way (no scale).
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float4* __restrict__ part, int S, long n4, int ld4, float4* __restrict__ out,
+                                                           const float* __restrict__ row_scale, const float4* __restrict__ part_bias,
+                                                           int o4, float4* __restrict__ out_bias, int accumulate) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n4) return;
-  float4 a = part[i];
-  for (int s = 1; s < S; ++s) {
-    const float4 v = part[(long)s * n4 + i];
-    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  if (i < n4) {
+    float4 a = part[i];
+    for (int s = 1; s < S; ++s) {
+      const float4 v = part[(long)s * n4 + i];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    if (row_scale) {
+      const float sc = row_scale[i / ld4];
+      a.x *= sc; a.y *= sc; a.z *= sc; a.w *= sc;
+    }
+    if (accumulate) {
+      const float4 v = out[i];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    out[i] = a;
+  } else if (i < n4 + o4) {
+    const long j = i - n4;
+    float4 a = part_bias[j];
+    for (int s = 1; s < S; ++s) {
+      const float4 v = part_bias[(long)s * o4 + j];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    if (accumulate) {
+      const float4 v = out_bias[j];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    out_bias[j] = a;
   }
-  out[i] = a;
 }
 
 template <int MB>
-static int launch_wgrad(const uint16_t* Gp, const uint16_t* Xp, float* part, long g_plane, long x_plane, WgradGeom wg, int S, hipStream_t s) {
+static int launch_wgrad(const uint16_t* Gp, const uint16_t* Xp, float* part, float* part_bias, long g_plane, long x_plane, WgradGeom wg, int S,
+                        hipStream_t s) {
   constexpr int LDS = (32 * MB / 128 + 1) * 3 * 8192 * 2;
   static_assert(LDS <= 160 * 1024, "two stages must fit the CU's LDS");
   static_assert(32 * MB * (GBN + 4) * 4 <= LDS, "the output tile must fit the staging buffers");
   static bool once = false;
   if (!once) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_bf16x6_kernel<MB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16x6_kernel<MB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
     once = true;
   }
   const int n_items = S * wg.tiles_m * wg.tiles_n;
-  hipLaunchKernelGGL((wgrad3x3_bf16x6_kernel<MB>), dim3(n_items), dim3(GTHREADS), LDS, s, Gp, Xp, part, g_plane, x_plane, wg, n_items);
+  hipLaunchKernelGGL((wgrad_bf16x6_kernel<MB>), dim3(n_items), dim3(GTHREADS), LDS, s, Gp, Xp, part, part_bias, g_plane, x_plane, wg, n_items);
   return 0;
+}
+
+// -------------------------------------------------------------------------------------------- plane utilities --
+// fp32 [B, Hs, Ws, C] NHWC (row stride ld) -> ROW-MAJOR planes of the pixels (y * stride, x * stride), y < Ho, x < Wo: [3][(B Ho Wo + 1) * C],
+// last row zeros.  stride 1 = every pixel (what split3_rows_kernel does, without the backward preparation); stride 2 = the pixels a
+// stride-2 1 x 1 convolution reads (layer2's first Bottleneck: conv1 and downsample, resnet.py:153-158 caffe style).
+__global__ void __launch_bounds__(256)
+    split3_gather_kernel(const float* __restrict__ src, long ld, int Hs, int Ws, int Ho, int Wo, int stride, int P, int C,
+                         uint16_t* __restrict__ dst, long plane) {
+  const int c8 = C >> 3;
+  const long units = (long)(P + 1) * c8;
+  for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += (long)gridDim.x * blockDim.x) {
+    const long r = u / c8;
+    const int c = (int)(u - r * c8) << 3;
+    uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0, o2 = o0;
+    if (r < P) {
+      const int x = (int)(r % Wo), yq = (int)(r / Wo);
+      const int y = yq % Ho, b = yq / Ho;
+      const float* sp = src + (((long)b * Hs + (long)y * stride) * Ws + (long)x * stride) * ld + c;
+      const float4 lo = *reinterpret_cast<const float4*>(sp), hi = *reinterpret_cast<const float4*>(sp + 4);
+      split_pair(lo.x, lo.y, o0.x, o1.x, o2.x);
+      split_pair(lo.z, lo.w, o0.y, o1.y, o2.y);
+      split_pair(hi.x, hi.y, o0.z, o1.z, o2.z);
+      split_pair(hi.z, hi.w, o0.w, o1.w, o2.w);
+    }
+    uint16_t* d = dst + r * C + c;
+    *reinterpret_cast<uint4*>(d) = o0;
+    *reinterpret_cast<uint4*>(d + plane) = o1;
+    *reinterpret_cast<uint4*>(d + 2 * plane) = o2;
+  }
+}
+
+// out = split(mask * (a + b [+ c])) on row-major planes [P + 1][C] (c: fp32 [P][C]): the gradient of a tensor with two or three
+// consumers (a stage output feeding the next stage and an FPN lateral), and / or planes -> fp32 (out_f32).
+__global__ void __launch_bounds__(256)
+    planes_combine_kernel(const uint16_t* __restrict__ a, long a_plane, const uint16_t* __restrict__ b, long b_plane,
+                          const float* __restrict__ c, const uint16_t* __restrict__ mask, long n8, uint16_t* __restrict__ out, long out_plane,
+                          float* __restrict__ out_f32) {
+  for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < n8; u += (long)gridDim.x * blockDim.x) {
+    const long e = u << 3;
+    float o[8];
+    planes_sum8(*reinterpret_cast<const uint4*>(a + e), *reinterpret_cast<const uint4*>(a + a_plane + e),
+                *reinterpret_cast<const uint4*>(a + 2 * a_plane + e), o);
+    if (b) {
+      float r[8];
+      planes_sum8(*reinterpret_cast<const uint4*>(b + e), *reinterpret_cast<const uint4*>(b + b_plane + e),
+                  *reinterpret_cast<const uint4*>(b + 2 * b_plane + e), r);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += r[j];
+    }
+    if (c) {
+      const float4 ra = *reinterpret_cast<const float4*>(c + e), rb = *reinterpret_cast<const float4*>(c + e + 4);
+      o[0] += ra.x; o[1] += ra.y; o[2] += ra.z; o[3] += ra.w; o[4] += rb.x; o[5] += rb.y; o[6] += rb.z; o[7] += rb.w;
+    }
+    if (mask) {
+      const uint4 mk = *reinterpret_cast<const uint4*>(mask + e);
+      const unsigned mm[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (!((mm[j] & 0x7fffu) != 0 && (mm[j] & 0x8000u) == 0)) o[2 * j] = 0.f;
+        if (!((mm[j] & 0x7fff0000u) != 0 && (mm[j] & 0x80000000u) == 0)) o[2 * j + 1] = 0.f;
+      }
+    }
+    if (out_f32) {
+      *reinterpret_cast<float4*>(out_f32 + e) = make_float4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<float4*>(out_f32 + e + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+    if (out) {
+      uint4 p0, p1, p2;
+      split_pair(o[0], o[1], p0.x, p1.x, p2.x);
+      split_pair(o[2], o[3], p0.y, p1.y, p2.y);
+      split_pair(o[4], o[5], p0.z, p1.z, p2.z);
+      split_pair(o[6], o[7], p0.w, p1.w, p2.w);
+      *reinterpret_cast<uint4*>(out + e) = p0;
+      *reinterpret_cast<uint4*>(out + out_plane + e) = p1;
+      *reinterpret_cast<uint4*>(out + 2 * out_plane + e) = p2;
+    }
+  }
 }
 
 }  // namespace pt
@@ -690,7 +963,7 @@ extern "C" int pt_gemm_bf16x6_nt(const uint16_t* a_planes, int64_t a_plane_strid
   if (tile_rows <= 0) tile_rows = pt_gemm_bf16x6_tile_rows(M, N);
   PT_REQUIRE(tile_rows % 32 == 0 && tile_rows >= 96 && tile_rows <= 256, PT_EINVAL, "pt_gemm_bf16x6_nt: tile_rows in {96, 128, ..., 256}");
   const int rc = launch_by_rows<false>(tile_rows, a_planes, b_planes, c, bias, nullptr, M, N, Kp, a_plane_stride, b_plane_stride, ldc, relu,
-                                       ConvGeom{0, 0, 0, 0, 0}, as_stream(stream));
+                                       ConvGeom{}, ConvEpi{}, as_stream(stream));
   PT_REQUIRE(rc == 0, rc, "pt_gemm_bf16x6_nt: hipFuncSetAttribute failed (%d)", rc);
   PT_LAUNCH_CHECK("pt_gemm_bf16x6_nt");
   return PT_OK;
@@ -712,68 +985,169 @@ extern "C" int pt_split_bf16x3_rows(const float* src, int64_t ld, int P, int C, 
   return PT_OK;
 }
 
-extern "C" int pt_conv3x3_bf16x6_nhwc(const uint16_t* x_planes, int64_t x_plane_stride, const uint16_t* w_planes, int64_t w_plane_stride,
-                                      float* out, int64_t ldo, const float* bias, const float* scale, int B, int H, int W, int Cin,
-                                      int Cout, int relu, int tile_rows, void* stream) {
-  PT_REQUIRE(x_planes && w_planes && out && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && ldo >= Cout, PT_EINVAL, "pt_conv3x3_bf16x6_nhwc: bad argument");
-  PT_REQUIRE(Cin % 32 == 0, PT_EINVAL, "pt_conv3x3_bf16x6_nhwc: Cin must be a multiple of 32 (one k-step = 32 channels of one tap)");
-  const long P = (long)B * H * W;
-  PT_REQUIRE(P < (1L << 30), PT_ELIMIT, "pt_conv3x3_bf16x6_nhwc: B * H * W < 2^30");
-  PT_REQUIRE(x_plane_stride >= (P + 1) * Cin && w_plane_stride >= pt_split_bf16x3_plane_elems(Cout, 9 * Cin), PT_EINVAL,
-             "pt_conv3x3_bf16x6_nhwc: plane strides too small ([P + 1][Cin] row-major activations, blocked [Cout][9 Cin] weights)");
-  PT_REQUIRE(((((uintptr_t)x_planes) | ((uintptr_t)w_planes)) & 15) == 0 && (x_plane_stride & 7) == 0 && (w_plane_stride & 7) == 0, PT_EINVAL,
-             "pt_conv3x3_bf16x6_nhwc: planes must be 16-byte aligned");
-  if (tile_rows <= 0) tile_rows = pt_gemm_bf16x6_tile_rows((int)P, Cout);
-  PT_REQUIRE(tile_rows % 32 == 0 && tile_rows >= 96 && tile_rows <= 256, PT_EINVAL, "pt_conv3x3_bf16x6_nhwc: tile_rows in {96, 128, ..., 256}");
-  const ConvGeom cg{H, W, Cin, Cin / 32, (int)P};
-  const int rc = launch_by_rows<true>(tile_rows, x_planes, w_planes, out, bias, scale, (int)P, Cout, 9 * (Cin / 32), x_plane_stride, w_plane_stride,
-                                      ldo, relu, cg, as_stream(stream));
-  PT_REQUIRE(rc == 0, rc, "pt_conv3x3_bf16x6_nhwc: hipFuncSetAttribute failed (%d)", rc);
-  PT_LAUNCH_CHECK("pt_conv3x3_bf16x6_nhwc");
+extern "C" int pt_split_bf16x3_gather(const float* src, int64_t ld, int B, int Hs, int Ws, int C, int stride, uint16_t* planes,
+                                      int64_t plane_stride, void* stream) {
+  PT_REQUIRE(src && planes && B > 0 && Hs > 0 && Ws > 0 && C > 0 && (C & 7) == 0 && ld >= C && (ld & 3) == 0 && (stride == 1 || stride == 2),
+             PT_EINVAL, "pt_split_bf16x3_gather: bad argument (C, ld multiples of 8 / 4; stride 1 or 2)");
+  const int Ho = (Hs - 1) / stride + 1, Wo = (Ws - 1) / stride + 1;
+  const long P = (long)B * Ho * Wo;
+  PT_REQUIRE(P < (1L << 30), PT_ELIMIT, "pt_split_bf16x3_gather: B * Ho * Wo < 2^30");
+  PT_REQUIRE(plane_stride >= (P + 1) * C && (plane_stride & 7) == 0 && (((uintptr_t)planes) & 15) == 0 && (((uintptr_t)src) & 15) == 0,
+             PT_EINVAL, "pt_split_bf16x3_gather: plane_stride must cover (B * Ho * Wo + 1) * C, buffers 16-byte aligned");
+  const long units = (P + 1) * (C >> 3);
+  int nb = cdiv(units, 256);
+  nb = nb > 16384 ? 16384 : nb;
+  hipLaunchKernelGGL(split3_gather_kernel, dim3(nb), dim3(256), 0, as_stream(stream), src, (long)ld, Hs, Ws, Ho, Wo, stride, (int)P, C, planes,
+                     (long)plane_stride);
+  PT_LAUNCH_CHECK("pt_split_bf16x3_gather");
   return PT_OK;
 }
 
+extern "C" int pt_planes_combine(const uint16_t* a, int64_t a_plane_stride, const uint16_t* b, int64_t b_plane_stride, const float* c,
+                                 const uint16_t* mask, int64_t n, uint16_t* out, int64_t out_plane_stride, float* out_f32, void* stream) {
+  if (n == 0) return PT_OK;
+  PT_REQUIRE(a && n > 0 && (n & 7) == 0 && (out || out_f32), PT_EINVAL, "pt_planes_combine: bad argument (n a multiple of 8)");
+  PT_REQUIRE(((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)mask) | ((uintptr_t)out) | ((uintptr_t)out_f32)) & 15) == 0 &&
+                 (a_plane_stride & 7) == 0 && (b_plane_stride & 7) == 0 && (out_plane_stride & 7) == 0,
+             PT_EINVAL, "pt_planes_combine: buffers and plane strides must be 16-byte aligned");
+  PT_REQUIRE(a_plane_stride >= n && (!b || b_plane_stride >= n) && (!out || out_plane_stride >= n), PT_EINVAL, "pt_planes_combine: plane strides < n");
+  int nb = cdiv(n >> 3, 256);
+  nb = nb > 16384 ? 16384 : nb;
+  hipLaunchKernelGGL(planes_combine_kernel, dim3(nb), dim3(256), 0, as_stream(stream), a, (long)a_plane_stride, b, (long)b_plane_stride, c, mask,
+                     (long)(n >> 3), out, (long)out_plane_stride, out_f32);
+  PT_LAUNCH_CHECK("pt_planes_combine");
+  return PT_OK;
+}
+
+static int conv_check(const pt_conv_desc* d, const char* who) {
+  PT_REQUIRE(d && d->x_planes && d->w_planes && (d->out_f32 || d->out_planes), PT_EINVAL, "%s: bad argument (operands, one output)", who);
+  PT_REQUIRE(d->B > 0 && d->Hs > 0 && d->Ws > 0 && d->Cin > 0 && d->Cout > 0, PT_EINVAL, "%s: bad shape", who);
+  PT_REQUIRE((d->KH == 1 && d->KW == 1) || (d->KH == 3 && d->KW == 3), PT_EINVAL, "%s: 1 x 1 or 3 x 3 kernels", who);
+  PT_REQUIRE((d->stride == 1 || d->stride == 2) && d->pad >= 0 && d->pad < d->KH, PT_EINVAL, "%s: stride 1 or 2, pad < KH", who);
+  PT_REQUIRE(d->Cin % 32 == 0 && d->Cout % 8 == 0, PT_EINVAL, "%s: Cin %% 32 == 0 (one k-step = 32 channels of one tap), Cout %% 8 == 0", who);
+  return PT_OK;
+}
+
+extern "C" int pt_conv_bf16x6(const pt_conv_desc* d, void* stream) {
+  int rc = conv_check(d, "pt_conv_bf16x6");
+  if (rc != PT_OK) return rc;
+  const int Ho = (d->Hs + 2 * d->pad - d->KH) / d->stride + 1, Wo = (d->Ws + 2 * d->pad - d->KW) / d->stride + 1;
+  PT_REQUIRE(Ho > 0 && Wo > 0, PT_EINVAL, "pt_conv_bf16x6: empty output");
+  const long Ps = (long)d->B * d->Hs * d->Ws, M = (long)d->B * Ho * Wo;
+  PT_REQUIRE(Ps < (1L << 30) && Ps * d->Cin < (1L << 40), PT_ELIMIT, "pt_conv_bf16x6: B * Hs * Ws < 2^30");
+  const int taps = d->KH * d->KW;
+  PT_REQUIRE(d->x_plane_stride >= (Ps + 1) * d->Cin && d->w_plane_stride >= pt_split_bf16x3_plane_elems(d->Cout, taps * d->Cin), PT_EINVAL,
+             "pt_conv_bf16x6: plane strides too small ([Ps + 1][Cin] row-major activations, blocked [Cout][taps Cin] weights)");
+  PT_REQUIRE(((((uintptr_t)d->x_planes) | ((uintptr_t)d->w_planes) | ((uintptr_t)d->res_planes) | ((uintptr_t)d->res_f32) | ((uintptr_t)d->mask_planes) |
+               ((uintptr_t)d->out_f32) | ((uintptr_t)d->out_planes) | ((uintptr_t)d->scale) | ((uintptr_t)d->shift)) & 15) == 0 &&
+                 (d->x_plane_stride & 7) == 0 && (d->w_plane_stride & 7) == 0 && (d->res_plane_stride & 7) == 0 && (d->out_plane_stride & 7) == 0,
+             PT_EINVAL, "pt_conv_bf16x6: buffers and plane strides must be 16-byte aligned");
+  long rows_out = M;
+  ConvEpi ep{};
+  if (d->scatter_stride) {
+    PT_REQUIRE(d->scatter_stride == 2 && d->scatter_H >= (Ho - 1) * 2 + 1 && d->scatter_W >= (Wo - 1) * 2 + 1, PT_EINVAL,
+               "pt_conv_bf16x6: scatter_stride 2 into a grid that holds every (2 y, 2 x)");
+    rows_out = (long)d->B * d->scatter_H * d->scatter_W;
+    ep.sc_stride = 2; ep.sc_Ho = Ho; ep.sc_Wo = Wo; ep.sc_H = d->scatter_H; ep.sc_W = d->scatter_W;
+  }
+  PT_REQUIRE(!d->out_planes || d->out_plane_stride >= (rows_out + 1) * d->Cout, PT_EINVAL, "pt_conv_bf16x6: out_plane_stride < (rows + 1) * Cout");
+  PT_REQUIRE(!d->res_planes || d->res_plane_stride >= M * d->Cout, PT_EINVAL, "pt_conv_bf16x6: res_plane_stride < M * Cout");
+  ep.scale = d->scale; ep.shift = d->shift;
+  ep.res_planes = d->res_planes; ep.res_plane = d->res_plane_stride; ep.res_f32 = d->res_f32;
+  ep.mask_planes = d->mask_planes;
+  ep.out_f32 = d->out_f32; ep.ldc = d->Cout;
+  ep.out_planes = d->out_planes; ep.out_plane = d->out_plane_stride;
+  ep.relu = d->relu;
+  ep.zero_row = (d->out_planes && !d->scatter_stride) ? (int)M : -1;      // (a scattered result lands in a buffer the caller zeroed)
+  int tile_rows = d->tile_rows;
+  if (tile_rows <= 0) tile_rows = pt_gemm_bf16x6_tile_rows((int)M, d->Cout);
+  PT_REQUIRE(tile_rows % 32 == 0 && tile_rows >= 96 && tile_rows <= 256, PT_EINVAL, "pt_conv_bf16x6: tile_rows in {96, 128, ..., 256}");
+  const ConvGeom cg{d->Hs, d->Ws, Ho, Wo, d->Cin, d->Cin / 32, d->KW, taps, d->stride, d->pad, (int)Ps};
+  rc = launch_by_rows<true>(tile_rows, d->x_planes, d->w_planes, nullptr, nullptr, nullptr, (int)M, d->Cout, taps * (d->Cin / 32), d->x_plane_stride,
+                            d->w_plane_stride, d->Cout, 0, cg, ep, as_stream(stream));
+  PT_REQUIRE(rc == 0, rc, "pt_conv_bf16x6: hipFuncSetAttribute failed (%d)", rc);
+  PT_LAUNCH_CHECK("pt_conv_bf16x6");
+  return PT_OK;
+}
+
+extern "C" int pt_conv3x3_bf16x6_nhwc(const uint16_t* x_planes, int64_t x_plane_stride, const uint16_t* w_planes, int64_t w_plane_stride,
+                                      float* out, int64_t ldo, const float* bias, const float* scale, int B, int H, int W, int Cin,
+                                      int Cout, int relu, int tile_rows, void* stream) {
+  PT_REQUIRE(out && ldo == Cout, PT_EINVAL, "pt_conv3x3_bf16x6_nhwc: out must be dense [B*H*W, Cout] (ldo == Cout)");
+  pt_conv_desc d{};
+  d.B = B; d.Hs = H; d.Ws = W; d.Cin = Cin; d.Cout = Cout; d.KH = d.KW = 3; d.stride = 1; d.pad = 1;
+  d.x_planes = x_planes; d.x_plane_stride = x_plane_stride; d.w_planes = w_planes; d.w_plane_stride = w_plane_stride;
+  d.scale = scale; d.shift = bias; d.relu = relu; d.out_f32 = out; d.tile_rows = tile_rows;
+  return pt_conv_bf16x6(&d, stream);
+}
 
 // Pixel chunks of the weight gradient: about two workgroups per CU, at least 16 k-steps (512 pixels) each.
-extern "C" int pt_conv3x3_wgrad_bf16x6_splits(int B, int H, int W, int Cin, int Cout) {
-  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
-  const long P = (long)B * H * W;
+static int wgrad_splits(long P, int taps, int Cin, int Cout) {
   const int kbt = (int)((P + 31) / 32);
   const int bm = Cout % 256 == 0 ? 256 : 128;
-  const int per = (Cout / bm) * (9 * Cin / GBN);
+  const int per = (Cout / bm) * (taps * Cin / GBN);
   int S = (512 + per / 2) / (per > 0 ? per : 1);
   const int cap = kbt / 16;
   if (S > cap) S = cap;
   return S < 1 ? 1 : S;
 }
 
+extern "C" int pt_conv3x3_wgrad_bf16x6_splits(int B, int H, int W, int Cin, int Cout) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  return wgrad_splits((long)B * H * W, 9, Cin, Cout);
+}
+
+extern "C" int pt_conv_wgrad_bf16x6_splits(int B, int Ho, int Wo, int KH, int KW, int Cin, int Cout) {
+  if (B <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return 0;
+  return wgrad_splits((long)B * Ho * Wo, KH * KW, Cin, Cout);
+}
+
+extern "C" int pt_conv_wgrad_bf16x6(const pt_conv_wgrad_desc* d, void* stream) {
+  PT_REQUIRE(d && d->gy_planes && d->x_planes && d->dw && d->workspace && d->B > 0 && d->Hs > 0 && d->Ws > 0, PT_EINVAL, "pt_conv_wgrad_bf16x6: bad argument");
+  PT_REQUIRE((d->KH == 1 && d->KW == 1) || (d->KH == 3 && d->KW == 3), PT_EINVAL, "pt_conv_wgrad_bf16x6: 1 x 1 or 3 x 3 kernels");
+  PT_REQUIRE((d->stride == 1 || d->stride == 2) && d->pad >= 0 && d->pad < d->KH, PT_EINVAL, "pt_conv_wgrad_bf16x6: stride 1 or 2, pad < KH");
+  PT_REQUIRE(d->Cin > 0 && d->Cin % 128 == 0 && d->Cout > 0 && d->Cout % 128 == 0, PT_EINVAL,
+             "pt_conv_wgrad_bf16x6: Cin and Cout must be multiples of 128 (a tile = 128 channels of one tap x 128 or 256 outputs)");
+  const int Ho = (d->Hs + 2 * d->pad - d->KH) / d->stride + 1, Wo = (d->Ws + 2 * d->pad - d->KW) / d->stride + 1;
+  PT_REQUIRE(Ho > 0 && Wo > 0, PT_EINVAL, "pt_conv_wgrad_bf16x6: empty output");
+  const long P = (long)d->B * Ho * Wo, Ps = (long)d->B * d->Hs * d->Ws;
+  PT_REQUIRE(Ps < (1L << 30), PT_ELIMIT, "pt_conv_wgrad_bf16x6: B * Hs * Ws < 2^30");
+  PT_REQUIRE(d->gy_plane_stride >= (P + 1) * d->Cout && d->x_plane_stride >= (Ps + 1) * d->Cin, PT_EINVAL,
+             "pt_conv_wgrad_bf16x6: plane strides too small (row-major [rows + 1][C] planes with a zero last row)");
+  PT_REQUIRE(((((uintptr_t)d->gy_planes) | ((uintptr_t)d->x_planes) | ((uintptr_t)d->dw) | ((uintptr_t)d->workspace) | ((uintptr_t)d->dbias) |
+               ((uintptr_t)d->row_scale)) & 15) == 0 && (d->gy_plane_stride & 7) == 0 && (d->x_plane_stride & 7) == 0,
+             PT_EINVAL, "pt_conv_wgrad_bf16x6: buffers must be 16-byte aligned");
+  const int taps = d->KH * d->KW;
+  const int kbt = (int)((P + 31) / 32);
+  int S = d->splits > 0 ? d->splits : wgrad_splits(P, taps, d->Cin, d->Cout);
+  if (S > kbt) S = kbt;
+  const long n = (long)d->Cout * taps * d->Cin;
+  const long nbias = d->dbias ? d->Cout : 0;
+  PT_REQUIRE(d->workspace_elems >= (int64_t)S * (n + nbias), PT_EINVAL,
+             "pt_conv_wgrad_bf16x6: workspace must hold splits * (Cout * taps * Cin [+ Cout]) floats");
+  const int bm = d->Cout % 256 == 0 ? 256 : 128;
+  WgradGeom wg{d->Hs, d->Ws, Ho, Wo, d->Cin, d->Cout, d->KW, taps, d->stride, d->pad, (int)P, (int)Ps, kbt, (kbt + S - 1) / S, d->Cout / bm,
+               taps * d->Cin / GBN, d->dbias ? 1 : 0};
+  float* part_bias = d->workspace + (long)S * n;
+  const int rc = bm == 256 ? launch_wgrad<8>(d->gy_planes, d->x_planes, d->workspace, part_bias, d->gy_plane_stride, d->x_plane_stride, wg, S, as_stream(stream))
+                           : launch_wgrad<4>(d->gy_planes, d->x_planes, d->workspace, part_bias, d->gy_plane_stride, d->x_plane_stride, wg, S, as_stream(stream));
+  PT_REQUIRE(rc == 0, rc, "pt_conv_wgrad_bf16x6: hipFuncSetAttribute failed (%d)", rc);
+  PT_LAUNCH_CHECK("pt_conv_wgrad_bf16x6");
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n / 4 + nbias / 4, 256)), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const float4*>(d->workspace), S, n / 4, taps * d->Cin / 4, reinterpret_cast<float4*>(d->dw), d->row_scale,
+                     reinterpret_cast<const float4*>(part_bias), (int)(nbias / 4), reinterpret_cast<float4*>(d->dbias), d->accumulate);
+  PT_LAUNCH_CHECK("pt_conv_wgrad_bf16x6 (reduce)");
+  return PT_OK;
+}
+
 extern "C" int pt_conv3x3_wgrad_bf16x6_nhwc(const uint16_t* gy_planes, int64_t gy_plane_stride, const uint16_t* x_planes,
                                             int64_t x_plane_stride, float* dw, float* workspace, int64_t workspace_elems, int B, int H,
                                             int W, int Cin, int Cout, int splits, void* stream) {
-  PT_REQUIRE(gy_planes && x_planes && dw && workspace && B > 0 && H > 0 && W > 0, PT_EINVAL, "pt_conv3x3_wgrad_bf16x6_nhwc: bad argument");
-  PT_REQUIRE(Cin > 0 && Cin % 128 == 0 && Cout > 0 && Cout % 128 == 0, PT_EINVAL,
-             "pt_conv3x3_wgrad_bf16x6_nhwc: Cin and Cout must be multiples of 128 (a tile = 128 channels of one tap x 128 or 256 outputs)");
-  const long P = (long)B * H * W;
-  PT_REQUIRE(P < (1L << 30), PT_ELIMIT, "pt_conv3x3_wgrad_bf16x6_nhwc: B * H * W < 2^30");
-  PT_REQUIRE(gy_plane_stride >= (P + 1) * Cout && x_plane_stride >= (P + 1) * Cin, PT_EINVAL,
-             "pt_conv3x3_wgrad_bf16x6_nhwc: plane strides too small (row-major [P + 1][C] planes with a zero last row)");
-  PT_REQUIRE(((((uintptr_t)gy_planes) | ((uintptr_t)x_planes) | ((uintptr_t)dw) | ((uintptr_t)workspace)) & 15) == 0 &&
-                 (gy_plane_stride & 7) == 0 && (x_plane_stride & 7) == 0, PT_EINVAL, "pt_conv3x3_wgrad_bf16x6_nhwc: buffers must be 16-byte aligned");
-  const int kbt = (int)((P + 31) / 32);
-  int S = splits > 0 ? splits : pt_conv3x3_wgrad_bf16x6_splits(B, H, W, Cin, Cout);
-  if (S > kbt) S = kbt;
-  const long n = (long)Cout * 9 * Cin;
-  PT_REQUIRE(workspace_elems >= (int64_t)S * n, PT_EINVAL, "pt_conv3x3_wgrad_bf16x6_nhwc: workspace must hold splits * Cout * 9 * Cin floats");
-  const int bm = Cout % 256 == 0 ? 256 : 128;
-  WgradGeom wg{H, W, Cin, Cout, (int)P, kbt, (kbt + S - 1) / S, Cout / bm, 9 * Cin / GBN};
-  const int rc = bm == 256 ? launch_wgrad<8>(gy_planes, x_planes, workspace, gy_plane_stride, x_plane_stride, wg, S, as_stream(stream))
-                           : launch_wgrad<4>(gy_planes, x_planes, workspace, gy_plane_stride, x_plane_stride, wg, S, as_stream(stream));
-  PT_REQUIRE(rc == 0, rc, "pt_conv3x3_wgrad_bf16x6_nhwc: hipFuncSetAttribute failed (%d)", rc);
-  PT_LAUNCH_CHECK("pt_conv3x3_wgrad_bf16x6_nhwc");
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, as_stream(stream), reinterpret_cast<const float4*>(workspace),
-                     S, n / 4, reinterpret_cast<float4*>(dw));
-  PT_LAUNCH_CHECK("pt_conv3x3_wgrad_bf16x6_nhwc (reduce)");
-  return PT_OK;
+  pt_conv_wgrad_desc d{};
+  d.B = B; d.Hs = H; d.Ws = W; d.Cin = Cin; d.Cout = Cout; d.KH = d.KW = 3; d.stride = 1; d.pad = 1;
+  d.gy_planes = gy_planes; d.gy_plane_stride = gy_plane_stride; d.x_planes = x_planes; d.x_plane_stride = x_plane_stride;
+  d.dw = dw; d.workspace = workspace; d.workspace_elems = workspace_elems; d.splits = splits;
+  return pt_conv_wgrad_bf16x6(&d, stream);
 }
 
 
@@ -781,7 +1155,7 @@ static_assert(sizeof(pt::ConvWItem) == sizeof(pt_conv_weight_item), "the header'
 
 extern "C" int pt_conv_weight_planes_batch(const pt_conv_weight_item* items, int n_items, int total_blocks, void* stream) {
   if (n_items == 0 || total_blocks == 0) return PT_OK;
-  PT_REQUIRE(items && n_items > 0 && n_items <= 256 && total_blocks > 0, PT_EINVAL, "pt_conv_weight_planes_batch: bad argument (1 .. 256 items)");
+  PT_REQUIRE(items && n_items > 0 && n_items <= 4096 && total_blocks > 0, PT_EINVAL, "pt_conv_weight_planes_batch: bad argument (1 .. 4096 items)");
   hipLaunchKernelGGL(conv_weight_planes_kernel, dim3(cdiv(total_blocks, 4)), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const ConvWItem*>(items), n_items, total_blocks);
   PT_LAUNCH_CHECK("pt_conv_weight_planes_batch");

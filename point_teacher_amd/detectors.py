@@ -124,7 +124,12 @@ class Student_FCOS(BaseDetector):
     def extract_feat(self, img, stem=None):
         """`stem`: the output of `backbone_stem` for `img` (then `img` is not read)."""
         def run():
-            x = self.backbone(img) if stem is None else self.backbone(None, stem=stem)
+            if (self.with_neck and getattr(self.neck, 'accepts_planes', False) and getattr(self.backbone, 'plane_capable', False)
+                    and self.backbone_autocast is None):
+                # the trainable stages hand their outputs to the neck as split planes (planes.PlaneAct): no fp32 copy in between
+                x = self.backbone(img, planes=True) if stem is None else self.backbone(None, stem=stem, planes=True)
+            else:
+                x = self.backbone(img) if stem is None else self.backbone(None, stem=stem)
             if self.with_neck:
                 x = self.neck(x)
             if self.with_neck_agg:

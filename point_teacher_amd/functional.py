@@ -580,7 +580,7 @@ def gemm_bf16x6_nt(a, b, bias=None, relu=False, out=None, tile_rows=0):
 
 
 _SPLIT_WGRAD = os.environ.get('PT_SPLIT_WGRAD', '1') != '0'      # 0: the 3x3 convolutions' weight gradient stays with the library
-_SPLIT_W_CACHE = {}      # id(weight) -> (PARAM_EPOCH, data_ptr, planes of W, planes of W^T or None)
+_SPLIT_W_CACHE = {}      # id(weight) -> [PARAM_EPOCH, data_ptr, planes of W, planes of W^T or None, weight version]
 
 
 def _split_weight(w, transposed):
@@ -588,8 +588,8 @@ def _split_weight(w, transposed):
     the stack is evaluated 2-3 times per iteration (boxes, negatives, both MIL branches' backward) on the same weights."""
     key = id(w)
     ent = _SPLIT_W_CACHE.get(key)
-    if ent is None or ent[0] != PARAM_EPOCH[0] or ent[1] != w.data_ptr():
-        ent = [PARAM_EPOCH[0], w.data_ptr(), None, None]
+    if ent is None or ent[0] != PARAM_EPOCH[0] or ent[1] != w.data_ptr() or ent[4] != w._version:
+        ent = [PARAM_EPOCH[0], w.data_ptr(), None, None, w._version]      # (_version: load_state_dict / in-place torch edits)
         _SPLIT_W_CACHE[key] = ent
     i = 3 if transposed else 2
     if ent[i] is None:
@@ -634,85 +634,101 @@ def split_linear(x, weight, bias=None, relu=False):
 # --------------------------------------------------- fp32 3x3 convolution on the bf16 matrix cores (implicit GEMM, bf16x6) --
 
 class _ConvWeightPlanes:
-    """All 3x3 convolution weights' split planes, refreshed by ONE launch per parameter epoch (pt_conv_weight_planes_batch).
-    A (weight, form) pair registers itself at its first use; from then on the first request after the parameters changed
-    (optimizer step / EMA bump PARAM_EPOCH) re-splits every registered pair at once - the student's and the teacher's weights,
-    forward and input-gradient forms - instead of one split (and, for the second form, a flip and a copy) per weight and form."""
+    """All convolution weights' split planes (1x1 and 3x3), refreshed by ONE launch per parameter epoch (pt_conv_weight_planes_batch).
+    A (weight, form, folded scale) triple registers itself at its first use; from then on the first request after the parameters
+    changed (optimizer step / EMA bump PARAM_EPOCH; load_state_dict and in-place torch edits move the weight's version counter)
+    re-splits every registered triple at once - the student's and the teacher's weights, forward and input-gradient forms - instead
+    of one split (and, for the second form, a flip and a copy) per weight and form."""
 
     def __init__(self):
-        self.ent = {}            # (id(w), mode) -> [weakref(w), data_ptr, SplitPlanes]
+        self.ent = {}            # (id(w), mode, scale ptr) -> [weakref(w), data_ptr, SplitPlanes, scale tensor or None, version]
         self.table = None        # (device uint8 tensor of pt_conv_weight_item, n_items, total_blocks)
         self.epoch = -1
 
     @staticmethod
     def ok(w):
         O, I = w.shape[:2]
-        return (w.is_cuda and w.dtype == f32 and w.dim() == 4 and w.shape[2:] == (3, 3) and I % 32 == 0 and O % 32 == 0
+        return (w.is_cuda and w.dtype == f32 and w.dim() == 4 and tuple(w.shape[2:]) in ((3, 3), (1, 1)) and I % 32 == 0 and O % 32 == 0
                 and w.permute(0, 2, 3, 1).is_contiguous())
 
     def _build_table(self):
-        import weakref  # noqa: F401
         rec = np.zeros(len(self.ent), dtype=np.dtype([('w', '<u8'), ('dst', '<u8'), ('plane', '<i8'), ('O', '<i4'), ('I', '<i4'),
-                                                       ('mode', '<i4'), ('first', '<i4')]))
+                                                       ('mode', '<i4'), ('first', '<i4'), ('taps', '<i4'), ('reserved', '<i4'),
+                                                       ('scale', '<u8')]))
         first = 0
         dev = None
-        for i, ((_, mode), (ref, ptr, sp)) in enumerate(self.ent.items()):
+        for i, ((_, mode, _sp), (ref, ptr, sp, scale, _ver)) in enumerate(self.ent.items()):
             w = ref()
             O, I = w.shape[:2]
-            rows, k = (I, 9 * O) if mode else (O, 9 * I)
-            rec[i] = (ptr, sp.planes.data_ptr(), sp.planes.shape[1], O, I, mode, first)
+            taps = w.shape[2] * w.shape[3]
+            rows, k = (I, taps * O) if mode else (O, taps * I)
+            rec[i] = (ptr, sp.planes.data_ptr(), sp.planes.shape[1], O, I, mode, first, taps, 0, scale.data_ptr() if scale is not None else 0)
             first += ((rows + 15) // 16) * (k // 32)
             dev = w.device
         self.table = (torch.from_numpy(rec.view(np.uint8)).to(dev), len(self.ent), first)
 
-    def get(self, w, dgrad):
+    @staticmethod
+    def _alive(v):
+        w = v[0]()
+        return w is not None and w.data_ptr() == v[1]
+
+    def get(self, w, dgrad, scale=None):
         import weakref
         mode = int(bool(dgrad))
-        key = (id(w), mode)
+        key = (id(w), mode, scale.data_ptr() if scale is not None else 0)
         e = self.ent.get(key)
         if e is not None and (e[0]() is not w or e[1] != w.data_ptr()):
             e = None                                            # the id was reused, or the storage moved (re-layout of the flat buffer)
         if e is None:
-            # drop entries whose weight is gone or moved, then register this pair with planes of its own
-            self.ent = {k: v for k, v in self.ent.items() if v[0]() is not None and v[0]().data_ptr() == v[1] and k != key}
+            # drop entries whose weight is gone or moved, then register this triple with planes of its own
+            self.ent = {k: v for k, v in self.ent.items() if self._alive(v) and k != key}
             O, I = w.shape[:2]
-            rows, k = (I, 9 * O) if mode else (O, 9 * I)
+            taps = w.shape[2] * w.shape[3]
+            rows, k = (I, taps * O) if mode else (O, taps * I)
             n = ((rows + 15) // 16) * ((k + 31) // 32) * 512
             sp = SplitPlanes(torch.empty((3, n), dtype=torch.bfloat16, device=w.device), rows, k)
-            self.ent[key] = [weakref.ref(w), w.data_ptr(), sp]
+            e = self.ent[key] = [weakref.ref(w), w.data_ptr(), sp, scale, -1]
             self.table = None
             self.epoch = -1
+        if e[4] != w._version:                                  # torch wrote the weight (load_state_dict, init, copy_): re-split
+            self.epoch = -1
         if self.epoch != PARAM_EPOCH[0] or self.table is None:
-            if any(v[0]() is None or v[0]().data_ptr() != v[1] for v in self.ent.values()):
-                self.ent = {k: v for k, v in self.ent.items() if v[0]() is not None and v[0]().data_ptr() == v[1]}
+            if not all(self._alive(v) for v in self.ent.values()):
+                self.ent = {k: v for k, v in self.ent.items() if self._alive(v)}
                 self.table = None
             if self.table is None:
                 self._build_table()
             tab, n_items, blocks = self.table
             hip.call('pt_conv_weight_planes_batch', tab, n_items, blocks)
             self.epoch = PARAM_EPOCH[0]
+            for v in self.ent.values():
+                v[4] = v[0]()._version
         return self.ent[key][2]
 
 
 _CONV_W = _ConvWeightPlanes()
 
 
-def _conv_weight_planes(w, dgrad):
-    """Split planes of a [O, I, 3, 3] weight as the [O, 9 I] matrix with k = (ky, kx, i) (forward; a channels_last weight IS
-    that matrix) or as w'[i, (2 - ky, 2 - kx), o] (input gradient); cached until the parameters change (PARAM_EPOCH).  Channels_last
-    weights go through the batched refresh (_ConvWeightPlanes); any other layout is split on its own."""
+def _conv_weight_planes(w, dgrad, scale=None):
+    """Split planes of a [O, I, KH, KW] weight as the [O, taps I] matrix with k = (ky, kx, i) (forward; a channels_last weight IS
+    that matrix) or as w'[i, (KH - 1 - ky, KW - 1 - kx), o] (input gradient), optionally with a per-output-channel scale folded in;
+    cached until the parameters change (PARAM_EPOCH / the weight's version counter).  Channels_last weights go through the batched
+    refresh (_ConvWeightPlanes); any other layout is split on its own."""
     if _ConvWeightPlanes.ok(w):
-        return _CONV_W.get(w, dgrad)
-    key = (id(w), 'conv')
+        return _CONV_W.get(w, dgrad, scale)
+    key = (id(w), 'conv', scale.data_ptr() if scale is not None else 0)
     ent = _SPLIT_W_CACHE.get(key)
-    if ent is None or ent[0] != PARAM_EPOCH[0] or ent[1] != w.data_ptr():
-        ent = [PARAM_EPOCH[0], w.data_ptr(), None, None]
+    if ent is None or ent[0] != PARAM_EPOCH[0] or ent[1] != w.data_ptr() or ent[4] != w._version:
+        ent = [PARAM_EPOCH[0], w.data_ptr(), None, None, w._version]
         _SPLIT_W_CACHE[key] = ent
     i = 3 if dgrad else 2
     if ent[i] is None:
         wd = w.detach()
+        if scale is not None:
+            wd = wd * scale.view(-1, 1, 1, 1)
         O, I = wd.shape[:2]
-        m = (wd.flip(2, 3).permute(1, 2, 3, 0).reshape(I, 9 * O) if dgrad else wd.permute(0, 2, 3, 1).reshape(O, 9 * I))
+        taps = wd.shape[2] * wd.shape[3]
+        m = (wd.flip(2, 3).permute(1, 2, 3, 0).reshape(I, taps * O) if dgrad else wd.permute(0, 2, 3, 1).reshape(O, taps * I))
         ent[i] = split_bf16x3(m.contiguous())
     return ent[i]
 

@@ -45,7 +45,29 @@ def parse_header(path=HEADER_PATH):
     return protos
 
 
+def parse_structs(path=HEADER_PATH):
+    """-> {name: ctypes.Structure subclass} for every `typedef struct { ... } name;` of the header (host-side descriptors
+    such as pt_conv_desc: plain scalars and device pointers)."""
+    txt = open(path).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    txt = re.sub(r'//[^\n]*', '', txt)
+    scalars = {'int32_t': ctypes.c_int32, 'int64_t': ctypes.c_int64, 'float': ctypes.c_float, 'int': ctypes.c_int, 'double': ctypes.c_double}
+    out = {}
+    for m in re.finditer(r'typedef\s+struct\s*\{([^}]*)\}\s*(pt_\w+)\s*;', txt):
+        fields = []
+        for decl in [d.strip() for d in m.group(1).split(';') if d.strip()]:
+            if '*' in decl:
+                fields.append((decl.split('*')[-1].strip(), ctypes.c_void_p))
+            else:
+                typ, names = decl.split(None, 1)
+                for n in names.split(','):
+                    fields.append((n.strip(), scalars[typ]))
+        out[m.group(2)] = type(m.group(2), (ctypes.Structure,), {'_fields_': fields})
+    return out
+
+
 PROTOS = parse_header()
+STRUCTS = parse_structs()
 
 if not os.path.exists(LIB_PATH):
     raise RuntimeError(
@@ -82,6 +104,8 @@ def _ptr(x, name, ctype=None):
         return x.data_ptr()
     if isinstance(x, (ctypes.Array,)):
         return ctypes.cast(x, ctypes.c_void_p)
+    if isinstance(x, ctypes.Structure):
+        return ctypes.addressof(x)
     if isinstance(x, int):
         return x
     raise TypeError(f'{name}: cannot pass {type(x)} as a pointer')
@@ -102,9 +126,14 @@ def call(fn, *args):
         conv.append(torch.cuda.current_stream().cuda_stream)
     rc = getattr(_lib, fn)(*conv)
     if restype is ctypes.c_int and fn not in ('pt_abi_version', 'pt_focal_nblocks', 'pt_sqnorm_nblocks', 'pt_affine_train_rows', 'pt_gemm_bf16x6_tile_rows',
-                                            'pt_conv3x3_wgrad_bf16x6_splits') and rc != 0:
+                                            'pt_conv3x3_wgrad_bf16x6_splits', 'pt_conv_wgrad_bf16x6_splits') and rc != 0:
         raise RuntimeError(f'{fn} failed (code {rc}): {last_error()}')
     return rc
+
+
+def dptr(t, ctype=None):
+    """Device pointer of a tensor (or 0 for None) for a descriptor field, with the checks `call` applies to pointer arguments."""
+    return _ptr(t, 'descriptor field', ctype) or 0
 
 
 def host_doubles(vals):

@@ -14,10 +14,12 @@ import torch.nn as nn
 import torch.nn.functional as TF
 
 from . import functional as F
+from . import planes as PL
 from .registry import BACKBONES, NECKS, ROI_EXTRACTORS
 
 
 _SPLIT_CONV = os.environ.get('PT_SPLIT_CONV', '1') != '0'
+_PLANE_TRUNK = _SPLIT_CONV and os.environ.get('PT_PLANE_TRUNK', '1') != '0'     # 0: the round-3 routing (3x3 only, fp32 between layers)
 _GN_CL = os.environ.get('PT_GN_CL', '1') != '0'
 
 
@@ -77,6 +79,7 @@ class ConvModule(nn.Module):
     """The subset of mmcv.cnn.ConvModule on this path: conv (+GroupNorm) (+ReLU).  Parameter paths
     `.conv` and `.gn` (mmcv names the norm layer after its type); bias='auto' means "no bias when a
     norm layer follows" (mmcv/cnn/bricks/conv_module.py:113-116)."""
+    plane_min_pixels = int(os.environ.get('PT_PLANE_MIN_PIXELS', '2048'))     # below: the library's kernels (launch-bound shapes)
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, act=True, norm_cfg=None,
                  conv_cfg=None, dilation=1):
@@ -103,8 +106,19 @@ class ConvModule(nn.Module):
             else:
                 del self.bn
 
-    def forward(self, x):
+    def forward(self, x, out_planes=False):
         c = self.conv
+        if isinstance(x, PL.PlaneAct) or out_planes:
+            if (_PLANE_TRUNK and not self.with_norm and PL.plane_conv_ok(c) and (isinstance(x, PL.PlaneAct) or PL.f32_ok(x))):
+                return PL.conv_module(x, c, relu=self.with_activation, out_planes=out_planes)
+            if isinstance(x, PL.PlaneAct):
+                x = x.float()
+            assert not out_planes, 'this convolution cannot emit planes'
+        if (_PLANE_TRUNK and not self.with_norm and PL.plane_conv_ok(c) and PL.f32_ok(x)
+                and x.shape[0] * x.shape[2] * x.shape[3] >= self.plane_min_pixels):
+            # 1x1 / 3x3 convolutions of necks and towers (fp32 by the config): implicit GEMM on the bf16 matrix cores with split-bf16
+            # operands and fp32 accumulation, bias (+ ReLU) in its epilogue, input / weight / bias gradients on the same kernels
+            return PL.conv_module(x, c, relu=self.with_activation)
         if (_SPLIT_CONV and type(c) is nn.Conv2d and c.bias is not None and not self.with_norm and self.with_activation
                 and F.split_conv3x3_ok(x, c)):
             # the dense head's tower convolutions (fp32 by the config): implicit GEMM on the bf16 matrix cores with split-bf16
@@ -298,7 +312,42 @@ class Bottleneck(nn.Module):
         self.bn3 = nn.BatchNorm2d(planes * 4)
         self.downsample = downsample
 
+    def plane_ok(self):
+        """Frozen eval-mode BatchNorms, stride on conv1 (`caffe`) or none, no dilation, channel counts the weight-gradient tiles
+        take, channels_last fp32 weights on the device: the block can run plane-native (planes._BottleneckP)."""
+        bns = [self.bn1, self.bn2, self.bn3] + ([self.downsample[1]] if self.downsample is not None else [])
+        convs = [self.conv1, self.conv2, self.conv3] + ([self.downsample[0]] if self.downsample is not None else [])
+        return (_PLANE_TRUNK and all((not b.training) and (not b.weight.requires_grad) and getattr(b, 'fuse_epilogue', True) for b in bns)
+                and self.conv2.stride == (1, 1) and self.conv2.dilation == (1, 1) and self.conv1.stride[0] in (1, 2)
+                and (self.downsample is None or self.downsample[0].stride == self.conv1.stride)
+                and (self.downsample is not None or self.conv1.stride == (1, 1))
+                and all(c.in_channels % 128 == 0 and c.out_channels % 128 == 0 and c.weight.is_cuda and c.weight.dtype == torch.float32
+                        and F._ConvWeightPlanes.ok(c.weight) for c in convs)
+                and not torch.is_autocast_enabled())
+
+    def forward_planes(self, x):
+        """x: planes.PlaneAct (a ReLU output) or the fp32 channels_last output of the frozen stem -> PlaneAct."""
+        is_p = isinstance(x, PL.PlaneAct)
+        B, Cin, H, W = x.shape
+        s = self.conv1.stride[0]
+        ds = self.downsample
+        s1, h1 = _bn_affine(self.bn1)
+        s2, h2 = _bn_affine(self.bn2)
+        s3, h3 = _bn_affine(self.bn3)
+        sd, hd = _bn_affine(ds[1]) if ds is not None else (None, None)
+        p = self.conv1.out_channels
+        cfg = PL.BottleneckCfg(B=B, H=H, W=W, Cin=Cin, planes=p, stride=s, x_planes=is_p, x_relu=bool(is_p and x.relu),
+                               s1=s1, h1=h1, s2=s2, h2=h2, s3=s3, h3=h3, sd=sd, hd=hd, has_ds=ds is not None)
+        t = PL._BottleneckP.apply(x.t if is_p else x, self.conv1.weight, self.conv2.weight, self.conv3.weight,
+                                  ds[0].weight if ds is not None else None, cfg)
+        Ho, Wo = PL.out_hw(H, W, 1, s, 0)
+        return PL.PlaneAct(t, B, Ho, Wo, 4 * p, True)
+
     def forward(self, x):
+        if isinstance(x, PL.PlaneAct):
+            if self.plane_ok():
+                return self.forward_planes(x)
+            x = x.float()
         identity = x
         out = conv_bn(x, self.conv1, self.bn1, True)
         out = conv_bn(out, self.conv2, self.bn2, True)
@@ -388,13 +437,31 @@ class ResNet(nn.Module):
                 outs.append(x)
         return x, outs
 
-    def forward(self, x, stem=None):
+    plane_capable = True
+
+    def forward(self, x, stem=None, planes=False):
+        """`planes=True` (a caller whose neck reads planes.PlaneAct, i.e. FPN): the trainable stages run plane-native - their
+        outputs are PlaneActs - as soon as a block qualifies (Bottleneck.plane_ok); otherwise fp32 tensors as ever."""
         x, outs = self.forward_stem(x) if stem is None else stem
         outs = list(outs)
         for i in range(max(self.frozen_stages, 0), len(self.res_layers)):
-            x = getattr(self, self.res_layers[i])(x)
+            layer = getattr(self, self.res_layers[i])
+            if planes:
+                for blk in layer:
+                    if not isinstance(x, PL.PlaneAct) and PL.f32_ok(x) and blk.plane_ok():
+                        # enter plane mode: the frozen stem's output is read where the block's stride samples it; an input that takes
+                        # a gradient goes through a differentiable split first
+                        x = blk.forward_planes(PL.to_planes(x) if x.requires_grad else x)
+                    else:
+                        x = blk(x)                            # (a PlaneAct stays plane-native while the blocks qualify)
+            else:
+                x = layer(x)
             if i in self.out_indices:
-                outs.append(x)
+                if isinstance(x, PL.PlaneAct) and i + 1 < len(self.res_layers):
+                    x, o = PL.fan_out(x)                      # two consumers (the next stage, the neck): exact gradient addition
+                    outs.append(o)
+                else:
+                    outs.append(x)
         return tuple(outs)
 
     def train(self, mode=True):
@@ -456,9 +523,11 @@ class FPN(nn.Module):
                 self.fpn_convs.append(ConvModule(cin, out_channels, 3, stride=2, padding=1, act=act))
         _xavier_uniform_(self)
 
+    accepts_planes = True
+
     def forward(self, inputs):
         assert len(inputs) == len(self.in_channels)
-        laterals = [l(inputs[i + self.start_level]) for i, l in enumerate(self.lateral_convs)]
+        laterals = [l(inputs[i + self.start_level]) for i, l in enumerate(self.lateral_convs)]        # (PlaneAct inputs: ConvModule)
         n = len(laterals)
         for i in range(n - 1, 0, -1):
             if 'scale_factor' in self.upsample_cfg:

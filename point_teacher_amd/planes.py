@@ -1,0 +1,364 @@
+"""Plane-native convolutions of the trunk (csrc/gemm_split.hip, pt_conv_bf16x6 / pt_conv_wgrad_bf16x6).
+
+Every fp32 convolution of backbone / necks / towers is an implicit GEMM on the bf16 matrix cores whose operands are three-term
+bf16 splits (x = x0 + x1 + x2 exactly; six products, fp32 accumulation).  Instead of splitting every layer's fp32 input again, the
+activations TRAVEL as row-major split planes `[3, (pixels + 1) * C]` (last row zeros): a convolution's epilogue applies the frozen
+BatchNorm, the identity add and the ReLU and emits the planes its consumer stages straight into LDS; the backward emits gradient
+planes the same way (ReLU mask of the producer applied in the input-gradient kernel's epilogue, BatchNorm scale folded into the
+input-gradient weights and into the weight gradient's reduction, bias gradients formed by the weight-gradient kernel).
+
+Reference call sites: the Bottleneck of HBB_TOD/mmdet/models/backbones/resnet.py:262-303 (`caffe` style: stride on conv1,
+:153-158), FPN laterals / output convolutions necks/fpn.py:151-202, PSAGG necks/ps_fpn.py:56-75, the towers
+dense_heads/anchor_free_head.py:198-219.
+
+Gradient convention: the gradient of a plane tensor is a plane tensor of the same shape that is ALREADY multiplied by the ReLU mask
+of the activation it belongs to (its consumer holds that activation as its input and applies the mask in its epilogue)."""
+import torch
+
+from . import functional as F
+from . import hip
+
+f32 = torch.float32
+bf16 = torch.bfloat16
+
+
+class PlaneAct:
+    """An NHWC activation [B, H, W, C] as row-major split planes `t` = bf16 [3, (B*H*W + 1) * C]; `relu`: its values went through a
+    ReLU (so `plane 0 > 0` is the mask its gradient needs)."""
+    __slots__ = ('t', 'B', 'H', 'W', 'C', 'relu')
+
+    def __init__(self, t, B, H, W, C, relu):
+        self.t, self.B, self.H, self.W, self.C, self.relu = t, B, H, W, C, relu
+
+    @property
+    def P(self):
+        return self.B * self.H * self.W
+
+    @property
+    def shape(self):
+        return (self.B, self.C, self.H, self.W)
+
+    def float(self):
+        """-> fp32 [B, C, H, W] channels_last tensor (exact: x0 + x1 + x2), differentiable."""
+        return _PlanesToF32.apply(self.t, self)
+
+
+class _F32ToPlanes(torch.autograd.Function):
+    """fp32 channels_last [B, C, H, W] -> planes; backward: the gradient planes summed back to fp32."""
+
+    @staticmethod
+    def forward(ctx, x):
+        t, _, _ = split_nhwc(x)
+        ctx.shape = x.shape
+        return t
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, H, W = ctx.shape
+        _, of = combine(g.contiguous(), n=B * H * W * C, want_planes=False, want_f32=True)
+        return of.view(B, H, W, C).permute(0, 3, 1, 2)
+
+
+def to_planes(x):
+    """Differentiable entry into plane mode (relu=False: the producer of x masks its own gradient)."""
+    B, C, H, W = x.shape
+    return PlaneAct(_F32ToPlanes.apply(x), B, H, W, C, False)
+
+
+def out_hw(H, W, K, stride, pad):
+    return (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
+
+
+def _new_planes(rows, C, device, zero=False):
+    n = (rows + 1) * C
+    return (torch.zeros if zero else torch.empty)((3, n), dtype=bf16, device=device)
+
+
+def launch_conv(x_t, B, Hs, Ws, Cin, wp, Cout, K, stride, pad, scale=None, shift=None, res_planes=None, res_f32=None,
+                mask_planes=None, relu=False, want_planes=False, want_f32=False, scatter=None, tile_rows=0):
+    """pt_conv_bf16x6: x_t row-major planes of [B*Hs*Ws (+1), Cin]; wp SplitPlanes of the weight.  -> (planes or None, fp32 rows or
+    None).  scatter = (H, W): a stride-2 input gradient placed at (2y, 2x) of a zeroed [B, H, W] grid."""
+    Ho, Wo = out_hw(Hs, Ws, K, stride, pad)
+    M = B * Ho * Wo
+    rows = M if scatter is None else B * scatter[0] * scatter[1]
+    dev = x_t.device
+    out_p = _new_planes(rows, Cout, dev, zero=scatter is not None) if want_planes else None
+    out_f = (torch.zeros if scatter is not None else torch.empty)((rows, Cout), dtype=f32, device=dev) if want_f32 else None
+    d = hip.STRUCTS['pt_conv_desc']()
+    d.B, d.Hs, d.Ws, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad, d.relu = B, Hs, Ws, Cin, Cout, K, K, stride, pad, int(bool(relu))
+    d.x_planes, d.x_plane_stride = hip.dptr(x_t, 'uint16_t'), x_t.shape[1]
+    d.w_planes, d.w_plane_stride = hip.dptr(wp.planes, 'uint16_t'), wp.planes.shape[1]
+    d.scale, d.shift = hip.dptr(scale, 'float'), hip.dptr(shift, 'float')
+    if res_planes is not None:
+        d.res_planes, d.res_plane_stride = hip.dptr(res_planes, 'uint16_t'), res_planes.shape[1]
+    d.res_f32 = hip.dptr(res_f32, 'float')
+    d.mask_planes = hip.dptr(mask_planes, 'uint16_t')
+    d.out_f32 = hip.dptr(out_f, 'float')
+    if out_p is not None:
+        d.out_planes, d.out_plane_stride = hip.dptr(out_p, 'uint16_t'), out_p.shape[1]
+    if scatter is not None:
+        d.scatter_stride, d.scatter_H, d.scatter_W = 2, scatter[0], scatter[1]
+    d.tile_rows = int(tile_rows)
+    assert wp.rows == Cout and wp.k == K * K * Cin, (wp.rows, wp.k, Cout, K, Cin)
+    assert x_t.shape[1] >= (B * Hs * Ws + 1) * Cin
+    if mask_planes is not None:
+        assert mask_planes.shape[1] >= rows * Cout
+    if res_planes is not None:
+        assert res_planes.shape[1] >= M * Cout
+    if res_f32 is not None:
+        assert res_f32.numel() >= M * Cout
+    hip.call('pt_conv_bf16x6', d)
+    return out_p, out_f
+
+
+def wgrad_ok(Cin, Cout):
+    return Cin % 128 == 0 and Cout % 128 == 0
+
+
+def launch_wgrad(gy_t, x_t, B, Hs, Ws, Cin, Cout, K, stride, pad, row_scale=None, want_bias=False):
+    """pt_conv_wgrad_bf16x6 -> (dw as a channels_last [Cout, Cin, K, K] tensor, dbias or None)."""
+    Ho, Wo = out_hw(Hs, Ws, K, stride, pad)
+    dev = gy_t.device
+    S = hip.call('pt_conv_wgrad_bf16x6_splits', B, Ho, Wo, K, K, Cin, Cout)
+    n = Cout * K * K * Cin
+    ws = torch.empty((S * (n + (Cout if want_bias else 0)),), dtype=f32, device=dev)
+    dw = torch.empty((Cout, K, K, Cin), dtype=f32, device=dev)
+    db = torch.empty((Cout,), dtype=f32, device=dev) if want_bias else None
+    d = hip.STRUCTS['pt_conv_wgrad_desc']()
+    d.B, d.Hs, d.Ws, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad, d.accumulate = B, Hs, Ws, Cin, Cout, K, K, stride, pad, 0
+    d.gy_planes, d.gy_plane_stride = hip.dptr(gy_t, 'uint16_t'), gy_t.shape[1]
+    d.x_planes, d.x_plane_stride = hip.dptr(x_t, 'uint16_t'), x_t.shape[1]
+    d.dw, d.dbias, d.row_scale = hip.dptr(dw, 'float'), hip.dptr(db, 'float'), hip.dptr(row_scale, 'float')
+    d.workspace, d.workspace_elems, d.splits = hip.dptr(ws, 'float'), ws.numel(), S
+    assert gy_t.shape[1] >= (B * Ho * Wo + 1) * Cout and x_t.shape[1] >= (B * Hs * Ws + 1) * Cin
+    hip.call('pt_conv_wgrad_bf16x6', d)
+    return dw.permute(0, 3, 1, 2), db
+
+
+def split_nhwc(x, stride=1):
+    """fp32 channels_last [B, C, H, W] -> row-major planes of the pixels (y * stride, x * stride) (pt_split_bf16x3_gather)."""
+    B, C, H, W = x.shape
+    rows = x.permute(0, 2, 3, 1)
+    assert rows.is_contiguous() and x.dtype == f32
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    t = _new_planes(B * Ho * Wo, C, x.device)
+    hip.call('pt_split_bf16x3_gather', rows, C, B, H, W, C, stride, t, t.shape[1])
+    return t, Ho, Wo
+
+
+def combine(a, b=None, c=None, mask=None, n=None, want_planes=True, want_f32=False):
+    """pt_planes_combine over the first n elements of each plane: split(mask * (a + b + c)) and / or its fp32 value."""
+    n = n if n is not None else a.shape[1]
+    out = torch.empty_like(a) if want_planes else None
+    of = torch.empty((n,), dtype=f32, device=a.device) if want_f32 else None
+    hip.call('pt_planes_combine', a, a.shape[1], b, b.shape[1] if b is not None else 0, c, mask, n, out,
+             out.shape[1] if out is not None else 0, of)
+    assert out is None or n == a.shape[1], 'planes out: combine whole planes (the zero rows included)'
+    return out, of
+
+
+class _PlanesToF32(torch.autograd.Function):
+    """planes -> fp32 [B, C, H, W] channels_last; backward: split of the (masked) fp32 gradient."""
+
+    @staticmethod
+    def forward(ctx, t, act):
+        _, of = combine(t, n=act.P * act.C, want_planes=False, want_f32=True)
+        ctx.act = act
+        ctx.save_for_backward(t if act.relu else None)
+        return of.view(act.B, act.H, act.W, act.C).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        act = ctx.act
+        t, = ctx.saved_tensors
+        rows = g.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(act.P, act.C)
+        gp = F._split_rows(rows, relu_of=None)
+        if act.relu:
+            gp, _ = combine(gp, mask=t)
+        return gp, None
+
+
+# ------------------------------------------------------------------------------------------------ single convolution --
+class ConvCfg:
+    """Static description of one plane convolution call (not a tensor: autograd passes it through)."""
+    __slots__ = ('B', 'H', 'W', 'Cin', 'Cout', 'K', 'stride', 'pad', 'relu', 'x_planes', 'x_relu', 'out_planes', 'scale', 'bias_grad')
+
+    def __init__(self, **kw):
+        for k in self.__slots__:
+            setattr(self, k, kw.get(k))
+
+
+class _PlaneConv(torch.autograd.Function):
+    """y = [relu](conv(x, w) * scale + shift) for ONE consumer of x (stride 1 in the backward's input gradient).
+    x: plane tensor (cfg.x_planes) or fp32 channels_last [B, Cin, H, W]; y: plane tensor (cfg.out_planes) or fp32 channels_last."""
+
+    @staticmethod
+    def forward(ctx, x, w, shift, cfg):
+        c = cfg
+        if c.x_planes:
+            xt = x
+        else:
+            xt, _, _ = split_nhwc(x)
+        wp = F._conv_weight_planes(w, False)
+        yp, yf = launch_conv(xt, c.B, c.H, c.W, c.Cin, wp, c.Cout, c.K, c.stride, c.pad, scale=c.scale, shift=shift, relu=c.relu,
+                             want_planes=c.out_planes, want_f32=not c.out_planes)
+        Ho, Wo = out_hw(c.H, c.W, c.K, c.stride, c.pad)
+        ctx.cfg = c
+        ctx.out_hw = (Ho, Wo)
+        need_x_for_mask = c.x_planes and c.x_relu
+        ctx.save_for_backward(xt if (w.requires_grad or need_x_for_mask) else None, w, yf if (c.relu and not c.out_planes) else None)
+        if c.out_planes:
+            return yp
+        return yf.view(c.B, Ho, Wo, c.Cout).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        c = ctx.cfg
+        xt, w, yf = ctx.saved_tensors
+        Ho, Wo = ctx.out_hw
+        M = c.B * Ho * Wo
+        if c.out_planes:
+            E = g.contiguous()
+        else:
+            rows = g.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(M, c.Cout)
+            E = F._split_rows(rows, relu_of=yf)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            assert c.stride == 1, 'the single-consumer plane convolution back-propagates stride 1 only'
+            wd = F._conv_weight_planes(w, True, c.scale)
+            gp, gf = launch_conv(E, c.B, Ho, Wo, c.Cout, wd, c.Cin, c.K, 1, c.K - 1 - c.pad,
+                                 mask_planes=xt if (c.x_planes and c.x_relu) else None, want_planes=c.x_planes, want_f32=not c.x_planes)
+            gx = gp if c.x_planes else gf.view(c.B, c.H, c.W, c.Cin).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            gw, gb = launch_wgrad(E, xt, c.B, c.H, c.W, c.Cin, c.Cout, c.K, c.stride, c.pad, row_scale=c.scale,
+                                  want_bias=bool(c.bias_grad and ctx.needs_input_grad[2]))
+        return gx, gw, gb, None
+
+
+def plane_conv_ok(conv, x_channels_last_f32_or_planes=True):
+    """A convolution pt_conv_bf16x6 / pt_conv_wgrad_bf16x6 take: 1x1 (pad 0) or 3x3 (pad 1), stride 1, one group, no dilation,
+    channels multiples of 128 (the weight gradient's tile), channels_last fp32 weight."""
+    k = conv.kernel_size
+    return (type(conv) is torch.nn.Conv2d and k in ((1, 1), (3, 3)) and conv.stride == (1, 1) and conv.padding == ((k[0] - 1) // 2,) * 2
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels % 128 == 0 and conv.out_channels % 128 == 0
+            and conv.weight.is_cuda and conv.weight.dtype == f32 and F._ConvWeightPlanes.ok(conv.weight)
+            and not torch.is_autocast_enabled())
+
+
+def conv_module(x, conv, relu=False, out_planes=False, scale=None, shift=None):
+    """[relu](conv(x) (* scale) + bias) through the plane kernels.  x: PlaneAct or fp32 channels_last tensor.
+    -> PlaneAct (out_planes) or fp32 channels_last tensor."""
+    is_p = isinstance(x, PlaneAct)
+    B, Cin, H, W = x.shape
+    k = conv.kernel_size[0]
+    cfg = ConvCfg(B=B, H=H, W=W, Cin=Cin, Cout=conv.out_channels, K=k, stride=1, pad=conv.padding[0], relu=bool(relu), x_planes=is_p,
+                  x_relu=bool(is_p and x.relu), out_planes=bool(out_planes), scale=scale, bias_grad=scale is None and conv.bias is not None)
+    sh = shift if shift is not None else conv.bias
+    y = _PlaneConv.apply(x.t if is_p else x, conv.weight, sh, cfg)
+    if out_planes:
+        return PlaneAct(y, B, H, W, conv.out_channels, bool(relu))
+    return y
+
+
+def f32_ok(x):
+    return (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == f32 and x.dim() == 4 and x.shape[1] % 8 == 0
+            and x.is_contiguous(memory_format=torch.channels_last) and x.numel() > 0)
+
+
+# ------------------------------------------------------------------------------------------------------- fan-out --
+class _FanOut(torch.autograd.Function):
+    """One plane activation, two consumers: the backward adds the two (already masked) gradient plane sets exactly
+    (sum of six planes in fp32, split again) instead of autograd's bf16 addition of planes."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.view_as(t), t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        if g1 is None or g2 is None:
+            return g1 if g2 is None else g2
+        out, _ = combine(g1.contiguous(), g2.contiguous())          # (the zero rows add up to the zero row)
+        return out
+
+
+def fan_out(act):
+    a, b = _FanOut.apply(act.t)
+    return (PlaneAct(a, act.B, act.H, act.W, act.C, act.relu), PlaneAct(b, act.B, act.H, act.W, act.C, act.relu))
+
+
+# ---------------------------------------------------------------------------------------------------- Bottleneck --
+class BottleneckCfg:
+    __slots__ = ('B', 'H', 'W', 'Cin', 'planes', 'stride', 'x_planes', 'x_relu', 's1', 'h1', 's2', 'h2', 's3', 'h3', 'sd', 'hd', 'has_ds')
+
+    def __init__(self, **kw):
+        for k in self.__slots__:
+            setattr(self, k, kw.get(k))
+
+
+class _BottleneckP(torch.autograd.Function):
+    """backbones/resnet.py:262-303 with frozen eval-mode BatchNorms, `caffe` style (stride on conv1 / downsample), plane-native:
+        y1 = relu(bn1(conv1(x)))   y2 = relu(bn2(conv2(y1)))   out = relu(bn3(conv3(y2)) + identity)
+    identity = x, or bn_d(conv_d(x)) in a stage's first block.  x: plane tensor (block input, a ReLU output) or - first block of the
+    first trainable stage - the fp32 channels_last output of the frozen stem, read at the stride's pixels.  Four (three) launches
+    forward; backward three input-gradient launches (the identity's gradient and the ReLU masks ride in their epilogues), the weight
+    gradients with the BatchNorm scale in their reduction."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, w3, wd, cfg):
+        c = cfg
+        p, s = c.planes, c.stride
+        if c.x_planes:
+            xt, H1, W1 = x, *out_hw(c.H, c.W, 1, s, 0)
+            xs, xH, xW, xstride = xt, c.H, c.W, s                 # conv1 / downsample read x through the stride
+        else:
+            xt, H1, W1 = split_nhwc(x, s)                          # compact planes of the pixels the stride-s 1x1 convolutions read
+            xs, xH, xW, xstride = xt, H1, W1, 1
+        cw = F._conv_weight_planes
+        y1, _ = launch_conv(xs, c.B, xH, xW, c.Cin, cw(w1, False), p, 1, xstride, 0, scale=c.s1, shift=c.h1, relu=True, want_planes=True)
+        y2, _ = launch_conv(y1, c.B, H1, W1, p, cw(w2, False), p, 3, 1, 1, scale=c.s2, shift=c.h2, relu=True, want_planes=True)
+        if c.has_ds:
+            _, idn = launch_conv(xs, c.B, xH, xW, c.Cin, cw(wd, False), 4 * p, 1, xstride, 0, scale=c.sd, shift=c.hd, want_f32=True)
+            out, _ = launch_conv(y2, c.B, H1, W1, p, cw(w3, False), 4 * p, 1, 1, 0, scale=c.s3, shift=c.h3, res_f32=idn, relu=True,
+                                 want_planes=True)
+        else:
+            out, _ = launch_conv(y2, c.B, H1, W1, p, cw(w3, False), 4 * p, 1, 1, 0, scale=c.s3, shift=c.h3, res_planes=xt, relu=True,
+                                 want_planes=True)
+        ctx.cfg, ctx.geo = c, (H1, W1, xH, xW, xstride)
+        ctx.save_for_backward(xs, y1, y2, w1, w2, w3, wd)
+        return out
+
+    @staticmethod
+    def backward(ctx, E):
+        c = ctx.cfg
+        H1, W1, xH, xW, xstride = ctx.geo
+        xs, y1, y2, w1, w2, w3, wd = ctx.saved_tensors
+        p = c.planes
+        E = E.contiguous()
+        cw = F._conv_weight_planes
+        need_x = ctx.needs_input_grad[0]
+        g1 = g2 = g3 = gd = gx = None
+        # conv3: gradient of y2 (masked by y2's ReLU), weight gradient
+        E2, _ = launch_conv(E, c.B, H1, W1, 4 * p, cw(w3, True, c.s3), p, 1, 1, 0, mask_planes=y2, want_planes=True)
+        if ctx.needs_input_grad[3]:
+            g3, _ = launch_wgrad(E, y2, c.B, H1, W1, p, 4 * p, 1, 1, 0, row_scale=c.s3)
+        # conv2
+        E1, _ = launch_conv(E2, c.B, H1, W1, p, cw(w2, True, c.s2), p, 3, 1, 1, mask_planes=y1, want_planes=True)
+        if ctx.needs_input_grad[2]:
+            g2, _ = launch_wgrad(E2, y1, c.B, H1, W1, p, p, 3, 1, 1, row_scale=c.s2)
+        # conv1 (+ downsample) weights
+        if ctx.needs_input_grad[1]:
+            g1, _ = launch_wgrad(E1, xs, c.B, xH, xW, c.Cin, p, 1, xstride, 0, row_scale=c.s1)
+        if c.has_ds and ctx.needs_input_grad[4]:
+            gd, _ = launch_wgrad(E, xs, c.B, xH, xW, c.Cin, 4 * p, 1, xstride, 0, row_scale=c.sd)
+        if need_x:
+            assert c.x_planes, 'a trainable stage behind an fp32 input is not plane-native'
+            mask = xs if c.x_relu else None
+            if c.has_ds:
+                # identity path through the downsample convolution: fp32 on the coarse grid, added in conv1's input-gradient epilogue
+                _, gdx = launch_conv(E, c.B, H1, W1, 4 * p, cw(wd, True, c.sd), c.Cin, 1, 1, 0, want_f32=True)
+                gx, _ = launch_conv(E1, c.B, H1, W1, p, cw(w1, True, c.s1), c.Cin, 1, 1, 0, res_f32=gdx, mask_planes=mask, want_planes=True,
+                                    scatter=(c.H, c.W) if c.stride == 2 else None)
+            else:
+                gx, _ = launch_conv(E1, c.B, H1, W1, p, cw(w1, True, c.s1), c.Cin, 1, 1, 0, res_planes=E, mask_planes=mask, want_planes=True)
+        return gx, g1, g2, g3, gd, None

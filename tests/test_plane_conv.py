@@ -1,0 +1,305 @@
+"""Plane-native convolutions (csrc/gemm_split.hip: pt_conv_bf16x6, pt_conv_wgrad_bf16x6, pt_split_bf16x3_gather, pt_planes_combine,
+point_teacher_amd/planes.py): the Bottlenecks of backbones/resnet.py:262-303, FPN / PSAGG 1x1 and 3x3 convolutions
+(necks/fpn.py:151-202, necks/ps_fpn.py:56-75) and the towers (anchor_free_head.py:198-219) with activations travelling as split planes.
+Every product is checked against a float64 convolution; the bar is the fp32 library kernel's own error on the same inputs."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _planes_to_f32(t, rows, C):
+    p = t.float().view(3, -1, C)
+    assert float(p[:, rows].abs().max()) == 0, 'the zero row'
+    return (p[0, :rows] + p[1, :rows]) + p[2, :rows]
+
+
+def _rows(x):                                        # [B, C, H, W] -> [B*H*W, C]
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1])
+
+
+def _nchw(rows, B, H, W):
+    return rows.view(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout,K,stride', [
+    (6, 100, 100, 128, 512, 1, 1),       # layer2 conv3
+    (6, 100, 100, 512, 128, 1, 1),       # layer2 conv1
+    (2, 50, 50, 1024, 256, 1, 1),        # teacher layer3 conv1
+    (6, 25, 25, 2048, 512, 1, 1),        # layer4 conv1
+    (3, 100, 100, 256, 128, 1, 2),       # layer2.0 conv1 read through the stride
+    (2, 51, 37, 256, 512, 1, 2),         # odd sizes, stride 2
+    (6, 25, 25, 512, 512, 3, 1),         # layer4 conv2
+    (2, 33, 29, 128, 128, 3, 1),
+    (2, 33, 29, 128, 64, 3, 2),          # 3x3 stride 2 (forward only)
+    (1, 9, 7, 32, 8, 1, 1),              # narrow output
+])
+def test_conv_forward_epilogues_vs_fp64(B, H, W, Cin, Cout, K, stride):
+    from point_teacher_amd import functional as F, planes as PL
+    g = torch.Generator().manual_seed(B * H + Cin + K)
+    pad = (K - 1) // 2
+    x = torch.randn(B, Cin, H, W, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, K, K, generator=g) * (2.0 / (Cin * K * K)) ** 0.5).to(DEV).contiguous(memory_format=torch.channels_last)
+    scale = (torch.rand(Cout, generator=g) + 0.5).to(DEV)
+    shift = torch.randn(Cout, generator=g).to(DEV)
+    xt, _, _ = PL.split_nhwc(x)
+    assert torch.equal(_planes_to_f32(xt, B * H * W, Cin), _rows(x))                     # planes are exact
+    Ho, Wo = PL.out_hw(H, W, K, stride, pad)
+    M = B * Ho * Wo
+    res = torch.randn(M, Cout, generator=g).to(DEV)
+    rt, _, _ = PL.split_nhwc(_nchw(res, B, Ho, Wo).contiguous(memory_format=torch.channels_last))
+    wp = F._conv_weight_planes(w, False)
+    ref0 = torch.nn.functional.conv2d(x.double(), w.double(), None, stride, pad)
+    mag = torch.nn.functional.conv2d(x.double().abs(), w.double().abs(), None, stride, pad)
+    lib = torch.nn.functional.conv2d(x, w, None, stride, pad)
+    # plain product
+    _, y = PL.launch_conv(xt, B, H, W, Cin, wp, Cout, K, stride, pad, want_f32=True)
+    e_mine = float(((_nchw(y, B, Ho, Wo).double() - ref0).abs() / mag).max())
+    e_lib = float(((lib.double() - ref0).abs() / mag).max())
+    print(f'[{B}x{H}x{W} {Cin}->{Cout} k{K} s{stride}] bf16x6 {e_mine:.3e}  fp32 library {e_lib:.3e}')
+    assert e_mine <= max(e_lib, 2.0 ** -23) and e_mine < 3e-7
+    # full epilogue: scale, shift, planes residual, fp32 residual, ReLU; planes and fp32 outputs agree exactly
+    yp, yf = PL.launch_conv(xt, B, H, W, Cin, wp, Cout, K, stride, pad, scale=scale, shift=shift, res_planes=rt, res_f32=res, relu=True,
+                            want_planes=True, want_f32=True)
+    want = torch.relu(y * scale + shift + res + res)
+    torch.testing.assert_close(yf, want, rtol=1e-6, atol=1e-6)
+    assert torch.equal(_planes_to_f32(yp, M, Cout), yf)
+    # every tile height gives the same numbers
+    for rows in (96, 160, 256):
+        d_y = PL.launch_conv(xt, B, H, W, Cin, wp, Cout, K, stride, pad, want_f32=True, tile_rows=rows)[1]
+        assert torch.equal(d_y, y)
+
+
+def test_gather_split_reads_the_stride_pixels():
+    from point_teacher_amd import planes as PL
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 64, 11, 9, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    t, Ho, Wo = PL.split_nhwc(x, 2)
+    assert (Ho, Wo) == (6, 5)
+    assert torch.equal(_planes_to_f32(t, 2 * 6 * 5, 64), _rows(x[:, :, ::2, ::2]))
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout,K', [(6, 100, 100, 512, 128, 1), (2, 25, 25, 512, 2048, 1), (2, 40, 36, 128, 128, 3), (6, 25, 25, 512, 512, 3)])
+def test_input_gradient_with_mask_and_identity_vs_fp64(B, H, W, Cin, Cout, K):
+    """dx = mask * (g (diag(scale) W) + identity gradient): the mode-1 weight planes with the BatchNorm scale folded in, the ReLU mask
+    of x read from x's own planes, the by-passing gradient added from planes."""
+    from point_teacher_amd import functional as F, planes as PL
+    gen = torch.Generator().manual_seed(Cin + K)
+    pad = (K - 1) // 2
+    P = B * H * W
+    x = torch.relu(torch.randn(P, Cin, generator=gen)).to(DEV)                 # a ReLU output: ~half zeros
+    xt, _, _ = PL.split_nhwc(_nchw(x, B, H, W).contiguous(memory_format=torch.channels_last))
+    w = (torch.randn(Cout, Cin, K, K, generator=gen) * (2.0 / (Cout * K * K)) ** 0.5).to(DEV).contiguous(memory_format=torch.channels_last)
+    scale = (torch.rand(Cout, generator=gen) + 0.5).to(DEV)
+    gy = torch.randn(P, Cout, generator=gen).to(DEV)
+    idn = torch.randn(P, Cin, generator=gen).to(DEV)
+    gt, _, _ = PL.split_nhwc(_nchw(gy, B, H, W).contiguous(memory_format=torch.channels_last))
+    it, _, _ = PL.split_nhwc(_nchw(idn, B, H, W).contiguous(memory_format=torch.channels_last))
+    wd = F._conv_weight_planes(w, True, scale)
+    gp, gf = PL.launch_conv(gt, B, H, W, Cout, wd, Cin, K, 1, K - 1 - pad, res_planes=it, mask_planes=xt, want_planes=True, want_f32=True)
+    ref = torch.nn.grad.conv2d_input((B, Cin, H, W), w.double(), (_nchw(gy, B, H, W).double() * scale.double().view(1, -1, 1, 1)), 1, pad)
+    ref = (_rows(ref) + idn.double()) * (x > 0)
+    err = float((gf.double() - ref).abs().max() / ref.abs().max())
+    print(f'[{B}x{H}x{W} {Cout}->{Cin} k{K}] input gradient rel err {err:.3e}')
+    assert err < 2e-6
+    assert torch.equal(_planes_to_f32(gp, P, Cin), gf)
+    assert float(gf[x <= 0].abs().max()) == 0
+
+
+def test_stride2_input_gradient_is_scattered():
+    """The input gradient of a stride-2 1x1 convolution: computed on the coarse grid, added to the downsample path's fp32 gradient,
+    masked by x at (2y, 2x) and written there; every other pixel keeps the zero the caller provided."""
+    from point_teacher_amd import functional as F, planes as PL
+    gen = torch.Generator().manual_seed(5)
+    B, H, W, Cin, Cout = 2, 51, 38, 256, 128
+    Ho, Wo = 26, 19
+    x = torch.relu(torch.randn(B, Cin, H, W, generator=gen)).to(DEV).contiguous(memory_format=torch.channels_last)
+    xt, _, _ = PL.split_nhwc(x)
+    w = (torch.randn(Cout, Cin, 1, 1, generator=gen) * 0.05).to(DEV).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(B * Ho * Wo, Cout, generator=gen).to(DEV)
+    other = torch.randn(B * Ho * Wo, Cin, generator=gen).to(DEV)
+    gt, _, _ = PL.split_nhwc(_nchw(gy, B, Ho, Wo).contiguous(memory_format=torch.channels_last))
+    gp, gf = PL.launch_conv(gt, B, Ho, Wo, Cout, F._conv_weight_planes(w, True), Cin, 1, 1, 0, res_f32=other, mask_planes=xt,
+                            want_planes=True, want_f32=True, scatter=(H, W))
+    ref = torch.zeros(B, Cin, H, W, dtype=torch.float64, device=DEV)
+    coarse = _nchw(gy.double() @ w.double().view(Cout, Cin) + other.double(), B, Ho, Wo)
+    ref[:, :, ::2, ::2] = coarse
+    ref = ref * (x > 0)
+    got = _nchw(gf, B, H, W)
+    assert float((got.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    assert torch.equal(_planes_to_f32(gp, B * H * W, Cin), gf)
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout,K,stride,bias', [
+    (6, 100, 100, 128, 512, 1, 1, False), (6, 100, 100, 512, 128, 1, 1, True), (3, 100, 100, 256, 128, 1, 2, False),
+    (2, 25, 25, 2048, 512, 1, 1, False), (2, 50, 50, 256, 256, 3, 1, True), (2, 17, 23, 128, 256, 3, 1, True), (1, 6, 5, 128, 128, 1, 1, True)])
+def test_weight_and_bias_gradient_vs_fp64(B, H, W, Cin, Cout, K, stride, bias):
+    from point_teacher_amd import planes as PL
+    gen = torch.Generator().manual_seed(Cin + Cout + K)
+    pad = (K - 1) // 2
+    Ho, Wo = PL.out_hw(H, W, K, stride, pad)
+    x = torch.randn(B, Cin, H, W, generator=gen).to(DEV).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(B, Cout, Ho, Wo, generator=gen).to(DEV).contiguous(memory_format=torch.channels_last)
+    scale = (torch.rand(Cout, generator=gen) + 0.5).to(DEV)
+    xt, _, _ = PL.split_nhwc(x)
+    gt, _, _ = PL.split_nhwc(gy)
+    dw, db = PL.launch_wgrad(gt, xt, B, H, W, Cin, Cout, K, stride, pad, row_scale=scale, want_bias=bias)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, K, K), gy.double(), stride, pad) * scale.double().view(-1, 1, 1, 1)
+    lib = torch.nn.grad.conv2d_weight(x, (Cout, Cin, K, K), gy, stride, pad) * scale.view(-1, 1, 1, 1)
+    mag = torch.nn.grad.conv2d_weight(x.double().abs(), (Cout, Cin, K, K), gy.double().abs(), stride, pad) * scale.double().view(-1, 1, 1, 1)
+    e_mine = float(((dw.double() - ref).abs() / mag).max())
+    e_lib = float(((lib.double() - ref).abs() / mag).max())
+    print(f'[{B}x{H}x{W} {Cin}->{Cout} k{K} s{stride}] wgrad bf16x6 {e_mine:.3e}  fp32 library {e_lib:.3e}')
+    assert dw.shape == (Cout, Cin, K, K)
+    assert e_mine <= max(e_lib, 2.0 ** -23) and e_mine < 3e-7
+    if bias:
+        rb = gy.double().sum((0, 2, 3))
+        assert float((db.double() - rb).abs().max() / gy.double().abs().sum((0, 2, 3)).max()) < 3e-7
+    dw2, _ = PL.launch_wgrad(gt, xt, B, H, W, Cin, Cout, K, stride, pad, row_scale=scale, want_bias=bias)
+    assert torch.equal(dw, dw2)                                                           # deterministic
+
+
+def test_weight_planes_of_1x1_and_3x3_in_one_launch_with_folded_scale(monkeypatch):
+    from point_teacher_amd import functional as F, hip
+    g = torch.Generator().manual_seed(1)
+    ws = [(torch.randn(o, i, k, k, generator=g)).to(DEV).contiguous(memory_format=torch.channels_last)
+          for o, i, k in ((128, 256, 1), (256, 128, 3), (512, 128, 1), (64, 32, 3))]
+    sc = [(torch.rand(w.shape[0], generator=g) + 0.5).to(DEV) for w in ws]
+
+    def expect(w, dgrad, s):
+        wd = w if s is None else w * s.view(-1, 1, 1, 1)
+        O, I, k = wd.shape[0], wd.shape[1], wd.shape[2]
+        m = wd.flip(2, 3).permute(1, 2, 3, 0).reshape(I, k * k * O) if dgrad else wd.permute(0, 2, 3, 1).reshape(O, k * k * I)
+        return F.split_bf16x3(m.contiguous())
+    calls = []
+    real = hip.call
+    monkeypatch.setattr(hip, 'call', lambda fn, *a: (calls.append(fn), real(fn, *a))[1])
+    F.PARAM_EPOCH[0] += 1
+    for w, s in zip(ws, sc):
+        for dgrad in (False, True):
+            for use in (None, s):
+                F._conv_weight_planes(w, dgrad, use)
+    calls.clear()
+    F.PARAM_EPOCH[0] += 1
+    for w, s in zip(ws, sc):
+        for dgrad in (False, True):
+            for use in (None, s):
+                got, ref = F._conv_weight_planes(w, dgrad, use), expect(w, dgrad, use)
+                assert (got.rows, got.k) == (ref.rows, ref.k)
+                assert torch.equal(got.planes, ref.planes), (w.shape, dgrad, use is not None)
+    assert calls.count('pt_conv_weight_planes_batch') == 1
+    # a torch in-place edit of a weight (load_state_dict, init) re-splits although no optimizer step bumped the epoch
+    with torch.no_grad():
+        ws[0].mul_(2.0)
+    assert torch.equal(F._conv_weight_planes(ws[0], False).planes, expect(ws[0], False, None).planes)
+
+
+def _ref_bottleneck(blk, x):
+    """The block in float64 torch (eval-mode BatchNorm as an affine map)."""
+    import torch.nn.functional as TF
+
+    def cb(x, conv, bn, relu, res=None):
+        y = TF.conv2d(x, conv.weight.double(), None, conv.stride, conv.padding)
+        sc = (bn.weight.double() * torch.rsqrt(bn.running_var.double() + bn.eps)).view(1, -1, 1, 1)
+        y = y * sc + (bn.bias.double().view(1, -1, 1, 1) - bn.running_mean.double().view(1, -1, 1, 1) * sc)
+        if res is not None:
+            y = y + res
+        return torch.relu(y) if relu else y
+    idn = x if blk.downsample is None else cb(x, blk.downsample[0], blk.downsample[1], False)
+    out = cb(x, blk.conv1, blk.bn1, True)
+    out = cb(out, blk.conv2, blk.bn2, True)
+    return cb(out, blk.conv3, blk.bn3, True, idn)
+
+
+def _make_block(inplanes, planes, stride, ds, seed):
+    from point_teacher_amd.nn_modules import Bottleneck
+    import torch.nn as nn
+    torch.manual_seed(seed)
+    down = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False), nn.BatchNorm2d(planes * 4)) if ds else None
+    blk = Bottleneck(inplanes, planes, stride, 1, down, 'caffe').to(DEV).to(memory_format=torch.channels_last)
+    for m in blk.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            with torch.no_grad():
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+            m.weight.requires_grad = False
+            m.bias.requires_grad = False
+    blk.eval()
+    return blk
+
+
+@pytest.mark.parametrize('inplanes,planes,stride,ds,B,H,W,from_stem', [
+    (512, 128, 1, False, 2, 40, 36, False),       # identity block
+    (256, 128, 2, True, 2, 41, 36, True),         # layer2.0: fp32 stem output read at the stride's pixels, no input gradient
+    (512, 256, 2, True, 2, 40, 37, False),        # layer3.0: plane input, stride-2 input gradient scattered
+    (512, 128, 1, True, 2, 20, 20, False),        # a first block without stride
+])
+def test_bottleneck_planes_vs_fp64(inplanes, planes, stride, ds, B, H, W, from_stem):
+    from point_teacher_amd import planes as PL
+    blk = _make_block(inplanes, planes, stride, ds, 11)
+    assert blk.plane_ok()
+    g = torch.Generator().manual_seed(3)
+    x = torch.relu(torch.randn(B, inplanes, H, W, generator=g)).to(DEV).contiguous(memory_format=torch.channels_last)
+    if from_stem:
+        out = blk.forward_planes(x)
+    else:
+        x.requires_grad_(True)
+        xa = PL.to_planes(x)
+        xa.relu = True                              # (x is a ReLU output; the test plays its producer)
+        out = blk.forward_planes(xa)
+    y = out.float()
+    xr = x.detach().double().requires_grad_(not from_stem)
+    ref = _ref_bottleneck(blk, xr)
+    assert y.shape == ref.shape
+    assert float((y.double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    gy = torch.randn(y.shape, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    params = [blk.conv1.weight, blk.conv2.weight, blk.conv3.weight] + ([blk.downsample[0].weight] if ds else [])
+    ins = params + ([] if from_stem else [x])
+    got = torch.autograd.grad(y, ins, gy)
+    want = torch.autograd.grad(ref, params + ([] if from_stem else [xr]), gy.double())
+    for name, a, b in zip(['w1', 'w2', 'w3'] + (['wd'] if ds else []) + ([] if from_stem else ['x']), got, want):
+        if name == 'x':
+            b = b * (x > 0)                        # the producer's ReLU mask is applied by the block's epilogue (gradient convention)
+        err = float((a.double() - b).abs().max() / b.abs().max())
+        print(name, f'{err:.3e}')
+        assert err < 5e-6, (name, err)
+
+
+def test_resnet_fpn_planes_equal_the_fp32_routing(monkeypatch):
+    """ResNet-50 (caffe, frozen stem + layer1, frozen eval-mode BatchNorms) + FPN + PSAGG: plane-native trunk vs the round-3 routing
+    (PT_PLANE_TRUNK off) on the same weights - outputs and every parameter gradient."""
+    from point_teacher_amd import nn_modules as NM
+    torch.manual_seed(0)
+    bb = NM.ResNet(50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1, norm_cfg=dict(type='BN', requires_grad=False),
+                   norm_eval=True, style='caffe').to(DEV).to(memory_format=torch.channels_last)
+    fpn = NM.FPN([256, 512, 1024, 2048], 256, 5, start_level=1, add_extra_convs='on_output', relu_before_extra_convs=True).to(DEV).to(memory_format=torch.channels_last)
+    agg = NM.PSAGG(5, 256, 256).to(DEV).to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        bb.conv1.weight.mul_(1 / 64)
+    bb.train()
+    x = (torch.rand(2, 3, 256, 256, device=DEV) * 255).contiguous(memory_format=torch.channels_last)
+    params = [p for m in (bb, fpn, agg) for p in m.parameters() if p.requires_grad]
+
+    def run(planes):
+        monkeypatch.setattr(NM, '_PLANE_TRUNK', planes)
+        feats = bb(x, planes=planes)
+        if planes:
+            from point_teacher_amd import planes as PL
+            assert all(isinstance(f, PL.PlaneAct) for f in feats[1:]), [type(f) for f in feats]
+        out = agg(fpn(feats))[0]
+        gy = torch.randn(out.shape, generator=torch.Generator().manual_seed(9)).to(DEV)
+        grads = torch.autograd.grad(out, params, gy.contiguous(memory_format=torch.channels_last), allow_unused=True)
+        return out.detach(), grads
+    o1, g1 = run(True)
+    o0, g0 = run(False)
+    assert float((o1 - o0).abs().max()) < 1e-4 * float(o0.abs().max())
+    worst = 0.0
+    for p, a, b in zip(params, g1, g0):
+        assert (a is None) == (b is None)
+        if a is not None:
+            worst = max(worst, float((a - b).abs().max() / (b.abs().max() + 1e-30)))
+    print('worst parameter-gradient difference between the two routings', worst)
+    assert worst < 2e-4
