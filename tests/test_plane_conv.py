@@ -268,9 +268,11 @@ def test_bottleneck_planes_vs_fp64(inplanes, planes, stride, ds, B, H, W, from_s
         assert err < 5e-6, (name, err)
 
 
-def test_resnet_fpn_planes_equal_the_fp32_routing(monkeypatch):
-    """ResNet-50 (caffe, frozen stem + layer1, frozen eval-mode BatchNorms) + FPN + PSAGG: plane-native trunk vs the round-3 routing
-    (PT_PLANE_TRUNK off) on the same weights - outputs and every parameter gradient."""
+def test_resnet_fpn_planes_vs_fp64_and_the_fp32_routing(monkeypatch):
+    """ResNet-50 (caffe, frozen stem + layer1, frozen eval-mode BatchNorms) + FPN + PSAGG: the plane-native trunk and the round-3
+    routing (PT_PLANE_TRUNK off: library 1x1 convolutions, fp32 between layers) on the same weights against the same network in
+    float64 - outputs and every parameter gradient; the plane trunk may not be further from float64 than the fp32 routing is."""
+    import copy
     from point_teacher_amd import nn_modules as NM
     torch.manual_seed(0)
     bb = NM.ResNet(50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1, norm_cfg=dict(type='BN', requires_grad=False),
@@ -281,25 +283,43 @@ def test_resnet_fpn_planes_equal_the_fp32_routing(monkeypatch):
         bb.conv1.weight.mul_(1 / 64)
     bb.train()
     x = (torch.rand(2, 3, 256, 256, device=DEV) * 255).contiguous(memory_format=torch.channels_last)
-    params = [p for m in (bb, fpn, agg) for p in m.parameters() if p.requires_grad]
+    mods = (bb, fpn, agg)
+    names = [f'{i}.{n}' for i, m in enumerate(mods) for n, p in m.named_parameters() if p.requires_grad]
+    gy = None
 
-    def run(planes):
+    def run(mods, planes, xin):
+        nonlocal gy
         monkeypatch.setattr(NM, '_PLANE_TRUNK', planes)
-        feats = bb(x, planes=planes)
+        params = [p for m in mods for p in m.parameters() if p.requires_grad]
+        feats = mods[0](xin, planes=planes)
         if planes:
             from point_teacher_amd import planes as PL
             assert all(isinstance(f, PL.PlaneAct) for f in feats[1:]), [type(f) for f in feats]
-        out = agg(fpn(feats))[0]
-        gy = torch.randn(out.shape, generator=torch.Generator().manual_seed(9)).to(DEV)
-        grads = torch.autograd.grad(out, params, gy.contiguous(memory_format=torch.channels_last), allow_unused=True)
+        out = mods[2](mods[1](feats))[0]
+        if gy is None:
+            gy = torch.randn(out.shape, generator=torch.Generator().manual_seed(9)).to(DEV).contiguous(memory_format=torch.channels_last)
+        grads = torch.autograd.grad(out, params, gy.to(out.dtype), allow_unused=True)
         return out.detach(), grads
-    o1, g1 = run(True)
-    o0, g0 = run(False)
-    assert float((o1 - o0).abs().max()) < 1e-4 * float(o0.abs().max())
-    worst = 0.0
-    for p, a, b in zip(params, g1, g0):
-        assert (a is None) == (b is None)
+    o1, g1 = run(mods, True, x)
+    o0, g0 = run(mods, False, x)
+    m64 = tuple(copy.deepcopy(m).double() for m in mods)
+    m64[0].train()
+    o64, g64 = run(m64, False, x.double())
+    e1, e0 = float((o1.double() - o64).abs().max() / o64.abs().max()), float((o0.double() - o64).abs().max() / o64.abs().max())
+    print(f'output vs float64: plane trunk {e1:.3e}, fp32 routing {e0:.3e}')
+    assert e1 <= max(2 * e0, 2e-6)
+    # Gradients: one ReLU decision that differs between an fp32 and the float64 evaluation (a pre-activation within an ulp of zero;
+    # ~1e7 activations here) moves every gradient upstream of it by 1e-4 ... 1e-2 - in either fp32 routing, on different elements.
+    # The per-kernel and per-block tests above pin the arithmetic at 1e-6; this one pins the WIRING (identity / downsample
+    # gradients, fan-out at the stage outputs, masks, bias gradients): a missing term is an O(1) error.
+    d1s, d0s = [], []
+    for n, a, b, r in zip(names, g1, g0, g64):
+        assert (a is None) == (r is None), n
         if a is not None:
-            worst = max(worst, float((a - b).abs().max() / (b.abs().max() + 1e-30)))
-    print('worst parameter-gradient difference between the two routings', worst)
-    assert worst < 2e-4
+            d1s.append(float((a.double() - r).abs().max() / (r.abs().max() + 1e-300)))
+            d0s.append(float((b.double() - r).abs().max() / (r.abs().max() + 1e-300)))
+            print(f'{n:40s} plane {d1s[-1]:.3e}  fp32 {d0s[-1]:.3e}')
+            assert d1s[-1] <= max(3 * d0s[-1], 2e-2), (n, d1s[-1], d0s[-1])
+    med = sorted(d1s)[len(d1s) // 2]
+    print(f'parameter-gradient error vs float64: plane trunk worst {max(d1s):.3e} median {med:.3e}, fp32 routing worst {max(d0s):.3e}')
+    assert med < 1e-4
