@@ -244,13 +244,20 @@ def test_conv_weight_planes_are_refreshed_in_one_launch_per_parameter_epoch():
         with torch.no_grad():
             for w in ws:
                 w.mul_(1.5)
-        stale = F._conv_weight_planes(ws[0], False)                    # same epoch: the cached planes, no launch
-        assert not calls and not torch.equal(stale.planes, expect(ws[0], False).planes)
-        F.PARAM_EPOCH[0] += 1
+        # a torch in-place edit moves the weight's version counter: the planes follow without an optimizer step (round-3 advice:
+        # load_state_dict / init / copy_ must not leave stale planes) - still ONE launch for all six (weight, form) pairs
         for w in ws:
             for dgrad in (False, True):
                 assert torch.equal(F._conv_weight_planes(w, dgrad).planes, expect(w, dgrad).planes)
-        assert calls.count('pt_conv_weight_planes_batch') == 1       # ONE launch for the six (weight, form) pairs
+        assert calls.count('pt_conv_weight_planes_batch') == 1
+        calls.clear()
+        F._conv_weight_planes(ws[0], False)                            # same epoch, same version: the cached planes, no launch
+        assert 'pt_conv_weight_planes_batch' not in calls
+        F.PARAM_EPOCH[0] += 1                                          # raw-pointer updates (fused SGD / EMA) announce themselves
+        for w in ws:
+            for dgrad in (False, True):
+                assert torch.equal(F._conv_weight_planes(w, dgrad).planes, expect(w, dgrad).planes)
+        assert calls.count('pt_conv_weight_planes_batch') == 1
     finally:
         F.hip.call = orig
     n = len(F._CONV_W.ent)
