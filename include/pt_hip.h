@@ -277,7 +277,10 @@ int pt_conv3x3_wgrad_bf16x6_nhwc(const uint16_t* gy_planes, int64_t gy_plane_str
  * the input gradient of a stride-2 1 x 1 convolution computed on the coarse grid and placed into a buffer the caller zeroed
  * (res_* stay indexed by the coarse row).  Every pointer of the epilogue may be NULL; at least one output is required.
  * w_planes: blocked planes of [Cout][KH * KW * Cin] (pt_conv_weight_planes_batch / pt_split_bf16x3).  Cin % 32 == 0, Cout % 8 == 0.
- * [host] struct; device pointers inside. */
+ * Split-k: a launch with few output tiles and a long reduce dimension (the teacher's batch of 2; layer4's 25 x 25 maps) cuts the k-steps
+ * into `splits` chunks (0 = pt_conv_bf16x6_splits(...) when a workspace is given, else 1), every (tile, chunk) workgroup stores its
+ * raw fp32 tile to workspace[splits][M][Cout] and a second launch adds them in a fixed order and runs the epilogue (deterministic).
+ * tile_rows: 64, 96, ..., 256 or 0 = pt_gemm_bf16x6_tile_rows.  [host] struct; device pointers inside. */
 typedef struct {
   int32_t B, Hs, Ws, Cin, Cout, KH, KW, stride, pad;
   int32_t relu;
@@ -296,7 +299,12 @@ typedef struct {
   int64_t out_plane_stride;
   int32_t scatter_stride, scatter_H, scatter_W;
   int32_t tile_rows;
+  float* workspace;
+  int64_t workspace_elems;
+  int32_t splits;
+  int32_t reserved;
 } pt_conv_desc;
+int pt_conv_bf16x6_splits(int B, int Hs, int Ws, int Cin, int Cout, int KH, int KW, int stride, int pad, int tile_rows);
 int pt_conv_bf16x6(const pt_conv_desc* desc, void* stream);
 
 /* Weight (and bias) gradient of the same convolutions: dw[Cout][KH][KW][Cin] (+)= row_scale[o] * sum over output pixels p of

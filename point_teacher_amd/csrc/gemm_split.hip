@@ -28,6 +28,8 @@
 //     per-column scale / bias / ReLU of the caller (Linear bias, frozen BatchNorm);
 //   blockIdx -> tile mapping is XCD-aware: the blocks of one XCD (b % 8) walk consecutive tiles of the column-fastest tile list,
 //     so the tiles that share an A row panel are in flight together behind the same L2.
+#include <stdlib.h>
+
 #include "pt_common.h"
 
 namespace pt {
@@ -254,6 +256,9 @@ struct ConvEpi {
   int zero_row;                     // >= 0: this row of out_planes is written with zeros (by the last row tile)
   int sc_stride, sc_Ho, sc_Wo, sc_H, sc_W;   // sc_stride != 0: output row (b, y, x) of [sc_Ho, sc_Wo] leaves as row
                                     //   (b * sc_H + y * sc_stride) * sc_W + x * sc_stride of mask / out (a stride-2 1 x 1 input gradient)
+  float* part;                      // splits > 1 (few output tiles, long k: the teacher's batch, layer4): workgroup (tile, s) multiplies
+  int splits, ks_per;               //   k-steps [s * ks_per, (s + 1) * ks_per) and stores its raw fp32 tile to part[s][M][N];
+                                    //   conv_splitk_finish_kernel adds the parts in a fixed order and runs this epilogue
 };
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -270,7 +275,96 @@ __device__ __forceinline__ void planes_sum8(const uint4 a, const uint4 b, const 
   }
 }
 
-template <int MB, bool CONV>
+
+// The epilogue of one row x 8 columns (see ConvEpi); o = the accumulated products.
+__device__ __forceinline__ void conv_epilogue8(float (&o)[8], int grow, int gcol, int N, const ConvEpi& ep) {
+  if (ep.scale) {
+    const float4 sa = *reinterpret_cast<const float4*>(ep.scale + gcol), sb = *reinterpret_cast<const float4*>(ep.scale + gcol + 4);
+    o[0] *= sa.x; o[1] *= sa.y; o[2] *= sa.z; o[3] *= sa.w; o[4] *= sb.x; o[5] *= sb.y; o[6] *= sb.z; o[7] *= sb.w;
+  }
+  if (ep.shift) {
+    const float4 sa = *reinterpret_cast<const float4*>(ep.shift + gcol), sb = *reinterpret_cast<const float4*>(ep.shift + gcol + 4);
+    o[0] += sa.x; o[1] += sa.y; o[2] += sa.z; o[3] += sa.w; o[4] += sb.x; o[5] += sb.y; o[6] += sb.z; o[7] += sb.w;
+  }
+  const long rin = (long)grow * N + gcol;
+  if (ep.res_planes) {
+    float r[8];
+    planes_sum8(*reinterpret_cast<const uint4*>(ep.res_planes + rin), *reinterpret_cast<const uint4*>(ep.res_planes + ep.res_plane + rin),
+                *reinterpret_cast<const uint4*>(ep.res_planes + 2 * ep.res_plane + rin), r);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] += r[e];
+  }
+  if (ep.res_f32) {
+    const float4 ra = *reinterpret_cast<const float4*>(ep.res_f32 + rin), rb2 = *reinterpret_cast<const float4*>(ep.res_f32 + rin + 4);
+    o[0] += ra.x; o[1] += ra.y; o[2] += ra.z; o[3] += ra.w; o[4] += rb2.x; o[5] += rb2.y; o[6] += rb2.z; o[7] += rb2.w;
+  }
+  if (ep.relu) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
+  }
+  long orow = grow;
+  if (ep.sc_stride) {
+    const int x = grow % ep.sc_Wo, yq = grow / ep.sc_Wo;
+    const int y = yq % ep.sc_Ho, bi = yq / ep.sc_Ho;
+    orow = ((long)bi * ep.sc_H + y * ep.sc_stride) * ep.sc_W + x * ep.sc_stride;
+  }
+  const long rout = orow * N + gcol;
+  if (ep.mask_planes) {
+    const uint4 mk = *reinterpret_cast<const uint4*>(ep.mask_planes + rout);
+    const unsigned mm[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                   // bf16 > 0: sign clear and not zero
+      if (!((mm[j] & 0x7fffu) != 0 && (mm[j] & 0x8000u) == 0)) o[2 * j] = 0.f;
+      if (!((mm[j] & 0x7fff0000u) != 0 && (mm[j] & 0x80000000u) == 0)) o[2 * j + 1] = 0.f;
+    }
+  }
+  if (ep.out_f32) {
+    float* dst = ep.out_f32 + orow * ep.ldc + gcol;
+    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+  }
+  if (ep.out_planes) {
+    uint4 p0, p1, p2;
+    split_pair(o[0], o[1], p0.x, p1.x, p2.x);
+    split_pair(o[2], o[3], p0.y, p1.y, p2.y);
+    split_pair(o[4], o[5], p0.z, p1.z, p2.z);
+    split_pair(o[6], o[7], p0.w, p1.w, p2.w);
+    uint16_t* d = ep.out_planes + rout;
+    *reinterpret_cast<uint4*>(d) = p0;
+    *reinterpret_cast<uint4*>(d + ep.out_plane) = p1;
+    *reinterpret_cast<uint4*>(d + 2 * ep.out_plane) = p2;
+  }
+}
+
+// Second half of a split-k convolution: out = epilogue(sum_s part[s]) for M x N results, 8 columns per thread; the zero row of the
+// output planes is written by the last block.
+__global__ void __launch_bounds__(256) conv_splitk_finish_kernel(int M, int N, ConvEpi ep) {
+  const int n8 = N >> 3;
+  const long items = (long)M * n8;
+  const long MN = (long)M * N;
+  for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < items; u += (long)gridDim.x * blockDim.x) {
+    const int grow = (int)(u / n8), gcol = (int)(u - (long)grow * n8) << 3;
+    const float* p = ep.part + (long)grow * N + gcol;
+    float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    for (int s = 1; s < ep.splits; ++s) {
+      const float4 va = *reinterpret_cast<const float4*>(p + s * MN), vb = *reinterpret_cast<const float4*>(p + s * MN + 4);
+      a.x += va.x; a.y += va.y; a.z += va.z; a.w += va.w; b.x += vb.x; b.y += vb.y; b.z += vb.z; b.w += vb.w;
+    }
+    float o[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    conv_epilogue8(o, grow, gcol, N, ep);
+  }
+  if (ep.out_planes && ep.zero_row >= 0 && blockIdx.x == gridDim.x - 1) {
+    for (int c = threadIdx.x * 8; c < N; c += blockDim.x * 8) {
+      uint16_t* d = ep.out_planes + (long)ep.zero_row * N + c;
+      const uint4 z = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(d) = z;
+      *reinterpret_cast<uint4*>(d + ep.out_plane) = z;
+      *reinterpret_cast<uint4*>(d + 2 * ep.out_plane) = z;
+    }
+  }
+}
+
+template <int MB, bool CONV, int NST>
 __global__ void __launch_bounds__(GTHREADS)
     gemm_bf16x6_kernel(const uint16_t* __restrict__ Ap, const uint16_t* __restrict__ Bp, float* __restrict__ C,
                        const float* __restrict__ bias, const float* __restrict__ scale, int M, int N, int KB, long a_plane, long b_plane,
@@ -287,6 +381,14 @@ __global__ void __launch_bounds__(GTHREADS)
   {
     const int b = blockIdx.x, q = n_tiles >> 3, r = n_tiles & 7, x = b & 7;
     tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+  }
+  int kb0 = 0, kb1 = KB, sp = 0;                         // this workgroup's k-steps (all of them unless the launch splits k)
+  if (CONV && ep.splits > 1) {
+    const int per = n_tiles / ep.splits;
+    sp = tile / per;
+    tile -= sp * per;
+    kb0 = sp * ep.ks_per;
+    kb1 = min(KB, kb0 + ep.ks_per);
   }
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   const int m0 = tm * BM, n0 = tn * GBN;
@@ -329,12 +431,19 @@ __global__ void __launch_bounds__(GTHREADS)
         cmask[j] = mask;
         gsrc[j] = reinterpret_cast<const unsigned char*>(base) + sl * 16;
       } else {
-        gsrc[j] = reinterpret_cast<const unsigned char*>(base + ((long)rb * KB << 9)) + lane * 16;
+        gsrc[j] = reinterpret_cast<const unsigned char*>(base + (((long)rb * KB + kb0) << 9)) + lane * 16;
       }
     }
   }
   // (tap, channel block) of the stage that is issued next: wave-uniform counters instead of divisions per k-step
   int s_tap = 0, s_cb = 0, s_off = 0, s_kx = 0;         // s_off = ky * Ws + kx of s_tap
+  if (CONV && kb0 > 0) {
+    s_tap = kb0 / cg.CB;
+    s_cb = kb0 - s_tap * cg.CB;
+    const int ky = s_tap / cg.KW;
+    s_kx = s_tap - ky * cg.KW;
+    s_off = ky * cg.Ws + s_kx;
+  }
   auto issue1 = [&](int j, int buf) {                   // one 1-KiB block of the next stage
     if (j < NJ && w + 8 * j < NI) {                     // wave-uniform
       if (CONV && w + 8 * j < 3 * (BM / 16)) {          // wave-uniform: an activation piece
@@ -378,11 +487,58 @@ __global__ void __launch_bounds__(GTHREADS)
 #pragma unroll
   for (int j = 0; j < NJ; ++j) issue1(j, 0);
   next_stage();
-  for (int ks = 0; ks < KB; ++ks) {
+  if constexpr (NST == 3) {
+    // Three-stage ring (BM = 128: every wave issues exactly NJ = 6 pieces per stage): stage ks + 2 is issued while stage ks is
+    // multiplied, so a whole stage stays in flight ACROSS the barrier - the wait in front of it is COUNTED (`vmcnt(NJ)`: all but
+    // the youngest stage's pieces have landed) and the barrier is the bare instruction (`__syncthreads()` would drain the queue).
+    static_assert(NI % 8 == 0, "a counted wait needs the same number of pieces on every wave");
+    if (kb0 + 1 < kb1) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) issue1(j, 1);
+      next_stage();
+    }
+    int cur = 0;
+    for (int ks = kb0; ks < kb1; ++ks) {
+      if (ks + 1 < kb1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");   // stage ks has landed for every wave; every wave has left stage ks - 1's buffer
+      const bool more = ks + 2 < kb1;
+      const int nbuf = cur == 0 ? 2 : cur - 1;  // (cur + 2) % 3: the buffer stage ks - 1 occupied
+      const unsigned char* st = smem + cur * STAGE;
+      bf16x8_t b[2][3];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b[c][p] = *reinterpret_cast<const bf16x8_t*>(st + b_off + p * GBN * 64 + c * 16 * 64);
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        const unsigned char* ap = st + a_off + i * 16 * 64;
+        const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(ap);
+        const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(ap + BM * 64);
+        const bf16x8_t a2 = *reinterpret_cast<const bf16x8_t*>(ap + 2 * BM * 64);
+        if (more) {
+#pragma unroll
+          for (int q = 0; q < PER; ++q) issue1(i * PER + q, nbuf);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {                   // smallest terms first
+          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b[c][0], cor[i][c], 0, 0, 0);
+          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b[c][1], cor[i][c], 0, 0, 0);
+          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[c][2], cor[i][c], 0, 0, 0);
+          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b[c][0], cor[i][c], 0, 0, 0);
+          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[c][1], cor[i][c], 0, 0, 0);
+          acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[c][0], acc[i][c], 0, 0, 0);
+        }
+      }
+      if (more) next_stage();
+      cur = cur == 2 ? 0 : cur + 1;
+    }
+  } else {
+  for (int ks = kb0; ks < kb1; ++ks) {
     __syncthreads();          // (emits s_waitcnt vmcnt(0)): stage ks has landed, every wave is done reading the other buffer
-    const bool more = ks + 1 < KB;
-    const int nbuf = (ks + 1) & 1;
-    const unsigned char* st = smem + (ks & 1) * STAGE;
+    const bool more = ks + 1 < kb1;
+    const int nbuf = (ks - kb0 + 1) & 1;
+    const unsigned char* st = smem + ((ks - kb0) & 1) * STAGE;
     bf16x8_t b[2][3];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -409,6 +565,7 @@ __global__ void __launch_bounds__(GTHREADS)
       }
     }
     next_stage();
+  }
   }
   __syncthreads();            // everyone is done with the staging buffers: they become the output tile [BM][132] (fp32)
   constexpr int TLD = GBN + 4;
@@ -451,65 +608,16 @@ __global__ void __launch_bounds__(GTHREADS)
       const int grow = m0 + row, gcol = n0 + c8;
       if (grow >= M || gcol >= N) continue;
       const float4 va = *reinterpret_cast<const float4*>(otile + row * TLD + c8), vb = *reinterpret_cast<const float4*>(otile + row * TLD + c8 + 4);
+      if (ep.splits > 1) {                              // a raw part of a split-k product
+        float* dst = ep.part + ((long)sp * M + grow) * N + gcol;
+        *reinterpret_cast<float4*>(dst) = va;
+        *reinterpret_cast<float4*>(dst + 4) = vb;
+        continue;
+      }
       float o[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
-      if (ep.scale) {
-        const float4 sa = *reinterpret_cast<const float4*>(ep.scale + gcol), sb = *reinterpret_cast<const float4*>(ep.scale + gcol + 4);
-        o[0] *= sa.x; o[1] *= sa.y; o[2] *= sa.z; o[3] *= sa.w; o[4] *= sb.x; o[5] *= sb.y; o[6] *= sb.z; o[7] *= sb.w;
-      }
-      if (ep.shift) {
-        const float4 sa = *reinterpret_cast<const float4*>(ep.shift + gcol), sb = *reinterpret_cast<const float4*>(ep.shift + gcol + 4);
-        o[0] += sa.x; o[1] += sa.y; o[2] += sa.z; o[3] += sa.w; o[4] += sb.x; o[5] += sb.y; o[6] += sb.z; o[7] += sb.w;
-      }
-      const long rin = (long)grow * N + gcol;
-      if (ep.res_planes) {
-        float r[8];
-        planes_sum8(*reinterpret_cast<const uint4*>(ep.res_planes + rin), *reinterpret_cast<const uint4*>(ep.res_planes + ep.res_plane + rin),
-                    *reinterpret_cast<const uint4*>(ep.res_planes + 2 * ep.res_plane + rin), r);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] += r[e];
-      }
-      if (ep.res_f32) {
-        const float4 ra = *reinterpret_cast<const float4*>(ep.res_f32 + rin), rb2 = *reinterpret_cast<const float4*>(ep.res_f32 + rin + 4);
-        o[0] += ra.x; o[1] += ra.y; o[2] += ra.z; o[3] += ra.w; o[4] += rb2.x; o[5] += rb2.y; o[6] += rb2.z; o[7] += rb2.w;
-      }
-      if (ep.relu) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
-      }
-      long orow = grow;
-      if (ep.sc_stride) {
-        const int x = grow % ep.sc_Wo, yq = grow / ep.sc_Wo;
-        const int y = yq % ep.sc_Ho, bi = yq / ep.sc_Ho;
-        orow = ((long)bi * ep.sc_H + y * ep.sc_stride) * ep.sc_W + x * ep.sc_stride;
-      }
-      const long rout = orow * N + gcol;
-      if (ep.mask_planes) {
-        const uint4 mk = *reinterpret_cast<const uint4*>(ep.mask_planes + rout);
-        const unsigned mm[4] = {mk.x, mk.y, mk.z, mk.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {                   // bf16 > 0: sign clear and not zero
-          if (!((mm[j] & 0x7fffu) != 0 && (mm[j] & 0x8000u) == 0)) o[2 * j] = 0.f;
-          if (!((mm[j] & 0x7fff0000u) != 0 && (mm[j] & 0x80000000u) == 0)) o[2 * j + 1] = 0.f;
-        }
-      }
-      if (ep.out_f32) {
-        float* dst = ep.out_f32 + orow * ep.ldc + gcol;
-        *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-        *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
-      }
-      if (ep.out_planes) {
-        uint4 p0, p1, p2;
-        split_pair(o[0], o[1], p0.x, p1.x, p2.x);
-        split_pair(o[2], o[3], p0.y, p1.y, p2.y);
-        split_pair(o[4], o[5], p0.z, p1.z, p2.z);
-        split_pair(o[6], o[7], p0.w, p1.w, p2.w);
-        uint16_t* d = ep.out_planes + rout;
-        *reinterpret_cast<uint4*>(d) = p0;
-        *reinterpret_cast<uint4*>(d + ep.out_plane) = p1;
-        *reinterpret_cast<uint4*>(d + 2 * ep.out_plane) = p2;
-      }
+      conv_epilogue8(o, grow, gcol, N, ep);
     }
-    if (ep.out_planes && ep.zero_row >= 0 && m0 + BM >= M && threadIdx.x < 16 && n0 + threadIdx.x * 8 < N) {
+    if (ep.splits <= 1 && ep.out_planes && ep.zero_row >= 0 && m0 + BM >= M && threadIdx.x < 16 && n0 + threadIdx.x * 8 < N) {
       uint16_t* d = ep.out_planes + (long)ep.zero_row * N + n0 + threadIdx.x * 8;
       const uint4 z = make_uint4(0, 0, 0, 0);
       *reinterpret_cast<uint4*>(d) = z;
@@ -519,22 +627,32 @@ __global__ void __launch_bounds__(GTHREADS)
   }
 }
 
-template <int MB, bool CONV>
+static int ring3_enabled() {                            // PT_GEMM_RING3=1: the three-stage ring for 128-row tiles (measured: no gain, profiles/r04)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("PT_GEMM_RING3");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v;
+}
+
+template <int MB, bool CONV, int NST>
 static int launch_gemm(const uint16_t* Ap, const uint16_t* Bp, float* C, const float* bias, const float* scale, int M, int N, int KB,
                        long a_plane, long b_plane, long ldc, int relu, ConvGeom cg, ConvEpi ep, hipStream_t s) {
   constexpr int BM = 32 * MB;
-  constexpr int LDS = (BM + GBN) * 3 * 64 * 2;
-  static_assert(LDS <= 160 * 1024, "two stages must fit the CU's LDS");
+  constexpr int LDS = (BM + GBN) * 3 * 64 * NST;
+  static_assert(LDS <= 160 * 1024, "the stages must fit the CU's LDS");
   static_assert(BM * (GBN + 4) * 4 <= LDS, "the output tile must fit the staging buffers");
   const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, GBN);
+  const int items = tiles_m * tiles_n * ((CONV && ep.splits > 1) ? ep.splits : 1);
   static bool once = false;
   if (!once) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x6_kernel<MB, CONV>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x6_kernel<MB, CONV, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
     once = true;
   }
-  hipLaunchKernelGGL((gemm_bf16x6_kernel<MB, CONV>), dim3(tiles_m * tiles_n), dim3(GTHREADS), LDS, s, Ap, Bp, C, bias, scale, M, N, KB,
-                     a_plane, b_plane, ldc, relu, tiles_n, tiles_m * tiles_n, cg, ep);
+  hipLaunchKernelGGL((gemm_bf16x6_kernel<MB, CONV, NST>), dim3(items), dim3(GTHREADS), LDS, s, Ap, Bp, C, bias, scale, M, N, KB,
+                     a_plane, b_plane, ldc, relu, tiles_n, items, cg, ep);
   return 0;
 }
 
@@ -542,12 +660,15 @@ template <bool CONV>
 static int launch_by_rows(int tile_rows, const uint16_t* Ap, const uint16_t* Bp, float* C, const float* bias, const float* scale, int M,
                           int N, int KB, long a_plane, long b_plane, long ldc, int relu, ConvGeom cg, ConvEpi ep, hipStream_t s) {
   switch (tile_rows / 32) {
-    case 3: return launch_gemm<3, CONV>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
-    case 4: return launch_gemm<4, CONV>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
-    case 5: return launch_gemm<5, CONV>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
-    case 6: return launch_gemm<6, CONV>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
-    case 7: return launch_gemm<7, CONV>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
-    default: return launch_gemm<8, CONV>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
+    case 2: return launch_gemm<2, CONV, 2>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
+    case 3: return launch_gemm<3, CONV, 2>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
+    case 4:
+      if (ring3_enabled()) return launch_gemm<4, CONV, 3>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
+      return launch_gemm<4, CONV, 2>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
+    case 5: return launch_gemm<5, CONV, 2>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
+    case 6: return launch_gemm<6, CONV, 2>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
+    case 7: return launch_gemm<7, CONV, 2>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
+    default: return launch_gemm<8, CONV, 2>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
   }
 }
 
@@ -625,7 +746,7 @@ __device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* lo, const unsig
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
-template <int MB>
+template <int MB, int NST>
 __global__ void __launch_bounds__(GTHREADS)
     wgrad_bf16x6_kernel(const uint16_t* __restrict__ Gp, const uint16_t* __restrict__ Xp, float* __restrict__ part,
                         float* __restrict__ part_bias, long g_plane, long x_plane, WgradGeom wg, int n_items) {
@@ -716,6 +837,51 @@ __global__ void __launch_bounds__(GTHREADS)
 #pragma unroll
     for (int img = 0; img < NIMG; ++img) issue(img, 0);
   }
+  if constexpr (NST == 3) {
+    // three-stage ring with a counted wait (see gemm_bf16x6_kernel): every wave issues NIMG * 3 pieces per stage
+    if (k_begin + 1 < k_end) {
+      next_rows();
+#pragma unroll
+      for (int img = 0; img < NIMG; ++img) issue(img, 1);
+    }
+    int cur = 0;
+    for (int ks = k_begin; ks < k_end; ++ks) {
+      if (ks + 1 < k_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIMG * 3) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+      const bool more = ks + 2 < k_end;
+      const int nbuf = cur == 0 ? 2 : cur - 1;
+      const unsigned char* st = smem + cur * STAGE;
+      if (more) next_rows();
+      bf16x8_t b[2][3];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b[c][p] = tr_frag(st + b_off[c][0] + p * IMG, st + b_off[c][1] + p * IMG);
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        const bf16x8_t a0 = tr_frag(st + a_off[i][0], st + a_off[i][1]);
+        const bf16x8_t a1 = tr_frag(st + a_off[i][0] + IMG, st + a_off[i][1] + IMG);
+        const bf16x8_t a2 = tr_frag(st + a_off[i][0] + 2 * IMG, st + a_off[i][1] + 2 * IMG);
+        if (more && i < NIMG) issue(i, nbuf);          // wave-uniform
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {                   // smallest terms first
+          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b[c][0], cor[i][c], 0, 0, 0);
+          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b[c][1], cor[i][c], 0, 0, 0);
+          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[c][2], cor[i][c], 0, 0, 0);
+          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b[c][0], cor[i][c], 0, 0, 0);
+          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[c][1], cor[i][c], 0, 0, 0);
+          acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[c][0], acc[i][c], 0, 0, 0);
+        }
+        if (bias_tile && (i & 3) == nb) {               // wave-uniform
+          bsum[i >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, ones, bsum[i >> 2], 0, 0, 0);
+          bsum[i >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, ones, bsum[i >> 2], 0, 0, 0);
+          bsum[i >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, ones, bsum[i >> 2], 0, 0, 0);
+        }
+      }
+      cur = cur == 2 ? 0 : cur + 1;
+    }
+  } else {
   for (int ks = k_begin; ks < k_end; ++ks) {
     __syncthreads();          // the stage has landed (s_waitcnt vmcnt(0)) and every wave has left the other buffer
     const bool more = ks + 1 < k_end;
@@ -748,6 +914,7 @@ __global__ void __launch_bounds__(GTHREADS)
         bsum[i >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, ones, bsum[i >> 2], 0, 0, 0);
       }
     }
+  }
   }
   __syncthreads();            // the staging buffers become the output tile [BM][132] (fp32)
   constexpr int TLD = GBN + 4;
@@ -812,20 +979,20 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float4* __restr
   }
 }
 
-template <int MB>
+template <int MB, int NST>
 static int launch_wgrad(const uint16_t* Gp, const uint16_t* Xp, float* part, float* part_bias, long g_plane, long x_plane, WgradGeom wg, int S,
                         hipStream_t s) {
-  constexpr int LDS = (32 * MB / 128 + 1) * 3 * 8192 * 2;
-  static_assert(LDS <= 160 * 1024, "two stages must fit the CU's LDS");
+  constexpr int LDS = (32 * MB / 128 + 1) * 3 * 8192 * NST;
+  static_assert(LDS <= 160 * 1024, "the stages must fit the CU's LDS");
   static_assert(32 * MB * (GBN + 4) * 4 <= LDS, "the output tile must fit the staging buffers");
   static bool once = false;
   if (!once) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16x6_kernel<MB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16x6_kernel<MB, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
     once = true;
   }
   const int n_items = S * wg.tiles_m * wg.tiles_n;
-  hipLaunchKernelGGL((wgrad_bf16x6_kernel<MB>), dim3(n_items), dim3(GTHREADS), LDS, s, Gp, Xp, part, part_bias, g_plane, x_plane, wg, n_items);
+  hipLaunchKernelGGL((wgrad_bf16x6_kernel<MB, NST>), dim3(n_items), dim3(GTHREADS), LDS, s, Gp, Xp, part, part_bias, g_plane, x_plane, wg, n_items);
   return 0;
 }
 
@@ -939,6 +1106,12 @@ extern "C" int pt_split_bf16x3(const float* src, int64_t ld, int R, int C, int t
 // Tile height for an [M, N] output: the MB in 3..8 with the least (waves of 256 tiles) x (tile rows); ties -> the larger tile
 // (fewer staged bytes per MFMA).
 extern "C" int pt_gemm_bf16x6_tile_rows(int M, int N) {
+  static int forced = -1;                               // PT_GEMM_TILE_ROWS=96..256: one tile height everywhere (measurements)
+  if (forced < 0) {
+    const char* e = getenv("PT_GEMM_TILE_ROWS");
+    forced = e ? atoi(e) : 0;
+  }
+  if (forced >= 64 && forced <= 256 && forced % 32 == 0) return forced;
   const long tn = cdiv(N, GBN);
   int best = 8;
   long best_cost = -1;
@@ -961,7 +1134,7 @@ extern "C" int pt_gemm_bf16x6_nt(const uint16_t* a_planes, int64_t a_plane_strid
   PT_REQUIRE(((((uintptr_t)a_planes) | ((uintptr_t)b_planes)) & 15) == 0 && (a_plane_stride & 7) == 0 && (b_plane_stride & 7) == 0, PT_EINVAL,
              "pt_gemm_bf16x6_nt: planes must be 16-byte aligned");
   if (tile_rows <= 0) tile_rows = pt_gemm_bf16x6_tile_rows(M, N);
-  PT_REQUIRE(tile_rows % 32 == 0 && tile_rows >= 96 && tile_rows <= 256, PT_EINVAL, "pt_gemm_bf16x6_nt: tile_rows in {96, 128, ..., 256}");
+  PT_REQUIRE(tile_rows % 32 == 0 && tile_rows >= 64 && tile_rows <= 256, PT_EINVAL, "pt_gemm_bf16x6_nt: tile_rows in {64, 96, ..., 256}");
   const int rc = launch_by_rows<false>(tile_rows, a_planes, b_planes, c, bias, nullptr, M, N, Kp, a_plane_stride, b_plane_stride, ldc, relu,
                                        ConvGeom{}, ConvEpi{}, as_stream(stream));
   PT_REQUIRE(rc == 0, rc, "pt_gemm_bf16x6_nt: hipFuncSetAttribute failed (%d)", rc);
@@ -1028,6 +1201,36 @@ static int conv_check(const pt_conv_desc* d, const char* who) {
   return PT_OK;
 }
 
+// k-splits of a convolution with M x N results and KB k-steps at tile height tile_rows: 1 while the tiles fill the chip; else the
+// count (each chunk at least 8 k-steps) that minimises rounds-of-256-workgroups x work per workgroup.
+static int conv_splits(long M, int N, int KB, int tile_rows) {
+  static int off = -1;
+  if (off < 0) {
+    const char* e = getenv("PT_CONV_SPLITK");             // PT_CONV_SPLITK=0: never split (measurements)
+    off = (e && e[0] == '0') ? 1 : 0;
+  }
+  if (off) return 1;
+  const long tiles = (long)cdiv(M, tile_rows) * cdiv(N, GBN);
+  if (tiles >= 256 || KB < 16) return 1;
+  // rounds of 256 workgroups x (k-steps per workgroup + ~6 k-steps' worth of prologue / epilogue / part traffic)
+  int best = 1;
+  long best_cost = -1;
+  for (int S = 1; S <= 16 && S * 8 <= KB; ++S) {
+    const long cost = ((tiles * S + 255) / 256) * ((KB + S - 1) / S + 6);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = S; }
+  }
+  return best;
+}
+
+extern "C" int pt_conv_bf16x6_splits(int B, int Hs, int Ws, int Cin, int Cout, int KH, int KW, int stride, int pad, int tile_rows) {
+  if (B <= 0 || Hs <= 0 || Ws <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return 1;
+  const int Ho = (Hs + 2 * pad - KH) / stride + 1, Wo = (Ws + 2 * pad - KW) / stride + 1;
+  if (Ho <= 0 || Wo <= 0) return 1;
+  const long M = (long)B * Ho * Wo;
+  if (tile_rows <= 0) tile_rows = pt_gemm_bf16x6_tile_rows((int)M, Cout);
+  return conv_splits(M, Cout, KH * KW * (Cin / 32), tile_rows);
+}
+
 extern "C" int pt_conv_bf16x6(const pt_conv_desc* d, void* stream) {
   int rc = conv_check(d, "pt_conv_bf16x6");
   if (rc != PT_OK) return rc;
@@ -1061,12 +1264,30 @@ extern "C" int pt_conv_bf16x6(const pt_conv_desc* d, void* stream) {
   ep.zero_row = (d->out_planes && !d->scatter_stride) ? (int)M : -1;      // (a scattered result lands in a buffer the caller zeroed)
   int tile_rows = d->tile_rows;
   if (tile_rows <= 0) tile_rows = pt_gemm_bf16x6_tile_rows((int)M, d->Cout);
-  PT_REQUIRE(tile_rows % 32 == 0 && tile_rows >= 96 && tile_rows <= 256, PT_EINVAL, "pt_conv_bf16x6: tile_rows in {96, 128, ..., 256}");
+  PT_REQUIRE(tile_rows % 32 == 0 && tile_rows >= 64 && tile_rows <= 256, PT_EINVAL, "pt_conv_bf16x6: tile_rows in {64, 96, ..., 256}");
   const ConvGeom cg{d->Hs, d->Ws, Ho, Wo, d->Cin, d->Cin / 32, d->KW, taps, d->stride, d->pad, (int)Ps};
-  rc = launch_by_rows<true>(tile_rows, d->x_planes, d->w_planes, nullptr, nullptr, nullptr, (int)M, d->Cout, taps * (d->Cin / 32), d->x_plane_stride,
+  const int KB = taps * (d->Cin / 32);
+  int S = d->splits;
+  if (S <= 0) S = d->workspace ? conv_splits(M, d->Cout, KB, tile_rows) : 1;
+  if (S > KB) S = KB;
+  if (S > 1) {
+    PT_REQUIRE(d->workspace && (((uintptr_t)d->workspace) & 15) == 0 && d->workspace_elems >= (int64_t)S * M * d->Cout, PT_EINVAL,
+               "pt_conv_bf16x6: a split-k launch needs a 16-byte aligned workspace of splits * M * Cout floats");
+    ep.part = d->workspace;
+    ep.splits = S;
+    ep.ks_per = (KB + S - 1) / S;
+  }
+  rc = launch_by_rows<true>(tile_rows, d->x_planes, d->w_planes, nullptr, nullptr, nullptr, (int)M, d->Cout, KB, d->x_plane_stride,
                             d->w_plane_stride, d->Cout, 0, cg, ep, as_stream(stream));
   PT_REQUIRE(rc == 0, rc, "pt_conv_bf16x6: hipFuncSetAttribute failed (%d)", rc);
   PT_LAUNCH_CHECK("pt_conv_bf16x6");
+  if (S > 1) {
+    const long items = M * (d->Cout >> 3);
+    int nb = cdiv(items, 256);
+    nb = nb > 8192 ? 8192 : nb;
+    hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(nb), dim3(256), 0, as_stream(stream), (int)M, d->Cout, ep);
+    PT_LAUNCH_CHECK("pt_conv_bf16x6 (split-k finish)");
+  }
   return PT_OK;
 }
 
@@ -1129,8 +1350,9 @@ extern "C" int pt_conv_wgrad_bf16x6(const pt_conv_wgrad_desc* d, void* stream) {
   WgradGeom wg{d->Hs, d->Ws, Ho, Wo, d->Cin, d->Cout, d->KW, taps, d->stride, d->pad, (int)P, (int)Ps, kbt, (kbt + S - 1) / S, d->Cout / bm,
                taps * d->Cin / GBN, d->dbias ? 1 : 0};
   float* part_bias = d->workspace + (long)S * n;
-  const int rc = bm == 256 ? launch_wgrad<8>(d->gy_planes, d->x_planes, d->workspace, part_bias, d->gy_plane_stride, d->x_plane_stride, wg, S, as_stream(stream))
-                           : launch_wgrad<4>(d->gy_planes, d->x_planes, d->workspace, part_bias, d->gy_plane_stride, d->x_plane_stride, wg, S, as_stream(stream));
+  const int rc = bm == 256 ? launch_wgrad<8, 2>(d->gy_planes, d->x_planes, d->workspace, part_bias, d->gy_plane_stride, d->x_plane_stride, wg, S, as_stream(stream))
+                 : ring3_enabled() ? launch_wgrad<4, 3>(d->gy_planes, d->x_planes, d->workspace, part_bias, d->gy_plane_stride, d->x_plane_stride, wg, S, as_stream(stream))
+                                   : launch_wgrad<4, 2>(d->gy_planes, d->x_planes, d->workspace, part_bias, d->gy_plane_stride, d->x_plane_stride, wg, S, as_stream(stream));
   PT_REQUIRE(rc == 0, rc, "pt_conv_wgrad_bf16x6: hipFuncSetAttribute failed (%d)", rc);
   PT_LAUNCH_CHECK("pt_conv_wgrad_bf16x6");
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n / 4 + nbias / 4, 256)), dim3(256), 0, as_stream(stream),

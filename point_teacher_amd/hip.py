@@ -126,7 +126,7 @@ def call(fn, *args):
         conv.append(torch.cuda.current_stream().cuda_stream)
     rc = getattr(_lib, fn)(*conv)
     if restype is ctypes.c_int and fn not in ('pt_abi_version', 'pt_focal_nblocks', 'pt_sqnorm_nblocks', 'pt_affine_train_rows', 'pt_gemm_bf16x6_tile_rows',
-                                            'pt_conv3x3_wgrad_bf16x6_splits', 'pt_conv_wgrad_bf16x6_splits') and rc != 0:
+                                            'pt_conv3x3_wgrad_bf16x6_splits', 'pt_conv_wgrad_bf16x6_splits', 'pt_conv_bf16x6_splits') and rc != 0:
         raise RuntimeError(f'{fn} failed (code {rc}): {last_error()}')
     return rc
 

@@ -75,7 +75,7 @@ def _new_planes(rows, C, device, zero=False):
 
 
 def launch_conv(x_t, B, Hs, Ws, Cin, wp, Cout, K, stride, pad, scale=None, shift=None, res_planes=None, res_f32=None,
-                mask_planes=None, relu=False, want_planes=False, want_f32=False, scatter=None, tile_rows=0):
+                mask_planes=None, relu=False, want_planes=False, want_f32=False, scatter=None, tile_rows=0, splits=None):
     """pt_conv_bf16x6: x_t row-major planes of [B*Hs*Ws (+1), Cin]; wp SplitPlanes of the weight.  -> (planes or None, fp32 rows or
     None).  scatter = (H, W): a stride-2 input gradient placed at (2y, 2x) of a zeroed [B, H, W] grid."""
     Ho, Wo = out_hw(Hs, Ws, K, stride, pad)
@@ -99,6 +99,12 @@ def launch_conv(x_t, B, Hs, Ws, Cin, wp, Cout, K, stride, pad, scale=None, shift
     if scatter is not None:
         d.scatter_stride, d.scatter_H, d.scatter_W = 2, scatter[0], scatter[1]
     d.tile_rows = int(tile_rows)
+    S = hip.call('pt_conv_bf16x6_splits', B, Hs, Ws, Cin, Cout, K, K, stride, pad, int(tile_rows)) if splits is None else int(splits)
+    if S > 1:
+        ws = torch.empty((S * M * Cout,), dtype=f32, device=dev)
+        d.workspace, d.workspace_elems, d.splits = hip.dptr(ws, 'float'), ws.numel(), S
+    else:
+        d.splits = 1
     assert wp.rows == Cout and wp.k == K * K * Cin, (wp.rows, wp.k, Cout, K, Cin)
     assert x_t.shape[1] >= (B * Hs * Ws + 1) * Cin
     if mask_planes is not None:
