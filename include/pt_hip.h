@@ -134,6 +134,13 @@ int pt_delta2bbox_bwd(const float* rois, const float* deltas, const float* grad_
 int pt_roi_align_fwd(const float* feat, const float* rois, int B, int C, int H, int W, int K,
                      int out_size, float spatial_scale, int sampling_ratio, int aligned,
                      int channels_last, int group, float* out, void* stream);
+/* The out-7 channels_last forward writing the RoI blocks as three bf16 planes (x = x0 + x1 + x2 exactly; row-major
+ * [3][(K + 1) * C * 49], row K zeros) - the operand format of the FC stack's matrix kernel (pt_conv_bf16x6 with the RoIs as pixels
+ * of a 1 x 1 convolution, fcos_head_p2b_ts.py:1202-1236): neither the fp32 block [K, C, 7, 7] nor a split pass over it touches HBM.
+ * Same values as pt_roi_align_fwd (the planes sum to them bit for bit).  feat [B,H,W,C]; C * 49 a multiple of 8. */
+int pt_roi_align_fwd_planes(const float* feat, const float* rois, int B, int C, int H, int W, int K, float spatial_scale,
+                            int sampling_ratio, int aligned, int group, uint16_t* planes, int64_t plane_stride,
+                            void* stream);
 int pt_roi_align_bwd(const float* grad_out, const float* rois, int B, int C, int H, int W, int K,
                      int out_size, float spatial_scale, int sampling_ratio, int aligned,
                      int channels_last, int group, float* grad_feat, void* stream);

@@ -40,24 +40,6 @@ constexpr int GK = 32;              // k-step (bf16 elements): 64 bytes per row 
 constexpr int GBN = 128;            // tile columns
 constexpr int GTHREADS = 512;
 
-__device__ __forceinline__ unsigned bf16_rne_pair(float a, float b) {
-  // v_cvt_pk_bf16_f32: two fp32 -> packed bf16 (a in the low half), round to nearest even, NaN stays NaN
-  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-  bf16x2_t v;
-  v[0] = (__bf16)a;
-  v[1] = (__bf16)b;
-  return __builtin_bit_cast(unsigned, v);
-}
-
-// x -> (x0, x1, x2) for two values at once; planes receive the packed pairs
-__device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
-  p0 = bf16_rne_pair(a, b);
-  const float a1 = a - __uint_as_float(p0 << 16), b1 = b - __uint_as_float(p0 & 0xffff0000u);   // exact
-  p1 = bf16_rne_pair(a1, b1);
-  const float a2 = a1 - __uint_as_float(p1 << 16), b2 = b1 - __uint_as_float(p1 & 0xffff0000u); // exact
-  p2 = bf16_rne_pair(a2, b2);
-}
-
 // ---------------------------------------------------------------------------------------------- split --
 // Plane layout ("blocked"): [3 planes][RB = ceil(rows / 16)][KB = ceil(k / 32)][16 rows][4 slots][8 bf16] - every (16 rows x 32 k)
 // block is 1 KiB of CONTIGUOUS memory in exactly the order it will have in LDS, the 16-byte k-slot of a row XOR-swizzled with
@@ -1263,7 +1245,12 @@ extern "C" int pt_conv_bf16x6(const pt_conv_desc* d, void* stream) {
   ep.relu = d->relu;
   ep.zero_row = (d->out_planes && !d->scatter_stride) ? (int)M : -1;      // (a scattered result lands in a buffer the caller zeroed)
   int tile_rows = d->tile_rows;
-  if (tile_rows <= 0) tile_rows = pt_gemm_bf16x6_tile_rows((int)M, d->Cout);
+  if (tile_rows <= 0) {
+    tile_rows = pt_gemm_bf16x6_tile_rows((int)M, d->Cout);
+    // a reduce dimension of <= 128 with many rows (a Bottleneck's expanding 1 x 1, the input gradient of its reducing one) is bound
+    // by its epilogue's HBM traffic: 64-row tiles fit two workgroups per CU, one's stores overlap the other's products
+    if (taps * (d->Cin / 32) <= 4 && M >= 16384 && d->Cout >= 256) tile_rows = 64;
+  }
   PT_REQUIRE(tile_rows % 32 == 0 && tile_rows >= 64 && tile_rows <= 256, PT_EINVAL, "pt_conv_bf16x6: tile_rows in {64, 96, ..., 256}");
   const ConvGeom cg{d->Hs, d->Ws, Ho, Wo, d->Cin, d->Cin / 32, d->KW, taps, d->stride, d->pad, (int)Ps};
   const int KB = taps * (d->Cin / 32);
@@ -1302,15 +1289,19 @@ extern "C" int pt_conv3x3_bf16x6_nhwc(const uint16_t* x_planes, int64_t x_plane_
   return pt_conv_bf16x6(&d, stream);
 }
 
-// Pixel chunks of the weight gradient: about two workgroups per CU, at least 16 k-steps (512 pixels) each.
+// Pixel chunks of the weight gradient: the count that minimises (rounds of 256 workgroups) x (k-steps per workgroup + ~6 k-steps'
+// worth of prologue, partial-tile store and its share of the reduction), every chunk at least 4 k-steps (128 pixels).
 static int wgrad_splits(long P, int taps, int Cin, int Cout) {
   const int kbt = (int)((P + 31) / 32);
   const int bm = Cout % 256 == 0 ? 256 : 128;
-  const int per = (Cout / bm) * (taps * Cin / GBN);
-  int S = (512 + per / 2) / (per > 0 ? per : 1);
-  const int cap = kbt / 16;
-  if (S > cap) S = cap;
-  return S < 1 ? 1 : S;
+  const long per = (long)(Cout / bm) * (taps * Cin / GBN);
+  int best = 1;
+  long best_cost = -1;
+  for (int S = 1; S <= 128 && (S == 1 || S * 4 <= kbt); ++S) {
+    const long cost = ((per * S + 255) / 256) * ((kbt + S - 1) / S + 6);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = S; }
+  }
+  return best;
 }
 
 extern "C" int pt_conv3x3_wgrad_bf16x6_splits(int B, int H, int W, int Cin, int Cout) {
@@ -1349,12 +1340,16 @@ extern "C" int pt_conv_wgrad_bf16x6(const pt_conv_wgrad_desc* d, void* stream) {
   const int bm = d->Cout % 256 == 0 ? 256 : 128;
   WgradGeom wg{d->Hs, d->Ws, Ho, Wo, d->Cin, d->Cout, d->KW, taps, d->stride, d->pad, (int)P, (int)Ps, kbt, (kbt + S - 1) / S, d->Cout / bm,
                taps * d->Cin / GBN, d->dbias ? 1 : 0};
-  float* part_bias = d->workspace + (long)S * n;
-  const int rc = bm == 256 ? launch_wgrad<8, 2>(d->gy_planes, d->x_planes, d->workspace, part_bias, d->gy_plane_stride, d->x_plane_stride, wg, S, as_stream(stream))
-                 : ring3_enabled() ? launch_wgrad<4, 3>(d->gy_planes, d->x_planes, d->workspace, part_bias, d->gy_plane_stride, d->x_plane_stride, wg, S, as_stream(stream))
-                                   : launch_wgrad<4, 2>(d->gy_planes, d->x_planes, d->workspace, part_bias, d->gy_plane_stride, d->x_plane_stride, wg, S, as_stream(stream));
+  // one chunk and nothing to apply afterwards: the tiles ARE the result
+  const bool direct = S == 1 && !d->row_scale && !d->accumulate;
+  float* part = direct ? d->dw : d->workspace;
+  float* part_bias = direct ? d->dbias : d->workspace + (long)S * n;
+  const int rc = bm == 256 ? launch_wgrad<8, 2>(d->gy_planes, d->x_planes, part, part_bias, d->gy_plane_stride, d->x_plane_stride, wg, S, as_stream(stream))
+                 : ring3_enabled() ? launch_wgrad<4, 3>(d->gy_planes, d->x_planes, part, part_bias, d->gy_plane_stride, d->x_plane_stride, wg, S, as_stream(stream))
+                                   : launch_wgrad<4, 2>(d->gy_planes, d->x_planes, part, part_bias, d->gy_plane_stride, d->x_plane_stride, wg, S, as_stream(stream));
   PT_REQUIRE(rc == 0, rc, "pt_conv_wgrad_bf16x6: hipFuncSetAttribute failed (%d)", rc);
   PT_LAUNCH_CHECK("pt_conv_wgrad_bf16x6");
+  if (direct) return PT_OK;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n / 4 + nbias / 4, 256)), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const float4*>(d->workspace), S, n / 4, taps * d->Cin / 4, reinterpret_cast<float4*>(d->dw), d->row_scale,
                      reinterpret_cast<const float4*>(part_bias), (int)(nbias / 4), reinterpret_cast<float4*>(d->dbias), d->accumulate);

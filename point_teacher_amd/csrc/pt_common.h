@@ -66,6 +66,27 @@ __device__ __forceinline__ float block_sum(float v, float* sm) {
   return t;
 }
 
+// fp32 -> three bf16 terms x = x0 + x1 + x2 (8 + 8 + 8 significant bits, round-to-nearest at each step, exact): the operand format of
+// the bf16x6 matrix kernels (csrc/gemm_split.hip)
+__device__ __forceinline__ unsigned bf16_rne_pair(float a, float b) {
+  // v_cvt_pk_bf16_f32: two fp32 -> packed bf16 (a in the low half), round to nearest even, NaN stays NaN
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  bf16x2_t v;
+  v[0] = (__bf16)a;
+  v[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, v);
+}
+
+// x -> (x0, x1, x2) for two values at once; planes receive the packed pairs
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+  p0 = bf16_rne_pair(a, b);
+  const float a1 = a - __uint_as_float(p0 << 16), b1 = b - __uint_as_float(p0 & 0xffff0000u);   // exact
+  p1 = bf16_rne_pair(a1, b1);
+  const float a2 = a1 - __uint_as_float(p1 << 16), b2 = b1 - __uint_as_float(p1 & 0xffff0000u); // exact
+  p2 = bf16_rne_pair(a2, b2);
+}
+
+
 // sigmoid exactly as torch's CPU/CUDA kernels compute it: 1 / (1 + exp(-x))
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 

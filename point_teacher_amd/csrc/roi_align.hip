@@ -345,6 +345,21 @@ __device__ __forceinline__ void tile_store(const float* __restrict__ tile, float
     for (int i = threadIdx.x; i < nf; i += blockDim.x) dst[i] = tile[i];
   }
 }
+// The same block as three bf16 planes (x = x0 + x1 + x2): what the FC stack's matrix kernel stages (csrc/gemm_split.hip), so
+// neither the fp32 block nor a split pass over it ever touches HBM.  nf % 8 == 0, dst 16-byte aligned.
+__device__ __forceinline__ void tile_store_planes(const float* __restrict__ tile, uint16_t* __restrict__ dst, long plane, int nf) {
+  for (int i = threadIdx.x; i < (nf >> 3); i += blockDim.x) {
+    const float4 lo = *reinterpret_cast<const float4*>(tile + 8 * i), hi = *reinterpret_cast<const float4*>(tile + 8 * i + 4);
+    uint4 o0, o1, o2;
+    split_pair(lo.x, lo.y, o0.x, o1.x, o2.x);
+    split_pair(lo.z, lo.w, o0.y, o1.y, o2.y);
+    split_pair(hi.x, hi.y, o0.z, o1.z, o2.z);
+    split_pair(hi.z, hi.w, o0.w, o1.w, o2.w);
+    *reinterpret_cast<uint4*>(dst + 8 * i) = o0;
+    *reinterpret_cast<uint4*>(dst + plane + 8 * i) = o1;
+    *reinterpret_cast<uint4*>(dst + 2 * plane + 8 * i) = o2;
+  }
+}
 __device__ __forceinline__ void tile_load(float* __restrict__ tile, const float* __restrict__ src, int nf) {
   if (((nf & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
     float4* t4 = reinterpret_cast<float4*>(tile);
@@ -482,11 +497,17 @@ __device__ void rows_path(const float* __restrict__ gout, int k0, int m, int C, 
 
 __global__ void __launch_bounds__(256)
     roi_align7_fwd(const float* __restrict__ feat, const float* __restrict__ rois, int B, int C, int H, int W, int K,
-                   int gs, float scale, int sampling_ratio, int aligned, float* __restrict__ out, int tile_bytes) {
+                   int gs, float scale, int sampling_ratio, int aligned, float* __restrict__ out, int tile_bytes,
+                   uint16_t* __restrict__ out_planes, long plane) {
   extern __shared__ __align__(16) unsigned char smem[];
   float* tile = reinterpret_cast<float*>(smem);                       // [<=256][49]
   Roi7Lds& S = *reinterpret_cast<Roi7Lds*>(smem + tile_bytes);
   const int k0 = blockIdx.x * gs, n = min(gs, K - k0);
+  if (out_planes && blockIdx.x == 0) {                                 // row K of the planes: the zero row the matrix kernels read
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (int i = threadIdx.x; i < (C * 49) >> 3; i += blockDim.x)
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(out_planes + p * plane + (size_t)K * C * 49 + 8 * i) = z;
+  }
   run_setup(rois, k0, n, B, H, W, scale, sampling_ratio, aligned, S);
   const bool path_a = S.ub[5] != 0;
   const int ux = S.ub[0], uy = S.ub[1], ub = S.ub[4];
@@ -526,7 +547,8 @@ __global__ void __launch_bounds__(256)
             }
         }
         __syncthreads();
-        tile_store(tile, out + ((size_t)(k0 + r) * C + c0) * 49, nc * 49);
+        if (out_planes) tile_store_planes(tile, out_planes + ((size_t)(k0 + r) * C + c0) * 49, plane, nc * 49);
+        else tile_store(tile, out + ((size_t)(k0 + r) * C + c0) * 49, nc * 49);
         __syncthreads();
       }
     } else {
@@ -620,7 +642,8 @@ __global__ void __launch_bounds__(256)
           }
         }
         __syncthreads();
-        tile_store(tile, out + ((size_t)(k0 + r) * C + c0) * 49, nc * 49);
+        if (out_planes) tile_store_planes(tile, out_planes + ((size_t)(k0 + r) * C + c0) * 49, plane, nc * 49);
+        else tile_store(tile, out + ((size_t)(k0 + r) * C + c0) * 49, nc * 49);
         __syncthreads();
       }
     }
@@ -909,7 +932,7 @@ extern "C" int pt_roi_align_fwd(const float* feat, const float* rois, int B, int
     if (e != hipSuccess) { set_error("pt_roi_align_fwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
     const int gs = run_length(group, K, 2048);
     hipLaunchKernelGGL(roi_align7_fwd, dim3(cdiv(K, gs)), dim3(256), ROI7_LDS, s, feat, rois, B, C, H, W, K, gs,
-                       spatial_scale, sampling_ratio, aligned, out, ROI7_TILE_BYTES);
+                       spatial_scale, sampling_ratio, aligned, out, ROI7_TILE_BYTES, (uint16_t*)nullptr, 0L);
   } else if (channels_last) {
     const size_t lds = (size_t)(C + 1) * out_size * out_size * sizeof(float);
     hipError_t e = roi_generic_attr();
@@ -925,6 +948,28 @@ extern "C" int pt_roi_align_fwd(const float* feat, const float* rois, int B, int
                        spatial_scale, sampling_ratio, aligned, out);
   }
   PT_LAUNCH_CHECK("pt_roi_align_fwd");
+  return PT_OK;
+}
+
+extern "C" int pt_roi_align_fwd_planes(const float* feat, const float* rois, int B, int C, int H, int W, int K, float spatial_scale,
+                                       int sampling_ratio, int aligned, int group, uint16_t* planes, int64_t plane_stride,
+                                       void* stream) {
+  PT_REQUIRE(planes && K >= 0 && C > 0 && (C * 49) % 8 == 0 && plane_stride >= (int64_t)(K + 1) * C * 49 && (plane_stride & 7) == 0 &&
+                 (((uintptr_t)planes) & 15) == 0,
+             PT_EINVAL, "pt_roi_align_fwd_planes: planes of (K + 1) * C * 49 elements each, 16-byte aligned, C * 49 a multiple of 8");
+  if (K == 0) {
+    for (int p = 0; p < 3; ++p)
+      if (hipMemsetAsync(planes + p * plane_stride, 0, (size_t)C * 49 * 2, as_stream(stream)) != hipSuccess) return PT_EINVAL;
+    return PT_OK;
+  }
+  int rc = roi_check("pt_roi_align_fwd_planes", feat, rois, planes, B, C, H, W, K, NB, 1);
+  if (rc) return rc;
+  hipError_t e = roi7_attr();
+  if (e != hipSuccess) { set_error("pt_roi_align_fwd_planes: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+  const int gs = run_length(group, K, 2048);
+  hipLaunchKernelGGL(roi_align7_fwd, dim3(cdiv(K, gs)), dim3(256), ROI7_LDS, as_stream(stream), feat, rois, B, C, H, W, K, gs, spatial_scale,
+                     sampling_ratio, aligned, (float*)nullptr, ROI7_TILE_BYTES, planes, (long)plane_stride);
+  PT_LAUNCH_CHECK("pt_roi_align_fwd_planes");
   return PT_OK;
 }
 

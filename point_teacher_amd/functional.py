@@ -405,6 +405,47 @@ class _RoIAlign(torch.autograd.Function):
         return gfeat.to(in_dtype), None, None, None, None, None, None
 
 
+class _RoIAlignPlanes(torch.autograd.Function):
+    """The out-7 channels_last RoIAlign whose result leaves as the split planes of the [K, C * 49] operand of the FC stack
+    (pt_roi_align_fwd_planes) - no fp32 block, no split pass.  Its gradient arrives in a CARRIER: a tensor of the planes' shape
+    whose first K * C * 49 * 4 bytes hold the fp32 gradient block [K, C, 7, 7] (planes._PlaneConv with `x_gcarrier`); autograd only
+    checks shape and dtype."""
+
+    @staticmethod
+    def forward(ctx, feat, rois, scale, sampling_ratio, aligned, group):
+        B, C, H, W = feat.shape
+        assert feat.dtype == f32 and feat.is_contiguous(memory_format=torch.channels_last)
+        fbuf = feat.permute(0, 2, 3, 1)
+        rois = _f(rois)
+        K = rois.shape[0]
+        n = (K + 1) * C * 49
+        t = torch.empty((3, n), dtype=torch.bfloat16, device=feat.device)
+        hip.call('pt_roi_align_fwd_planes', fbuf, rois, B, C, H, W, K, float(scale), sampling_ratio, int(aligned), int(group), t, n)
+        ctx.save_for_backward(rois)
+        ctx.cfg = (B, C, H, W, float(scale), sampling_ratio, int(aligned), int(group))
+        return t
+
+    @staticmethod
+    def backward(ctx, carrier):
+        rois, = ctx.saved_tensors
+        B, C, H, W, scale, sr, aligned, group = ctx.cfg
+        K = rois.shape[0]
+        g = carrier.contiguous().view(-1).view(f32)[:K * C * 49]
+        gbuf = torch.zeros((B, H, W, C), dtype=f32, device=g.device)
+        hip.call('pt_roi_align_bwd', g, rois, B, C, H, W, K, 7, scale, sr, aligned, 1, group, gbuf)
+        return gbuf.permute(0, 3, 1, 2), None, None, None, None, None
+
+
+def roi_align_planes_ok(feat, rois, output_size):
+    return (output_size == 7 and feat.is_cuda and feat.dtype == f32 and feat.dim() == 4 and (feat.shape[1] * 49) % 128 == 0
+            and feat.is_contiguous(memory_format=torch.channels_last) and not torch.is_autocast_enabled())
+
+
+def roi_align_planes(feat, rois, spatial_scale=1.0, sampling_ratio=0, aligned=True, group=1):
+    """-> bf16 [3, (K + 1) * C * 49]: row-major split planes of roi_align(...).flatten(1) (+ a zero row)."""
+    return _RoIAlignPlanes.apply(feat, rois, spatial_scale, int(sampling_ratio), bool(aligned), int(group))
+
+
 def roi_align(feat, rois, output_size=7, spatial_scale=1.0, sampling_ratio=0, aligned=True, group=1):
     """mmcv.ops.roi_align(input, rois, output_size, spatial_scale, sampling_ratio, 'avg', aligned).
     `group`: how many consecutive RoIs belong together (the U2 boxes of one MIL bag overlap); a locality hint, any value
@@ -648,8 +689,14 @@ class _ConvWeightPlanes:
     @staticmethod
     def ok(w):
         O, I = w.shape[:2]
+        if w.dim() == 2:                                         # a Linear weight = the weight of a 1x1 convolution over rows
+            return w.is_cuda and w.dtype == f32 and I % 32 == 0 and O % 32 == 0 and w.is_contiguous()
         return (w.is_cuda and w.dtype == f32 and w.dim() == 4 and tuple(w.shape[2:]) in ((3, 3), (1, 1)) and I % 32 == 0 and O % 32 == 0
                 and w.permute(0, 2, 3, 1).is_contiguous())
+
+    @staticmethod
+    def taps(w):
+        return w.shape[2] * w.shape[3] if w.dim() == 4 else 1
 
     def _build_table(self):
         rec = np.zeros(len(self.ent), dtype=np.dtype([('w', '<u8'), ('dst', '<u8'), ('plane', '<i8'), ('O', '<i4'), ('I', '<i4'),
@@ -660,7 +707,7 @@ class _ConvWeightPlanes:
         for i, ((_, mode, _sp), (ref, ptr, sp, scale, _ver)) in enumerate(self.ent.items()):
             w = ref()
             O, I = w.shape[:2]
-            taps = w.shape[2] * w.shape[3]
+            taps = self.taps(w)
             rows, k = (I, taps * O) if mode else (O, taps * I)
             rec[i] = (ptr, sp.planes.data_ptr(), sp.planes.shape[1], O, I, mode, first, taps, 0, scale.data_ptr() if scale is not None else 0)
             first += ((rows + 15) // 16) * (k // 32)
@@ -683,7 +730,7 @@ class _ConvWeightPlanes:
             # drop entries whose weight is gone or moved, then register this triple with planes of its own
             self.ent = {k: v for k, v in self.ent.items() if self._alive(v) and k != key}
             O, I = w.shape[:2]
-            taps = w.shape[2] * w.shape[3]
+            taps = self.taps(w)
             rows, k = (I, taps * O) if mode else (O, taps * I)
             n = ((rows + 15) // 16) * ((k + 31) // 32) * 512
             sp = SplitPlanes(torch.empty((3, n), dtype=torch.bfloat16, device=w.device), rows, k)

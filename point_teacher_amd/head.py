@@ -12,6 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as TF
 
 from . import functional as F
+from . import planes as PL
 from .core import (bbox2roi, bbox_cxcywh_to_xyxy, bbox_overlaps, bbox_xyxy_to_cxcywh, distance2bbox, mean0, multi_apply,
                    multiclass_nms, reduce_mean, reduce_mean_many)
 from .losses import diou_forward_masked
@@ -20,6 +21,7 @@ from .proposals import MIL_gen_proposals_from_cfg
 from .registry import HEADS, build_assigner, build_bbox_coder, build_loss, build_roi_extractor
 
 _SPLIT_GEMM = os.environ.get('PT_SPLIT_GEMM', '1') != '0'
+_PLANE_FC = _SPLIT_GEMM and os.environ.get('PT_PLANE_FC', '1') != '0'       # 0: the round-3 routing (fp32 RoI blocks, blocked-plane GEMMs)
 
 INF = 1e8
 
@@ -309,6 +311,14 @@ class TS_P2BFCOSHead(nn.Module):
         split-bf16 MFMA products with fp32 accumulation (`functional.split_linear`, csrc/gemm_split.hip: error against float64
         below the fp32 library kernel's, 1.4-1.6x its speed at K >= 5 000 RoIs); bias + ReLU are the GEMM's epilogue.
         PT_SPLIT_GEMM=0: library GEMMs."""
+        if isinstance(x, PL.PlaneAct) or (_PLANE_FC and x.is_cuda and x.dtype == torch.float32 and x.shape[0] >= self.SPLIT_GEMM_MIN_ROWS
+                                          and all(PL.linear_ok(fc, x.shape[0]) for fc in fcs)):
+            # the RoI blocks arrive as split planes (RoIAlign wrote them) and stay planes between the layers: every product is a
+            # 1x1 convolution over the RoIs on pt_conv_bf16x6, bias + ReLU in its epilogue; backward: ReLU masks in the epilogues,
+            # weight AND bias gradients from pt_conv_wgrad_bf16x6 (no transposed split, no column-sum pass)
+            for i, fc in enumerate(fcs):
+                x = PL.linear(x, fc, relu=True, out_planes=i + 1 < len(fcs))
+            return x
         use = x.is_cuda and x.dtype == torch.float32 and x.shape[0] >= self.SPLIT_GEMM_MIN_ROWS and _SPLIT_GEMM
         for fc in fcs:
             if use:
@@ -316,6 +326,16 @@ class TS_P2BFCOSHead(nn.Module):
             else:
                 x = TF.relu(fc(x), inplace=True)
         return x
+
+    def _roi_feats(self, x, rois, group=1):
+        """RoI blocks [K, C * 49] for an FC stack: as split planes straight from RoIAlign when the stack runs on the plane kernels
+        (K >= SPLIT_GEMM_MIN_ROWS on the MI355X), else the flattened fp32 block."""
+        ext = self.bbox_roi_extractor
+        if (_PLANE_FC and rois.shape[0] >= self.SPLIT_GEMM_MIN_ROWS and ext.num_inputs == 1 and type(ext).__name__ == 'SingleRoIExtractor'
+                and x[0].is_cuda and not torch.is_autocast_enabled()):
+            f = ext(x[:1], rois, group=group, planes=True)
+            return f if isinstance(f, PL.PlaneAct) else f.flatten(1)
+        return ext(x[:ext.num_inputs], rois, group=group).flatten(1)
 
     @staticmethod
     def _bag_group(U1, U2):
@@ -350,7 +370,7 @@ class TS_P2BFCOSHead(nn.Module):
             wgt, avg = valid.float() * bw, wsum
         bbox_results['extensive_shaking_num'] = U2 = num_aug
         rois = bbox2roi(ext)
-        feats = self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois, group=self._bag_group(U1, U2)).flatten(1)
+        feats = self._roi_feats(x, rois, group=self._bag_group(U1, U2))
         bbox_pred = self.fc_reg[stage](self._fc_stack(self.shared_fcs_reg[stage], feats))
         del feats
         bbox_pred = self.mil_bbox_decoder.decode(bags, bbox_pred, max_shape=img_metas[0]['img_shape'])
@@ -372,9 +392,7 @@ class TS_P2BFCOSHead(nn.Module):
         """:1240-1256"""
         rois = bbox2roi(bbox_results['extensive_bags'])
         U1, U2 = bbox_results['base_shaking_num'], bbox_results['extensive_shaking_num']
-        feats = self._fc_stack(self.shared_fcs_bag[stage],
-                               self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois,
-                                                       group=self._bag_group(U1, U2)).flatten(1))
+        feats = self._fc_stack(self.shared_fcs_bag[stage], self._roi_feats(x, rois, group=self._bag_group(U1, U2)))
         bbox_results['cls_score'] = self.fc_cls[stage](feats).view(num_gt, U1, U2, self.num_classes)
         bbox_results['ins_score'] = self.fc_ins[stage](feats).view(num_gt, U1, U2, self.num_classes)
 

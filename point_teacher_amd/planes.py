@@ -25,10 +25,12 @@ bf16 = torch.bfloat16
 class PlaneAct:
     """An NHWC activation [B, H, W, C] as row-major split planes `t` = bf16 [3, (B*H*W + 1) * C]; `relu`: its values went through a
     ReLU (so `plane 0 > 0` is the mask its gradient needs)."""
-    __slots__ = ('t', 'B', 'H', 'W', 'C', 'relu')
+    __slots__ = ('t', 'B', 'H', 'W', 'C', 'relu', 'gcarrier')
+    dtype = f32                         # what the planes represent
 
-    def __init__(self, t, B, H, W, C, relu):
+    def __init__(self, t, B, H, W, C, relu, gcarrier=False):
         self.t, self.B, self.H, self.W, self.C, self.relu = t, B, H, W, C, relu
+        self.gcarrier = gcarrier         # the gradient of `t` travels as fp32 inside a tensor of t's shape (functional._RoIAlignPlanes)
 
     @property
     def P(self):
@@ -75,7 +77,7 @@ def _new_planes(rows, C, device, zero=False):
 
 
 def launch_conv(x_t, B, Hs, Ws, Cin, wp, Cout, K, stride, pad, scale=None, shift=None, res_planes=None, res_f32=None,
-                mask_planes=None, relu=False, want_planes=False, want_f32=False, scatter=None, tile_rows=0, splits=None):
+                mask_planes=None, relu=False, want_planes=False, want_f32=False, scatter=None, tile_rows=0, splits=None, f32_out=None):
     """pt_conv_bf16x6: x_t row-major planes of [B*Hs*Ws (+1), Cin]; wp SplitPlanes of the weight.  -> (planes or None, fp32 rows or
     None).  scatter = (H, W): a stride-2 input gradient placed at (2y, 2x) of a zeroed [B, H, W] grid."""
     Ho, Wo = out_hw(Hs, Ws, K, stride, pad)
@@ -84,6 +86,9 @@ def launch_conv(x_t, B, Hs, Ws, Cin, wp, Cout, K, stride, pad, scale=None, shift
     dev = x_t.device
     out_p = _new_planes(rows, Cout, dev, zero=scatter is not None) if want_planes else None
     out_f = (torch.zeros if scatter is not None else torch.empty)((rows, Cout), dtype=f32, device=dev) if want_f32 else None
+    if f32_out is not None:                                   # a caller-provided fp32 buffer of rows * Cout elements
+        assert f32_out.numel() == rows * Cout and f32_out.dtype == f32 and scatter is None
+        out_f = f32_out
     d = hip.STRUCTS['pt_conv_desc']()
     d.B, d.Hs, d.Ws, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad, d.relu = B, Hs, Ws, Cin, Cout, K, K, stride, pad, int(bool(relu))
     d.x_planes, d.x_plane_stride = hip.dptr(x_t, 'uint16_t'), x_t.shape[1]
@@ -187,7 +192,7 @@ class _PlanesToF32(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------ single convolution --
 class ConvCfg:
     """Static description of one plane convolution call (not a tensor: autograd passes it through)."""
-    __slots__ = ('B', 'H', 'W', 'Cin', 'Cout', 'K', 'stride', 'pad', 'relu', 'x_planes', 'x_relu', 'out_planes', 'scale', 'bias_grad')
+    __slots__ = ('B', 'H', 'W', 'Cin', 'Cout', 'K', 'stride', 'pad', 'relu', 'x_planes', 'x_relu', 'out_planes', 'scale', 'bias_grad', 'x_gcarrier')
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -232,12 +237,20 @@ class _PlaneConv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             assert c.stride == 1, 'the single-consumer plane convolution back-propagates stride 1 only'
             wd = F._conv_weight_planes(w, True, c.scale)
-            gp, gf = launch_conv(E, c.B, Ho, Wo, c.Cout, wd, c.Cin, c.K, 1, c.K - 1 - c.pad,
-                                 mask_planes=xt if (c.x_planes and c.x_relu) else None, want_planes=c.x_planes, want_f32=not c.x_planes)
-            gx = gp if c.x_planes else gf.view(c.B, c.H, c.W, c.Cin).permute(0, 3, 1, 2)
+            if c.x_planes and c.x_gcarrier:
+                # the producer of x (RoIAlign) wants its gradient as fp32: it travels in the head of a tensor of x's shape
+                gx = torch.empty((3, (c.B * c.H * c.W + 1) * c.Cin), dtype=bf16, device=E.device)
+                launch_conv(E, c.B, Ho, Wo, c.Cout, wd, c.Cin, c.K, 1, c.K - 1 - c.pad,
+                            f32_out=gx.view(-1).view(f32)[:c.B * c.H * c.W * c.Cin])
+            else:
+                gp, gf = launch_conv(E, c.B, Ho, Wo, c.Cout, wd, c.Cin, c.K, 1, c.K - 1 - c.pad,
+                                     mask_planes=xt if (c.x_planes and c.x_relu) else None, want_planes=c.x_planes, want_f32=not c.x_planes)
+                gx = gp if c.x_planes else gf.view(c.B, c.H, c.W, c.Cin).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
             gw, gb = launch_wgrad(E, xt, c.B, c.H, c.W, c.Cin, c.Cout, c.K, c.stride, c.pad, row_scale=c.scale,
                                   want_bias=bool(c.bias_grad and ctx.needs_input_grad[2]))
+            if w.dim() == 2:
+                gw = gw.reshape(w.shape)
         return gx, gw, gb, None
 
 
@@ -264,6 +277,27 @@ def conv_module(x, conv, relu=False, out_planes=False, scale=None, shift=None):
     if out_planes:
         return PlaneAct(y, B, H, W, conv.out_channels, bool(relu))
     return y
+
+
+def linear_ok(fc, rows):
+    """torch.nn.Linear layers the plane kernels take as 1x1 convolutions over `rows` pixels (both widths multiples of 128)."""
+    return (fc.in_features % 128 == 0 and fc.out_features % 128 == 0 and fc.weight.is_cuda and fc.weight.dtype == f32
+            and fc.weight.is_contiguous() and rows > 0 and not torch.is_autocast_enabled())
+
+
+def linear(x, fc, relu=False, out_planes=False):
+    """[relu](x W^T + b) with the rows of x as the pixels of a 1x1 convolution (fcos_head_p2b_ts.py:1202-1236 FC stacks).
+    x: PlaneAct [B=1, H=rows, W=1, C=in_features] or fp32 [rows, in_features] -> PlaneAct or fp32 [rows, out_features]."""
+    is_p = isinstance(x, PlaneAct)
+    rows = x.H if is_p else x.shape[0]
+    cfg = ConvCfg(B=1, H=rows, W=1, Cin=fc.in_features, Cout=fc.out_features, K=1, stride=1, pad=0, relu=bool(relu), x_planes=is_p,
+                  x_relu=bool(is_p and x.relu), out_planes=bool(out_planes), scale=None, bias_grad=fc.bias is not None,
+                  x_gcarrier=bool(is_p and x.gcarrier))
+    xin = x.t if is_p else x.view(1, rows, 1, fc.in_features).permute(0, 3, 1, 2)
+    y = _PlaneConv.apply(xin, fc.weight, fc.bias, cfg)
+    if out_planes:
+        return PlaneAct(y, 1, rows, 1, fc.out_features, bool(relu))
+    return y.permute(0, 2, 3, 1).reshape(rows, fc.out_features)
 
 
 def f32_ok(x):

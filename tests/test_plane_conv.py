@@ -354,3 +354,73 @@ def test_resnet_fpn_planes_vs_fp64_and_the_fp32_routing(monkeypatch):
     med = sorted(d1s)[len(d1s) // 2]
     print(f'parameter-gradient error vs float64: plane trunk worst {max(d1s):.3e} median {med:.3e}, fp32 routing worst {max(d0s):.3e}')
     assert med < 1e-4
+
+
+def test_roi_planes_and_fc_stack_vs_fp64():
+    """RoIAlign writing split planes + the FC stack as 1x1 convolutions over the RoIs (fcos_head_p2b_ts.py:1202-1236): the planes sum
+    to pt_roi_align_fwd's block bit for bit; Linear -> ReLU -> Linear -> ReLU and every gradient (input map through the fp32
+    carrier, weights, biases) against the same stack in float64."""
+    from point_teacher_amd import functional as F, planes as PL
+    g = torch.Generator().manual_seed(4)
+    B, C, H, W, K = 2, 256, 40, 36, 2500
+    feat = torch.randn(B, C, H, W, generator=g).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    cx, cy = torch.rand(K, generator=g) * (W * 8 - 40) + 20, torch.rand(K, generator=g) * (H * 8 - 40) + 20
+    wh = torch.rand(K, 2, generator=g) * 60 + 4
+    rois = torch.stack([torch.randint(0, B, (K,), generator=g).float(), cx - wh[:, 0] / 2, cy - wh[:, 1] / 2, cx + wh[:, 0] / 2, cy + wh[:, 1] / 2], 1).to(DEV)
+    ref_block = F.roi_align(feat.detach(), rois, 7, 0.125, 0, True, 5)
+    assert F.roi_align_planes_ok(feat, rois, 7)
+    t = F.roi_align_planes(feat, rois, 0.125, 0, True, 5)
+    assert torch.equal(_planes_to_f32(t.detach(), K, C * 49), ref_block.flatten(1))
+    torch.manual_seed(1)
+    fc1, fc2 = torch.nn.Linear(C * 49, 1024).to(DEV), torch.nn.Linear(1024, 1024).to(DEV)
+    x = PL.PlaneAct(t, 1, K, 1, C * 49, False, gcarrier=True)
+    y1 = PL.linear(x, fc1, relu=True, out_planes=True)
+    y = PL.linear(y1, fc2, relu=True)
+    f64 = feat.detach().double().requires_grad_(True)
+    blk = _roi_ref(f64, rois.double(), 0.125)
+    y1r = torch.relu(blk @ fc1.weight.double().t() + fc1.bias.double())
+    yr = torch.relu(y1r @ fc2.weight.double().t() + fc2.bias.double())
+    assert float((y.detach().double() - yr.detach()).abs().max() / yr.detach().abs().max()) < 1e-5      # (the fp32 RoIAlign feeds 12544-term sums)
+    # a ReLU whose pre-activation is within rounding of zero may decide differently in fp32 and float64 (2 x 2.5 M of them here);
+    # the gradient of such a RoI then differs by a whole term - rows with any such element take no gradient in this comparison
+    flip = ((_planes_to_f32(y1.t.detach(), K, 1024) > 0) != (y1r.detach() > 0)).any(1) | ((y.detach() > 0) != (yr.detach() > 0)).any(1)
+    print('rows with a ReLU decided differently in fp32 and float64:', int(flip.sum()))
+    assert int(flip.sum()) <= 20
+    gy = torch.randn(K, 1024, generator=g).to(DEV) * (~flip)[:, None]
+    got = torch.autograd.grad(y, [feat, fc1.weight, fc1.bias, fc2.weight, fc2.bias], gy)
+    want = torch.autograd.grad(yr, [f64, fc1.weight, fc1.bias, fc2.weight, fc2.bias], gy.double())
+    for n, a, b in zip(('feat', 'w1', 'b1', 'w2', 'b2'), got, want):
+        err = float((a.double() - b).abs().max() / b.abs().max())
+        print(n, f'{err:.3e}')
+        assert err < 5e-6, (n, err)
+
+
+def _roi_ref(feat, rois, scale):
+    """RoIAlign (aligned, adaptive grid) in plain differentiable torch float64: [K, C*49]."""
+    import math
+    B, C, H, W = feat.shape
+    out = []
+    for r in rois.tolist():
+        b = int(r[0])
+        x1, y1, x2, y2 = [v * scale - 0.5 for v in r[1:]]
+        rw, rh = x2 - x1, y2 - y1
+        gh, gw = max(int(math.ceil(rh / 7)), 1), max(int(math.ceil(rw / 7)), 1)
+        ys = torch.tensor([y1 + ph * rh / 7 + (iy + .5) * rh / 7 / gh for ph in range(7) for iy in range(gh)], dtype=torch.float64, device=feat.device)
+        xs = torch.tensor([x1 + pw * rw / 7 + (ix + .5) * rw / 7 / gw for pw in range(7) for ix in range(gw)], dtype=torch.float64, device=feat.device)
+
+        def axis(v, L):
+            valid = (v >= -1.0) & (v <= L)
+            v = v.clamp(min=0)
+            lo = v.floor().long().clamp(max=L - 1)
+            hi = (lo + 1).clamp(max=L - 1)
+            v = torch.where(lo >= L - 1, lo.double(), v)
+            fr = v - lo.double()
+            Wm = torch.zeros(v.numel(), L, dtype=torch.float64, device=feat.device)
+            Wm.scatter_add_(1, lo[:, None], ((1 - fr) * valid)[:, None])
+            Wm.scatter_add_(1, hi[:, None], (fr * valid)[:, None])
+            return Wm
+        Ay = axis(ys, H).view(7, gh, H).sum(1)
+        Ax = axis(xs, W).view(7, gw, W).sum(1)
+        o = torch.einsum('ph,chw,qw->cpq', Ay, feat[b], Ax) / (gh * gw)
+        out.append(o.reshape(-1))
+    return torch.stack(out)
