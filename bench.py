@@ -48,6 +48,8 @@ def parse():
 
 # algorithmic HBM bytes per launch of the custom kernels
 def algorithmic_bytes(name, shapes):
+    if name == 'pt_roi_align_fwd_planes':   # the same block written as three bf16 planes (6 B per element instead of 4)
+        return shapes['K'] * shapes['C'] * 49 * 6 + shapes.get('footprint_px', 9 * shapes['K']) * shapes['C'] * 4
     if name in ('pt_roi_align_fwd', 'pt_roi_align_bwd', 'pt_roi_align_rotated_fwd', 'pt_roi_align_rotated_bwd'):
         K, C, o = shapes['K'], shapes['C'], shapes['out']
         # "K*256*49*4 B written (fwd) / read (bwd) + <= 9 feature pixels x 1 KB read per RoI": `footprint_px` is
@@ -100,13 +102,28 @@ def algorithmic_flops(name, shapes):
         return 2.0 * shapes['M'] * shapes['N'] * shapes['K']
     if name in ('pt_conv3x3_bf16x6_nhwc', 'pt_conv3x3_wgrad_bf16x6_nhwc'):
         return 2.0 * shapes['P'] * shapes['Cout'] * 9 * shapes['Cin']
+    if name in ('pt_conv_bf16x6', 'pt_conv_wgrad_bf16x6'):         # M output pixels x Cout x (taps * Cin)
+        return 2.0 * shapes['M'] * shapes['Cout'] * shapes['taps'] * shapes['Cin']
     return None
 
 
-MFMA_FAMILY = ('pt_bf16x6 (gemm + conv3x3)', ('pt_gemm_bf16x6_nt', 'pt_conv3x3_bf16x6_nhwc', 'pt_conv3x3_wgrad_bf16x6_nhwc'))
+def conv_desc_shapes(d):
+    """Shapes out of a pt_conv_desc / pt_conv_wgrad_desc (host struct)."""
+    Ho = (d.Hs + 2 * d.pad - d.KH) // d.stride + 1
+    Wo = (d.Ws + 2 * d.pad - d.KW) // d.stride + 1
+    return dict(M=d.B * Ho * Wo, Cin=d.Cin, Cout=d.Cout, taps=d.KH * d.KW)
+
+
+# the matrix kernels: every fp32 product of backbone / necks / towers / MIL FC stacks as six bf16 MFMA products (csrc/gemm_split.hip)
+MFMA_FAMILY = ('pt_bf16x6 (conv + gemm + wgrad)', ('pt_conv_bf16x6', 'pt_conv_wgrad_bf16x6', 'pt_gemm_bf16x6_nt', 'pt_conv3x3_bf16x6_nhwc',
+                                                  'pt_conv3x3_wgrad_bf16x6_nhwc'))
+# their companion launches: fp32 -> split planes at the edges of the plane-native region, the once-per-update weight planes, the
+# exact addition of gradient planes where an activation has two consumers (round-3 advice: report them beside the family)
+SPLIT_FNS = ('pt_split_bf16x3', 'pt_split_bf16x3_rows', 'pt_split_bf16x3_gather', 'pt_conv_weight_planes_batch', 'pt_planes_combine')
+BF16_PEAK_TFLOPS = 2500.0          # dense bf16 MFMA (MI355X_MICROARCH.md); 6 products per fp32 product -> 416.7 TFLOP/s fp32-equivalent ceiling
 
 FAMILIES = {                                                    # op families for the roofline line
-    'pt_roi_align': ('pt_roi_align_fwd', 'pt_roi_align_bwd'),
+    'pt_roi_align': ('pt_roi_align_fwd', 'pt_roi_align_fwd_planes', 'pt_roi_align_bwd'),
     'pt_roi_align_rotated': ('pt_roi_align_rotated_fwd', 'pt_roi_align_rotated_bwd'),
     'pt_affine_relu': ('pt_affine_relu_fwd', 'pt_affine_relu_bwd', 'pt_affine_relu_bwd_train'),
     'pt_optimizer (ema + sqnorm + sgd)': ('pt_ema_update', 'pt_sqnorm_partial', 'pt_sgd_step', 'pt_sgd_step_groups'),
@@ -226,7 +243,9 @@ def main():
     orig_call = hip.call
     import point_teacher_amd.functional as PF
     SKIP = ('pt_focal_nblocks', 'pt_sqnorm_nblocks', 'pt_abi_version', 'pt_affine_train_rows', 'pt_gemm_bf16x6_tile_rows',
-            'pt_conv3x3_wgrad_bf16x6_splits', 'pt_group_norm_cl_workspace_bytes', 'pt_split_bf16x3_plane_elems')
+            'pt_conv3x3_wgrad_bf16x6_splits', 'pt_group_norm_cl_workspace_bytes', 'pt_split_bf16x3_plane_elems', 'pt_conv_bf16x6_splits',
+            'pt_conv_wgrad_bf16x6_splits')
+    import point_teacher_amd.planes as PPL
 
     def make_hook(prof, only=None):
         def timed_call(fn, *a):
@@ -238,6 +257,8 @@ def main():
                 shp = None
                 if fn in ('pt_roi_align_fwd', 'pt_roi_align_bwd'):
                     shp = dict(K=a[6], C=a[3], out=a[7], rois=a[1], scale=a[8], H=a[4], W=a[5])    # footprints are counted afterwards
+                elif fn == 'pt_roi_align_fwd_planes':
+                    shp = dict(K=a[6], C=a[3], out=7, rois=a[1], scale=a[7], H=a[4], W=a[5])
                 elif fn in ('pt_roi_align_rotated_fwd', 'pt_roi_align_rotated_bwd'):
                     shp = dict(K=a[6], C=a[3], out=a[7])
                 elif fn == 'pt_affine_relu_fwd':
@@ -246,6 +267,8 @@ def main():
                     shp = dict(n=a[3], streams=1 + (a[1] is not None) + (a[7] is not None) + (a[8] is not None))
                 elif fn == 'pt_affine_relu_bwd_train':
                     shp = dict(n=a[4], streams=2 + (a[1] is not None) + (a[7] is not None) + (a[8] is not None))
+                elif fn in ('pt_conv_bf16x6', 'pt_conv_wgrad_bf16x6'):   # (the weight gradient includes its fixed-order reduction)
+                    shp = conv_desc_shapes(a[0])
                 elif fn == 'pt_gemm_bf16x6_nt':
                     shp = dict(M=a[7], N=a[8], K=a[9])
                 elif fn == 'pt_conv3x3_bf16x6_nhwc':
@@ -262,6 +285,7 @@ def main():
     def set_hook(h):
         hip.call = h
         PF.hip.call = h
+        PPL.hip.call = h
 
     def footprint_px(r, scale, H, W):      # feature pixels an aligned RoI samples: the bilinear taps of its first and last sample
         x1, y1, x2, y2 = (r[:, i] * scale - 0.5 for i in (1, 2, 3, 4))
@@ -295,6 +319,9 @@ def main():
         # the matrix kernels of the path (fp32 products as six bf16 MFMA products): MFMA-bound, priced against the dense bf16 peak
         mk = [kern[m] for m in MFMA_FAMILY[1] if m in kern and kern[m].get('flops')]
         mfma = dict(calls=sum(k['calls'] for k in mk), total_ms=sum(k['total_ms'] for k in mk), flops=sum(k['flops'] for k in mk)) if mk else None
+        if mfma:
+            sk = [kern[m] for m in SPLIT_FNS if m in kern]
+            mfma['split_ms'], mfma['split_calls'] = sum(k['total_ms'] for k in sk), sum(k['calls'] for k in sk)
         return kern, fam, mfma
 
     def dominant(fam, mfma):
@@ -312,7 +339,7 @@ def main():
     set_hook(orig_call)
     _, sfam, smfma = summarise(survey)
     dom = dominant(sfam, smfma)
-    dom_fns = set(MFMA_FAMILY[1] if dom == MFMA_FAMILY[0] else FAMILIES[dom])
+    dom_fns = set(MFMA_FAMILY[1] + SPLIT_FNS if dom == MFMA_FAMILY[0] else FAMILIES[dom])
     del survey
 
     # what an (event, event) pair measures with NOTHING in between: the per-launch bias of the HIP-event timings below
@@ -326,12 +353,22 @@ def main():
     cal = sorted(a.elapsed_time(b) for a, b in cal)
     event_overhead_us = cal[len(cal) // 2] * 1e3
 
+    # The family is ~280 launches per iteration now (every convolution of the trunk): an event pair around each of them in every
+    # timed step costs the step ~1.8 ms of stream bubbles, so the timed region carries events on every EVENT_EVERY-th step
+    # (5 of the default 20) - `achieved` is still measured live inside the timed region, on a sample of its steps.
+    EVENT_EVERY = 4
     prof = {}
-    set_hook(make_hook(prof, only=dom_fns))
+    family_hook = make_hook(prof, only=dom_fns)
+    n_event_steps = 0
     barrier()
     t0 = time.perf_counter()
     for it in range(args.steps):
+        if it % EVENT_EVERY == 0:
+            set_hook(family_hook)
+            n_event_steps += 1
         out = trainer.step(data.batch(args.warmup + it, args.batch))
+        if it % EVENT_EVERY == 0:
+            set_hook(orig_call)
         traced(args.warmup + it, out)
     barrier()
     dt = time.perf_counter() - t0
@@ -344,7 +381,8 @@ def main():
 
     # per-kernel table of ALL custom kernels: 3 un-timed steps after the timed region
     BREAKDOWN_STEPS = 3
-    INSTR = (f'timed region: HIP events around the launches of the dominant family only; other families and custom_kernels_ms_per_step: '
+    INSTR = (f'timed region: HIP events around the launches of the dominant family (and its operand-format passes) on every '
+             f'{EVENT_EVERY}th step ({n_event_steps} of {args.steps}); other families and custom_kernels_ms_per_step: '
              f'{BREAKDOWN_STEPS} un-timed steps after it with events around every custom call')
     full = {}
     set_hook(make_hook(full))
@@ -365,7 +403,7 @@ def main():
     traffic = None
     try:
         import hashlib
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r03', 'pmc_traffic.json')))
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r04', 'pmc_traffic.json')))
         ent = pmc.get(('obb_' if obb else '') + args.workload + ('_bf16' if args.dtype == 'bf16' else ''), {}).get(dom)
         if ent:
             src = os.path.join(ROOT, 'point_teacher_amd', 'csrc', ent['source'])
@@ -377,23 +415,33 @@ def main():
     fams = {k: dict(ms_per_step=round(v['total_ms'] / BREAKDOWN_STEPS, 3), achieved_GBps=round(v['bytes'] / (v['total_ms'] * 1e-3) / 1e9, 1))
             for k, v in sorted(fam.items())}
     if dom in tfam:
-        fams[dom] = dict(ms_per_step=round(tfam[dom]['total_ms'] / args.steps, 3),
+        fams[dom] = dict(ms_per_step=round(tfam[dom]['total_ms'] / n_event_steps, 3),
                          achieved_GBps=round(tfam[dom]['bytes'] / (tfam[dom]['total_ms'] * 1e-3) / 1e9, 1))
     bmfma = summarise({k: v for k, v in full.items() if k in MFMA_FAMILY[1]})[2] if dom != MFMA_FAMILY[0] else mfma
-    msteps = BREAKDOWN_STEPS if dom != MFMA_FAMILY[0] else args.steps
+    msteps = BREAKDOWN_STEPS if dom != MFMA_FAMILY[0] else n_event_steps
     if bmfma:
         ex = 6.0 * bmfma['flops'] / (bmfma['total_ms'] * 1e-3) / 1e12
         fams[MFMA_FAMILY[0]] = dict(ms_per_step=round(bmfma['total_ms'] / msteps, 3), executed_bf16_TFLOPs=round(ex, 1),
                                     fp32_equivalent_TFLOPs=round(ex / 6.0, 1))
+    def mfma_roofline(m, steps_, **extra):
+        # achieved = EXECUTED bf16 FLOPs (6 MFMA products per fp32 product) / HIP-event time, peak = dense bf16 MFMA (guide).
+        # frac_algorithmic prices the ALGORITHMIC work (2 M N K fp32 FLOPs) against the same peak - SURVEY 8(d)'s fraction; the
+        # scheme's own ceiling is peak / 6.  split_overhead_ms: the family's companion launches (operand-format passes), timed in the
+        # same region; fp32_equivalent_incl_split charges them to the family as well.
+        ex = 6.0 * m['flops'] / (m['total_ms'] * 1e-3) / 1e12
+        incl = m['flops'] / ((m['total_ms'] + m.get('split_ms', 0.0)) * 1e-3) / 1e12
+        return dict(bound='mfma', kernel=MFMA_FAMILY[0], achieved=round(ex, 1), peak=BF16_PEAK_TFLOPS, unit='TFLOP/s',
+                    frac=round(ex / BF16_PEAK_TFLOPS, 4), frac_algorithmic=round(ex / 6.0 / BF16_PEAK_TFLOPS, 4),
+                    scheme_ceiling_tflops=round(BF16_PEAK_TFLOPS / 6.0, 1), fp32_equivalent_tflops=round(ex / 6.0, 1),
+                    fp32_equivalent_incl_split_tflops=round(incl, 1), fp32_mfma_peak_tflops=157.3,
+                    ms_per_step=round(m['total_ms'] / steps_, 3), split_overhead_ms=round(m.get('split_ms', 0.0) / steps_, 3),
+                    split_launches_per_step=round(m.get('split_calls', 0) / steps_, 1),
+                    avg_launch_us=round(m['total_ms'] / m['calls'] * 1e3, 2), event_pair_overhead_us=round(event_overhead_us, 2),
+                    launches=m['calls'], flops_per_launch=int(6.0 * m['flops'] / m['calls']),
+                    algorithmic_flops_per_launch=int(m['flops'] / m['calls']), **extra)
+
     if dom == MFMA_FAMILY[0]:
-        # achieved = EXECUTED bf16 FLOPs (6 MFMA products per fp32 product) / HIP-event time, peak = dense bf16 MFMA (guide);
-        # the fp32 work it replaces (2 M N K) runs at achieved / 6 against a 157.3 TFLOP/s fp32 matrix peak
-        ex = 6.0 * mfma['flops'] / (mfma['total_ms'] * 1e-3) / 1e12
-        roofline = dict(bound='mfma', kernel=dom, achieved=round(ex, 1), peak=2500.0, unit='TFLOP/s', frac=round(ex / 2500.0, 4),
-                        traffic=traffic, fp32_equivalent_tflops=round(ex / 6.0, 1), fp32_mfma_peak_tflops=157.3,
-                        avg_launch_us=round(mfma['total_ms'] / mfma['calls'] * 1e3, 2), event_pair_overhead_us=round(event_overhead_us, 2),
-                        launches=mfma['calls'], flops_per_launch=int(6.0 * mfma['flops'] / mfma['calls']), families=fams,
-                        instrumentation=INSTR)
+        roofline = mfma_roofline(mfma, n_event_steps, traffic=traffic, families=fams, instrumentation=INSTR)
     else:
         roofline = dict(bound='hbm', kernel=dom, achieved=round(achieved, 1), peak=8000.0, unit='GB/s',
                         frac=round(achieved / 8000.0, 4), traffic=traffic,
@@ -401,23 +449,36 @@ def main():
                         launches=d['calls'], bytes_per_launch=int(d['bytes'] / d['calls']), families=fams, instrumentation=INSTR)
 
     # ---- the steady-state phase as well (94 % of a 12-epoch run is phase 2): same model, phase switch flipped ----
+    def timed_with_family(tr_, base):
+        """args.steps timed steps of `tr_` with HIP events around the matrix family (and its companions) -> (seconds, roofline or None)."""
+        p_ = {}
+        h_ = make_hook(p_, only=set(MFMA_FAMILY[1] + SPLIT_FNS))
+        n_ = 0
+        barrier()
+        t0_ = time.perf_counter()
+        for it_ in range(args.steps):
+            if it_ % EVENT_EVERY == 0:
+                set_hook(h_)
+                n_ += 1
+            tr_.step(data.batch(base + it_, args.batch))
+            set_hook(orig_call)
+        barrier()
+        d_ = torch.tensor([time.perf_counter() - t0_], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(d_, op=dist.ReduceOp.MAX)
+        m_ = summarise(p_)[2]
+        return float(d_.item()), (mfma_roofline(m_, n_) if m_ else None)
+
     phase2 = None
     if args.workload == 'step1' and not args.no_phase2:
         model.burn_in_step = -1
         for it in range(max(args.warmup, 3)):
             trainer.step(data.batch(1000 + it, args.batch))
-        barrier()
-        t0 = time.perf_counter()
-        for it in range(args.steps):
-            trainer.step(data.batch(2000 + it, args.batch))
-        barrier()
-        dt2 = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(dt2, op=dist.ReduceOp.MAX)
-        dt2 = float(dt2.item())
+        dt2, roof2 = timed_with_family(trainer, 2000)
         f2 = iteration_flops('step2', cfg.to_dict()['model'], args.batch, args.size, args.objects)
         phase2 = dict(workload='phase 2 (MIL on, steady state), same model and inputs', value=round(args.steps * world / dt2, 4), unit='iters/s',
-                      ms_per_step=round(dt2 / args.steps * 1e3, 3), flops=f2, achieved_tflops=round(f2 * args.steps / dt2 / 1e12, 2))
+                      ms_per_step=round(dt2 / args.steps * 1e3, 3), flops=f2, achieved_tflops=round(f2 * args.steps / dt2 / 1e12, 2),
+                      roofline=roof2)
         model.burn_in_step = 10 ** 9
 
     # ---- BASELINE configs[2] (bf16 backbone / FPN / PSAGG + fp32 heads, two-phase = MIL on): timed by THIS run as well, so
@@ -439,20 +500,13 @@ def main():
                               autocast_dtype=torch.bfloat16, channels_last=True)
         for it in range(max(args.warmup, 5)):
             trainer.step(data.batch(3000 + it, args.batch))
-        barrier()
-        t0 = time.perf_counter()
-        for it in range(args.steps):
-            trainer.step(data.batch(4000 + it, args.batch))
-        barrier()
-        dt3 = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(dt3, op=dist.ReduceOp.MAX)
-        dt3 = float(dt3.item())
+        dt3, roof3 = timed_with_family(trainer, 4000)       # (the fp32 head's matrix family; the bf16 trunk runs library kernels)
         f3 = iteration_flops('step2', cfg2.to_dict()['model'], args.batch, args.size, args.objects)
         configs2 = dict(workload=f'BASELINE configs[2]: aitodv2_point_teacher_{args.percent}% phase 2 (MIL on), bf16 backbone / FPN / PSAGG (autocast) + '
                                  f'fp32 dense head, MIL head and losses, bs {args.batch}/GPU, {args.size}x{args.size}',
                         value=round(args.steps * world / dt3, 4), unit='iters/s', ms_per_step=round(dt3 / args.steps * 1e3, 3),
-                        steps=args.steps, dtype='bf16 backbone + f32 head', flops=f3, achieved_tflops=round(f3 * args.steps / dt3 / 1e12, 2))
+                        steps=args.steps, dtype='bf16 backbone + f32 head', flops=f3, achieved_tflops=round(f3 * args.steps / dt3 / 1e12, 2),
+                        roofline=roof3)
 
     if rank == 0:
         cpu_baseline = None
@@ -480,11 +534,11 @@ def main():
             metric=f'train iters/sec ({args.size}x{args.size}, ~{args.objects} pts/img)', value=round(iters_s * world, 4), unit='iters/s',
             n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),
             higher_is_better=True, scaling='weak', vs_baseline=None,
-            # arithmetic type of the path; the MIL FC GEMMs and the dense head's 3x3 tower convolutions (forward, input gradient)
-            # form every fp32 product from six bf16 MFMA products with fp32 accumulation (csrc/gemm_split.hip: error vs float64
-            # below the fp32 library kernels')
-            dtype=('f32' + (' (MIL FC GEMMs' + (' + tower convolutions' if os.environ.get('PT_SPLIT_CONV', '1') != '0' else '')
-                            + ': bf16x6 split MFMA, fp32 accumulate)' if os.environ.get('PT_SPLIT_GEMM', '1') != '0' else ''))
+            # arithmetic type of the path; every fp32 product of the trainable trunk, the necks, the towers and the MIL FC stacks is
+            # formed from six bf16 MFMA products with fp32 accumulation (csrc/gemm_split.hip: error vs float64 below the fp32
+            # library kernels'; activations travel between the layers as exact three-term bf16 splits of their fp32 values)
+            dtype=('f32' + (' (backbone / neck / tower convolutions and MIL FC stacks: bf16x6 split MFMA, fp32 accumulate)'
+                            if os.environ.get('PT_SPLIT_GEMM', '1') != '0' and os.environ.get('PT_SPLIT_CONV', '1') != '0' else ''))
             if args.dtype == 'fp32' else 'bf16', data='synthetic',
             config=dict(workload=(f'sodaa_fcos_pointteacher_1x (oriented) ' if obb else f'aitodv2_point_teacher_{args.percent}% ')
                                  + f'{"burn-in phase 1" if args.workload == "step1" else "phase 2 (MIL on)"}, '

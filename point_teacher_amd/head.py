@@ -151,8 +151,29 @@ class TS_P2BFCOSHead(nn.Module):
     def _towers(self, x, branches):
         """(cls_feat | None, reg_feat | None) as `branches` and `centerness_on_reg` need them."""
         need_cls, need_reg = branches != 'reg', branches != 'cls'
+        need_cls = need_cls or (need_reg and not self.centerness_on_reg)
         cls_feat = reg_feat = None
-        if need_cls or (need_reg and not self.centerness_on_reg):
+        convs = (list(self.cls_convs) if need_cls else []) + (list(self.reg_convs) if need_reg else [])
+        if (_PLANE_FC and convs and PL.f32_ok(x) and x.shape[0] * x.shape[2] * x.shape[3] >= ConvModule.plane_min_pixels
+                and all(l.with_activation and not l.with_norm and PL.plane_conv_ok(l.conv) for l in convs)):
+            # plane-native towers (anchor_free_head.py:198-219): the map is split ONCE, the activations travel between the four
+            # convolutions of a tower as split planes (bias + ReLU in the epilogues, masks in the input-gradient epilogues) and
+            # only the last one writes the fp32 map the 8 / 4 / 1-channel output convolutions read
+            if need_cls and need_reg:
+                xa, xb = PL.to_planes2(x)
+            else:
+                xa = xb = PL.to_planes(x)
+
+            def tower(t, layers):
+                for i, l in enumerate(layers):
+                    t = l(t, out_planes=i + 1 < len(layers))
+                return t
+            if need_cls:
+                cls_feat = tower(xa, self.cls_convs)
+            if need_reg:
+                reg_feat = tower(xb, self.reg_convs)
+            return cls_feat, reg_feat
+        if need_cls:
             cls_feat = x
             for l in self.cls_convs:
                 cls_feat = l(cls_feat)

@@ -61,6 +61,32 @@ class _F32ToPlanes(torch.autograd.Function):
         return of.view(B, H, W, C).permute(0, 3, 1, 2)
 
 
+class _F32ToPlanes2(torch.autograd.Function):
+    """One split of an fp32 map for TWO consumers (the two towers of the dense head): backward adds the two gradient plane sets and
+    returns fp32 in one pass."""
+
+    @staticmethod
+    def forward(ctx, x):
+        t, _, _ = split_nhwc(x)
+        ctx.shape = x.shape
+        return t.view_as(t), t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        B, C, H, W = ctx.shape
+        if g1 is None or g2 is None:
+            g1, g2 = (g1 if g2 is None else g2), None
+        _, of = combine(g1.contiguous(), g2.contiguous() if g2 is not None else None, n=B * H * W * C, want_planes=False, want_f32=True)
+        return of.view(B, H, W, C).permute(0, 3, 1, 2)
+
+
+def to_planes2(x):
+    """x as planes for two consumers -> (PlaneAct, PlaneAct) sharing one set of planes."""
+    B, C, H, W = x.shape
+    a, b = _F32ToPlanes2.apply(x)
+    return PlaneAct(a, B, H, W, C, False), PlaneAct(b, B, H, W, C, False)
+
+
 def to_planes(x):
     """Differentiable entry into plane mode (relu=False: the producer of x masks its own gradient)."""
     B, C, H, W = x.shape

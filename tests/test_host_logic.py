@@ -189,15 +189,25 @@ def test_epoch_batches_report_the_epoch_a_resume_must_start_with():
 
 
 def test_bench_matrix_family_accounting():
-    """bench.py prices the matrix family by the EXECUTED bf16 FLOPs: 2 M N K per GEMM launch, 2 P Cout 9 Cin per convolution
-    launch - forward / input gradient and the weight gradient alike - and the three entry points form one family."""
+    """bench.py prices the matrix family by the EXECUTED bf16 FLOPs: 2 M N K per GEMM launch, 2 M Cout taps Cin per convolution
+    launch - forward / input gradient and the weight gradient alike; the operand-format passes are its companions."""
     import bench
     assert bench.algorithmic_flops('pt_gemm_bf16x6_nt', dict(M=5000, N=1024, K=12544)) == 2.0 * 5000 * 1024 * 12544
     conv = dict(P=2 * 100 * 100, Cin=256, Cout=256)
     assert bench.algorithmic_flops('pt_conv3x3_bf16x6_nhwc', conv) == 2.0 * 20000 * 256 * 9 * 256
     assert bench.algorithmic_flops('pt_conv3x3_wgrad_bf16x6_nhwc', conv) == bench.algorithmic_flops('pt_conv3x3_bf16x6_nhwc', conv)
     assert bench.algorithmic_flops('pt_roi_align_fwd', dict(K=1)) is None
-    assert set(bench.MFMA_FAMILY[1]) == {'pt_gemm_bf16x6_nt', 'pt_conv3x3_bf16x6_nhwc', 'pt_conv3x3_wgrad_bf16x6_nhwc'}
+    assert set(bench.MFMA_FAMILY[1]) == {'pt_conv_bf16x6', 'pt_conv_wgrad_bf16x6', 'pt_gemm_bf16x6_nt', 'pt_conv3x3_bf16x6_nhwc',
+                                         'pt_conv3x3_wgrad_bf16x6_nhwc'}
     import point_teacher_amd.hip as hip
-    for fn in bench.MFMA_FAMILY[1] + tuple(m for ms in bench.FAMILIES.values() for m in ms):
+    # the plane-native entry points carry their shapes in a host descriptor: M = B * Ho * Wo output pixels, taps = KH * KW
+    d = hip.STRUCTS['pt_conv_desc']()
+    d.B, d.Hs, d.Ws, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad = 6, 100, 100, 512, 256, 1, 1, 2, 0
+    shp = bench.conv_desc_shapes(d)
+    assert shp == dict(M=6 * 50 * 50, Cin=512, Cout=256, taps=1)
+    assert bench.algorithmic_flops('pt_conv_bf16x6', shp) == bench.algorithmic_flops('pt_conv_wgrad_bf16x6', shp) == 2.0 * 15000 * 256 * 512
+    d.KH = d.KW = 3
+    d.stride, d.pad = 1, 1
+    assert bench.conv_desc_shapes(d)['M'] == 60000 and bench.conv_desc_shapes(d)['taps'] == 9
+    for fn in bench.MFMA_FAMILY[1] + bench.SPLIT_FNS + tuple(m for ms in bench.FAMILIES.values() for m in ms):
         assert fn in hip.PROTOS, fn                                # every entry point the roofline names exists in the header

@@ -291,7 +291,8 @@ def test_full_size_noisy_point_configs(percent):
     data = SyntheticTiles(n=2, size=800, mean_objects=300, seed=2, device=dev)
     ks = []
     ext = model.student.bbox_head.bbox_roi_extractor
-    hook = ext.register_forward_hook(lambda m, i, o: ks.append(int(o.shape[0])))
+    # (RoI blocks leave as fp32 [K, C, 7, 7] or - into the FC stacks on the plane kernels - as planes.PlaneAct with the K RoIs as rows)
+    hook = ext.register_forward_hook(lambda m, i, o: ks.append(int(o.H if type(o).__name__ == 'PlaneAct' else o.shape[0])))
     torch.cuda.reset_peak_memory_stats()
     keys = None
     pts_seen = []
