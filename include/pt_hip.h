@@ -196,7 +196,9 @@ int pt_sqnorm_partial(const float* g, int64_t n, float* partial, void* stream);
 /* mmcv OptimizerHook grad-clip (max_norm, L2) + torch.optim.SGD(momentum, weight_decay)
  * with the paramwise_cfg of aitodv2_point_teacher_0%.py:212-215 (bias lr x2, bias decay 0):
  * elements [0,split) are weights, [split,n) biases.  sqnorm[0] = total squared grad
- * norm (device scalar, already reduced over ranks if any); lr is a device scalar. */
+ * norm (device scalar, already reduced over ranks if any); lr is a device scalar.
+ * Since ABI 3 the kernel moves 16 bytes per lane: param / grad / momentum_buf must be 16-byte aligned and `split` a multiple of
+ * 4 (pad the weight segment), else PT_EINVAL - the two-group form of pt_sgd_step_groups below, same preconditions. */
 int pt_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, int64_t split,
                 const float* lr, float momentum, float weight_decay, float bias_lr_mult,
                 float bias_decay_mult, const float* sqnorm, float max_norm, int first_step,

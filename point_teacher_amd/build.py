@@ -16,6 +16,8 @@ SOURCES = ['assign.hip', 'losses.hip', 'roi_align.hip', 'mil.hip', 'optim.hip', 
 # as the reference's un-fused torch ops; kernels that want FMA ask for it with fmaf().
 # -pragma-unroll-threshold: `#pragma unroll` over the 49 bins x 4 samples of a RoI must really unroll (49 per-channel values live in
 # registers; a partially unrolled loop indexes them dynamically and the whole array moves to scratch memory - measured 3x slower).
+if os.environ.get('PT_BUILD_SOURCES'):       # a subset of the translation units (tests of the build command itself)
+    SOURCES = [x for x in os.environ['PT_BUILD_SOURCES'].split(',') if x]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-ffp-contract=off', '-Wall',
          '-Wno-unused-function', '-Wno-unused-variable', '-mllvm', '-pragma-unroll-threshold=200000']
 

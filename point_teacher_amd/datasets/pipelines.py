@@ -311,78 +311,68 @@ class Resize:
         self.backend, self.multiscale_mode, self.ratio_range = backend, multiscale_mode, ratio_range
         self.keep_ratio, self.override, self.bbox_clip_border = keep_ratio, override, bbox_clip_border
 
-    @staticmethod
-    def random_select(img_scales):
-        scale_idx = np.random.randint(len(img_scales))
-        return img_scales[scale_idx], scale_idx
-
-    @staticmethod
-    def random_sample(img_scales):
-        assert len(img_scales) == 2
-        longs, shorts = [max(s) for s in img_scales], [min(s) for s in img_scales]
-        long_edge = np.random.randint(min(longs), max(longs) + 1)
-        short_edge = np.random.randint(min(shorts), max(shorts) + 1)
-        return (long_edge, short_edge), None
-
-    @staticmethod
-    def random_sample_ratio(img_scale, ratio_range):
-        assert isinstance(img_scale, tuple) and len(img_scale) == 2
-        min_ratio, max_ratio = ratio_range
-        assert min_ratio <= max_ratio
-        ratio = np.random.random_sample() * (max_ratio - min_ratio) + min_ratio
-        return (int(img_scale[0] * ratio), int(img_scale[1] * ratio)), None
-
-    def _random_scale(self, results):
+    def _pick_scale(self):
+        """-> (scale, index or None).  One place for the three sampling rules of transforms.py:92-186; the order and kind of the
+        numpy draws is the reference's (tests/golden/pipeline_flow.npz pins it):
+          ratio_range            one uniform draw r in [lo, hi): the single img_scale times r, truncated per edge
+          one img_scale          that scale, no draw
+          'range' (two scales)   an integer long edge, then an integer short edge, each uniform between the two scales' edges
+          'value'                one integer draw: an entry of the list."""
+        scales = self.img_scale
         if self.ratio_range is not None:
-            scale, idx = self.random_sample_ratio(self.img_scale[0], self.ratio_range)
-        elif len(self.img_scale) == 1:
-            scale, idx = self.img_scale[0], 0
-        elif self.multiscale_mode == 'range':
-            scale, idx = self.random_sample(self.img_scale)
-        else:
-            scale, idx = self.random_select(self.img_scale)
-        results['scale'], results['scale_idx'] = scale, idx
+            lo, hi = self.ratio_range
+            assert lo <= hi and len(scales[0]) == 2
+            r = np.random.random_sample() * (hi - lo) + lo
+            return tuple(int(edge * r) for edge in scales[0]), None
+        if len(scales) == 1:
+            return scales[0], 0
+        if self.multiscale_mode == 'range':
+            assert len(scales) == 2
+            edges = [sorted((max(s) for s in scales)), sorted((min(s) for s in scales))]       # [long lo..hi], [short lo..hi]
+            long_edge, short_edge = (np.random.randint(lo, hi + 1) for lo, hi in edges)
+            return (long_edge, short_edge), None
+        i = np.random.randint(len(scales))
+        return scales[i], i
 
     def _resize_img(self, results):
+        keep = self.keep_ratio
         for key in results.get('img_fields', ['img']):
             img = results[key]
             h, w = img.shape[:2]
-            if self.keep_ratio:
-                new_w, new_h = rescale_size((w, h), results['scale'])
-            else:
-                new_w, new_h = results['scale']
+            new_w, new_h = rescale_size((w, h), results['scale']) if keep else results['scale']
             img.resize((new_w, new_h))
-            w_scale, h_scale = new_w / w, new_h / h
-            results['scale_factor'] = np.array([w_scale, h_scale, w_scale, h_scale], dtype=np.float32)
-            results['img_shape'] = img.shape
-            results['pad_shape'] = img.shape
-            results['keep_ratio'] = self.keep_ratio
+            fx, fy = new_w / w, new_h / h
+            results.update(scale_factor=np.array([fx, fy, fx, fy], dtype=np.float32), img_shape=img.shape, pad_shape=img.shape, keep_ratio=keep)
 
     def _resize_bboxes(self, results):
-        for key in results.get('bbox_fields', []):
-            bboxes = results[key] * results['scale_factor']
+        """boxes x (fx, fy, fx, fy), then (bbox_clip_border) every x into [0, width] and every y into [0, height] with one
+        minimum / maximum against a per-column limit row."""
+        fields = results.get('bbox_fields', [])
+        if not fields:
+            return
+        hh, ww = results['img_shape'][:2]
+        for key in fields:
+            boxes = results[key] * results['scale_factor']
             if self.bbox_clip_border:
-                img_shape = results['img_shape']
-                bboxes[:, 0::2] = np.clip(bboxes[:, 0::2], 0, img_shape[1])
-                bboxes[:, 1::2] = np.clip(bboxes[:, 1::2], 0, img_shape[0])
-            results[key] = bboxes
+                upper = np.resize(np.asarray([ww, hh], dtype=boxes.dtype), boxes.shape[-1])
+                boxes = np.minimum(np.maximum(boxes, 0), upper)
+            results[key] = boxes
 
     def __call__(self, results):
-        if 'scale' not in results:
-            if 'scale_factor' in results:
-                img_shape = results['img'].shape[:2]
-                scale_factor = results['scale_factor']
-                assert isinstance(scale_factor, float)
-                results['scale'] = tuple([int(x * scale_factor) for x in img_shape][::-1])
+        have_scale, have_factor = 'scale' in results, 'scale_factor' in results
+        if have_scale and not self.override:
+            assert not have_factor, 'scale and scale_factor cannot be both set.'
+        elif have_scale:                                   # override: forget what an earlier Resize chose and draw again
+            del results['scale']
+            results.pop('scale_factor', None)
+            have_scale = have_factor = False
+        if not have_scale:
+            if have_factor:                                # a caller-given float factor on the current image size, (w, h) order
+                f = results['scale_factor']
+                assert isinstance(f, float)
+                results['scale'] = tuple(int(side * f) for side in results['img'].shape[1::-1])
             else:
-                self._random_scale(results)
-        else:
-            if not self.override:
-                assert 'scale_factor' not in results, 'scale and scale_factor cannot be both set.'
-            else:
-                results.pop('scale')
-                results.pop('scale_factor', None)
-                self._random_scale(results)
+                results['scale'], results['scale_idx'] = self._pick_scale()
         self._resize_img(results)
         self._resize_bboxes(results)
         return results
@@ -434,42 +424,45 @@ class RandomFlip:
         if isinstance(flip_ratio, list):
             assert len(self.flip_ratio) == len(self.direction)
 
+    # direction -> (source column of every output column, sign, which image side is added): x' = W - x swaps the x columns,
+    # y' = H - y the y columns; 'diagonal' does both.  One gather + one fused multiply-add instead of a branch per direction.
+    _FLIP = {'horizontal': ((2, 1, 0, 3), (-1, 1, -1, 1), (1, 0, 1, 0)),
+             'vertical': ((0, 3, 2, 1), (1, -1, 1, -1), (0, 1, 0, 1)),
+             'diagonal': ((2, 3, 0, 1), (-1, -1, -1, -1), (1, 1, 1, 1))}
+
     def bbox_flip(self, bboxes, img_shape, direction):
-        assert bboxes.shape[-1] % 4 == 0
-        flipped = bboxes.copy()
-        h, w = img_shape[0], img_shape[1]
-        if direction == 'horizontal':
-            flipped[..., 0::4] = w - bboxes[..., 2::4]
-            flipped[..., 2::4] = w - bboxes[..., 0::4]
-        elif direction == 'vertical':
-            flipped[..., 1::4] = h - bboxes[..., 3::4]
-            flipped[..., 3::4] = h - bboxes[..., 1::4]
-        elif direction == 'diagonal':
-            flipped[..., 0::4] = w - bboxes[..., 2::4]
-            flipped[..., 1::4] = h - bboxes[..., 3::4]
-            flipped[..., 2::4] = w - bboxes[..., 0::4]
-            flipped[..., 3::4] = h - bboxes[..., 1::4]
-        else:
+        """[..., 4k] (x1, y1, x2, y2) groups mirrored inside an image of `img_shape` (h, w, ...)."""
+        if direction not in self._FLIP:
             raise ValueError(f"Invalid flipping direction '{direction}'")
-        return flipped
+        n = bboxes.shape[-1]
+        assert n % 4 == 0
+        src, sign, side = (np.asarray(t) for t in self._FLIP[direction])
+        cols = (np.arange(n) // 4 * 4)[:, None].reshape(-1, 4)[:, :1] + src                  # per group of four: its source columns
+        h, w = img_shape[0], img_shape[1]
+        extent = np.where(np.tile(side, n // 4) == 1, np.tile([w, h, w, h], n // 4), 0).astype(bboxes.dtype)
+        return extent + np.tile(sign, n // 4).astype(bboxes.dtype) * bboxes[..., cols.reshape(-1)]
+
+    def _draw_direction(self):
+        """None (no flip) or a direction, drawn with ONE np.random.choice over [directions..., None] (transforms.py:415-433): a
+        list of ratios pairs with the list of directions, a single ratio is shared equally between them."""
+        dirs = list(self.direction) if isinstance(self.direction, list) else [self.direction]
+        if isinstance(self.flip_ratio, list):
+            probs = self.flip_ratio + [1 - sum(self.flip_ratio)]
+        else:
+            probs = [self.flip_ratio / len(dirs)] * len(dirs) + [1 - self.flip_ratio]
+        return np.random.choice(dirs + [None], p=probs)
 
     def __call__(self, results):
         if 'flip' not in results:
-            direction_list = (self.direction if isinstance(self.direction, list) else [self.direction]) + [None]
-            if isinstance(self.flip_ratio, list):
-                flip_ratio_list = self.flip_ratio + [1 - sum(self.flip_ratio)]
-            else:
-                single = self.flip_ratio / (len(direction_list) - 1)
-                flip_ratio_list = [single] * (len(direction_list) - 1) + [1 - self.flip_ratio]
-            cur_dir = np.random.choice(direction_list, p=flip_ratio_list)
-            results['flip'] = cur_dir is not None
-        if 'flip_direction' not in results:
-            results['flip_direction'] = cur_dir
+            drawn = self._draw_direction()
+            results['flip'] = drawn is not None
+            results.setdefault('flip_direction', drawn)
         if results['flip']:
+            d = results['flip_direction']
             for key in results.get('img_fields', ['img']):
-                results[key].flip_(results['flip_direction'])
+                results[key].flip_(d)
             for key in results.get('bbox_fields', []):
-                results[key] = self.bbox_flip(results[key], results['img_shape'], results['flip_direction'])
+                results[key] = self.bbox_flip(results[key], results['img_shape'], d)
         return results
 
     def __repr__(self):

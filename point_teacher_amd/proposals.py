@@ -192,6 +192,33 @@ def strong_augmentation(img, gt_points, gt_labels, pseudo_points, pseudo_labels,
 DRAW_ROWS = ('scale', 'x', 'y', 'wn', 'rn', 'a', 'boost', 'itv', 'itv2', 'dev')      # row order of pt_black_paper_rects
 
 
+SEGMENT_MAX_IMAGES, SEGMENT_MAX_CANDIDATES = 16, 8192      # limits of pt_nms_rotated_sorted_segments (PT_ELIMIT beyond)
+
+
+def plan_black_paper_groups(counts, shapes):
+    """Host logic of the fallback: consecutive images are grouped while a group stays within one segmented launch (<= 16 images,
+    <= 8192 candidates = 2 G + 10 per image, one image shape / dtype); an image beyond the candidate limit forms a group of one
+    (per-image NMS).  -> list of (start, stop)."""
+    groups, start = [], 0
+    for i in range(len(counts) + 1):
+        close = i == len(counts)
+        if not close and i > start:
+            big = 2 * counts[i] + 10 > SEGMENT_MAX_CANDIDATES or 2 * counts[i - 1] + 10 > SEGMENT_MAX_CANDIDATES
+            close = i - start >= SEGMENT_MAX_IMAGES or shapes[i] != shapes[start] or big
+        if close and i > start:
+            groups.append((start, i))
+            start = i
+    return groups
+
+
+def _black_paper_in_groups(imgs, gt_bboxes, prior_size, dense_cls, imgsize, draws, fill, return_obb, counts):
+    out = []
+    for a, b in plan_black_paper_groups(counts, [(tuple(im.shape), im.dtype) for im in imgs]):
+        out += generate_black_paper_batch(imgs[a:b], gt_bboxes[a:b], prior_size, dense_cls, imgsize, None if draws is None else draws[a:b],
+                                          fill=fill, return_obb=return_obb)
+    return out
+
+
 def generate_black_paper_batch(imgs, gt_bboxes, prior_size, dense_cls, imgsize, draws=None, fill=255.0, return_obb=False):
     """GPU, sync-free form of generate_black_paper (syn_images_generator_v2.py:591-690) for a BATCH of images
     [C,H,W] whose real objects are gt_bboxes[i] [G_i,4] (xyxy).
@@ -216,9 +243,15 @@ def generate_black_paper_batch(imgs, gt_bboxes, prior_size, dense_cls, imgsize, 
     OBB_TOD/.../syn_images_generator_v2.py:722, whose inputs are mean/std-normalised);
     return_obb=True returns the rectangles as (cx,cy,w,h,a) rows instead of their hulls."""
     B = len(imgs)
+    counts = [int(b.shape[0]) for b in gt_bboxes]
+    if (B > SEGMENT_MAX_IMAGES or (B > 1 and max(2 * c + 10 for c in counts) > SEGMENT_MAX_CANDIDATES)
+            or len({(tuple(im.shape), im.dtype) for im in imgs}) > 1):
+        # beyond what one segmented launch takes (pt_nms_rotated_sorted_segments: 16 images x 8192 candidates; the batched rasteriser:
+        # one shape): groups of images it does take; an image with more candidates than a segment holds goes through the
+        # per-image NMS inside a group of one (round-3 advice: samples_per_gpu > 16 used to raise in the middle of training)
+        return _black_paper_in_groups(imgs, gt_bboxes, prior_size, dense_cls, imgsize, draws, fill, return_obb, counts)
     C, H, W = imgs[0].shape
     dev = imgs[0].device
-    counts = [int(b.shape[0]) for b in gt_bboxes]
     sumG = sum(counts)
     L = prior_size.shape[0]
     prior = prior_size if prior_size.device == dev else prior_size.to(dev)   # callers on the training path pass a device copy
@@ -236,8 +269,11 @@ def generate_black_paper_batch(imgs, gt_bboxes, prior_size, dense_cls, imgsize, 
     sb, nms_in, polys, hull, pre = F.black_paper_sorted(table, order, exist, imgsize)
     keep = torch.ones_like(pre)
     Ms = [2 * c + 10 for c in counts]
-    # one rotated NMS and one rasteriser pass for the whole batch (each image's serial scan is its own workgroup)
-    F.nms_rotated_mask_segments(nms_in, Ms, 0.05, keep)
+    if B == 1 and Ms[0] > SEGMENT_MAX_CANDIDATES:
+        F.nms_rotated_mask(nms_in, 0.05, keep)                    # the per-image kernels take up to 32 768 candidates
+    else:
+        # one rotated NMS and one rasteriser pass for the whole batch (each image's serial scan is its own workgroup)
+        F.nms_rotated_mask_segments(nms_in, Ms, 0.05, keep)
     alive_all = (keep & pre).bool()
     img_of = F.upload_i32(np.repeat(np.arange(B, dtype=np.int32), Ms), dev)
     if fill == 'max':          # device-side value: rasterise a 0/1 mask, then select (no host read of img.max())

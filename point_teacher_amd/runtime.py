@@ -217,15 +217,23 @@ class FlatParams:
         for p in self.train_params:
             p.grad = None
 
-    def take_revived(self):
+    def take_revived(self, keep=None):
         """Names of dead parameters autograd produced a gradient for in the backward that just ran (host-side knowledge:
-        `.grad` is no longer None - no synchronisation); their gradient tensors are dropped."""
+        `.grad` is no longer None - no synchronisation).  `keep` (a dict) receives / accumulates their gradient tensors, so that
+        the revival applies them instead of dropping them (round-3 advice); without it they are dropped."""
         out = []
         for name, p in self.dead_params:
             if p.grad is not None:
                 out.append(name)
+                if keep is not None:
+                    keep[name] = p.grad.detach() if name not in keep else keep[name] + p.grad.detach()
                 p.grad = None
         return out
+
+    def add_to_grad(self, name, g):
+        """Add `g` to the flat gradient slice of the (live) parameter `name`."""
+        off, n = self.slices[name]
+        self.grad_flat[off:off + n].add_(g.reshape(-1).to(self.grad_flat.dtype))
 
     def gather_grads(self, seen=None):
         """Copy the gradients autograd left in `.grad` into the flat buffer with multi-tensor copies (segments of
@@ -477,6 +485,7 @@ class Trainer:
         self.dead_known = False
         self.revive_interval = 100
         self._revived = set()
+        self._revived_grads = {}              # name -> gradient(s) a dead parameter received since the last agreement point
         # BASELINE configs[2] "bf16 backbone + fp32 head": autocast covers backbone / FPN / PSAGG only (Student_FCOS.extract_feat)
         self.autocast_dtype = autocast_dtype
         for m in model.modules():
@@ -541,25 +550,36 @@ class Trainer:
         """torch.optim.SGD skips parameters whose `.grad is None` and DDP reduces nothing for them: the parameters no backward
         has ever reached (TS_P2BFCOSHead.shared_fcs / shared_fcs_refine / fc_iou: 31 % of the student) leave the live groups.
         First step: dead = trainable parameters without a gradient on ANY rank.  Later: a dead parameter that received a
-        gradient is revived (N == 1: in the same step, before the update; N > 1: at the next agreement point, so that every
-        rank re-lays its buffers in the same step - its gradients of the steps in between are dropped, documented)."""
+        gradient is revived (N == 1: in the same step, before the update, WITH that gradient; N > 1: at the next agreement point,
+        so that every rank re-lays its buffers in the same step - the gradients of the steps in between are summed and enter
+        the update of the revival step, averaged over the ranks)."""
         f = self.flat
         trainable = [n for n, p in f.order if p.requires_grad]
         if not self.dead_known:
-            live = self._agree(seen | set(f.take_revived()), trainable)
+            live = self._agree(seen | set(f.take_revived()), trainable)       # (first step: every trainable parameter is still live)
             self.dead_known = True
             self._relayout(set(trainable) - live)
             return
-        self._revived.update(f.take_revived())
+        self._revived.update(f.take_revived(self._revived_grads))
         if self.world == 1:
             if self._revived:
                 self._relayout(set(f.dead) - self._revived)
-                self._revived = set()
+                for n, g in self._revived_grads.items():           # the gradient that revived it takes part in THIS update
+                    self.flat.add_to_grad(n, g)
+                self._revived, self._revived_grads = set(), {}
         elif (self.iter + 1) % self.revive_interval == 0 and f.dead:
             rev = self._agree(self._revived, sorted(f.dead))
-            self._revived = set()
             if rev:
                 self._relayout(set(f.dead) - rev)
+                # the gradients the ranks saw since the last agreement point (summed per rank, averaged over the ranks here - the
+                # one collective of a revival) enter this update instead of being dropped
+                for n in sorted(rev):
+                    off, cnt = self.flat.slices[n]
+                    g = self._revived_grads.get(n)
+                    buf = (g.reshape(-1).float() if g is not None else torch.zeros(cnt, device=self.flat.grad_flat.device)).contiguous()
+                    dist.all_reduce(buf)
+                    self.flat.add_to_grad(n, buf / self.world)
+            self._revived, self._revived_grads = set(), {}
 
     def _relayout(self, dead):
         if self.flat.relayout(dead) and self.exchange is not None:

@@ -102,3 +102,25 @@ def test_integration_stub_runs_on_gpu():
     rois = torch.tensor([[0, 8., 8., 40., 56.], [1, 20.3, 11.1, 23.9, 14.2], [1, 1., 1., 150., 150.]], device=dev)
     o = ns['roi_align_forward'](feat, rois, 7, 0.125)
     torch.testing.assert_close(o, F.roi_align(feat, rois, 7, 0.125), rtol=1e-6, atol=1e-6)
+
+
+def test_documented_build_command_works_from_a_clean_copy(tmp_path):
+    """`python -m point_teacher_amd.build` - the command the missing-library error prints - on a copy of the sources WITHOUT
+    libpt_hip.so and without object files (round-3 verdict P6): the package import must not need the library it is about to
+    build; any other import of the package without the library still fails loudly."""
+    import shutil
+    import sys
+    src = os.path.join(ROOT, 'point_teacher_amd')
+    dst = tmp_path / 'point_teacher_amd'
+    shutil.copytree(src, dst, ignore=shutil.ignore_patterns('*.so', 'build', '__pycache__', '*.o'))
+    shutil.copytree(os.path.join(ROOT, 'include'), tmp_path / 'include')
+    # only the two translation units that share no heavy templates are compiled here (the full build is __graft_entry__.build());
+    # the build module takes its source list from a variable this test narrows through the environment
+    env = dict(os.environ, PT_BUILD_SOURCES='glue.hip,image_prep.hip')
+    r = subprocess.run([sys.executable, '-m', 'point_teacher_amd.build'], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert (dst / 'libpt_hip.so').exists()
+    shutil.rmtree(dst / 'build')
+    os.remove(dst / 'libpt_hip.so')
+    r = subprocess.run([sys.executable, '-c', 'import point_teacher_amd'], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and 'python -m point_teacher_amd.build' in r.stderr

@@ -81,23 +81,18 @@ def test_random_draws_match_reference():
     t = D.Resize(img_scale=[(1333, 640), (1333, 800)], multiscale_mode='range')
     got = []
     for _ in range(8):
-        d = {}
-        t._random_scale(d)
-        got.append(d['scale'])
+        got.append(t._pick_scale()[0])
     np.testing.assert_array_equal(np.array(got), G['scale_range'])
     t = D.Resize(img_scale=[(1333, 640), (1000, 600), (800, 800)], multiscale_mode='value')
     got = []
     for _ in range(8):
-        d = {}
-        t._random_scale(d)
-        got.append(d['scale'] + (d['scale_idx'],))
+        scale, idx = t._pick_scale()
+        got.append(scale + (idx,))
     np.testing.assert_array_equal(np.array(got), G['scale_value'])
     t = D.Resize(img_scale=(800, 800), ratio_range=(0.5, 1.5))
     got = []
     for _ in range(8):
-        d = {}
-        t._random_scale(d)
-        got.append(d['scale'])
+        got.append(t._pick_scale()[0])
     np.testing.assert_array_equal(np.array(got), G['scale_ratio'])
     np.random.seed(5)
     f = D.RandomFlip(flip_ratio=[0.3, 0.3, 0.2], direction=list(DIRS))

@@ -211,3 +211,21 @@ def test_bench_matrix_family_accounting():
     assert bench.conv_desc_shapes(d)['M'] == 60000 and bench.conv_desc_shapes(d)['taps'] == 9
     for fn in bench.MFMA_FAMILY[1] + bench.SPLIT_FNS + tuple(m for ms in bench.FAMILIES.values() for m in ms):
         assert fn in hip.PROTOS, fn                                # every entry point the roofline names exists in the header
+
+
+def test_black_paper_batches_beyond_one_segmented_launch_are_grouped():
+    """samples_per_gpu > 16, an image with more than 4 091 objects (2 G + 10 > 8192 candidates) or mixed image shapes: the batch is
+    cut into groups one segmented NMS / rasteriser launch takes instead of raising PT_ELIMIT in the middle of training."""
+    from point_teacher_amd.proposals import SEGMENT_MAX_CANDIDATES, SEGMENT_MAX_IMAGES, plan_black_paper_groups
+    assert (SEGMENT_MAX_IMAGES, SEGMENT_MAX_CANDIDATES) == (16, 8192)
+    sh = ((3, 800, 800), 'f32')
+    assert plan_black_paper_groups([300] * 2, [sh] * 2) == [(0, 2)]
+    assert plan_black_paper_groups([300] * 40, [sh] * 40) == [(0, 16), (16, 32), (32, 40)]
+    assert plan_black_paper_groups([300, 5000, 300, 300], [sh] * 4) == [(0, 1), (1, 2), (2, 4)]        # 2 * 5000 + 10 candidates: alone
+    other = ((3, 640, 800), 'f32')
+    assert plan_black_paper_groups([10, 10, 10], [sh, other, other]) == [(0, 1), (1, 3)]
+    assert plan_black_paper_groups([], []) == []
+    for counts in ([7] * 33, [4091, 4092, 1], [1]):
+        g = plan_black_paper_groups(counts, [sh] * len(counts))
+        assert [i for a, b in g for i in range(a, b)] == list(range(len(counts)))                       # a partition, in order
+        assert all(b - a <= 16 and (b - a == 1 or max(2 * c + 10 for c in counts[a:b]) <= 8192) for a, b in g)

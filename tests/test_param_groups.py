@@ -111,6 +111,17 @@ def test_dead_segment_and_relayout():
     assert off < flat.n_weights and float(flat.grad_flat[off:off + k].abs().sum()) == 0 and torch.equal(net[1].weight, before['1.weight'])
     with pytest.raises(AssertionError, match='not trainable'):
         flat.relayout({'2.weight'})
+    # the gradient that revives a parameter is kept for the update of that step (round-3 advice): take_revived(keep) hands it
+    # over (summing several steps' worth), add_to_grad places it in the re-laid buffer
+    net[1].bias.grad = torch.full_like(net[1].bias, 2.0)
+    keep = {}
+    assert flat.take_revived(keep) == ['1.bias'] and net[1].bias.grad is None and torch.equal(keep['1.bias'], torch.full((7,), 2.0))
+    net[1].bias.grad = torch.full_like(net[1].bias, 0.5)
+    assert flat.take_revived(keep) == ['1.bias'] and torch.equal(keep['1.bias'], torch.full((7,), 2.5))
+    assert flat.relayout(set()) and flat.n_dead == 0
+    flat.add_to_grad('1.bias', keep['1.bias'])
+    off, k = flat.slices['1.bias']
+    assert torch.equal(flat.grad_flat[off:off + k], torch.full((7,), 2.5)) and torch.equal(net[1].bias.grad, torch.full((7,), 2.5))
 
 
 def test_retinanet_baseline_config_groups():

@@ -200,7 +200,7 @@ def test_product_obb_iteration_vs_reference():
         seen.setdefault('merged', []).append(torch.cat(r).detach().cpu())
         return r
     head.mil_bag_selection = spy_sel
-    report = {}
+    report, grads_by_it = {}, {}
     for it in range(2):
         model._inject = _inject(G, it, dev)
         seen.pop('merged', None)
@@ -218,6 +218,7 @@ def test_product_obb_iteration_vs_reference():
         torch.testing.assert_close(got_merged[-ref_merged.shape[0]:] if got_merged.shape[0] >= ref_merged.shape[0] else got_merged,
                                    ref_merged[-got_merged.shape[0]:], rtol=1e-4, atol=2e-3)
         grads = {k: p.grad for k, p in model.student.named_parameters() if k in GRAD_KEYS}
+        grads_by_it[it] = {k: g.clone() for k, g in grads.items() if g is not None}
         report[it] = _check_grads(grads, G, it, rel=GRAD_TOL)
         if it == 0:            # the generator through the product: survivors in the reference's order, painted pixels
             for i in range(2):
@@ -227,3 +228,21 @@ def test_product_obb_iteration_vs_reference():
                 assert np.array_equal((im[0] != img[i][0]).numpy() | (im == im.max()).all(0).numpy(), mask_ref)
     assert model.count == 2
     print('gradient errors (relative to the sample norm):', {it: {k: f'{v:.1e}' for k, v in r.items()} for it, r in report.items()})
+    # The five ill-conditioned tensors against the FLOAT64 evaluation of the same iteration (tests/golden/ref_iter_obb_fp64.npz,
+    # oracle/gen_golden_obb_fp64.py): the golden above is the reference's own fp32 run, itself 5e-3 ... 5e-2 away from float64 on
+    # these tensors - a 2e-2 bound against it cannot tell a 1 % kernel error from conditioning (round-3 verdict P2).  Against
+    # float64 the product's fp32 gradients must not be further away than the reference's fp32 gradients are (x 1.5 + 3e-3: both
+    # are single fp32 runs scattered around the float64 value).
+    G64 = load_golden('ref_iter_obb_fp64')
+    cmp64 = {}
+    for it in range(2):
+        for k in ILL_CONDITIONED:
+            if f'it{it}_grad64_{k}' not in G64:
+                continue
+            r64 = G64.t(f'it{it}_grad64_{k}').double()
+            ref32 = G.t(f'it{it}_grad_{k}').double()
+            got = _sample(grads_by_it[it][k].detach().cpu()).double()
+            e_prod, e_ref = float((got - r64).norm() / r64.norm()), float((ref32 - r64).norm() / r64.norm())
+            cmp64[(it, k)] = (e_prod, e_ref)
+            assert e_prod <= 1.5 * e_ref + GRAD_TOL, (it, k, e_prod, e_ref)
+    print('ill-conditioned gradients vs float64 (product, reference fp32):', {f'{it}:{k}': (f'{a:.1e}', f'{b:.1e}') for (it, k), (a, b) in cmp64.items()})
