@@ -510,10 +510,13 @@ def main():
 
     if rank == 0:
         cpu_baseline = None
-        if obb:
-            cpu_baseline = dict(value=None, unit='iters/s', cores=None, kind='port',
-                                sample='not timed for the oriented variant (its oracle, oracle/ref_obb.py, loops over RoIs '
-                                       'in python); the CPU leg is reported on the default hbb workload')
+        if obb and not args.no_cpu_baseline and world == 1:
+            try:       # the oriented oracle loops over RoIs in python: ONE iteration of a 1/8 sample (same object density), scaled
+                from oracle import ref_obb
+                cpu_baseline = ref_obb.cpu_baseline(args.workload, args.batch, args.size, args.objects, sample_div=8)
+                cpu_baseline['cpu'] = cpu_info()
+            except Exception as e:
+                cpu_baseline = dict(value=None, unit='iters/s', cores=os.cpu_count(), kind='port', sample=f'failed: {type(e).__name__}: {e}')
         elif not args.no_cpu_baseline and args.cpu_baseline_iters > 0 and world == 1:
             try:
                 from oracle import ref_model

@@ -593,3 +593,55 @@ MODEL_CFG = dict(num_stages=1, num_training_burninstep1=100, num_training_burnin
                              [20, 50, 0.5, 0.5], [30, 20, 0.5, 0.5], [35, 40, 0.6, 0.5]],   # sodaa_fcos_pointteacher_1x.py:22-24
                  fine_proposal_cfg=[dict(base_ratios=[1.0], shake_ratio=None, min_scale=0)],
                  fine_proposal_extensive_cfg=[dict(base_ratios=[1.0, 1.2, 1.3, 0.8, 0.6], shake_ratio=None, min_scale=4)])
+
+
+def cpu_baseline(workload='step2', batch=2, size=1200, objects=300, sample_div=4):
+    """Time ONE iteration of this oracle (forward + backward + clip + SGD + EMA) on the host cores for bench.py's `cpu_baseline` of
+    the oriented variant.  The oracle evaluates RoIAlignRotated, rotated IoU and their gradients RoI by RoI in python, so the
+    full-size iteration (1200 x 1200, ~300 objects) takes minutes; the timed SAMPLE keeps the object density and divides the
+    pixels AND the objects by `sample_div` - every part of the iteration (convolutions ~ pixels; bags, RoIs, rotated IoU ~ objects)
+    shrinks by that factor - and the reported value is the sample's rate / sample_div."""
+    import time
+    cores = M.effective_cpus()
+    torch.set_num_threads(cores)
+    s_size = int(round(size / math.sqrt(sample_div) / 32)) * 32
+    s_obj = max(1, int(round(objects / sample_div)))
+    g = torch.Generator().manual_seed(0)
+    sd_s, sd_t = init_detector_state_obb(1, 1), init_detector_state_obb(2, 1)
+    if workload == 'step2':
+        for sd in (sd_s, sd_t):
+            sd['bbox_head.conv_reg.bias'] = torch.ones(4)
+
+    def one(size_, objects_):
+        nonlocal sd_t
+        img = (torch.rand(batch, 3, size_, size_, generator=g) * 2 - 1)                      # mean / std normalised pixels
+        boxes, labels = [], []
+        for _ in range(batch):
+            c = torch.rand(objects_, 2, generator=g) * (size_ - 64) + 32
+            wh = torch.exp(torch.randn(objects_, 2, generator=g) * 0.4 + math.log(14.0)).clamp(5, 36)
+            a = (torch.rand(objects_, 1, generator=g) - 0.5) * math.pi * 0.98
+            boxes.append(torch.cat([c, wh, a], 1))
+            labels.append(torch.randint(0, NUM_CLASSES, (objects_,), generator=g))
+        points = [b[:, :2] for b in boxes]
+        inject = dict(neg0=torch.rand(batch, 5, 200, generator=g), aug=((['horizontal', 'None'] * batch)[:batch], ([0, 90] * batch)[:batch],
+                                                                      ([0.9, 1.1] * batch)[:batch]))
+        params = {k: (v.clone().requires_grad_(True) if trainable_obb(k) else v) for k, v in sd_s.items()}
+        sd_t = M.ema(sd_t, sd_s)
+        if workload == 'step1':
+            inject.update(img_syn=img.clone(), syn_boxes=[b[: max(1, len(b) // 2)].clone() for b in boxes])
+            losses, _ = forward_train_step1(params, sd_t, img, boxes, labels, points, dict(MODEL_CFG), inject)
+        else:
+            losses, _ = forward_train_step2(params, sd_t, img, boxes, labels, points, dict(MODEL_CFG), inject)
+        loss = M.total_loss(losses)
+        names = [k for k in params if trainable_obb(k)]
+        gr = torch.autograd.grad(loss, [params[k] for k in names], allow_unused=True)
+        M.sgd_clip_step(sd_s, dict(zip(names, gr)), {}, 0.005 / 3, True)
+        return float(loss)
+    one(256, 8)                                   # warm-up (allocator, thread pools)
+    t0 = time.perf_counter()
+    one(s_size, s_obj)
+    dt = time.perf_counter() - t0
+    return dict(value=round(1.0 / (dt * sample_div), 6), unit='iters/s', cores=cores, kind='port',
+                sample=f'ONE {workload} iteration of oracle/ref_obb.py (torch-CPU fp32, {cores} threads; RoIAlignRotated / rotated IoU RoI by RoI in '
+                       f'python) on a 1/{sample_div} sample: bs {batch}, {s_size}x{s_size}, {s_obj} objects/img (same object density as '
+                       f'{size}x{size} with {objects}) took {dt:.1f} s; value = sample rate / {sample_div} (pixels and objects both scale the work)')
