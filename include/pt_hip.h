@@ -289,6 +289,10 @@ int pt_conv3x3_wgrad_bf16x6_nhwc(const uint16_t* gy_planes, int64_t gy_plane_str
  * Split-k: a launch with few output tiles and a long reduce dimension (the teacher's batch of 2; layer4's 25 x 25 maps) cuts the k-steps
  * into `splits` chunks (0 = pt_conv_bf16x6_splits(...) when a workspace is given, else 1), every (tile, chunk) workgroup stores its
  * raw fp32 tile to workspace[splits][M][Cout] and a second launch adds them in a fixed order and runs the epilogue (deterministic).
+ * dstride == 2: the INPUT GRADIENT of a 3 x 3 stride-2 convolution (a `pytorch`-style Bottleneck's conv2, resnet.py:153-158) as a
+ * transposed convolution: x_planes = the output gradient on the coarse grid [B, Hs, Ws], the result lives on the convolution's
+ * input grid [B, out_H, out_W]; stride = 1, pad = KH - 1 - (forward padding), w_planes in the mode-1 form; taps whose coordinate is
+ * odd read the zero row.  dstride == 0 / 1: off.
  * tile_rows: 64, 96, ..., 256 or 0 = pt_gemm_bf16x6_tile_rows.  [host] struct; device pointers inside. */
 typedef struct {
   int32_t B, Hs, Ws, Cin, Cout, KH, KW, stride, pad;
@@ -311,7 +315,7 @@ typedef struct {
   float* workspace;
   int64_t workspace_elems;
   int32_t splits;
-  int32_t reserved;
+  int32_t dstride, out_H, out_W;
 } pt_conv_desc;
 int pt_conv_bf16x6_splits(int B, int Hs, int Ws, int Cin, int Cout, int KH, int KW, int stride, int pad, int tile_rows);
 int pt_conv_bf16x6(const pt_conv_desc* desc, void* stream);
@@ -338,6 +342,13 @@ typedef struct {
   int32_t reserved;
 } pt_conv_wgrad_desc;
 int pt_conv_wgrad_bf16x6_splits(int B, int Ho, int Wo, int KH, int KW, int Cin, int Cout);
+/* Trainable BatchNorm (eval-mode statistics) behind a convolution - OBB config 5, `norm_cfg=dict(type='BN', requires_grad=True)`,
+ * `norm_eval=True` (OBB_TOD/configs/point teacher/sodaa_fcos_pointteacher_1x.py:36-38): after pt_conv_wgrad_bf16x6 with
+ * row_scale == NULL and dbias = sum_e, this turns the raw weight gradient dw[Cout][rowlen] into the three parameter gradients
+ *   dgamma[o] = rstd[o] * (<w[o], dw[o]> - mean[o] * sum_e[o])      dbeta[o] = sum_e[o]      dw[o] *= scale[o]  (in place)
+ * (sum_p e * conv = <w[o], dw[o]> because conv = w x: no pass over the activations).  rowlen = KH * KW * Cin, a multiple of 4. */
+int pt_bn_wgrad_finish(float* dw, const float* w, int Cout, int rowlen, const float* scale, const float* rstd, const float* mean,
+                       const float* sum_e, float* dgamma, void* stream);
 int pt_conv_wgrad_bf16x6(const pt_conv_wgrad_desc* desc, void* stream);
 
 /* fp32 NHWC [B, Hs, Ws, C] (pixel stride ld) -> row-major planes of the pixels (y * stride, x * stride): [3][(B * Ho * Wo + 1) * C],

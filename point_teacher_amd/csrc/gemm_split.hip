@@ -218,6 +218,8 @@ struct ConvGeom {
   int KW, taps;                     // taps = KH * KW
   int stride, pad;                  // source pixel of output (y, x) under tap (ky, kx): (y * stride - pad + ky, x * stride - pad + kx)
   int Ps;                           // B * Hs * Ws: the zero row of the A planes
+  int dstride;                      // 2: the INPUT GRADIENT of a stride-2 convolution (a transposed convolution): the coordinate above
+                                    //    must be even and is halved - taps of the wrong parity read the zero row
 };
 
 // What happens to a finished tile (CONV kernels): v = acc * scale[col] + shift[col] (+ residual) -> ReLU -> mask -> fp32 and / or
@@ -403,14 +405,29 @@ __global__ void __launch_bounds__(GTHREADS)
         const int y = yq % cg.Ho, bi = yq / cg.Ho;
         const int yb = y * cg.stride - cg.pad, xb = x * cg.stride - cg.pad;
         int mask = 0;
-        if (pix < M) {
-          for (int t = 0; t < cg.taps; ++t) {
-            const int yy = yb + t / cg.KW, xx = xb + t % cg.KW;
-            mask |= (yy >= 0 && yy < cg.Hs && xx >= 0 && xx < cg.Ws) ? (1 << t) : 0;
+        if (cg.dstride > 1) {
+          // yb + ky must be even: ky in {py, py + 2} with py = yb & 1 (yb >= -pad >= -2); source row (yb + py) / 2 + (ky - py) / 2
+          const int py = yb & 1, px = xb & 1;
+          if (pix < M) {
+            for (int t = 0; t < cg.taps; ++t) {
+              const int ky = t / cg.KW, kx = t % cg.KW;
+              const int yn = yb + ky, xn = xb + kx;
+              const bool ok = ((ky ^ py) & 1) == 0 && ((kx ^ px) & 1) == 0 && yn >= 0 && xn >= 0 && (yn >> 1) < cg.Hs && (xn >> 1) < cg.Ws;
+              mask |= ok ? (1 << t) : 0;
+            }
           }
+          cpix[j] = (bi * cg.Hs + ((yb + py) >> 1)) * cg.Ws + ((xb + px) >> 1);
+          cmask[j] = mask | (py << 9) | (px << 10);
+        } else {
+          if (pix < M) {
+            for (int t = 0; t < cg.taps; ++t) {
+              const int yy = yb + t / cg.KW, xx = xb + t % cg.KW;
+              mask |= (yy >= 0 && yy < cg.Hs && xx >= 0 && xx < cg.Ws) ? (1 << t) : 0;
+            }
+          }
+          cpix[j] = (bi * cg.Hs + yb) * cg.Ws + xb;
+          cmask[j] = mask;
         }
-        cpix[j] = (bi * cg.Hs + yb) * cg.Ws + xb;
-        cmask[j] = mask;
         gsrc[j] = reinterpret_cast<const unsigned char*>(base) + sl * 16;
       } else {
         gsrc[j] = reinterpret_cast<const unsigned char*>(base + (((long)rb * KB + kb0) << 9)) + lane * 16;
@@ -418,18 +435,20 @@ __global__ void __launch_bounds__(GTHREADS)
     }
   }
   // (tap, channel block) of the stage that is issued next: wave-uniform counters instead of divisions per k-step
-  int s_tap = 0, s_cb = 0, s_off = 0, s_kx = 0;         // s_off = ky * Ws + kx of s_tap
+  int s_tap = 0, s_cb = 0, s_off = 0, s_kx = 0, s_ky = 0;   // s_off = ky * Ws + kx of s_tap
   if (CONV && kb0 > 0) {
     s_tap = kb0 / cg.CB;
     s_cb = kb0 - s_tap * cg.CB;
-    const int ky = s_tap / cg.KW;
-    s_kx = s_tap - ky * cg.KW;
-    s_off = ky * cg.Ws + s_kx;
+    s_ky = s_tap / cg.KW;
+    s_kx = s_tap - s_ky * cg.KW;
+    s_off = s_ky * cg.Ws + s_kx;
   }
   auto issue1 = [&](int j, int buf) {                   // one 1-KiB block of the next stage
     if (j < NJ && w + 8 * j < NI) {                     // wave-uniform
       if (CONV && w + 8 * j < 3 * (BM / 16)) {          // wave-uniform: an activation piece
-        const int pix = ((cmask[j] >> s_tap) & 1) ? cpix[j] + s_off : cg.Ps;
+        int pix = cg.Ps;
+        if ((cmask[j] >> s_tap) & 1)
+          pix = cg.dstride > 1 ? cpix[j] + ((s_ky - ((cmask[j] >> 9) & 1)) >> 1) * cg.Ws + ((s_kx - ((cmask[j] >> 10) & 1)) >> 1) : cpix[j] + s_off;
         glds16(gsrc[j] + ((long)pix * cg.Cin + s_cb * 32) * 2, smem + buf * STAGE + (w + 8 * j) * 1024);
       } else {
         glds16(gsrc[j], smem + buf * STAGE + (w + 8 * j) * 1024);
@@ -443,7 +462,7 @@ __global__ void __launch_bounds__(GTHREADS)
         s_cb = 0;
         ++s_tap;
         ++s_off;
-        if (++s_kx == cg.KW) { s_kx = 0; s_off += cg.Ws - cg.KW; }
+        if (++s_kx == cg.KW) { s_kx = 0; ++s_ky; s_off += cg.Ws - cg.KW; }
       }
     }
   };
@@ -961,6 +980,36 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float4* __restr
   }
 }
 
+// Trainable BatchNorm behind a convolution (eval-mode statistics; OBB config 5: norm_cfg requires_grad=True, norm_eval=True):
+// y = gamma * rstd * (conv - mean) + beta.  With G[o][:] = sum_p e[p][o] x[src(p)][:] (the raw weight gradient) and
+// sum_e[o] = sum_p e[p][o] (the bias sums of the same launch):
+//     d beta[o]  = sum_e[o]
+//     d gamma[o] = rstd[o] * (sum_p e[p][o] conv[p][o] - mean[o] sum_e[o]),   sum_p e conv = <W[o][:], G[o][:]>   (conv = W x)
+//     d W[o][:]  = scale[o] * G[o][:]                                                        (scale = gamma * rstd)
+// - no pass over the activations.  One workgroup per output channel: the row dot in a fixed order, then the row is scaled in place.
+__global__ void __launch_bounds__(256)
+    bn_wgrad_finish_kernel(float* __restrict__ dw, const float* __restrict__ w, int rowlen, const float* __restrict__ scale,
+                           const float* __restrict__ rstd, const float* __restrict__ mean, const float* __restrict__ sum_e,
+                           float* __restrict__ dgamma) {
+  __shared__ float sm[32];
+  const int o = blockIdx.x;
+  float* g = dw + (long)o * rowlen;
+  const float* wr = w + (long)o * rowlen;
+  float acc = 0.f;
+  for (int i = threadIdx.x * 4; i < rowlen; i += blockDim.x * 4) {
+    const float4 a = *reinterpret_cast<const float4*>(g + i), b = *reinterpret_cast<const float4*>(wr + i);
+    acc += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+  }
+  const float dot = block_sum(acc, sm);
+  const float sc = scale[o];
+  for (int i = threadIdx.x * 4; i < rowlen; i += blockDim.x * 4) {
+    float4 a = *reinterpret_cast<const float4*>(g + i);
+    a.x *= sc; a.y *= sc; a.z *= sc; a.w *= sc;
+    *reinterpret_cast<float4*>(g + i) = a;
+  }
+  if (threadIdx.x == 0) dgamma[o] = rstd[o] * (dot - mean[o] * sum_e[o]);
+}
+
 template <int MB, int NST>
 static int launch_wgrad(const uint16_t* Gp, const uint16_t* Xp, float* part, float* part_bias, long g_plane, long x_plane, WgradGeom wg, int S,
                         hipStream_t s) {
@@ -1216,7 +1265,16 @@ extern "C" int pt_conv_bf16x6_splits(int B, int Hs, int Ws, int Cin, int Cout, i
 extern "C" int pt_conv_bf16x6(const pt_conv_desc* d, void* stream) {
   int rc = conv_check(d, "pt_conv_bf16x6");
   if (rc != PT_OK) return rc;
-  const int Ho = (d->Hs + 2 * d->pad - d->KH) / d->stride + 1, Wo = (d->Ws + 2 * d->pad - d->KW) / d->stride + 1;
+  int Ho = (d->Hs + 2 * d->pad - d->KH) / d->stride + 1, Wo = (d->Ws + 2 * d->pad - d->KW) / d->stride + 1;
+  if (d->dstride > 1) {
+    // transposed form: x_planes = the output gradient on the coarse grid [B, Hs, Ws], result on the convolution's INPUT grid
+    // [B, out_H, out_W]; pad = KH - 1 - (the forward convolution's padding), weights in the mode-1 (flipped, transposed) form
+    PT_REQUIRE(d->dstride == 2 && d->stride == 1 && d->KH == 3 && d->out_H > 0 && d->out_W > 0 && (d->out_H + 1) / 2 >= d->Hs &&
+                   (d->out_W + 1) / 2 >= d->Ws && !d->scatter_stride,
+               PT_EINVAL, "pt_conv_bf16x6: dstride 2 = the input gradient of a 3 x 3 stride-2 convolution onto its [out_H, out_W] input grid");
+    Ho = d->out_H;
+    Wo = d->out_W;
+  }
   PT_REQUIRE(Ho > 0 && Wo > 0, PT_EINVAL, "pt_conv_bf16x6: empty output");
   const long Ps = (long)d->B * d->Hs * d->Ws, M = (long)d->B * Ho * Wo;
   PT_REQUIRE(Ps < (1L << 30) && Ps * d->Cin < (1L << 40), PT_ELIMIT, "pt_conv_bf16x6: B * Hs * Ws < 2^30");
@@ -1252,7 +1310,7 @@ extern "C" int pt_conv_bf16x6(const pt_conv_desc* d, void* stream) {
     if (taps * (d->Cin / 32) <= 4 && M >= 16384 && d->Cout >= 256) tile_rows = 64;
   }
   PT_REQUIRE(tile_rows % 32 == 0 && tile_rows >= 64 && tile_rows <= 256, PT_EINVAL, "pt_conv_bf16x6: tile_rows in {64, 96, ..., 256}");
-  const ConvGeom cg{d->Hs, d->Ws, Ho, Wo, d->Cin, d->Cin / 32, d->KW, taps, d->stride, d->pad, (int)Ps};
+  const ConvGeom cg{d->Hs, d->Ws, Ho, Wo, d->Cin, d->Cin / 32, d->KW, taps, d->stride, d->pad, (int)Ps, d->dstride > 1 ? 2 : 1};
   const int KB = taps * (d->Cin / 32);
   int S = d->splits;
   if (S <= 0) S = d->workspace ? conv_splits(M, d->Cout, KB, tile_rows) : 1;
@@ -1354,6 +1412,16 @@ extern "C" int pt_conv_wgrad_bf16x6(const pt_conv_wgrad_desc* d, void* stream) {
                      reinterpret_cast<const float4*>(d->workspace), S, n / 4, taps * d->Cin / 4, reinterpret_cast<float4*>(d->dw), d->row_scale,
                      reinterpret_cast<const float4*>(part_bias), (int)(nbias / 4), reinterpret_cast<float4*>(d->dbias), d->accumulate);
   PT_LAUNCH_CHECK("pt_conv_wgrad_bf16x6 (reduce)");
+  return PT_OK;
+}
+
+extern "C" int pt_bn_wgrad_finish(float* dw, const float* w, int Cout, int rowlen, const float* scale, const float* rstd, const float* mean,
+                                  const float* sum_e, float* dgamma, void* stream) {
+  PT_REQUIRE(dw && w && scale && rstd && mean && sum_e && dgamma && Cout > 0 && rowlen > 0 && rowlen % 4 == 0, PT_EINVAL,
+             "pt_bn_wgrad_finish: bad argument (rowlen a multiple of 4)");
+  PT_REQUIRE(((((uintptr_t)dw) | ((uintptr_t)w)) & 15) == 0, PT_EINVAL, "pt_bn_wgrad_finish: dw / w must be 16-byte aligned");
+  hipLaunchKernelGGL(bn_wgrad_finish_kernel, dim3(Cout), dim3(256), 0, as_stream(stream), dw, w, rowlen, scale, rstd, mean, sum_e, dgamma);
+  PT_LAUNCH_CHECK("pt_bn_wgrad_finish");
   return PT_OK;
 }
 

@@ -20,6 +20,7 @@ from .registry import BACKBONES, NECKS, ROI_EXTRACTORS
 
 _SPLIT_CONV = os.environ.get('PT_SPLIT_CONV', '1') != '0'
 _PLANE_TRUNK = _SPLIT_CONV and os.environ.get('PT_PLANE_TRUNK', '1') != '0'     # 0: the round-3 routing (3x3 only, fp32 between layers)
+_PLANE_BN_TRAIN = os.environ.get('PT_PLANE_BN_TRAIN', '1') != '0'               # 0: blocks with a trainable BatchNorm keep the round-3 routing
 _GN_CL = os.environ.get('PT_GN_CL', '1') != '0'
 
 
@@ -224,33 +225,38 @@ def _bn_affine(bn):
     return cache[1], cache[2]
 
 
-def refresh_bn_affines(model):
-    """Recompute the cached (scale, shift) of EVERY eval-mode, non-trainable BatchNorm of `model` with a
-    handful of launches (4 concatenations + 4 element-wise ops into persistent buffers) instead of four tiny
-    kernels per layer.  Called after the teacher EMA; the per-layer pairs are views of two persistent
-    buffers, so HIP graphs that captured them keep reading current values."""
-    bns = [m for m in model.modules() if isinstance(m, nn.BatchNorm2d) and not m.training and not m.weight.requires_grad]
+def refresh_bn_affines(model, trainable=False):
+    """Recompute the cached (scale, shift) of EVERY eval-mode BatchNorm of `model` whose affine is frozen (`trainable=False`) or
+    trains (`trainable=True`: OBB config 5 - eval statistics, trainable gamma / beta; also caches rstd for d gamma) with a handful
+    of launches (4 concatenations + 4 element-wise ops into persistent buffers) instead of four tiny kernels per layer.  Called
+    after the teacher EMA and, for trainable affines, once per parameter update; the per-layer triples are views of persistent
+    buffers (the plane kernels' weight-plane cache holds pointers to the scales)."""
+    bns = [m for m in model.modules() if isinstance(m, nn.BatchNorm2d) and not m.training and bool(m.weight.requires_grad) == trainable]
     if not bns:
         return
     eps = bns[0].eps
     assert all(b.eps == eps for b in bns)
     n = sum(b.num_features for b in bns)
-    buf = getattr(model, '_bn_affine_buf', None)
+    name = '_bn_affine_buf_t' if trainable else '_bn_affine_buf'
+    buf = getattr(model, name, None)
     if buf is None or buf[0].numel() != n or buf[0].device != bns[0].weight.device:
-        buf = (torch.empty(n, dtype=torch.float32, device=bns[0].weight.device),
-               torch.empty(n, dtype=torch.float32, device=bns[0].weight.device))
-        model._bn_affine_buf = buf
+        buf = tuple(torch.empty(n, dtype=torch.float32, device=bns[0].weight.device) for _ in range(3))
+        setattr(model, name, buf)
     with torch.no_grad():
-        w = torch.cat([b.weight.float() for b in bns])
+        w = torch.cat([b.weight.detach().float() for b in bns])
         var = torch.cat([b.running_var.float() for b in bns])
-        torch.mul(w, torch.rsqrt(var + eps), out=buf[0])
+        torch.rsqrt(var + eps, out=buf[2])
+        torch.mul(w, buf[2], out=buf[0])
         mean = torch.cat([b.running_mean.float() for b in bns])
-        bias = torch.cat([b.bias.float() for b in bns])
+        bias = torch.cat([b.bias.detach().float() for b in bns])
         torch.sub(bias, mean * buf[0], out=buf[1])
     o = 0
     for b in bns:
         c = b.num_features
+        if trainable:
+            b._affine_dynamic = True                 # the fused SGD kernel rewrites gamma / beta through raw pointers
         b._affine = (_bn_key(b), buf[0][o:o + c], buf[1][o:o + c])
+        b._rstd = buf[2][o:o + c]
         o += c
 
 
@@ -313,14 +319,19 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def plane_ok(self):
-        """Frozen eval-mode BatchNorms, stride on conv1 (`caffe`) or none, no dilation, channel counts the weight-gradient tiles
-        take, channels_last fp32 weights on the device: the block can run plane-native (planes._BottleneckP)."""
+        """Eval-mode BatchNorms (frozen affine, or all of them trainable - OBB config 5), one stride in the block (on conv1 -
+        `caffe` - or on conv2 - `pytorch`) matched by the downsample, no dilation, channel counts the weight-gradient tiles take,
+        channels_last fp32 weights on the device: the block can run plane-native (planes._BottleneckP)."""
         bns = [self.bn1, self.bn2, self.bn3] + ([self.downsample[1]] if self.downsample is not None else [])
         convs = [self.conv1, self.conv2, self.conv3] + ([self.downsample[0]] if self.downsample is not None else [])
-        return (_PLANE_TRUNK and all((not b.training) and (not b.weight.requires_grad) and getattr(b, 'fuse_epilogue', True) for b in bns)
-                and self.conv2.stride == (1, 1) and self.conv2.dilation == (1, 1) and self.conv1.stride[0] in (1, 2)
-                and (self.downsample is None or self.downsample[0].stride == self.conv1.stride)
-                and (self.downsample is not None or self.conv1.stride == (1, 1))
+        s1, s2 = self.conv1.stride[0], self.conv2.stride[0]
+        train = [bool(b.weight.requires_grad) for b in bns]
+        return (_PLANE_TRUNK and all((not b.training) and getattr(b, 'fuse_epilogue', True) and b.weight.requires_grad == b.bias.requires_grad
+                                     for b in bns)
+                and (not any(train) or (all(train) and _PLANE_BN_TRAIN))
+                and self.conv2.dilation == (1, 1) and s1 in (1, 2) and s2 in (1, 2) and s1 * s2 in (1, 2)
+                and (self.downsample is None or self.downsample[0].stride[0] == s1 * s2)
+                and (self.downsample is not None or s1 * s2 == 1)
                 and all(c.in_channels % 128 == 0 and c.out_channels % 128 == 0 and c.weight.is_cuda and c.weight.dtype == torch.float32
                         and F._ConvWeightPlanes.ok(c.weight) for c in convs)
                 and not torch.is_autocast_enabled())
@@ -329,18 +340,27 @@ class Bottleneck(nn.Module):
         """x: planes.PlaneAct (a ReLU output) or the fp32 channels_last output of the frozen stem -> PlaneAct."""
         is_p = isinstance(x, PL.PlaneAct)
         B, Cin, H, W = x.shape
-        s = self.conv1.stride[0]
+        s1, s2 = self.conv1.stride[0], self.conv2.stride[0]
         ds = self.downsample
-        s1, h1 = _bn_affine(self.bn1)
-        s2, h2 = _bn_affine(self.bn2)
-        s3, h3 = _bn_affine(self.bn3)
-        sd, hd = _bn_affine(ds[1]) if ds is not None else (None, None)
+        train = bool(self.bn1.weight.requires_grad)
+        bns = {'1': self.bn1, '2': self.bn2, '3': self.bn3}
+        if ds is not None:
+            bns['d'] = ds[1]
+        terms = {}
+        for k, bn in bns.items():
+            sc, sh = _bn_affine(bn)
+            terms[k] = (sc, sh, getattr(bn, '_rstd', None) if train else None, bn.running_mean if train else None)
+            assert not train or terms[k][2] is not None, 'trainable BatchNorm terms are refreshed by ResNet.forward'
+        if ds is None:
+            terms['d'] = (None, None, None, None)
         p = self.conv1.out_channels
-        cfg = PL.BottleneckCfg(B=B, H=H, W=W, Cin=Cin, planes=p, stride=s, x_planes=is_p, x_relu=bool(is_p and x.relu),
-                               s1=s1, h1=h1, s2=s2, h2=h2, s3=s3, h3=h3, sd=sd, hd=hd, has_ds=ds is not None)
+        cfg = PL.BottleneckCfg(B=B, H=H, W=W, Cin=Cin, planes=p, s1=s1, s2=s2, x_planes=is_p, x_relu=bool(is_p and x.relu),
+                               bn=terms, has_ds=ds is not None, bn_train=train)
+        gb = [(bn.weight, bn.bias) if train else (None, None) for bn in (self.bn1, self.bn2, self.bn3)]
+        gb.append((ds[1].weight, ds[1].bias) if (train and ds is not None) else (None, None))
         t = PL._BottleneckP.apply(x.t if is_p else x, self.conv1.weight, self.conv2.weight, self.conv3.weight,
-                                  ds[0].weight if ds is not None else None, cfg)
-        Ho, Wo = PL.out_hw(H, W, 1, s, 0)
+                                  ds[0].weight if ds is not None else None, *[t_ for pair in gb for t_ in pair], cfg)
+        Ho, Wo = PL.out_hw(H, W, 1, s1 * s2, 0)
         return PL.PlaneAct(t, B, Ho, Wo, 4 * p, True)
 
     def forward(self, x):
@@ -444,6 +464,9 @@ class ResNet(nn.Module):
         outputs are PlaneActs - as soon as a block qualifies (Bottleneck.plane_ok); otherwise fp32 tensors as ever."""
         x, outs = self.forward_stem(x) if stem is None else stem
         outs = list(outs)
+        if planes and _PLANE_BN_TRAIN and getattr(self, '_bn_terms_epoch', None) != (F.PARAM_EPOCH[0], self.training):
+            refresh_bn_affines(self, trainable=True)          # gamma * rstd, beta - mean * gamma * rstd, rstd of every trainable BatchNorm
+            self._bn_terms_epoch = (F.PARAM_EPOCH[0], self.training)
         for i in range(max(self.frozen_stages, 0), len(self.res_layers)):
             layer = getattr(self, self.res_layers[i])
             if planes:

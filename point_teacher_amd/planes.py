@@ -103,10 +103,11 @@ def _new_planes(rows, C, device, zero=False):
 
 
 def launch_conv(x_t, B, Hs, Ws, Cin, wp, Cout, K, stride, pad, scale=None, shift=None, res_planes=None, res_f32=None,
-                mask_planes=None, relu=False, want_planes=False, want_f32=False, scatter=None, tile_rows=0, splits=None, f32_out=None):
+                mask_planes=None, relu=False, want_planes=False, want_f32=False, scatter=None, tile_rows=0, splits=None, f32_out=None,
+                transposed_out=None):
     """pt_conv_bf16x6: x_t row-major planes of [B*Hs*Ws (+1), Cin]; wp SplitPlanes of the weight.  -> (planes or None, fp32 rows or
     None).  scatter = (H, W): a stride-2 input gradient placed at (2y, 2x) of a zeroed [B, H, W] grid."""
-    Ho, Wo = out_hw(Hs, Ws, K, stride, pad)
+    Ho, Wo = out_hw(Hs, Ws, K, stride, pad) if transposed_out is None else transposed_out
     M = B * Ho * Wo
     rows = M if scatter is None else B * scatter[0] * scatter[1]
     dev = x_t.device
@@ -130,6 +131,9 @@ def launch_conv(x_t, B, Hs, Ws, Cin, wp, Cout, K, stride, pad, scale=None, shift
     if scatter is not None:
         d.scatter_stride, d.scatter_H, d.scatter_W = 2, scatter[0], scatter[1]
     d.tile_rows = int(tile_rows)
+    if transposed_out is not None:            # the input gradient of a 3x3 stride-2 convolution onto its input grid (Ho, Wo)
+        d.dstride, d.out_H, d.out_W = 2, Ho, Wo
+        splits = 1
     S = hip.call('pt_conv_bf16x6_splits', B, Hs, Ws, Cin, Cout, K, K, stride, pad, int(tile_rows)) if splits is None else int(splits)
     if S > 1:
         ws = torch.empty((S * M * Cout,), dtype=f32, device=dev)
@@ -152,8 +156,12 @@ def wgrad_ok(Cin, Cout):
     return Cin % 128 == 0 and Cout % 128 == 0
 
 
-def launch_wgrad(gy_t, x_t, B, Hs, Ws, Cin, Cout, K, stride, pad, row_scale=None, want_bias=False):
-    """pt_conv_wgrad_bf16x6 -> (dw as a channels_last [Cout, Cin, K, K] tensor, dbias or None)."""
+def launch_wgrad(gy_t, x_t, B, Hs, Ws, Cin, Cout, K, stride, pad, row_scale=None, want_bias=False, bn=None, w=None):
+    """pt_conv_wgrad_bf16x6 -> (dw as a channels_last [Cout, Cin, K, K] tensor, dbias or None).
+    bn = (scale, rstd, mean) of a TRAINABLE eval-mode BatchNorm behind the convolution (w = its weight): -> (dw, dbeta, dgamma)
+    through pt_bn_wgrad_finish."""
+    if bn is not None:
+        row_scale, want_bias = None, True
     Ho, Wo = out_hw(Hs, Ws, K, stride, pad)
     dev = gy_t.device
     S = hip.call('pt_conv_wgrad_bf16x6_splits', B, Ho, Wo, K, K, Cin, Cout)
@@ -169,6 +177,13 @@ def launch_wgrad(gy_t, x_t, B, Hs, Ws, Cin, Cout, K, stride, pad, row_scale=None
     d.workspace, d.workspace_elems, d.splits = hip.dptr(ws, 'float'), ws.numel(), S
     assert gy_t.shape[1] >= (B * Ho * Wo + 1) * Cout and x_t.shape[1] >= (B * Hs * Ws + 1) * Cin
     hip.call('pt_conv_wgrad_bf16x6', d)
+    if bn is not None:
+        scale, rstd, mean = bn
+        dg = torch.empty((Cout,), dtype=f32, device=dev)
+        wr = w.detach().permute(0, 2, 3, 1)
+        assert wr.is_contiguous()
+        hip.call('pt_bn_wgrad_finish', dw, wr, Cout, K * K * Cin, scale, rstd, mean, db, dg)
+        return dw.permute(0, 3, 1, 2), db, dg
     return dw.permute(0, 3, 1, 2), db
 
 
@@ -355,7 +370,10 @@ def fan_out(act):
 
 # ---------------------------------------------------------------------------------------------------- Bottleneck --
 class BottleneckCfg:
-    __slots__ = ('B', 'H', 'W', 'Cin', 'planes', 'stride', 'x_planes', 'x_relu', 's1', 'h1', 's2', 'h2', 's3', 'h3', 'sd', 'hd', 'has_ds')
+    """B, H, W, Cin, planes: the block's input and width; s1 / s2: strides of conv1 / conv2 (`caffe`: (s, 1), `pytorch`: (1, s));
+    bn[i] for i in ('1', '2', '3', 'd'): (scale, shift, rstd, mean) of the eval-mode BatchNorm behind conv i; bn_train: their
+    affines take gradients."""
+    __slots__ = ('B', 'H', 'W', 'Cin', 'planes', 's1', 's2', 'x_planes', 'x_relu', 'bn', 'has_ds', 'bn_train')
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -363,68 +381,100 @@ class BottleneckCfg:
 
 
 class _BottleneckP(torch.autograd.Function):
-    """backbones/resnet.py:262-303 with frozen eval-mode BatchNorms, `caffe` style (stride on conv1 / downsample), plane-native:
+    """backbones/resnet.py:262-303 with eval-mode BatchNorms (frozen affine - the HBB configs - or trainable affine - OBB config 5),
+    stride on conv1 (`caffe`, :153-158) or on conv2 (`pytorch`), plane-native:
         y1 = relu(bn1(conv1(x)))   y2 = relu(bn2(conv2(y1)))   out = relu(bn3(conv3(y2)) + identity)
     identity = x, or bn_d(conv_d(x)) in a stage's first block.  x: plane tensor (block input, a ReLU output) or - first block of the
-    first trainable stage - the fp32 channels_last output of the frozen stem, read at the stride's pixels.  Four (three) launches
-    forward; backward three input-gradient launches (the identity's gradient and the ReLU masks ride in their epilogues), the weight
-    gradients with the BatchNorm scale in their reduction."""
+    first trainable stage - the fp32 channels_last output of the frozen stem.  Four (three) launches forward; backward three
+    input-gradient launches (the identity's gradient and the ReLU masks ride in their epilogues), the weight gradients with the
+    BatchNorm scale in their reduction - or, for a trainable affine, with d gamma / d beta formed from the raw weight gradient and the
+    bias sums of the same launch (pt_bn_wgrad_finish): no pass over an activation for either."""
 
     @staticmethod
-    def forward(ctx, x, w1, w2, w3, wd, cfg):
+    def forward(ctx, x, w1, w2, w3, wd, g1, b1, g2, b2, g3, b3, gd, bd, cfg):
         c = cfg
-        p, s = c.planes, c.stride
+        p, s1, s2 = c.planes, c.s1, c.s2
+        st = s1 * s2
+        H1, W1 = out_hw(c.H, c.W, 1, st, 0)                       # the block's output grid
         if c.x_planes:
-            xt, H1, W1 = x, *out_hw(c.H, c.W, 1, s, 0)
-            xs, xH, xW, xstride = xt, c.H, c.W, s                 # conv1 / downsample read x through the stride
+            xs, xH, xW, xst = x, c.H, c.W, 1                      # dense planes of x; strided reads map through them
+        elif s1 > 1:
+            xs, xH, xW = split_nhwc(x, s1)                        # `caffe`: only the stride's pixels are ever read
+            xst = s1
         else:
-            xt, H1, W1 = split_nhwc(x, s)                          # compact planes of the pixels the stride-s 1x1 convolutions read
-            xs, xH, xW, xstride = xt, H1, W1, 1
+            xs, xH, xW = split_nhwc(x)[0], c.H, c.W
+            xst = 1
+        r1 = s1 // xst                                            # strides on the planes at hand
+        rd = st // xst
+        Ha, Wa = out_hw(xH, xW, 1, r1, 0)                         # conv1's output grid
         cw = F._conv_weight_planes
-        y1, _ = launch_conv(xs, c.B, xH, xW, c.Cin, cw(w1, False), p, 1, xstride, 0, scale=c.s1, shift=c.h1, relu=True, want_planes=True)
-        y2, _ = launch_conv(y1, c.B, H1, W1, p, cw(w2, False), p, 3, 1, 1, scale=c.s2, shift=c.h2, relu=True, want_planes=True)
+        S = c.bn
+        y1, _ = launch_conv(xs, c.B, xH, xW, c.Cin, cw(w1, False), p, 1, r1, 0, scale=S['1'][0], shift=S['1'][1], relu=True, want_planes=True)
+        y2, _ = launch_conv(y1, c.B, Ha, Wa, p, cw(w2, False), p, 3, s2, 1, scale=S['2'][0], shift=S['2'][1], relu=True, want_planes=True)
         if c.has_ds:
-            _, idn = launch_conv(xs, c.B, xH, xW, c.Cin, cw(wd, False), 4 * p, 1, xstride, 0, scale=c.sd, shift=c.hd, want_f32=True)
-            out, _ = launch_conv(y2, c.B, H1, W1, p, cw(w3, False), 4 * p, 1, 1, 0, scale=c.s3, shift=c.h3, res_f32=idn, relu=True,
+            _, idn = launch_conv(xs, c.B, xH, xW, c.Cin, cw(wd, False), 4 * p, 1, rd, 0, scale=S['d'][0], shift=S['d'][1], want_f32=True)
+            out, _ = launch_conv(y2, c.B, H1, W1, p, cw(w3, False), 4 * p, 1, 1, 0, scale=S['3'][0], shift=S['3'][1], res_f32=idn, relu=True,
                                  want_planes=True)
         else:
-            out, _ = launch_conv(y2, c.B, H1, W1, p, cw(w3, False), 4 * p, 1, 1, 0, scale=c.s3, shift=c.h3, res_planes=xt, relu=True,
+            out, _ = launch_conv(y2, c.B, H1, W1, p, cw(w3, False), 4 * p, 1, 1, 0, scale=S['3'][0], shift=S['3'][1], res_planes=xs, relu=True,
                                  want_planes=True)
-        ctx.cfg, ctx.geo = c, (H1, W1, xH, xW, xstride)
+        ctx.cfg, ctx.geo = c, (H1, W1, Ha, Wa, xH, xW, r1, rd)
         ctx.save_for_backward(xs, y1, y2, w1, w2, w3, wd)
         return out
 
     @staticmethod
     def backward(ctx, E):
         c = ctx.cfg
-        H1, W1, xH, xW, xstride = ctx.geo
+        H1, W1, Ha, Wa, xH, xW, r1, rd = ctx.geo
         xs, y1, y2, w1, w2, w3, wd = ctx.saved_tensors
-        p = c.planes
+        p, s2 = c.planes, c.s2
+        S = c.bn
         E = E.contiguous()
         cw = F._conv_weight_planes
         need_x = ctx.needs_input_grad[0]
-        g1 = g2 = g3 = gd = gx = None
+        gw = {}                                                   # conv -> (dw, dbeta, dgamma)
+
+        def wgrad(tag, w, gy, xin, Hs_, Ws_, Ci, Co, K, stride, pad, need):
+            if not need:
+                gw[tag] = (None, None, None)
+            elif c.bn_train:
+                gw[tag] = launch_wgrad(gy, xin, c.B, Hs_, Ws_, Ci, Co, K, stride, pad, bn=(S[tag][0], S[tag][2], S[tag][3]), w=w)
+            else:
+                gw[tag] = (launch_wgrad(gy, xin, c.B, Hs_, Ws_, Ci, Co, K, stride, pad, row_scale=S[tag][0])[0], None, None)
+        ni = ctx.needs_input_grad
         # conv3: gradient of y2 (masked by y2's ReLU), weight gradient
-        E2, _ = launch_conv(E, c.B, H1, W1, 4 * p, cw(w3, True, c.s3), p, 1, 1, 0, mask_planes=y2, want_planes=True)
-        if ctx.needs_input_grad[3]:
-            g3, _ = launch_wgrad(E, y2, c.B, H1, W1, p, 4 * p, 1, 1, 0, row_scale=c.s3)
-        # conv2
-        E1, _ = launch_conv(E2, c.B, H1, W1, p, cw(w2, True, c.s2), p, 3, 1, 1, mask_planes=y1, want_planes=True)
-        if ctx.needs_input_grad[2]:
-            g2, _ = launch_wgrad(E2, y1, c.B, H1, W1, p, p, 3, 1, 1, row_scale=c.s2)
+        E2, _ = launch_conv(E, c.B, H1, W1, 4 * p, cw(w3, True, S['3'][0]), p, 1, 1, 0, mask_planes=y2, want_planes=True)
+        wgrad('3', w3, E, y2, H1, W1, p, 4 * p, 1, 1, 0, ni[3])
+        # conv2 (a stride on it makes its input gradient a transposed convolution onto y1's grid)
+        if s2 == 1:
+            E1, _ = launch_conv(E2, c.B, H1, W1, p, cw(w2, True, S['2'][0]), p, 3, 1, 1, mask_planes=y1, want_planes=True)
+        else:
+            E1, _ = launch_conv(E2, c.B, H1, W1, p, cw(w2, True, S['2'][0]), p, 3, 1, 1, mask_planes=y1, want_planes=True,
+                                transposed_out=(Ha, Wa))
+        wgrad('2', w2, E2, y1, Ha, Wa, p, p, 3, s2, 1, ni[2])
         # conv1 (+ downsample) weights
-        if ctx.needs_input_grad[1]:
-            g1, _ = launch_wgrad(E1, xs, c.B, xH, xW, c.Cin, p, 1, xstride, 0, row_scale=c.s1)
-        if c.has_ds and ctx.needs_input_grad[4]:
-            gd, _ = launch_wgrad(E, xs, c.B, xH, xW, c.Cin, 4 * p, 1, xstride, 0, row_scale=c.sd)
+        wgrad('1', w1, E1, xs, xH, xW, c.Cin, p, 1, r1, 0, ni[1])
+        if c.has_ds:
+            wgrad('d', wd, E, xs, xH, xW, c.Cin, 4 * p, 1, rd, 0, ni[4])
+        else:
+            gw['d'] = (None, None, None)
+        gx = None
         if need_x:
             assert c.x_planes, 'a trainable stage behind an fp32 input is not plane-native'
             mask = xs if c.x_relu else None
-            if c.has_ds:
-                # identity path through the downsample convolution: fp32 on the coarse grid, added in conv1's input-gradient epilogue
-                _, gdx = launch_conv(E, c.B, H1, W1, 4 * p, cw(wd, True, c.sd), c.Cin, 1, 1, 0, want_f32=True)
-                gx, _ = launch_conv(E1, c.B, H1, W1, p, cw(w1, True, c.s1), c.Cin, 1, 1, 0, res_f32=gdx, mask_planes=mask, want_planes=True,
-                                    scatter=(c.H, c.W) if c.stride == 2 else None)
+            if not c.has_ds:
+                gx, _ = launch_conv(E1, c.B, Ha, Wa, p, cw(w1, True, S['1'][0]), c.Cin, 1, 1, 0, res_planes=E, mask_planes=mask, want_planes=True)
+            elif r1 == rd:
+                # `caffe` (or no stride): conv1 and the downsample read the same pixels - the downsample path's gradient (fp32, coarse
+                # grid) is added in conv1's input-gradient epilogue, the sum is scattered to the stride's pixels of a zeroed map
+                _, gdx = launch_conv(E, c.B, H1, W1, 4 * p, cw(wd, True, S['d'][0]), c.Cin, 1, 1, 0, want_f32=True)
+                gx, _ = launch_conv(E1, c.B, Ha, Wa, p, cw(w1, True, S['1'][0]), c.Cin, 1, 1, 0, res_f32=gdx, mask_planes=mask, want_planes=True,
+                                    scatter=(c.H, c.W) if r1 == 2 else None)
             else:
-                gx, _ = launch_conv(E1, c.B, H1, W1, p, cw(w1, True, c.s1), c.Cin, 1, 1, 0, res_planes=E, mask_planes=mask, want_planes=True)
-        return gx, g1, g2, g3, gd, None
+                # `pytorch`: conv1 reads every pixel, the downsample the stride's - its gradient is scattered into a zeroed fp32 map
+                # that conv1's (dense) input-gradient epilogue adds
+                _, gdx = launch_conv(E, c.B, H1, W1, 4 * p, cw(wd, True, S['d'][0]), c.Cin, 1, 1, 0, want_f32=True, scatter=(c.H, c.W))
+                gx, _ = launch_conv(E1, c.B, Ha, Wa, p, cw(w1, True, S['1'][0]), c.Cin, 1, 1, 0, res_f32=gdx, mask_planes=mask, want_planes=True)
+        g = gw
+        return (gx, g['1'][0], g['2'][0], g['3'][0], g['d'][0], g['1'][2], g['1'][1], g['2'][2], g['2'][1], g['3'][2], g['3'][1],
+                g['d'][2], g['d'][1], None)

@@ -243,12 +243,12 @@ def _ref_bottleneck(blk, x):
     return cb(out, blk.conv3, blk.bn3, True, idn)
 
 
-def _make_block(inplanes, planes, stride, ds, seed):
-    from point_teacher_amd.nn_modules import Bottleneck
+def _make_block(inplanes, planes, stride, ds, seed, style='caffe', train_bn=False):
+    from point_teacher_amd import nn_modules as NM
     import torch.nn as nn
     torch.manual_seed(seed)
     down = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False), nn.BatchNorm2d(planes * 4)) if ds else None
-    blk = Bottleneck(inplanes, planes, stride, 1, down, 'caffe').to(DEV).to(memory_format=torch.channels_last)
+    blk = NM.Bottleneck(inplanes, planes, stride, 1, down, style).to(DEV).to(memory_format=torch.channels_last)
     for m in blk.modules():
         if isinstance(m, nn.BatchNorm2d):
             with torch.no_grad():
@@ -256,21 +256,29 @@ def _make_block(inplanes, planes, stride, ds, seed):
                 m.bias.normal_(0, 0.2)
                 m.running_mean.normal_(0, 0.2)
                 m.running_var.uniform_(0.5, 1.5)
-            m.weight.requires_grad = False
-            m.bias.requires_grad = False
+            m.weight.requires_grad = train_bn
+            m.bias.requires_grad = train_bn
     blk.eval()
+    if train_bn:
+        NM.refresh_bn_affines(blk, trainable=True)          # (ResNet.forward does this once per parameter update)
     return blk
 
 
-@pytest.mark.parametrize('inplanes,planes,stride,ds,B,H,W,from_stem', [
-    (512, 128, 1, False, 2, 40, 36, False),       # identity block
-    (256, 128, 2, True, 2, 41, 36, True),         # layer2.0: fp32 stem output read at the stride's pixels, no input gradient
-    (512, 256, 2, True, 2, 40, 37, False),        # layer3.0: plane input, stride-2 input gradient scattered
-    (512, 128, 1, True, 2, 20, 20, False),        # a first block without stride
+@pytest.mark.parametrize('inplanes,planes,stride,ds,B,H,W,from_stem,style,train_bn', [
+    (512, 128, 1, False, 2, 40, 36, False, 'caffe', False),       # identity block
+    (256, 128, 2, True, 2, 41, 36, True, 'caffe', False),         # layer2.0: fp32 stem output read at the stride's pixels, no input gradient
+    (512, 256, 2, True, 2, 40, 37, False, 'caffe', False),        # layer3.0: plane input, stride-2 input gradient scattered
+    (512, 128, 1, True, 2, 20, 20, False, 'caffe', False),        # a first block without stride
+    # OBB config 5: `pytorch` style (stride on the 3x3: its input gradient is a transposed convolution), eval-mode BatchNorm whose
+    # affine trains (d gamma / d beta from the raw weight gradient and the bias sums)
+    (512, 128, 1, False, 2, 40, 36, False, 'pytorch', True),
+    (256, 128, 2, True, 2, 41, 36, True, 'pytorch', True),
+    (512, 256, 2, True, 2, 40, 37, False, 'pytorch', True),
+    (512, 256, 2, True, 2, 38, 38, False, 'caffe', True),
 ])
-def test_bottleneck_planes_vs_fp64(inplanes, planes, stride, ds, B, H, W, from_stem):
+def test_bottleneck_planes_vs_fp64(inplanes, planes, stride, ds, B, H, W, from_stem, style, train_bn):
     from point_teacher_amd import planes as PL
-    blk = _make_block(inplanes, planes, stride, ds, 11)
+    blk = _make_block(inplanes, planes, stride, ds, 11, style, train_bn)
     assert blk.plane_ok()
     g = torch.Generator().manual_seed(3)
     x = torch.relu(torch.randn(B, inplanes, H, W, generator=g)).to(DEV).contiguous(memory_format=torch.channels_last)
@@ -288,10 +296,15 @@ def test_bottleneck_planes_vs_fp64(inplanes, planes, stride, ds, B, H, W, from_s
     assert float((y.double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
     gy = torch.randn(y.shape, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
     params = [blk.conv1.weight, blk.conv2.weight, blk.conv3.weight] + ([blk.downsample[0].weight] if ds else [])
+    names = ['w1', 'w2', 'w3'] + (['wd'] if ds else [])
+    if train_bn:
+        for n, bn in (('1', blk.bn1), ('2', blk.bn2), ('3', blk.bn3)) + ((('d', blk.downsample[1]),) if ds else ()):
+            params += [bn.weight, bn.bias]
+            names += ['gamma' + n, 'beta' + n]
     ins = params + ([] if from_stem else [x])
     got = torch.autograd.grad(y, ins, gy)
     want = torch.autograd.grad(ref, params + ([] if from_stem else [xr]), gy.double())
-    for name, a, b in zip(['w1', 'w2', 'w3'] + (['wd'] if ds else []) + ([] if from_stem else ['x']), got, want):
+    for name, a, b in zip(names + ([] if from_stem else ['x']), got, want):
         if name == 'x':
             b = b * (x > 0)                        # the producer's ReLU mask is applied by the block's epilogue (gradient convention)
         err = float((a.double() - b).abs().max() / b.abs().max())
