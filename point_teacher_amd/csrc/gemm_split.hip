@@ -735,6 +735,8 @@ struct WgradGeom {
   int KBT, KS;                      // k-steps (32 pixels) in total / per chunk
   int tiles_m, tiles_n;
   int want_bias;
+  int tm_fast;                      // consecutive workgroups walk the row tiles of one column tile (they share the x columns - the
+                                    // larger operand when Cin > Cout, e.g. the FC stacks' 12544 -> 1024) instead of the column tiles of one row tile
 };
 
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
@@ -764,7 +766,7 @@ __global__ void __launch_bounds__(GTHREADS)
   }
   const int per = wg.tiles_m * wg.tiles_n;
   const int s = item / per, t = item - s * per;
-  const int tm = t / wg.tiles_n, tn = t - tm * wg.tiles_n;
+  const int tm = wg.tm_fast ? t % wg.tiles_m : t / wg.tiles_n, tn = wg.tm_fast ? t / wg.tiles_m : t - tm * wg.tiles_n;
   const int m0 = tm * BM, n0 = tn * GBN;
   const int tap = n0 / wg.C, c0 = n0 - tap * wg.C;
   const int ky = tap / wg.KW, kx = tap - ky * wg.KW;
@@ -1355,8 +1357,12 @@ static int wgrad_splits(long P, int taps, int Cin, int Cout) {
   const long per = (long)(Cout / bm) * (taps * Cin / GBN);
   int best = 1;
   long best_cost = -1;
+  // in units of one k-step of one workgroup (~3 us measured with both operands streamed): the reduction launch moves
+  // (S + 1) * n * 4 bytes at ~4 TB/s for everybody
+  const double n_bytes = 4.0 * Cout * (double)taps * Cin;
   for (int S = 1; S <= 128 && (S == 1 || S * 4 <= kbt); ++S) {
-    const long cost = ((per * S + 255) / 256) * ((kbt + S - 1) / S + 6);
+    const double reduce = S > 1 ? (S + 1) * n_bytes / 4e12 / 3e-6 : 0.0;
+    const long cost = ((per * S + 255) / 256) * ((kbt + S - 1) / S + 6) + (long)(reduce + 0.5);
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = S; }
   }
   return best;
@@ -1397,7 +1403,7 @@ extern "C" int pt_conv_wgrad_bf16x6(const pt_conv_wgrad_desc* d, void* stream) {
              "pt_conv_wgrad_bf16x6: workspace must hold splits * (Cout * taps * Cin [+ Cout]) floats");
   const int bm = d->Cout % 256 == 0 ? 256 : 128;
   WgradGeom wg{d->Hs, d->Ws, Ho, Wo, d->Cin, d->Cout, d->KW, taps, d->stride, d->pad, (int)P, (int)Ps, kbt, (kbt + S - 1) / S, d->Cout / bm,
-               taps * d->Cin / GBN, d->dbias ? 1 : 0};
+               taps * d->Cin / GBN, d->dbias ? 1 : 0, (d->Cout / bm > 1 && (long)taps * d->Cin > d->Cout) ? 1 : 0};
   // one chunk and nothing to apply afterwards: the tiles ARE the result
   const bool direct = S == 1 && !d->row_scale && !d->accumulate;
   float* part = direct ? d->dw : d->workspace;
