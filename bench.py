@@ -108,10 +108,17 @@ def algorithmic_flops(name, shapes):
 
 
 def conv_desc_shapes(d):
-    """Shapes out of a pt_conv_desc / pt_conv_wgrad_desc (host struct)."""
+    """Shapes out of a pt_conv_desc / pt_conv_wgrad_desc (host struct); np: planes per operand (3: fp32 as six bf16 products,
+    1: bf16 operands, one product - the bf16 trunk of BASELINE configs[2])."""
     Ho = (d.Hs + 2 * d.pad - d.KH) // d.stride + 1
     Wo = (d.Ws + 2 * d.pad - d.KW) // d.stride + 1
-    return dict(M=d.B * Ho * Wo, Cin=d.Cin, Cout=d.Cout, taps=d.KH * d.KW)
+    return dict(M=d.B * Ho * Wo, Cin=d.Cin, Cout=d.Cout, taps=d.KH * d.KW, np=(getattr(d, 'np', 3) or 3))
+
+
+def executed_flops(name, shapes):
+    """bf16 MFMA FLOPs a matrix launch executes: six products per fp32 product (three-plane operands), one for bf16 operands."""
+    f = algorithmic_flops(name, shapes)
+    return None if f is None else f * (1.0 if shapes.get('np', 3) == 1 else 6.0)
 
 
 # the matrix kernels: every fp32 product of backbone / necks / towers / MIL FC stacks as six bf16 MFMA products (csrc/gemm_split.hip)
@@ -309,8 +316,10 @@ def main():
             ms = [e0.elapsed_time(e1) for e0, e1, _ in evs]
             byts = [algorithmic_bytes(fn, s) if s else None for _, _, s in evs]
             fl = [algorithmic_flops(fn, s) if s else None for _, _, s in evs]
+            ex = [executed_flops(fn, s) if s else None for _, _, s in evs]
             kern[fn] = dict(calls=len(ms), total_ms=sum(ms), bytes=sum(b for b in byts if b) if all(b for b in byts) else None,
-                            flops=sum(f for f in fl if f) if all(f for f in fl) else None)
+                            flops=sum(f for f in fl if f) if all(f for f in fl) else None,
+                            exec_flops=sum(f for f in ex if f) if all(f for f in ex) else None)
         fam = {}
         for name, members in FAMILIES.items():
             ks = [kern[m] for m in members if m in kern and kern[m]['bytes']]
@@ -318,7 +327,8 @@ def main():
                 fam[name] = dict(calls=sum(k['calls'] for k in ks), total_ms=sum(k['total_ms'] for k in ks), bytes=sum(k['bytes'] for k in ks))
         # the matrix kernels of the path (fp32 products as six bf16 MFMA products): MFMA-bound, priced against the dense bf16 peak
         mk = [kern[m] for m in MFMA_FAMILY[1] if m in kern and kern[m].get('flops')]
-        mfma = dict(calls=sum(k['calls'] for k in mk), total_ms=sum(k['total_ms'] for k in mk), flops=sum(k['flops'] for k in mk)) if mk else None
+        mfma = dict(calls=sum(k['calls'] for k in mk), total_ms=sum(k['total_ms'] for k in mk), flops=sum(k['flops'] for k in mk),
+                    exec_flops=sum(k['exec_flops'] for k in mk)) if mk else None
         if mfma:
             sk = [kern[m] for m in SPLIT_FNS if m in kern]
             mfma['split_ms'], mfma['split_calls'] = sum(k['total_ms'] for k in sk), sum(k['calls'] for k in sk)
@@ -420,24 +430,26 @@ def main():
     bmfma = summarise({k: v for k, v in full.items() if k in MFMA_FAMILY[1]})[2] if dom != MFMA_FAMILY[0] else mfma
     msteps = BREAKDOWN_STEPS if dom != MFMA_FAMILY[0] else n_event_steps
     if bmfma:
-        ex = 6.0 * bmfma['flops'] / (bmfma['total_ms'] * 1e-3) / 1e12
+        ex = bmfma['exec_flops'] / (bmfma['total_ms'] * 1e-3) / 1e12
         fams[MFMA_FAMILY[0]] = dict(ms_per_step=round(bmfma['total_ms'] / msteps, 3), executed_bf16_TFLOPs=round(ex, 1),
-                                    fp32_equivalent_TFLOPs=round(ex / 6.0, 1))
+                                    fp32_equivalent_TFLOPs=round(bmfma['flops'] / (bmfma['total_ms'] * 1e-3) / 1e12, 1))
     def mfma_roofline(m, steps_, **extra):
         # achieved = EXECUTED bf16 FLOPs (6 MFMA products per fp32 product) / HIP-event time, peak = dense bf16 MFMA (guide).
         # frac_algorithmic prices the ALGORITHMIC work (2 M N K fp32 FLOPs) against the same peak - SURVEY 8(d)'s fraction; the
         # scheme's own ceiling is peak / 6.  split_overhead_ms: the family's companion launches (operand-format passes), timed in the
         # same region; fp32_equivalent_incl_split charges them to the family as well.
-        ex = 6.0 * m['flops'] / (m['total_ms'] * 1e-3) / 1e12
+        ppp = m['exec_flops'] / m['flops']                      # MFMA products per algorithmic product: 6 (fp32 operands) ... 1 (bf16 operands)
+        ex = m['exec_flops'] / (m['total_ms'] * 1e-3) / 1e12
         incl = m['flops'] / ((m['total_ms'] + m.get('split_ms', 0.0)) * 1e-3) / 1e12
         return dict(bound='mfma', kernel=MFMA_FAMILY[0], achieved=round(ex, 1), peak=BF16_PEAK_TFLOPS, unit='TFLOP/s',
-                    frac=round(ex / BF16_PEAK_TFLOPS, 4), frac_algorithmic=round(ex / 6.0 / BF16_PEAK_TFLOPS, 4),
-                    scheme_ceiling_tflops=round(BF16_PEAK_TFLOPS / 6.0, 1), fp32_equivalent_tflops=round(ex / 6.0, 1),
+                    frac=round(ex / BF16_PEAK_TFLOPS, 4), frac_algorithmic=round(ex / ppp / BF16_PEAK_TFLOPS, 4),
+                    products_per_algorithmic_product=round(ppp, 3),
+                    scheme_ceiling_tflops=round(BF16_PEAK_TFLOPS / ppp, 1), fp32_equivalent_tflops=round(ex / ppp, 1),
                     fp32_equivalent_incl_split_tflops=round(incl, 1), fp32_mfma_peak_tflops=157.3,
                     ms_per_step=round(m['total_ms'] / steps_, 3), split_overhead_ms=round(m.get('split_ms', 0.0) / steps_, 3),
                     split_launches_per_step=round(m.get('split_calls', 0) / steps_, 1),
                     avg_launch_us=round(m['total_ms'] / m['calls'] * 1e3, 2), event_pair_overhead_us=round(event_overhead_us, 2),
-                    launches=m['calls'], flops_per_launch=int(6.0 * m['flops'] / m['calls']),
+                    launches=m['calls'], flops_per_launch=int(m['exec_flops'] / m['calls']),
                     algorithmic_flops_per_launch=int(m['flops'] / m['calls']), **extra)
 
     if dom == MFMA_FAMILY[0]:

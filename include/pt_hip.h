@@ -293,6 +293,9 @@ int pt_conv3x3_wgrad_bf16x6_nhwc(const uint16_t* gy_planes, int64_t gy_plane_str
  * transposed convolution: x_planes = the output gradient on the coarse grid [B, Hs, Ws], the result lives on the convolution's
  * input grid [B, out_H, out_W]; stride = 1, pad = KH - 1 - (forward padding), w_planes in the mode-1 form; taps whose coordinate is
  * odd read the zero row.  dstride == 0 / 1: off.
+ * np == 1: every operand and result is ONE bf16 plane - a bf16 NHWC tensor with a zero row behind it - and one MFMA product
+ * replaces the six: the same kernels as the bf16 trunk of BASELINE configs[2] (bf16 operands, fp32 accumulation, one rounding per
+ * fused epilogue).  np == 0 / 3: three planes.
  * tile_rows: 64, 96, ..., 256 or 0 = pt_gemm_bf16x6_tile_rows.  [host] struct; device pointers inside. */
 typedef struct {
   int32_t B, Hs, Ws, Cin, Cout, KH, KW, stride, pad;
@@ -316,6 +319,8 @@ typedef struct {
   int64_t workspace_elems;
   int32_t splits;
   int32_t dstride, out_H, out_W;
+  int32_t np;
+  int32_t reserved;
 } pt_conv_desc;
 int pt_conv_bf16x6_splits(int B, int Hs, int Ws, int Cin, int Cout, int KH, int KW, int stride, int pad, int tile_rows);
 int pt_conv_bf16x6(const pt_conv_desc* desc, void* stream);
@@ -339,7 +344,7 @@ typedef struct {
   float* workspace;
   int64_t workspace_elems;
   int32_t splits;
-  int32_t reserved;
+  int32_t np;
 } pt_conv_wgrad_desc;
 int pt_conv_wgrad_bf16x6_splits(int B, int Ho, int Wo, int KH, int KW, int Cin, int Cout);
 /* Trainable BatchNorm (eval-mode statistics) behind a convolution - OBB config 5, `norm_cfg=dict(type='BN', requires_grad=True)`,
@@ -351,15 +356,17 @@ int pt_bn_wgrad_finish(float* dw, const float* w, int Cout, int rowlen, const fl
                        const float* sum_e, float* dgamma, void* stream);
 int pt_conv_wgrad_bf16x6(const pt_conv_wgrad_desc* desc, void* stream);
 
-/* fp32 NHWC [B, Hs, Ws, C] (pixel stride ld) -> row-major planes of the pixels (y * stride, x * stride): [3][(B * Ho * Wo + 1) * C],
- * Ho = (Hs - 1) / stride + 1.  stride 2 = the pixels layer2's first Bottleneck reads from the frozen layer1 (resnet.py:153-158). */
-int pt_split_bf16x3_gather(const float* src, int64_t ld, int B, int Hs, int Ws, int C, int stride, uint16_t* planes,
-                           int64_t plane_stride, void* stream);
-/* out = split(m * (a + b + c)) element-wise on row-major planes (n elements per plane, n % 8 == 0): a, b planes (b may be NULL),
- * c fp32 (may be NULL), m = (mask's plane 0 > 0) or 1 when mask == NULL; out (planes) and / or out_f32.  The gradient of an
- * activation with several consumers (a stage output feeding the next stage and an FPN lateral), or planes -> fp32. */
+/* NHWC [B, Hs, Ws, C] (pixel stride ld; fp32, or bf16 when src_bf16 != 0) -> row-major planes of the pixels (y * stride, x * stride):
+ * [np][(B * Ho * Wo + 1) * C], Ho = (Hs - 1) / stride + 1, last row zeros.  np = 3: fp32 -> x0 + x1 + x2; np = 1: the bf16 rounding
+ * (fp32 source) or a copy (bf16 source: the autocast stem's output entering the bf16 trunk).  stride 2 = the pixels layer2's
+ * first Bottleneck reads from the frozen layer1 (resnet.py:153-158). */
+int pt_split_bf16x3_gather(const void* src, int src_bf16, int64_t ld, int B, int Hs, int Ws, int C, int stride, int np,
+                           uint16_t* planes, int64_t plane_stride, void* stream);
+/* out = split(m * (a + b + c)) element-wise on row-major planes (n elements per plane, n % 8 == 0; np = 3 or 1 planes each): a, b
+ * planes (b may be NULL), c fp32 (may be NULL), m = (mask's plane 0 > 0) or 1 when mask == NULL; out (planes) and / or out_f32.  The
+ * gradient of an activation with several consumers (a stage output feeding the next stage and an FPN lateral), or planes -> fp32. */
 int pt_planes_combine(const uint16_t* a, int64_t a_plane_stride, const uint16_t* b, int64_t b_plane_stride, const float* c,
-                      const uint16_t* mask, int64_t n, uint16_t* out, int64_t out_plane_stride, float* out_f32, void* stream);
+                      const uint16_t* mask, int64_t n, int np, uint16_t* out, int64_t out_plane_stride, float* out_f32, void* stream);
 
 /* GroupNorm (+ ReLU) on channels_last activations x[N, HW, C] (replaces torch.nn.GroupNorm behind the tower convolutions of the
  * oriented head: mmcv ConvModule with norm_cfg=dict(type='GN', num_groups=32) - the default of
@@ -385,7 +392,8 @@ int pt_group_norm_cl_bwd(const float* grad_y, const float* x, const float* y, co
  * [Cout], device): w[o] * scale[o] is what gets split - the scale of the frozen BatchNorm behind the convolution folded into the
  * input-gradient weights (backbones/resnet.py:262-303: dx = (g * scale) W = g (diag(scale) W)).  first_block = number of 16 x 32 blocks
  * of the items before this one (blocks of an item = ceil(rows / 16) * (taps * cols / 32)); total_blocks = their sum over all items.
- * ABI 4: the item grew `taps` and `scale`. */
+ * np: planes written - 3 (fp32 = x0 + x1 + x2), or 1 (the bf16 rounding of the weight alone: the operand of the bf16 trunk).
+ * ABI 4: the item grew `taps`, `np` and `scale`. */
 typedef struct {
   const float* w;
   uint16_t* dst;
@@ -394,7 +402,7 @@ typedef struct {
   int32_t mode;
   int32_t first_block;
   int32_t taps;
-  int32_t reserved;
+  int32_t np;
   const float* scale;
 } pt_conv_weight_item;
 int pt_conv_weight_planes_batch(const pt_conv_weight_item* items, int n_items, int total_blocks, void* stream);

@@ -144,7 +144,7 @@ struct ConvWItem {
   int mode;                         // 0: rows = Cout, k = (tap, cin);  1: rows = cin, k = (flipped tap, cout)
   int first_block;
   int taps;                         // KH * KW (1 or 9)
-  int pad_;
+  int np;                           // planes written: 3, or 1 (= the bf16 rounding of the weight: the bf16 trunk of configs[2])
   const float* scale;               // NULL or [Cout]: w[o] * scale[o] is split (the frozen BatchNorm's scale folded into the
                                     // input-gradient weights: dx = (g * scale) W = g (diag(scale) W))
 };
@@ -195,8 +195,10 @@ __global__ void __launch_bounds__(256)
   split_pair(v[6], v[7], o0.w, o1.w, o2.w);
   uint16_t* d = e.dst + block_off(rb, kb, KB, r16, q);
   *reinterpret_cast<uint4*>(d) = o0;
-  *reinterpret_cast<uint4*>(d + e.plane) = o1;
-  *reinterpret_cast<uint4*>(d + 2 * e.plane) = o2;
+  if (e.np != 1) {
+    *reinterpret_cast<uint4*>(d + e.plane) = o1;
+    *reinterpret_cast<uint4*>(d + 2 * e.plane) = o2;
+  }
 }
 
 // ----------------------------------------------------------------------------------------------- GEMM --
@@ -240,6 +242,7 @@ struct ConvEpi {
   int zero_row;                     // >= 0: this row of out_planes is written with zeros (by the last row tile)
   int sc_stride, sc_Ho, sc_Wo, sc_H, sc_W;   // sc_stride != 0: output row (b, y, x) of [sc_Ho, sc_Wo] leaves as row
                                     //   (b * sc_H + y * sc_stride) * sc_W + x * sc_stride of mask / out (a stride-2 1 x 1 input gradient)
+  int np;                           // planes of res / mask / out: 3 (fp32 as x0 + x1 + x2) or 1 (one bf16 plane = a bf16 NHWC tensor)
   float* part;                      // splits > 1 (few output tiles, long k: the teacher's batch, layer4): workgroup (tile, s) multiplies
   int splits, ks_per;               //   k-steps [s * ks_per, (s + 1) * ks_per) and stores its raw fp32 tile to part[s][M][N];
                                     //   conv_splitk_finish_kernel adds the parts in a fixed order and runs this epilogue
@@ -273,8 +276,12 @@ __device__ __forceinline__ void conv_epilogue8(float (&o)[8], int grow, int gcol
   const long rin = (long)grow * N + gcol;
   if (ep.res_planes) {
     float r[8];
-    planes_sum8(*reinterpret_cast<const uint4*>(ep.res_planes + rin), *reinterpret_cast<const uint4*>(ep.res_planes + ep.res_plane + rin),
-                *reinterpret_cast<const uint4*>(ep.res_planes + 2 * ep.res_plane + rin), r);
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    if (ep.np == 3)
+      planes_sum8(*reinterpret_cast<const uint4*>(ep.res_planes + rin), *reinterpret_cast<const uint4*>(ep.res_planes + ep.res_plane + rin),
+                  *reinterpret_cast<const uint4*>(ep.res_planes + 2 * ep.res_plane + rin), r);
+    else
+      planes_sum8(*reinterpret_cast<const uint4*>(ep.res_planes + rin), z, z, r);
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] += r[e];
   }
@@ -314,9 +321,11 @@ __device__ __forceinline__ void conv_epilogue8(float (&o)[8], int grow, int gcol
     split_pair(o[4], o[5], p0.z, p1.z, p2.z);
     split_pair(o[6], o[7], p0.w, p1.w, p2.w);
     uint16_t* d = ep.out_planes + rout;
-    *reinterpret_cast<uint4*>(d) = p0;
-    *reinterpret_cast<uint4*>(d + ep.out_plane) = p1;
-    *reinterpret_cast<uint4*>(d + 2 * ep.out_plane) = p2;
+    *reinterpret_cast<uint4*>(d) = p0;                 // (np == 1: the round-to-nearest bf16 of the value)
+    if (ep.np == 3) {
+      *reinterpret_cast<uint4*>(d + ep.out_plane) = p1;
+      *reinterpret_cast<uint4*>(d + 2 * ep.out_plane) = p2;
+    }
   }
 }
 
@@ -341,21 +350,19 @@ __global__ void __launch_bounds__(256) conv_splitk_finish_kernel(int M, int N, C
     for (int c = threadIdx.x * 8; c < N; c += blockDim.x * 8) {
       uint16_t* d = ep.out_planes + (long)ep.zero_row * N + c;
       const uint4 z = make_uint4(0, 0, 0, 0);
-      *reinterpret_cast<uint4*>(d) = z;
-      *reinterpret_cast<uint4*>(d + ep.out_plane) = z;
-      *reinterpret_cast<uint4*>(d + 2 * ep.out_plane) = z;
+      for (int p = 0; p < ep.np; ++p) *reinterpret_cast<uint4*>(d + p * ep.out_plane) = z;
     }
   }
 }
 
-template <int MB, bool CONV, int NST>
+template <int MB, bool CONV, int NP>
 __global__ void __launch_bounds__(GTHREADS)
     gemm_bf16x6_kernel(const uint16_t* __restrict__ Ap, const uint16_t* __restrict__ Bp, float* __restrict__ C,
                        const float* __restrict__ bias, const float* __restrict__ scale, int M, int N, int KB, long a_plane, long b_plane,
                        long ldc, int relu, int tiles_n, int n_tiles, ConvGeom cg, ConvEpi ep) {
   constexpr int BM = 32 * MB, ROWS = BM + GBN;
-  constexpr int STAGE = ROWS * 3 * 64;                 // bytes: A planes [3][BM][64] then B planes [3][128][64]
-  constexpr int NI = ROWS * 3 / 16;                    // staging instructions (one 1-KiB block each) per stage
+  constexpr int STAGE = ROWS * NP * 64;                // bytes: A planes [NP][BM][64] then B planes [NP][128][64]
+  constexpr int NI = ROWS * NP / 16;                   // staging instructions (one 1-KiB block each) per stage
   constexpr int NJ = (NI + 7) / 8;                     // per wave
   constexpr int PER = (NJ + MB - 1) / MB;              // staging instructions issued behind each row block's MFMAs
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -389,8 +396,8 @@ __global__ void __launch_bounds__(GTHREADS)
     gsrc[j] = nullptr;
     cpix[j] = cmask[j] = 0;
     if (i < NI) {
-      const bool isA = i < 3 * (BM / 16);
-      const int i2 = isA ? i : i - 3 * (BM / 16);
+      const bool isA = i < NP * (BM / 16);
+      const int i2 = isA ? i : i - NP * (BM / 16);
       const int rbs = isA ? BM / 16 : GBN / 16;
       const int p = i2 / rbs, rbi = i2 - p * rbs;
       const int lim = isA ? RBA : RBN;
@@ -445,7 +452,7 @@ __global__ void __launch_bounds__(GTHREADS)
   }
   auto issue1 = [&](int j, int buf) {                   // one 1-KiB block of the next stage
     if (j < NJ && w + 8 * j < NI) {                     // wave-uniform
-      if (CONV && w + 8 * j < 3 * (BM / 16)) {          // wave-uniform: an activation piece
+      if (CONV && w + 8 * j < NP * (BM / 16)) {         // wave-uniform: an activation piece
         int pix = cg.Ps;
         if ((cmask[j] >> s_tap) & 1)
           pix = cg.dstride > 1 ? cpix[j] + ((s_ky - ((cmask[j] >> 9) & 1)) >> 1) * cg.Ws + ((s_kx - ((cmask[j] >> 10) & 1)) >> 1) : cpix[j] + s_off;
@@ -474,7 +481,7 @@ __global__ void __launch_bounds__(GTHREADS)
   const int r16 = lane & 15, sq = lane >> 4;
   const int phys = (sq ^ slot_swz(r16)) * 16;
   const int a_off = (rg * MB * 16 + r16) * 64 + phys;                  // + p * BM * 64 + i * 16 * 64
-  const int b_off = 3 * BM * 64 + (nb * 32 + r16) * 64 + phys;         // + p * 128 * 64 + c * 16 * 64
+  const int b_off = NP * BM * 64 + (nb * 32 + r16) * 64 + phys;        // + p * 128 * 64 + c * 16 * 64
   // Two accumulators per output tile: the leading product a0 b0 and the five correction products (2^-8 ... 2^-16 of it).  Every
   // MFMA rounds the running fp32 sum once; kept apart, the long chain of corrections rounds at ITS magnitude and the leading
   // chain is 6x shorter - the error against float64 drops below the 32x32x16 form's (which sums two k-halves) again.
@@ -488,85 +495,39 @@ __global__ void __launch_bounds__(GTHREADS)
 #pragma unroll
   for (int j = 0; j < NJ; ++j) issue1(j, 0);
   next_stage();
-  if constexpr (NST == 3) {
-    // Three-stage ring (BM = 128: every wave issues exactly NJ = 6 pieces per stage): stage ks + 2 is issued while stage ks is
-    // multiplied, so a whole stage stays in flight ACROSS the barrier - the wait in front of it is COUNTED (`vmcnt(NJ)`: all but
-    // the youngest stage's pieces have landed) and the barrier is the bare instruction (`__syncthreads()` would drain the queue).
-    static_assert(NI % 8 == 0, "a counted wait needs the same number of pieces on every wave");
-    if (kb0 + 1 < kb1) {
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) issue1(j, 1);
-      next_stage();
-    }
-    int cur = 0;
-    for (int ks = kb0; ks < kb1; ++ks) {
-      if (ks + 1 < kb1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_barrier" ::: "memory");   // stage ks has landed for every wave; every wave has left stage ks - 1's buffer
-      const bool more = ks + 2 < kb1;
-      const int nbuf = cur == 0 ? 2 : cur - 1;  // (cur + 2) % 3: the buffer stage ks - 1 occupied
-      const unsigned char* st = smem + cur * STAGE;
-      bf16x8_t b[2][3];
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) b[c][p] = *reinterpret_cast<const bf16x8_t*>(st + b_off + p * GBN * 64 + c * 16 * 64);
-#pragma unroll
-      for (int i = 0; i < MB; ++i) {
-        const unsigned char* ap = st + a_off + i * 16 * 64;
-        const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(ap);
-        const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(ap + BM * 64);
-        const bf16x8_t a2 = *reinterpret_cast<const bf16x8_t*>(ap + 2 * BM * 64);
-        if (more) {
-#pragma unroll
-          for (int q = 0; q < PER; ++q) issue1(i * PER + q, nbuf);
-        }
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {                   // smallest terms first
-          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b[c][0], cor[i][c], 0, 0, 0);
-          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b[c][1], cor[i][c], 0, 0, 0);
-          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[c][2], cor[i][c], 0, 0, 0);
-          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b[c][0], cor[i][c], 0, 0, 0);
-          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[c][1], cor[i][c], 0, 0, 0);
-          acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[c][0], acc[i][c], 0, 0, 0);
-        }
-      }
-      if (more) next_stage();
-      cur = cur == 2 ? 0 : cur + 1;
-    }
-  } else {
   for (int ks = kb0; ks < kb1; ++ks) {
     __syncthreads();          // (emits s_waitcnt vmcnt(0)): stage ks has landed, every wave is done reading the other buffer
     const bool more = ks + 1 < kb1;
     const int nbuf = (ks - kb0 + 1) & 1;
     const unsigned char* st = smem + ((ks - kb0) & 1) * STAGE;
-    bf16x8_t b[2][3];
+    bf16x8_t b[2][NP];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) b[c][p] = *reinterpret_cast<const bf16x8_t*>(st + b_off + p * GBN * 64 + c * 16 * 64);
+      for (int p = 0; p < NP; ++p) b[c][p] = *reinterpret_cast<const bf16x8_t*>(st + b_off + p * GBN * 64 + c * 16 * 64);
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
       const unsigned char* ap = st + a_off + i * 16 * 64;
-      const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(ap);
-      const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(ap + BM * 64);
-      const bf16x8_t a2 = *reinterpret_cast<const bf16x8_t*>(ap + 2 * BM * 64);
+      bf16x8_t a[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) a[p] = *reinterpret_cast<const bf16x8_t*>(ap + p * BM * 64);
       if (more) {
 #pragma unroll
         for (int q = 0; q < PER; ++q) issue1(i * PER + q, nbuf);
       }
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {                     // smallest terms first
-        cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b[c][0], cor[i][c], 0, 0, 0);
-        cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b[c][1], cor[i][c], 0, 0, 0);
-        cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[c][2], cor[i][c], 0, 0, 0);
-        cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b[c][0], cor[i][c], 0, 0, 0);
-        cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[c][1], cor[i][c], 0, 0, 0);
-        acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[c][0], acc[i][c], 0, 0, 0);
+      for (int c = 0; c < 2; ++c) {
+        if constexpr (NP == 3) {                        // fp32 as three bf16 terms: the six leading products, smallest first
+          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[c][0], cor[i][c], 0, 0, 0);
+          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[c][1], cor[i][c], 0, 0, 0);
+          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[c][2], cor[i][c], 0, 0, 0);
+          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[c][0], cor[i][c], 0, 0, 0);
+          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[c][1], cor[i][c], 0, 0, 0);
+        }
+        acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[c][0], acc[i][c], 0, 0, 0);
       }
     }
     next_stage();
-  }
   }
   __syncthreads();            // everyone is done with the staging buffers: they become the output tile [BM][132] (fp32)
   constexpr int TLD = GBN + 4;
@@ -621,55 +582,42 @@ __global__ void __launch_bounds__(GTHREADS)
     if (ep.splits <= 1 && ep.out_planes && ep.zero_row >= 0 && m0 + BM >= M && threadIdx.x < 16 && n0 + threadIdx.x * 8 < N) {
       uint16_t* d = ep.out_planes + (long)ep.zero_row * N + n0 + threadIdx.x * 8;
       const uint4 z = make_uint4(0, 0, 0, 0);
-      *reinterpret_cast<uint4*>(d) = z;
-      *reinterpret_cast<uint4*>(d + ep.out_plane) = z;
-      *reinterpret_cast<uint4*>(d + 2 * ep.out_plane) = z;
+      for (int p = 0; p < NP; ++p) *reinterpret_cast<uint4*>(d + p * ep.out_plane) = z;
     }
   }
 }
 
-static int ring3_enabled() {                            // PT_GEMM_RING3=1: the three-stage ring for 128-row tiles (measured: no gain, profiles/r04)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("PT_GEMM_RING3");
-    v = (e && e[0] == '1') ? 1 : 0;
-  }
-  return v;
-}
-
-template <int MB, bool CONV, int NST>
+template <int MB, bool CONV, int NP>
 static int launch_gemm(const uint16_t* Ap, const uint16_t* Bp, float* C, const float* bias, const float* scale, int M, int N, int KB,
                        long a_plane, long b_plane, long ldc, int relu, ConvGeom cg, ConvEpi ep, hipStream_t s) {
   constexpr int BM = 32 * MB;
-  constexpr int LDS = (BM + GBN) * 3 * 64 * NST;
+  constexpr int STAGES = (BM + GBN) * NP * 64 * 2;
+  constexpr int LDS = STAGES > BM * (GBN + 4) * 4 ? STAGES : BM * (GBN + 4) * 4;      // the output tile [BM][132] fp32 reuses the stages
   static_assert(LDS <= 160 * 1024, "the stages must fit the CU's LDS");
-  static_assert(BM * (GBN + 4) * 4 <= LDS, "the output tile must fit the staging buffers");
   const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, GBN);
   const int items = tiles_m * tiles_n * ((CONV && ep.splits > 1) ? ep.splits : 1);
   static bool once = false;
   if (!once) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x6_kernel<MB, CONV, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x6_kernel<MB, CONV, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
     once = true;
   }
-  hipLaunchKernelGGL((gemm_bf16x6_kernel<MB, CONV, NST>), dim3(items), dim3(GTHREADS), LDS, s, Ap, Bp, C, bias, scale, M, N, KB,
+  hipLaunchKernelGGL((gemm_bf16x6_kernel<MB, CONV, NP>), dim3(items), dim3(GTHREADS), LDS, s, Ap, Bp, C, bias, scale, M, N, KB,
                      a_plane, b_plane, ldc, relu, tiles_n, items, cg, ep);
   return 0;
 }
 
-template <bool CONV>
+template <bool CONV, int NP>
 static int launch_by_rows(int tile_rows, const uint16_t* Ap, const uint16_t* Bp, float* C, const float* bias, const float* scale, int M,
                           int N, int KB, long a_plane, long b_plane, long ldc, int relu, ConvGeom cg, ConvEpi ep, hipStream_t s) {
   switch (tile_rows / 32) {
-    case 2: return launch_gemm<2, CONV, 2>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
-    case 3: return launch_gemm<3, CONV, 2>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
-    case 4:
-      if (ring3_enabled()) return launch_gemm<4, CONV, 3>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
-      return launch_gemm<4, CONV, 2>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
-    case 5: return launch_gemm<5, CONV, 2>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
-    case 6: return launch_gemm<6, CONV, 2>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
-    case 7: return launch_gemm<7, CONV, 2>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
-    default: return launch_gemm<8, CONV, 2>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
+    case 2: return launch_gemm<2, CONV, NP>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
+    case 3: return launch_gemm<3, CONV, NP>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
+    case 4: return launch_gemm<4, CONV, NP>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
+    case 5: return launch_gemm<5, CONV, NP>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
+    case 6: return launch_gemm<6, CONV, NP>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
+    case 7: return launch_gemm<7, CONV, NP>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
+    default: return launch_gemm<8, CONV, NP>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
   }
 }
 
@@ -749,13 +697,13 @@ __device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* lo, const unsig
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
-template <int MB, int NST>
+template <int MB, int NP>
 __global__ void __launch_bounds__(GTHREADS)
     wgrad_bf16x6_kernel(const uint16_t* __restrict__ Gp, const uint16_t* __restrict__ Xp, float* __restrict__ part,
                         float* __restrict__ part_bias, long g_plane, long x_plane, WgradGeom wg, int n_items) {
   constexpr int BM = 32 * MB, IMG_A = BM / 128, NIMG = IMG_A + 1;
   constexpr int IMG = 32 * 256;                        // bytes of one image
-  constexpr int STAGE = NIMG * 3 * IMG;                // [image][plane][32 rows][256 B]; images 0 .. IMG_A-1: gy, image IMG_A: x
+  constexpr int STAGE = NIMG * NP * IMG;               // [image][plane][32 rows][256 B]; images 0 .. IMG_A-1: gy, image IMG_A: x
   static_assert(BM % 128 == 0, "whole 128-column images");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
@@ -770,7 +718,9 @@ __global__ void __launch_bounds__(GTHREADS)
   const int m0 = tm * BM, n0 = tn * GBN;
   const int tap = n0 / wg.C, c0 = n0 - tap * wg.C;
   const int ky = tap / wg.KW, kx = tap - ky * wg.KW;
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // (the wave index as a SCALAR: the bias sums below are MFMAs behind a per-wave condition, and the matrix cores ignore EXEC - a
+  //  condition the compiler takes for divergent becomes an EXEC mask around an MFMA that then runs in every wave on stale operands)
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const bool bias_tile = wg.want_bias && tn == 0;      // block-uniform
 
   // staging: wave w owns rows 4w .. 4w+3 (one KiB) of every image; lane = (row, physical chunk)
@@ -794,11 +744,11 @@ __global__ void __launch_bounds__(GTHREADS)
     while (py >= wg.Ho) { py -= wg.Ho; sbase += wg.Hs * wg.Ws; }
   };
   auto issue = [&](int img, int buf) {                 // the three planes of one image
-    unsigned char* dst = smem + buf * STAGE + img * 3 * IMG + w * 1024;
+    unsigned char* dst = smem + buf * STAGE + img * NP * IMG + w * 1024;
     const uint16_t* src = img < IMG_A ? ga + arow + img * 128 : xb + brow;
     const long plane = img < IMG_A ? g_plane : x_plane;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) glds16(src + p * plane, dst + p * IMG);
+    for (int p = 0; p < NP; ++p) glds16(src + p * plane, dst + p * IMG);
   };
 
   // fragments: lane 16 g + 4 q + p2 supplies row 8 g + q (+ 4 for the second read), 8-byte half p2 & 1 of chunk c0 + (p2 >> 1)
@@ -813,10 +763,10 @@ __global__ void __launch_bounds__(GTHREADS)
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
       const int blk = rg * MB + i;                     // 16-channel block of the tile
-      a_off[i][h] = (blk >> 3) * 3 * IMG + base + 16 * ((2 * (blk & 7) + (p2 >> 1)) ^ X);
+      a_off[i][h] = (blk >> 3) * NP * IMG + base + 16 * ((2 * (blk & 7) + (p2 >> 1)) ^ X);
     }
 #pragma unroll
-    for (int c = 0; c < 2; ++c) b_off[c][h] = IMG_A * 3 * IMG + base + 16 * ((nb * 4 + c * 2 + (p2 >> 1)) ^ X);
+    for (int c = 0; c < 2; ++c) b_off[c][h] = IMG_A * NP * IMG + base + 16 * ((nb * 4 + c * 2 + (p2 >> 1)) ^ X);
   }
 
   f32x4_t acc[MB][2], cor[MB][2];
@@ -840,84 +790,39 @@ __global__ void __launch_bounds__(GTHREADS)
 #pragma unroll
     for (int img = 0; img < NIMG; ++img) issue(img, 0);
   }
-  if constexpr (NST == 3) {
-    // three-stage ring with a counted wait (see gemm_bf16x6_kernel): every wave issues NIMG * 3 pieces per stage
-    if (k_begin + 1 < k_end) {
-      next_rows();
-#pragma unroll
-      for (int img = 0; img < NIMG; ++img) issue(img, 1);
-    }
-    int cur = 0;
-    for (int ks = k_begin; ks < k_end; ++ks) {
-      if (ks + 1 < k_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIMG * 3) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_barrier" ::: "memory");
-      const bool more = ks + 2 < k_end;
-      const int nbuf = cur == 0 ? 2 : cur - 1;
-      const unsigned char* st = smem + cur * STAGE;
-      if (more) next_rows();
-      bf16x8_t b[2][3];
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) b[c][p] = tr_frag(st + b_off[c][0] + p * IMG, st + b_off[c][1] + p * IMG);
-#pragma unroll
-      for (int i = 0; i < MB; ++i) {
-        const bf16x8_t a0 = tr_frag(st + a_off[i][0], st + a_off[i][1]);
-        const bf16x8_t a1 = tr_frag(st + a_off[i][0] + IMG, st + a_off[i][1] + IMG);
-        const bf16x8_t a2 = tr_frag(st + a_off[i][0] + 2 * IMG, st + a_off[i][1] + 2 * IMG);
-        if (more && i < NIMG) issue(i, nbuf);          // wave-uniform
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {                   // smallest terms first
-          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b[c][0], cor[i][c], 0, 0, 0);
-          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b[c][1], cor[i][c], 0, 0, 0);
-          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[c][2], cor[i][c], 0, 0, 0);
-          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b[c][0], cor[i][c], 0, 0, 0);
-          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[c][1], cor[i][c], 0, 0, 0);
-          acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[c][0], acc[i][c], 0, 0, 0);
-        }
-        if (bias_tile && (i & 3) == nb) {               // wave-uniform
-          bsum[i >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, ones, bsum[i >> 2], 0, 0, 0);
-          bsum[i >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, ones, bsum[i >> 2], 0, 0, 0);
-          bsum[i >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, ones, bsum[i >> 2], 0, 0, 0);
-        }
-      }
-      cur = cur == 2 ? 0 : cur + 1;
-    }
-  } else {
   for (int ks = k_begin; ks < k_end; ++ks) {
     __syncthreads();          // the stage has landed (s_waitcnt vmcnt(0)) and every wave has left the other buffer
     const bool more = ks + 1 < k_end;
     const int cur = (ks - k_begin) & 1;
     const unsigned char* st = smem + cur * STAGE;
     if (more) next_rows();
-    bf16x8_t b[2][3];
+    bf16x8_t b[2][NP];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) b[c][p] = tr_frag(st + b_off[c][0] + p * IMG, st + b_off[c][1] + p * IMG);
+      for (int p = 0; p < NP; ++p) b[c][p] = tr_frag(st + b_off[c][0] + p * IMG, st + b_off[c][1] + p * IMG);
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
-      const bf16x8_t a0 = tr_frag(st + a_off[i][0], st + a_off[i][1]);
-      const bf16x8_t a1 = tr_frag(st + a_off[i][0] + IMG, st + a_off[i][1] + IMG);
-      const bf16x8_t a2 = tr_frag(st + a_off[i][0] + 2 * IMG, st + a_off[i][1] + 2 * IMG);
+      bf16x8_t a[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) a[p] = tr_frag(st + a_off[i][0] + p * IMG, st + a_off[i][1] + p * IMG);
       if (more && i < NIMG) issue(i, cur ^ 1);         // wave-uniform
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {                     // smallest terms first
-        cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b[c][0], cor[i][c], 0, 0, 0);
-        cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b[c][1], cor[i][c], 0, 0, 0);
-        cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[c][2], cor[i][c], 0, 0, 0);
-        cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b[c][0], cor[i][c], 0, 0, 0);
-        cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[c][1], cor[i][c], 0, 0, 0);
-        acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[c][0], acc[i][c], 0, 0, 0);
+      for (int c = 0; c < 2; ++c) {
+        if constexpr (NP == 3) {                        // smallest terms first
+          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[c][0], cor[i][c], 0, 0, 0);
+          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[c][1], cor[i][c], 0, 0, 0);
+          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[c][2], cor[i][c], 0, 0, 0);
+          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[c][0], cor[i][c], 0, 0, 0);
+          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[c][1], cor[i][c], 0, 0, 0);
+        }
+        acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[c][0], acc[i][c], 0, 0, 0);
       }
       if (bias_tile && (i & 3) == nb) {                 // wave-uniform
-        bsum[i >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, ones, bsum[i >> 2], 0, 0, 0);
-        bsum[i >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, ones, bsum[i >> 2], 0, 0, 0);
-        bsum[i >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, ones, bsum[i >> 2], 0, 0, 0);
+#pragma unroll
+        for (int p = NP - 1; p >= 0; --p) bsum[i >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[p], ones, bsum[i >> 2], 0, 0, 0);
       }
     }
-  }
   }
   __syncthreads();            // the staging buffers become the output tile [BM][132] (fp32)
   constexpr int TLD = GBN + 4;
@@ -1012,20 +917,20 @@ __global__ void __launch_bounds__(256)
   if (threadIdx.x == 0) dgamma[o] = rstd[o] * (dot - mean[o] * sum_e[o]);
 }
 
-template <int MB, int NST>
+template <int MB, int NP>
 static int launch_wgrad(const uint16_t* Gp, const uint16_t* Xp, float* part, float* part_bias, long g_plane, long x_plane, WgradGeom wg, int S,
                         hipStream_t s) {
-  constexpr int LDS = (32 * MB / 128 + 1) * 3 * 8192 * NST;
+  constexpr int STAGES = (32 * MB / 128 + 1) * NP * 8192 * 2;
+  constexpr int LDS = STAGES > 32 * MB * (GBN + 4) * 4 ? STAGES : 32 * MB * (GBN + 4) * 4;   // the output tile reuses the stages
   static_assert(LDS <= 160 * 1024, "the stages must fit the CU's LDS");
-  static_assert(32 * MB * (GBN + 4) * 4 <= LDS, "the output tile must fit the staging buffers");
   static bool once = false;
   if (!once) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16x6_kernel<MB, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16x6_kernel<MB, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
     once = true;
   }
   const int n_items = S * wg.tiles_m * wg.tiles_n;
-  hipLaunchKernelGGL((wgrad_bf16x6_kernel<MB, NST>), dim3(n_items), dim3(GTHREADS), LDS, s, Gp, Xp, part, part_bias, g_plane, x_plane, wg, n_items);
+  hipLaunchKernelGGL((wgrad_bf16x6_kernel<MB, NP>), dim3(n_items), dim3(GTHREADS), LDS, s, Gp, Xp, part, part_bias, g_plane, x_plane, wg, n_items);
   return 0;
 }
 
@@ -1033,8 +938,9 @@ static int launch_wgrad(const uint16_t* Gp, const uint16_t* Xp, float* part, flo
 // fp32 [B, Hs, Ws, C] NHWC (row stride ld) -> ROW-MAJOR planes of the pixels (y * stride, x * stride), y < Ho, x < Wo: [3][(B Ho Wo + 1) * C],
 // last row zeros.  stride 1 = every pixel (what split3_rows_kernel does, without the backward preparation); stride 2 = the pixels a
 // stride-2 1 x 1 convolution reads (layer2's first Bottleneck: conv1 and downsample, resnet.py:153-158 caffe style).
+template <typename SRC>
 __global__ void __launch_bounds__(256)
-    split3_gather_kernel(const float* __restrict__ src, long ld, int Hs, int Ws, int Ho, int Wo, int stride, int P, int C,
+    split3_gather_kernel(const SRC* __restrict__ src, long ld, int Hs, int Ws, int Ho, int Wo, int stride, int P, int C, int np,
                          uint16_t* __restrict__ dst, long plane) {
   const int c8 = C >> 3;
   const long units = (long)(P + 1) * c8;
@@ -1045,17 +951,23 @@ __global__ void __launch_bounds__(256)
     if (r < P) {
       const int x = (int)(r % Wo), yq = (int)(r / Wo);
       const int y = yq % Ho, b = yq / Ho;
-      const float* sp = src + (((long)b * Hs + (long)y * stride) * Ws + (long)x * stride) * ld + c;
-      const float4 lo = *reinterpret_cast<const float4*>(sp), hi = *reinterpret_cast<const float4*>(sp + 4);
-      split_pair(lo.x, lo.y, o0.x, o1.x, o2.x);
-      split_pair(lo.z, lo.w, o0.y, o1.y, o2.y);
-      split_pair(hi.x, hi.y, o0.z, o1.z, o2.z);
-      split_pair(hi.z, hi.w, o0.w, o1.w, o2.w);
+      const SRC* sp = src + (((long)b * Hs + (long)y * stride) * Ws + (long)x * stride) * ld + c;
+      if constexpr (sizeof(SRC) == 2) {                 // a bf16 map (the autocast stem): one plane, copied
+        o0 = *reinterpret_cast<const uint4*>(sp);
+      } else {
+        const float4 lo = *reinterpret_cast<const float4*>(sp), hi = *reinterpret_cast<const float4*>(sp + 4);
+        split_pair(lo.x, lo.y, o0.x, o1.x, o2.x);
+        split_pair(lo.z, lo.w, o0.y, o1.y, o2.y);
+        split_pair(hi.x, hi.y, o0.z, o1.z, o2.z);
+        split_pair(hi.z, hi.w, o0.w, o1.w, o2.w);
+      }
     }
     uint16_t* d = dst + r * C + c;
     *reinterpret_cast<uint4*>(d) = o0;
-    *reinterpret_cast<uint4*>(d + plane) = o1;
-    *reinterpret_cast<uint4*>(d + 2 * plane) = o2;
+    if (np == 3) {
+      *reinterpret_cast<uint4*>(d + plane) = o1;
+      *reinterpret_cast<uint4*>(d + 2 * plane) = o2;
+    }
   }
 }
 
@@ -1063,17 +975,24 @@ __global__ void __launch_bounds__(256)
 // consumers (a stage output feeding the next stage and an FPN lateral), and / or planes -> fp32 (out_f32).
 __global__ void __launch_bounds__(256)
     planes_combine_kernel(const uint16_t* __restrict__ a, long a_plane, const uint16_t* __restrict__ b, long b_plane,
-                          const float* __restrict__ c, const uint16_t* __restrict__ mask, long n8, uint16_t* __restrict__ out, long out_plane,
-                          float* __restrict__ out_f32) {
+                          const float* __restrict__ c, const uint16_t* __restrict__ mask, long n8, int np, uint16_t* __restrict__ out,
+                          long out_plane, float* __restrict__ out_f32) {
+  const uint4 z = make_uint4(0, 0, 0, 0);
   for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < n8; u += (long)gridDim.x * blockDim.x) {
     const long e = u << 3;
     float o[8];
-    planes_sum8(*reinterpret_cast<const uint4*>(a + e), *reinterpret_cast<const uint4*>(a + a_plane + e),
-                *reinterpret_cast<const uint4*>(a + 2 * a_plane + e), o);
+    if (np == 3)
+      planes_sum8(*reinterpret_cast<const uint4*>(a + e), *reinterpret_cast<const uint4*>(a + a_plane + e),
+                  *reinterpret_cast<const uint4*>(a + 2 * a_plane + e), o);
+    else
+      planes_sum8(*reinterpret_cast<const uint4*>(a + e), z, z, o);
     if (b) {
       float r[8];
-      planes_sum8(*reinterpret_cast<const uint4*>(b + e), *reinterpret_cast<const uint4*>(b + b_plane + e),
-                  *reinterpret_cast<const uint4*>(b + 2 * b_plane + e), r);
+      if (np == 3)
+        planes_sum8(*reinterpret_cast<const uint4*>(b + e), *reinterpret_cast<const uint4*>(b + b_plane + e),
+                    *reinterpret_cast<const uint4*>(b + 2 * b_plane + e), r);
+      else
+        planes_sum8(*reinterpret_cast<const uint4*>(b + e), z, z, r);
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] += r[j];
     }
@@ -1101,8 +1020,10 @@ __global__ void __launch_bounds__(256)
       split_pair(o[4], o[5], p0.z, p1.z, p2.z);
       split_pair(o[6], o[7], p0.w, p1.w, p2.w);
       *reinterpret_cast<uint4*>(out + e) = p0;
-      *reinterpret_cast<uint4*>(out + out_plane + e) = p1;
-      *reinterpret_cast<uint4*>(out + 2 * out_plane + e) = p2;
+      if (np == 3) {
+        *reinterpret_cast<uint4*>(out + out_plane + e) = p1;
+        *reinterpret_cast<uint4*>(out + 2 * out_plane + e) = p2;
+      }
     }
   }
 }
@@ -1168,7 +1089,7 @@ extern "C" int pt_gemm_bf16x6_nt(const uint16_t* a_planes, int64_t a_plane_strid
              "pt_gemm_bf16x6_nt: planes must be 16-byte aligned");
   if (tile_rows <= 0) tile_rows = pt_gemm_bf16x6_tile_rows(M, N);
   PT_REQUIRE(tile_rows % 32 == 0 && tile_rows >= 64 && tile_rows <= 256, PT_EINVAL, "pt_gemm_bf16x6_nt: tile_rows in {64, 96, ..., 256}");
-  const int rc = launch_by_rows<false>(tile_rows, a_planes, b_planes, c, bias, nullptr, M, N, Kp, a_plane_stride, b_plane_stride, ldc, relu,
+  const int rc = launch_by_rows<false, 3>(tile_rows, a_planes, b_planes, c, bias, nullptr, M, N, Kp, a_plane_stride, b_plane_stride, ldc, relu,
                                        ConvGeom{}, ConvEpi{}, as_stream(stream));
   PT_REQUIRE(rc == 0, rc, "pt_gemm_bf16x6_nt: hipFuncSetAttribute failed (%d)", rc);
   PT_LAUNCH_CHECK("pt_gemm_bf16x6_nt");
@@ -1191,10 +1112,11 @@ extern "C" int pt_split_bf16x3_rows(const float* src, int64_t ld, int P, int C, 
   return PT_OK;
 }
 
-extern "C" int pt_split_bf16x3_gather(const float* src, int64_t ld, int B, int Hs, int Ws, int C, int stride, uint16_t* planes,
-                                      int64_t plane_stride, void* stream) {
-  PT_REQUIRE(src && planes && B > 0 && Hs > 0 && Ws > 0 && C > 0 && (C & 7) == 0 && ld >= C && (ld & 3) == 0 && (stride == 1 || stride == 2),
-             PT_EINVAL, "pt_split_bf16x3_gather: bad argument (C, ld multiples of 8 / 4; stride 1 or 2)");
+extern "C" int pt_split_bf16x3_gather(const void* src, int src_bf16, int64_t ld, int B, int Hs, int Ws, int C, int stride, int np,
+                                      uint16_t* planes, int64_t plane_stride, void* stream) {
+  PT_REQUIRE(src && planes && B > 0 && Hs > 0 && Ws > 0 && C > 0 && (C & 7) == 0 && ld >= C && (ld & 7) == 0 && (stride == 1 || stride == 2),
+             PT_EINVAL, "pt_split_bf16x3_gather: bad argument (C, ld multiples of 8; stride 1 or 2)");
+  PT_REQUIRE((np == 3 && !src_bf16) || np == 1, PT_EINVAL, "pt_split_bf16x3_gather: np 3 (fp32 source) or 1 (fp32 or bf16 source)");
   const int Ho = (Hs - 1) / stride + 1, Wo = (Ws - 1) / stride + 1;
   const long P = (long)B * Ho * Wo;
   PT_REQUIRE(P < (1L << 30), PT_ELIMIT, "pt_split_bf16x3_gather: B * Ho * Wo < 2^30");
@@ -1203,16 +1125,21 @@ extern "C" int pt_split_bf16x3_gather(const float* src, int64_t ld, int B, int H
   const long units = (P + 1) * (C >> 3);
   int nb = cdiv(units, 256);
   nb = nb > 16384 ? 16384 : nb;
-  hipLaunchKernelGGL(split3_gather_kernel, dim3(nb), dim3(256), 0, as_stream(stream), src, (long)ld, Hs, Ws, Ho, Wo, stride, (int)P, C, planes,
-                     (long)plane_stride);
+  if (src_bf16)
+    hipLaunchKernelGGL(split3_gather_kernel<uint16_t>, dim3(nb), dim3(256), 0, as_stream(stream), (const uint16_t*)src, (long)ld, Hs, Ws, Ho, Wo,
+                       stride, (int)P, C, np, planes, (long)plane_stride);
+  else
+    hipLaunchKernelGGL(split3_gather_kernel<float>, dim3(nb), dim3(256), 0, as_stream(stream), (const float*)src, (long)ld, Hs, Ws, Ho, Wo, stride,
+                       (int)P, C, np, planes, (long)plane_stride);
   PT_LAUNCH_CHECK("pt_split_bf16x3_gather");
   return PT_OK;
 }
 
 extern "C" int pt_planes_combine(const uint16_t* a, int64_t a_plane_stride, const uint16_t* b, int64_t b_plane_stride, const float* c,
-                                 const uint16_t* mask, int64_t n, uint16_t* out, int64_t out_plane_stride, float* out_f32, void* stream) {
+                                 const uint16_t* mask, int64_t n, int np, uint16_t* out, int64_t out_plane_stride, float* out_f32,
+                                 void* stream) {
   if (n == 0) return PT_OK;
-  PT_REQUIRE(a && n > 0 && (n & 7) == 0 && (out || out_f32), PT_EINVAL, "pt_planes_combine: bad argument (n a multiple of 8)");
+  PT_REQUIRE(a && n > 0 && (n & 7) == 0 && (out || out_f32) && (np == 3 || np == 1), PT_EINVAL, "pt_planes_combine: bad argument (n a multiple of 8, np 3 or 1)");
   PT_REQUIRE(((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)mask) | ((uintptr_t)out) | ((uintptr_t)out_f32)) & 15) == 0 &&
                  (a_plane_stride & 7) == 0 && (b_plane_stride & 7) == 0 && (out_plane_stride & 7) == 0,
              PT_EINVAL, "pt_planes_combine: buffers and plane strides must be 16-byte aligned");
@@ -1220,7 +1147,7 @@ extern "C" int pt_planes_combine(const uint16_t* a, int64_t a_plane_stride, cons
   int nb = cdiv(n >> 3, 256);
   nb = nb > 16384 ? 16384 : nb;
   hipLaunchKernelGGL(planes_combine_kernel, dim3(nb), dim3(256), 0, as_stream(stream), a, (long)a_plane_stride, b, (long)b_plane_stride, c, mask,
-                     (long)(n >> 3), out, (long)out_plane_stride, out_f32);
+                     (long)(n >> 3), np, out, (long)out_plane_stride, out_f32);
   PT_LAUNCH_CHECK("pt_planes_combine");
   return PT_OK;
 }
@@ -1287,8 +1214,11 @@ extern "C" int pt_conv_bf16x6(const pt_conv_desc* d, void* stream) {
                ((uintptr_t)d->out_f32) | ((uintptr_t)d->out_planes) | ((uintptr_t)d->scale) | ((uintptr_t)d->shift)) & 15) == 0 &&
                  (d->x_plane_stride & 7) == 0 && (d->w_plane_stride & 7) == 0 && (d->res_plane_stride & 7) == 0 && (d->out_plane_stride & 7) == 0,
              PT_EINVAL, "pt_conv_bf16x6: buffers and plane strides must be 16-byte aligned");
+  const int np = d->np == 1 ? 1 : 3;
+  PT_REQUIRE(d->np == 0 || d->np == 1 || d->np == 3, PT_EINVAL, "pt_conv_bf16x6: np = 3 (or 0) planes per operand, or 1");
   long rows_out = M;
   ConvEpi ep{};
+  ep.np = np;
   if (d->scatter_stride) {
     PT_REQUIRE(d->scatter_stride == 2 && d->scatter_H >= (Ho - 1) * 2 + 1 && d->scatter_W >= (Wo - 1) * 2 + 1, PT_EINVAL,
                "pt_conv_bf16x6: scatter_stride 2 into a grid that holds every (2 y, 2 x)");
@@ -1305,7 +1235,11 @@ extern "C" int pt_conv_bf16x6(const pt_conv_desc* d, void* stream) {
   ep.relu = d->relu;
   ep.zero_row = (d->out_planes && !d->scatter_stride) ? (int)M : -1;      // (a scattered result lands in a buffer the caller zeroed)
   int tile_rows = d->tile_rows;
-  if (tile_rows <= 0) {
+  if (np == 1) {
+    // one bf16 plane: a sixth of the products - the convolutions are bound by their bytes; 64-row tiles keep the fp32 output tile
+    // (the LDS a workgroup needs) at 34 KB: four workgroups per CU overlap one another's loads, products and stores
+    if (tile_rows <= 0 || tile_rows > 128) tile_rows = M >= 32768 ? 128 : 64;
+  } else if (tile_rows <= 0) {
     tile_rows = pt_gemm_bf16x6_tile_rows((int)M, d->Cout);
     // a reduce dimension of <= 128 with many rows (a Bottleneck's expanding 1 x 1, the input gradient of its reducing one) is bound
     // by its epilogue's HBM traffic: 64-row tiles fit two workgroups per CU, one's stores overlap the other's products
@@ -1324,8 +1258,10 @@ extern "C" int pt_conv_bf16x6(const pt_conv_desc* d, void* stream) {
     ep.splits = S;
     ep.ks_per = (KB + S - 1) / S;
   }
-  rc = launch_by_rows<true>(tile_rows, d->x_planes, d->w_planes, nullptr, nullptr, nullptr, (int)M, d->Cout, KB, d->x_plane_stride,
-                            d->w_plane_stride, d->Cout, 0, cg, ep, as_stream(stream));
+  rc = np == 1 ? launch_by_rows<true, 1>(tile_rows, d->x_planes, d->w_planes, nullptr, nullptr, nullptr, (int)M, d->Cout, KB, d->x_plane_stride,
+                                         d->w_plane_stride, d->Cout, 0, cg, ep, as_stream(stream))
+               : launch_by_rows<true, 3>(tile_rows, d->x_planes, d->w_planes, nullptr, nullptr, nullptr, (int)M, d->Cout, KB, d->x_plane_stride,
+                                         d->w_plane_stride, d->Cout, 0, cg, ep, as_stream(stream));
   PT_REQUIRE(rc == 0, rc, "pt_conv_bf16x6: hipFuncSetAttribute failed (%d)", rc);
   PT_LAUNCH_CHECK("pt_conv_bf16x6");
   if (S > 1) {
@@ -1408,9 +1344,12 @@ extern "C" int pt_conv_wgrad_bf16x6(const pt_conv_wgrad_desc* d, void* stream) {
   const bool direct = S == 1 && !d->row_scale && !d->accumulate;
   float* part = direct ? d->dw : d->workspace;
   float* part_bias = direct ? d->dbias : d->workspace + (long)S * n;
-  const int rc = bm == 256 ? launch_wgrad<8, 2>(d->gy_planes, d->x_planes, part, part_bias, d->gy_plane_stride, d->x_plane_stride, wg, S, as_stream(stream))
-                 : ring3_enabled() ? launch_wgrad<4, 3>(d->gy_planes, d->x_planes, part, part_bias, d->gy_plane_stride, d->x_plane_stride, wg, S, as_stream(stream))
-                                   : launch_wgrad<4, 2>(d->gy_planes, d->x_planes, part, part_bias, d->gy_plane_stride, d->x_plane_stride, wg, S, as_stream(stream));
+  PT_REQUIRE(d->np == 0 || d->np == 1 || d->np == 3, PT_EINVAL, "pt_conv_wgrad_bf16x6: np = 3 (or 0) planes per operand, or 1");
+  const bool one = d->np == 1;
+  const int rc = bm == 256 ? (one ? launch_wgrad<8, 1>(d->gy_planes, d->x_planes, part, part_bias, d->gy_plane_stride, d->x_plane_stride, wg, S, as_stream(stream))
+                                  : launch_wgrad<8, 3>(d->gy_planes, d->x_planes, part, part_bias, d->gy_plane_stride, d->x_plane_stride, wg, S, as_stream(stream)))
+                           : (one ? launch_wgrad<4, 1>(d->gy_planes, d->x_planes, part, part_bias, d->gy_plane_stride, d->x_plane_stride, wg, S, as_stream(stream))
+                                  : launch_wgrad<4, 3>(d->gy_planes, d->x_planes, part, part_bias, d->gy_plane_stride, d->x_plane_stride, wg, S, as_stream(stream)));
   PT_REQUIRE(rc == 0, rc, "pt_conv_wgrad_bf16x6: hipFuncSetAttribute failed (%d)", rc);
   PT_LAUNCH_CHECK("pt_conv_wgrad_bf16x6");
   if (direct) return PT_OK;

@@ -125,7 +125,7 @@ class Student_FCOS(BaseDetector):
         """`stem`: the output of `backbone_stem` for `img` (then `img` is not read)."""
         def run():
             if (self.with_neck and getattr(self.neck, 'accepts_planes', False) and getattr(self.backbone, 'plane_capable', False)
-                    and self.backbone_autocast is None):
+                    and self.backbone_autocast in (None, torch.bfloat16)):
                 # the trainable stages hand their outputs to the neck as split planes (planes.PlaneAct): no fp32 copy in between
                 x = self.backbone(img, planes=True) if stem is None else self.backbone(None, stem=stem, planes=True)
             else:

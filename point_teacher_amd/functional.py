@@ -700,16 +700,16 @@ class _ConvWeightPlanes:
 
     def _build_table(self):
         rec = np.zeros(len(self.ent), dtype=np.dtype([('w', '<u8'), ('dst', '<u8'), ('plane', '<i8'), ('O', '<i4'), ('I', '<i4'),
-                                                       ('mode', '<i4'), ('first', '<i4'), ('taps', '<i4'), ('reserved', '<i4'),
+                                                       ('mode', '<i4'), ('first', '<i4'), ('taps', '<i4'), ('np', '<i4'),
                                                        ('scale', '<u8')]))
         first = 0
         dev = None
-        for i, ((_, mode, _sp), (ref, ptr, sp, scale, _ver)) in enumerate(self.ent.items()):
+        for i, ((_, mode, _sp, npl), (ref, ptr, sp, scale, _ver)) in enumerate(self.ent.items()):
             w = ref()
             O, I = w.shape[:2]
             taps = self.taps(w)
             rows, k = (I, taps * O) if mode else (O, taps * I)
-            rec[i] = (ptr, sp.planes.data_ptr(), sp.planes.shape[1], O, I, mode, first, taps, 0, scale.data_ptr() if scale is not None else 0)
+            rec[i] = (ptr, sp.planes.data_ptr(), sp.planes.shape[1], O, I, mode, first, taps, npl, scale.data_ptr() if scale is not None else 0)
             first += ((rows + 15) // 16) * (k // 32)
             dev = w.device
         self.table = (torch.from_numpy(rec.view(np.uint8)).to(dev), len(self.ent), first)
@@ -719,10 +719,10 @@ class _ConvWeightPlanes:
         w = v[0]()
         return w is not None and w.data_ptr() == v[1]
 
-    def get(self, w, dgrad, scale=None):
+    def get(self, w, dgrad, scale=None, np_=3):
         import weakref
         mode = int(bool(dgrad))
-        key = (id(w), mode, scale.data_ptr() if scale is not None else 0)
+        key = (id(w), mode, scale.data_ptr() if scale is not None else 0, np_)
         e = self.ent.get(key)
         if e is not None and (e[0]() is not w or e[1] != w.data_ptr()):
             e = None                                            # the id was reused, or the storage moved (re-layout of the flat buffer)
@@ -733,7 +733,7 @@ class _ConvWeightPlanes:
             taps = self.taps(w)
             rows, k = (I, taps * O) if mode else (O, taps * I)
             n = ((rows + 15) // 16) * ((k + 31) // 32) * 512
-            sp = SplitPlanes(torch.empty((3, n), dtype=torch.bfloat16, device=w.device), rows, k)
+            sp = SplitPlanes(torch.empty((np_, n), dtype=torch.bfloat16, device=w.device), rows, k)
             e = self.ent[key] = [weakref.ref(w), w.data_ptr(), sp, scale, -1]
             self.table = None
             self.epoch = -1
@@ -756,13 +756,19 @@ class _ConvWeightPlanes:
 _CONV_W = _ConvWeightPlanes()
 
 
-def _conv_weight_planes(w, dgrad, scale=None):
+def _conv_weight_planes(w, dgrad, scale=None, np_=3):
     """Split planes of a [O, I, KH, KW] weight as the [O, taps I] matrix with k = (ky, kx, i) (forward; a channels_last weight IS
     that matrix) or as w'[i, (KH - 1 - ky, KW - 1 - kx), o] (input gradient), optionally with a per-output-channel scale folded in;
     cached until the parameters change (PARAM_EPOCH / the weight's version counter).  Channels_last weights go through the batched
     refresh (_ConvWeightPlanes); any other layout is split on its own."""
+    c = _CONV_W
+    e = c.ent.get((id(w), 1 if dgrad else 0, scale.data_ptr() if scale is not None else 0, np_))
+    if (e is not None and c.epoch == PARAM_EPOCH[0] and c.table is not None and e[0]() is w and e[1] == w.data_ptr()
+            and e[4] == w._version):
+        return e[2]                                              # (the steady state: a registered weight, planes of this parameter epoch)
     if _ConvWeightPlanes.ok(w):
-        return _CONV_W.get(w, dgrad, scale)
+        return c.get(w, dgrad, scale, np_)
+    assert np_ == 3, 'one-plane (bf16) operands need a channels_last weight of the batched plane cache'
     key = (id(w), 'conv', scale.data_ptr() if scale is not None else 0)
     ent = _SPLIT_W_CACHE.get(key)
     if ent is None or ent[0] != PARAM_EPOCH[0] or ent[1] != w.data_ptr() or ent[4] != w._version:

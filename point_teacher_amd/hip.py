@@ -111,22 +111,40 @@ def _ptr(x, name, ctype=None):
     raise TypeError(f'{name}: cannot pass {type(x)} as a pointer')
 
 
+_NO_RC_CHECK = ('pt_abi_version', 'pt_focal_nblocks', 'pt_sqnorm_nblocks', 'pt_affine_train_rows', 'pt_gemm_bf16x6_tile_rows',
+                'pt_conv3x3_wgrad_bf16x6_splits', 'pt_conv_wgrad_bf16x6_splits', 'pt_conv_bf16x6_splits')
+_PLANS = {}
+
+
+def _plan(fn):
+    """Per entry point, once: the ctypes function, which arguments are pointers (with the element type the header declares), whether a
+    trailing `stream` may be filled in, whether the return code is an error code."""
+    restype, proto = PROTOS[fn]
+    dts = PTR_DTYPES.get(fn, {})
+    ptrs = tuple((f'{fn}.{an}', dts.get(an)) if ct is ctypes.c_void_p else None for ct, an in proto)
+    pl = _PLANS[fn] = (getattr(_lib, fn), ptrs, len(proto), proto[-1][1] == 'stream' if proto else False,
+                       restype is ctypes.c_int and fn not in _NO_RC_CHECK)
+    return pl
+
+
+def current_stream_handle():
+    """torch's current HIP stream on the current device as a raw handle (what every libpt_hip launch goes to)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
 def call(fn, *args):
     """Call a libpt_hip entry point.  Tensors become device pointers; the trailing `stream`
     argument is filled with torch's current stream when omitted."""
-    restype, proto = PROTOS[fn]
-    args = list(args)
-    auto_stream = len(args) == len(proto) - 1 and proto[-1][1] == 'stream'
-    if len(args) + int(auto_stream) != len(proto):
-        raise TypeError(f'{fn}: expected {len(proto)} arguments, got {len(args)}')
-    conv = []
-    for a, (ct, an) in zip(args, proto):
-        conv.append(_ptr(a, f'{fn}.{an}', PTR_DTYPES.get(fn, {}).get(an)) if ct is ctypes.c_void_p else a)
+    pl = _PLANS.get(fn) or _plan(fn)
+    cf, ptrs, n, has_stream, check = pl
+    auto_stream = len(args) != n
+    if auto_stream and not (has_stream and len(args) == n - 1):
+        raise TypeError(f'{fn}: expected {n} arguments, got {len(args)}')
+    conv = [a if (p is None or a is None) else _ptr(a, p[0], p[1]) for a, p in zip(args, ptrs)]      # (a CPU tensor fails here, loudly)
     if auto_stream:
-        conv.append(torch.cuda.current_stream().cuda_stream)
-    rc = getattr(_lib, fn)(*conv)
-    if restype is ctypes.c_int and fn not in ('pt_abi_version', 'pt_focal_nblocks', 'pt_sqnorm_nblocks', 'pt_affine_train_rows', 'pt_gemm_bf16x6_tile_rows',
-                                            'pt_conv3x3_wgrad_bf16x6_splits', 'pt_conv_wgrad_bf16x6_splits', 'pt_conv_bf16x6_splits') and rc != 0:
+        conv.append(current_stream_handle())
+    rc = cf(*conv)
+    if check and rc != 0:
         raise RuntimeError(f'{fn} failed (code {rc}): {last_error()}')
     return rc
 

@@ -110,12 +110,12 @@ class ConvModule(nn.Module):
     def forward(self, x, out_planes=False):
         c = self.conv
         if isinstance(x, PL.PlaneAct) or out_planes:
-            if (_PLANE_TRUNK and not self.with_norm and PL.plane_conv_ok(c) and (isinstance(x, PL.PlaneAct) or PL.f32_ok(x))):
+            if (_PLANE_TRUNK and not self.with_norm and PL.plane_conv_ok(c) and (isinstance(x, PL.PlaneAct) or PL.dense_ok(x))):
                 return PL.conv_module(x, c, relu=self.with_activation, out_planes=out_planes)
             if isinstance(x, PL.PlaneAct):
-                x = x.float()
+                x = x.tensor()
             assert not out_planes, 'this convolution cannot emit planes'
-        if (_PLANE_TRUNK and not self.with_norm and PL.plane_conv_ok(c) and PL.f32_ok(x)
+        if (_PLANE_TRUNK and not self.with_norm and PL.plane_conv_ok(c) and PL.dense_ok(x)
                 and x.shape[0] * x.shape[2] * x.shape[3] >= self.plane_min_pixels):
             # 1x1 / 3x3 convolutions of necks and towers (fp32 by the config): implicit GEMM on the bf16 matrix cores with split-bf16
             # operands and fp32 accumulation, bias (+ ReLU) in its epilogue, input / weight / bias gradients on the same kernels
@@ -231,7 +231,13 @@ def refresh_bn_affines(model, trainable=False):
     of launches (4 concatenations + 4 element-wise ops into persistent buffers) instead of four tiny kernels per layer.  Called
     after the teacher EMA and, for trainable affines, once per parameter update; the per-layer triples are views of persistent
     buffers (the plane kernels' weight-plane cache holds pointers to the scales)."""
-    bns = [m for m in model.modules() if isinstance(m, nn.BatchNorm2d) and not m.training and bool(m.weight.requires_grad) == trainable]
+    key = (bool(trainable), model.training)
+    cached = model.__dict__.setdefault('_bn_lists', {}).get(key)
+    allb = [m for m in model.modules() if isinstance(m, nn.BatchNorm2d)] if cached is None else cached[0]
+    state = tuple((m.training, m.weight.requires_grad) for m in allb)
+    if cached is None or cached[1] != state:         # (the module walk is 0.3 ms of host time: once per train() / eval() state)
+        cached = model._bn_lists[key] = (allb, state, [m for m in allb if not m.training and bool(m.weight.requires_grad) == trainable])
+    bns = cached[2]
     if not bns:
         return
     eps = bns[0].eps
@@ -322,6 +328,17 @@ class Bottleneck(nn.Module):
         """Eval-mode BatchNorms (frozen affine, or all of them trainable - OBB config 5), one stride in the block (on conv1 -
         `caffe` - or on conv2 - `pytorch`) matched by the downsample, no dilation, channel counts the weight-gradient tiles take,
         channels_last fp32 weights on the device: the block can run plane-native (planes._BottleneckP)."""
+        if not (_PLANE_TRUNK and PL.autocast_ok()):
+            return False
+        m = self._modules
+        key = (self.training, m['bn1'].training, m['bn1'].weight.requires_grad, m['conv1'].weight.data_ptr(), _PLANE_BN_TRAIN,
+               m['bn1'].__dict__.get('fuse_epilogue', True))
+        c = self.__dict__.get('_plane_ok_cache')
+        if c is None or c[0] != key:                    # (the module walk below is ~40 us of host time per block and pass)
+            c = self.__dict__['_plane_ok_cache'] = (key, self._plane_ok_static())
+        return c[1]
+
+    def _plane_ok_static(self):
         bns = [self.bn1, self.bn2, self.bn3] + ([self.downsample[1]] if self.downsample is not None else [])
         convs = [self.conv1, self.conv2, self.conv3] + ([self.downsample[0]] if self.downsample is not None else [])
         s1, s2 = self.conv1.stride[0], self.conv2.stride[0]
@@ -333,8 +350,7 @@ class Bottleneck(nn.Module):
                 and (self.downsample is None or self.downsample[0].stride[0] == s1 * s2)
                 and (self.downsample is not None or s1 * s2 == 1)
                 and all(c.in_channels % 128 == 0 and c.out_channels % 128 == 0 and c.weight.is_cuda and c.weight.dtype == torch.float32
-                        and F._ConvWeightPlanes.ok(c.weight) for c in convs)
-                and not torch.is_autocast_enabled())
+                        and F._ConvWeightPlanes.ok(c.weight) for c in convs))
 
     def forward_planes(self, x):
         """x: planes.PlaneAct (a ReLU output) or the fp32 channels_last output of the frozen stem -> PlaneAct."""
@@ -367,7 +383,7 @@ class Bottleneck(nn.Module):
         if isinstance(x, PL.PlaneAct):
             if self.plane_ok():
                 return self.forward_planes(x)
-            x = x.float()
+            x = x.tensor()
         identity = x
         out = conv_bn(x, self.conv1, self.bn1, True)
         out = conv_bn(out, self.conv2, self.bn2, True)
@@ -471,7 +487,7 @@ class ResNet(nn.Module):
             layer = getattr(self, self.res_layers[i])
             if planes:
                 for blk in layer:
-                    if not isinstance(x, PL.PlaneAct) and PL.f32_ok(x) and blk.plane_ok():
+                    if not isinstance(x, PL.PlaneAct) and PL.dense_ok(x) and blk.plane_ok():
                         # enter plane mode: the frozen stem's output is read where the block's stride samples it; an input that takes
                         # a gradient goes through a differentiable split first
                         x = blk.forward_planes(PL.to_planes(x) if x.requires_grad else x)

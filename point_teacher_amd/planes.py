@@ -37,12 +37,42 @@ class PlaneAct:
         return self.B * self.H * self.W
 
     @property
+    def np(self):
+        """Planes per value: 3 (fp32 = x0 + x1 + x2) or 1 (a bf16 NHWC tensor with a zero row behind it: the bf16 trunk)."""
+        return self.t.shape[0]
+
+    def tensor(self):
+        """The activation as a [B, C, H, W] channels_last tensor, differentiable: fp32 (np = 3, one pass) or bf16 (np = 1: a VIEW of the
+        plane - the backward copies the gradient behind a zero row)."""
+        return self.float() if self.np == 3 else _PlaneView.apply(self.t, self)
+
+    @property
     def shape(self):
         return (self.B, self.C, self.H, self.W)
 
     def float(self):
         """-> fp32 [B, C, H, W] channels_last tensor (exact: x0 + x1 + x2), differentiable."""
         return _PlanesToF32.apply(self.t, self)
+
+
+class _PlaneView(torch.autograd.Function):
+    """One bf16 plane [1, (P + 1) * C] <-> the bf16 channels_last tensor [B, C, H, W] it is (a view, no launch); backward: the
+    gradient is copied behind a zero row (and masked by the activation's ReLU, the gradient convention of this module)."""
+
+    @staticmethod
+    def forward(ctx, t, act):
+        ctx.act = act
+        ctx.save_for_backward(t if act.relu else None)
+        return t[0, :act.P * act.C].view(act.B, act.H, act.W, act.C).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        act = ctx.act
+        t, = ctx.saved_tensors
+        gp, _, _ = split_nhwc(g.to(bf16).contiguous(memory_format=torch.channels_last), np=1)
+        if act.relu:
+            gp, _ = combine(gp, mask=t)
+        return gp, None
 
 
 class _F32ToPlanes(torch.autograd.Function):
@@ -87,19 +117,45 @@ def to_planes2(x):
     return PlaneAct(a, B, H, W, C, False), PlaneAct(b, B, H, W, C, False)
 
 
+class _Bf16ToPlane(torch.autograd.Function):
+    """bf16 channels_last [B, C, H, W] -> one plane (a copy behind which the zero row sits); backward: the plane viewed as a tensor."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = x.shape
+        return split_nhwc(x, np=1)[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, H, W = ctx.shape
+        return g.contiguous()[0, :B * H * W * C].view(B, H, W, C).permute(0, 3, 1, 2)
+
+
 def to_planes(x):
-    """Differentiable entry into plane mode (relu=False: the producer of x masks its own gradient)."""
+    """Differentiable entry into plane mode (relu=False: the producer of x masks its own gradient): fp32 -> three planes, bf16 -> one."""
     B, C, H, W = x.shape
-    return PlaneAct(_F32ToPlanes.apply(x), B, H, W, C, False)
+    return PlaneAct((_Bf16ToPlane if x.dtype == bf16 else _F32ToPlanes).apply(x), B, H, W, C, False)
 
 
 def out_hw(H, W, K, stride, pad):
     return (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
 
 
-def _new_planes(rows, C, device, zero=False):
+def _new_planes(rows, C, device, zero=False, np=3):
     n = (rows + 1) * C
-    return (torch.zeros if zero else torch.empty)((3, n), dtype=bf16, device=device)
+    return (torch.zeros if zero else torch.empty)((np, n), dtype=bf16, device=device)
+
+
+_SPLITS = {}
+
+
+def _splits(fn, *shape):
+    """The launch's chunk count by the library's cost model (a pure function of the shape: asked once per shape)."""
+    k = (fn,) + shape
+    v = _SPLITS.get(k)
+    if v is None:
+        v = _SPLITS[k] = hip.call(fn, *shape)
+    return v
 
 
 def launch_conv(x_t, B, Hs, Ws, Cin, wp, Cout, K, stride, pad, scale=None, shift=None, res_planes=None, res_f32=None,
@@ -111,13 +167,15 @@ def launch_conv(x_t, B, Hs, Ws, Cin, wp, Cout, K, stride, pad, scale=None, shift
     M = B * Ho * Wo
     rows = M if scatter is None else B * scatter[0] * scatter[1]
     dev = x_t.device
-    out_p = _new_planes(rows, Cout, dev, zero=scatter is not None) if want_planes else None
+    np_ = x_t.shape[0]
+    out_p = _new_planes(rows, Cout, dev, zero=scatter is not None, np=np_) if want_planes else None
     out_f = (torch.zeros if scatter is not None else torch.empty)((rows, Cout), dtype=f32, device=dev) if want_f32 else None
     if f32_out is not None:                                   # a caller-provided fp32 buffer of rows * Cout elements
         assert f32_out.numel() == rows * Cout and f32_out.dtype == f32 and scatter is None
         out_f = f32_out
     d = hip.STRUCTS['pt_conv_desc']()
     d.B, d.Hs, d.Ws, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad, d.relu = B, Hs, Ws, Cin, Cout, K, K, stride, pad, int(bool(relu))
+    d.np = np_
     d.x_planes, d.x_plane_stride = hip.dptr(x_t, 'uint16_t'), x_t.shape[1]
     d.w_planes, d.w_plane_stride = hip.dptr(wp.planes, 'uint16_t'), wp.planes.shape[1]
     d.scale, d.shift = hip.dptr(scale, 'float'), hip.dptr(shift, 'float')
@@ -134,7 +192,7 @@ def launch_conv(x_t, B, Hs, Ws, Cin, wp, Cout, K, stride, pad, scale=None, shift
     if transposed_out is not None:            # the input gradient of a 3x3 stride-2 convolution onto its input grid (Ho, Wo)
         d.dstride, d.out_H, d.out_W = 2, Ho, Wo
         splits = 1
-    S = hip.call('pt_conv_bf16x6_splits', B, Hs, Ws, Cin, Cout, K, K, stride, pad, int(tile_rows)) if splits is None else int(splits)
+    S = _splits('pt_conv_bf16x6_splits', B, Hs, Ws, Cin, Cout, K, K, stride, pad, int(tile_rows)) if splits is None else int(splits)
     if S > 1:
         ws = torch.empty((S * M * Cout,), dtype=f32, device=dev)
         d.workspace, d.workspace_elems, d.splits = hip.dptr(ws, 'float'), ws.numel(), S
@@ -164,13 +222,15 @@ def launch_wgrad(gy_t, x_t, B, Hs, Ws, Cin, Cout, K, stride, pad, row_scale=None
         row_scale, want_bias = None, True
     Ho, Wo = out_hw(Hs, Ws, K, stride, pad)
     dev = gy_t.device
-    S = hip.call('pt_conv_wgrad_bf16x6_splits', B, Ho, Wo, K, K, Cin, Cout)
+    S = _splits('pt_conv_wgrad_bf16x6_splits', B, Ho, Wo, K, K, Cin, Cout)
     n = Cout * K * K * Cin
     ws = torch.empty((S * (n + (Cout if want_bias else 0)),), dtype=f32, device=dev)
     dw = torch.empty((Cout, K, K, Cin), dtype=f32, device=dev)
     db = torch.empty((Cout,), dtype=f32, device=dev) if want_bias else None
     d = hip.STRUCTS['pt_conv_wgrad_desc']()
     d.B, d.Hs, d.Ws, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad, d.accumulate = B, Hs, Ws, Cin, Cout, K, K, stride, pad, 0
+    d.np = gy_t.shape[0]
+    assert x_t.shape[0] == gy_t.shape[0]
     d.gy_planes, d.gy_plane_stride = hip.dptr(gy_t, 'uint16_t'), gy_t.shape[1]
     d.x_planes, d.x_plane_stride = hip.dptr(x_t, 'uint16_t'), x_t.shape[1]
     d.dw, d.dbias, d.row_scale = hip.dptr(dw, 'float'), hip.dptr(db, 'float'), hip.dptr(row_scale, 'float')
@@ -187,14 +247,17 @@ def launch_wgrad(gy_t, x_t, B, Hs, Ws, Cin, Cout, K, stride, pad, row_scale=None
     return dw.permute(0, 3, 1, 2), db
 
 
-def split_nhwc(x, stride=1):
-    """fp32 channels_last [B, C, H, W] -> row-major planes of the pixels (y * stride, x * stride) (pt_split_bf16x3_gather)."""
+def split_nhwc(x, stride=1, np=None):
+    """channels_last [B, C, H, W] (fp32, or bf16 -> np = 1) -> row-major planes of the pixels (y * stride, x * stride)
+    (pt_split_bf16x3_gather).  np: 3 (fp32 as x0 + x1 + x2) or 1 (one bf16 plane); default by the dtype."""
     B, C, H, W = x.shape
     rows = x.permute(0, 2, 3, 1)
-    assert rows.is_contiguous() and x.dtype == f32
+    is16 = x.dtype == bf16
+    np = (1 if is16 else 3) if np is None else np
+    assert rows.is_contiguous() and x.dtype in (f32, bf16) and (np == 1 or not is16)
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-    t = _new_planes(B * Ho * Wo, C, x.device)
-    hip.call('pt_split_bf16x3_gather', rows, C, B, H, W, C, stride, t, t.shape[1])
+    t = _new_planes(B * Ho * Wo, C, x.device, np=np)
+    hip.call('pt_split_bf16x3_gather', rows, int(is16), C, B, H, W, C, stride, np, t, t.shape[1])
     return t, Ho, Wo
 
 
@@ -203,7 +266,7 @@ def combine(a, b=None, c=None, mask=None, n=None, want_planes=True, want_f32=Fal
     n = n if n is not None else a.shape[1]
     out = torch.empty_like(a) if want_planes else None
     of = torch.empty((n,), dtype=f32, device=a.device) if want_f32 else None
-    hip.call('pt_planes_combine', a, a.shape[1], b, b.shape[1] if b is not None else 0, c, mask, n, out,
+    hip.call('pt_planes_combine', a, a.shape[1], b, b.shape[1] if b is not None else 0, c, mask, n, a.shape[0], out,
              out.shape[1] if out is not None else 0, of)
     assert out is None or n == a.shape[1], 'planes out: combine whole planes (the zero rows included)'
     return out, of
@@ -250,17 +313,23 @@ class _PlaneConv(torch.autograd.Function):
         if c.x_planes:
             xt = x
         else:
-            xt, _, _ = split_nhwc(x)
-        wp = F._conv_weight_planes(w, False)
+            xt, _, _ = split_nhwc(x)                               # fp32 -> three planes, bf16 -> one
+        np_ = xt.shape[0]
+        wp = F._conv_weight_planes(w, False, None, np_)
+        as_planes = c.out_planes or np_ == 1                       # (the one-plane result IS the bf16 tensor)
         yp, yf = launch_conv(xt, c.B, c.H, c.W, c.Cin, wp, c.Cout, c.K, c.stride, c.pad, scale=c.scale, shift=shift, relu=c.relu,
-                             want_planes=c.out_planes, want_f32=not c.out_planes)
+                             want_planes=as_planes, want_f32=not as_planes)
         Ho, Wo = out_hw(c.H, c.W, c.K, c.stride, c.pad)
         ctx.cfg = c
+        ctx.np = np_
         ctx.out_hw = (Ho, Wo)
         need_x_for_mask = c.x_planes and c.x_relu
-        ctx.save_for_backward(xt if (w.requires_grad or need_x_for_mask) else None, w, yf if (c.relu and not c.out_planes) else None)
+        keep_y = c.relu and not c.out_planes
+        ctx.save_for_backward(xt if (w.requires_grad or need_x_for_mask) else None, w, (yp if np_ == 1 else yf) if keep_y else None)
         if c.out_planes:
             return yp
+        if np_ == 1:
+            return yp[0, :c.B * Ho * Wo * c.Cout].view(c.B, Ho, Wo, c.Cout).permute(0, 3, 1, 2)
         return yf.view(c.B, Ho, Wo, c.Cout).permute(0, 3, 1, 2)
 
     @staticmethod
@@ -269,24 +338,35 @@ class _PlaneConv(torch.autograd.Function):
         xt, w, yf = ctx.saved_tensors
         Ho, Wo = ctx.out_hw
         M = c.B * Ho * Wo
+        np_ = ctx.np
         if c.out_planes:
             E = g.contiguous()
+        elif np_ == 1:                                             # a bf16 gradient tensor: behind a zero row, masked by the result's ReLU
+            E, _, _ = split_nhwc(g.to(bf16).contiguous(memory_format=torch.channels_last), np=1)
+            if yf is not None:
+                E, _ = combine(E, mask=yf)
         else:
             rows = g.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(M, c.Cout)
             E = F._split_rows(rows, relu_of=yf)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             assert c.stride == 1, 'the single-consumer plane convolution back-propagates stride 1 only'
-            wd = F._conv_weight_planes(w, True, c.scale)
+            wd = F._conv_weight_planes(w, True, c.scale, np_)
             if c.x_planes and c.x_gcarrier:
                 # the producer of x (RoIAlign) wants its gradient as fp32: it travels in the head of a tensor of x's shape
                 gx = torch.empty((3, (c.B * c.H * c.W + 1) * c.Cin), dtype=bf16, device=E.device)
                 launch_conv(E, c.B, Ho, Wo, c.Cout, wd, c.Cin, c.K, 1, c.K - 1 - c.pad,
                             f32_out=gx.view(-1).view(f32)[:c.B * c.H * c.W * c.Cin])
             else:
+                xp_out = c.x_planes or np_ == 1
                 gp, gf = launch_conv(E, c.B, Ho, Wo, c.Cout, wd, c.Cin, c.K, 1, c.K - 1 - c.pad,
-                                     mask_planes=xt if (c.x_planes and c.x_relu) else None, want_planes=c.x_planes, want_f32=not c.x_planes)
-                gx = gp if c.x_planes else gf.view(c.B, c.H, c.W, c.Cin).permute(0, 3, 1, 2)
+                                     mask_planes=xt if (c.x_planes and c.x_relu) else None, want_planes=xp_out, want_f32=not xp_out)
+                if c.x_planes:
+                    gx = gp
+                elif np_ == 1:
+                    gx = gp[0, :c.B * c.H * c.W * c.Cin].view(c.B, c.H, c.W, c.Cin).permute(0, 3, 1, 2)
+                else:
+                    gx = gf.view(c.B, c.H, c.W, c.Cin).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
             gw, gb = launch_wgrad(E, xt, c.B, c.H, c.W, c.Cin, c.Cout, c.K, c.stride, c.pad, row_scale=c.scale,
                                   want_bias=bool(c.bias_grad and ctx.needs_input_grad[2]))
@@ -302,7 +382,7 @@ def plane_conv_ok(conv, x_channels_last_f32_or_planes=True):
     return (type(conv) is torch.nn.Conv2d and k in ((1, 1), (3, 3)) and conv.stride == (1, 1) and conv.padding == ((k[0] - 1) // 2,) * 2
             and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels % 128 == 0 and conv.out_channels % 128 == 0
             and conv.weight.is_cuda and conv.weight.dtype == f32 and F._ConvWeightPlanes.ok(conv.weight)
-            and not torch.is_autocast_enabled())
+            and autocast_ok())
 
 
 def conv_module(x, conv, relu=False, out_planes=False, scale=None, shift=None):
@@ -317,7 +397,7 @@ def conv_module(x, conv, relu=False, out_planes=False, scale=None, shift=None):
     y = _PlaneConv.apply(x.t if is_p else x, conv.weight, sh, cfg)
     if out_planes:
         return PlaneAct(y, B, H, W, conv.out_channels, bool(relu))
-    return y
+    return y                                                      # fp32 (three-plane operands) or bf16 (one plane) [B, Cout, H, W]
 
 
 def linear_ok(fc, rows):
@@ -344,6 +424,24 @@ def linear(x, fc, relu=False, out_planes=False):
 def f32_ok(x):
     return (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == f32 and x.dim() == 4 and x.shape[1] % 8 == 0
             and x.is_contiguous(memory_format=torch.channels_last) and x.numel() > 0)
+
+
+def bf16_ok(x):
+    """A bf16 channels_last map (the autocast trunk of BASELINE configs[2]) the one-plane kernels take."""
+    return (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == bf16 and x.dim() == 4 and x.shape[1] % 8 == 0
+            and x.is_contiguous(memory_format=torch.channels_last) and x.numel() > 0)
+
+
+def dense_ok(x):
+    """fp32 outside autocast (three-plane operands), bf16 inside a bf16 autocast region (one plane)."""
+    if torch.is_autocast_enabled():
+        return torch.get_autocast_dtype('cuda') == bf16 and bf16_ok(x)
+    return f32_ok(x)
+
+
+def autocast_ok():
+    """No autocast, or bf16 autocast (one-plane operands)."""
+    return (not torch.is_autocast_enabled()) or torch.get_autocast_dtype('cuda') == bf16
 
 
 # ------------------------------------------------------------------------------------------------------- fan-out --
@@ -399,19 +497,26 @@ class _BottleneckP(torch.autograd.Function):
         if c.x_planes:
             xs, xH, xW, xst = x, c.H, c.W, 1                      # dense planes of x; strided reads map through them
         elif s1 > 1:
-            xs, xH, xW = split_nhwc(x, s1)                        # `caffe`: only the stride's pixels are ever read
+            xs, xH, xW = split_nhwc(x, s1)                        # `caffe`: only the stride's pixels are ever read (fp32 -> 3 planes, bf16 -> 1)
             xst = s1
         else:
             xs, xH, xW = split_nhwc(x)[0], c.H, c.W
             xst = 1
+        np_ = xs.shape[0]
         r1 = s1 // xst                                            # strides on the planes at hand
         rd = st // xst
         Ha, Wa = out_hw(xH, xW, 1, r1, 0)                         # conv1's output grid
-        cw = F._conv_weight_planes
+
+        def cw(w_, dgrad, sc=None):
+            return F._conv_weight_planes(w_, dgrad, sc, np_)
         S = c.bn
         y1, _ = launch_conv(xs, c.B, xH, xW, c.Cin, cw(w1, False), p, 1, r1, 0, scale=S['1'][0], shift=S['1'][1], relu=True, want_planes=True)
         y2, _ = launch_conv(y1, c.B, Ha, Wa, p, cw(w2, False), p, 3, s2, 1, scale=S['2'][0], shift=S['2'][1], relu=True, want_planes=True)
-        if c.has_ds:
+        if c.has_ds and np_ == 1:                                 # bf16 trunk: the identity travels as bf16 too
+            idn, _ = launch_conv(xs, c.B, xH, xW, c.Cin, cw(wd, False), 4 * p, 1, rd, 0, scale=S['d'][0], shift=S['d'][1], want_planes=True)
+            out, _ = launch_conv(y2, c.B, H1, W1, p, cw(w3, False), 4 * p, 1, 1, 0, scale=S['3'][0], shift=S['3'][1], res_planes=idn, relu=True,
+                                 want_planes=True)
+        elif c.has_ds:
             _, idn = launch_conv(xs, c.B, xH, xW, c.Cin, cw(wd, False), 4 * p, 1, rd, 0, scale=S['d'][0], shift=S['d'][1], want_f32=True)
             out, _ = launch_conv(y2, c.B, H1, W1, p, cw(w3, False), 4 * p, 1, 1, 0, scale=S['3'][0], shift=S['3'][1], res_f32=idn, relu=True,
                                  want_planes=True)
@@ -430,7 +535,10 @@ class _BottleneckP(torch.autograd.Function):
         p, s2 = c.planes, c.s2
         S = c.bn
         E = E.contiguous()
-        cw = F._conv_weight_planes
+        np_ = E.shape[0]
+
+        def cw(w_, dgrad, sc=None):
+            return F._conv_weight_planes(w_, dgrad, sc, np_)
         need_x = ctx.needs_input_grad[0]
         gw = {}                                                   # conv -> (dw, dbeta, dgamma)
 

@@ -417,7 +417,9 @@ def test_bf16_backbone_fp32_head(phase2):
     seen = {}
     pta, cfg, model = _build(dev, phase2=phase2)
     tr = pta.Trainer(model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config, autocast_dtype=torch.bfloat16)
-    hooks = [model.student.backbone.layer2[0].conv1.register_forward_hook(lambda m, i, o: seen.__setitem__('backbone', o.dtype)),
+    def trunk(m, i, o):            # plane-native under autocast: ONE bf16 plane per activation (planes.PlaneAct.np == 1)
+        seen['backbone'] = torch.bfloat16 if (type(o[-1]).__name__ == 'PlaneAct' and o[-1].np == 1) else getattr(o[-1], 'dtype', None)
+    hooks = [model.student.backbone.register_forward_hook(trunk),
              model.student.neck.fpn_convs[0].register_forward_hook(lambda m, i, o: seen.__setitem__('neck', o.dtype)),
              model.student.bbox_head.cls_convs[0].register_forward_hook(lambda m, i, o: seen.__setitem__('head', (i[0].dtype, o.dtype))),
              model.student.bbox_head.conv_reg.register_forward_hook(lambda m, i, o: seen.__setitem__('reg', o.dtype))]
@@ -585,8 +587,8 @@ def test_full_size_bf16_backbone_properties():
         tr = pta.Trainer(model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config, channels_last=True, autocast_dtype=dtype)
         data = SyntheticTiles(n=2, size=800, mean_objects=300, seed=1, device=dev)
         seen = {}
-        hooks = [model.student.backbone.layer3[0].conv1.register_forward_hook(lambda m, i, o: seen.__setitem__('backbone', o.dtype)),
-                 model.student.backbone.register_forward_hook(lambda m, i, o: seen.__setitem__('trunk', type(o[-1]).__name__)),
+        hooks = [model.student.backbone.register_forward_hook(
+                     lambda m, i, o: seen.__setitem__('trunk', (type(o[-1]).__name__, getattr(o[-1], 'np', None)))),
                  model.student.neck_agg.lateral_convs[0].register_forward_hook(lambda m, i, o: seen.__setitem__('psagg', o.dtype)),
                  model.student.bbox_head.reg_convs[0].register_forward_hook(lambda m, i, o: seen.__setitem__('head', (i[0].dtype, o.dtype))),
                  model.student.bbox_head.bbox_roi_extractor.register_forward_hook(lambda m, i, o: seen.__setitem__('roi', o.dtype)),
@@ -614,12 +616,12 @@ def test_full_size_bf16_backbone_properties():
         return seen, lvs
 
     seen16, lv16 = run(torch.bfloat16)
-    assert seen16['backbone'] == torch.bfloat16 and seen16['psagg'] == torch.bfloat16
+    assert seen16['trunk'] == ('PlaneAct', 1) and seen16['psagg'] == torch.bfloat16
     assert seen16['head'] == (torch.float32, torch.float32) and seen16['roi'] == torch.float32 and seen16['fc'] == (torch.float32, torch.float32)
     seen32, lv32 = run(None)
-    # fp32: the trainable stages run plane-native (planes.PlaneAct between the layers: exact three-term bf16 splits of fp32 values,
-    # the convolution modules themselves are not called); under autocast the library's bf16 kernels run and tensors travel
-    assert seen32['trunk'] == 'PlaneAct' and 'backbone' not in seen32 and seen16['trunk'] == 'Tensor'
+    # the trainable stages run plane-native (planes.PlaneAct between the layers, the convolution modules themselves are not called):
+    # exact three-term bf16 splits of fp32 values, or - under bf16 autocast - one bf16 plane per activation on the same kernels
+    assert seen32['trunk'] == ('PlaneAct', 3)
     for it, (a, b) in enumerate(zip(lv16, lv32)):
         assert set(a) == set(b) and all(v == v and abs(v) != float('inf') for v in a.values()), (it, a)
         if it == 0:          # same weights, inputs and draws: later iterations start from weights that already differ by an update

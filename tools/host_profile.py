@@ -19,6 +19,14 @@ data = SyntheticTiles(n=8, size=800, mean_objects=300, seed=7, device=dev)
 for it in range(6):
     tr.step(data.batch(it, 2))
 torch.cuda.synchronize()
+import time
+t0 = time.perf_counter()
+for it in range(10):
+    tr.step(data.batch(it, 2))
+t_issue = time.perf_counter() - t0
+torch.cuda.synchronize()
+t_all = time.perf_counter() - t0
+print(f'un-profiled: host issue {t_issue * 100:.2f} ms/iter, with the GPU drained {t_all * 100:.2f} ms/iter')
 pr = cProfile.Profile()
 pr.enable()
 for it in range(10):
@@ -26,4 +34,5 @@ for it in range(10):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats('tottime').print_stats(22)
+st.sort_stats('tottime').print_stats(30)
+st.sort_stats('cumulative').print_stats(60)
