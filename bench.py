@@ -462,24 +462,25 @@ def main():
 
     # ---- the steady-state phase as well (94 % of a 12-epoch run is phase 2): same model, phase switch flipped ----
     def timed_with_family(tr_, base):
-        """args.steps timed steps of `tr_` with HIP events around the matrix family (and its companions) -> (seconds, roofline or None)."""
-        p_ = {}
-        h_ = make_hook(p_, only=set(MFMA_FAMILY[1] + SPLIT_FNS))
-        n_ = 0
+        """args.steps timed steps of `tr_` with NO instrumentation (an event pair per matrix launch costs a host-bound iteration -
+        the bf16 configuration - up to 25 % of its step), then 3 un-timed steps with HIP events around the matrix family (and its
+        companions) for the roofline of this workload -> (seconds, roofline or None)."""
         barrier()
         t0_ = time.perf_counter()
         for it_ in range(args.steps):
-            if it_ % EVENT_EVERY == 0:
-                set_hook(h_)
-                n_ += 1
             tr_.step(data.batch(base + it_, args.batch))
-            set_hook(orig_call)
         barrier()
         d_ = torch.tensor([time.perf_counter() - t0_], device=dev, dtype=torch.float64)
         if world > 1:
             dist.all_reduce(d_, op=dist.ReduceOp.MAX)
+        p_ = {}
+        set_hook(make_hook(p_, only=set(MFMA_FAMILY[1] + SPLIT_FNS)))
+        for it_ in range(3):
+            tr_.step(data.batch(base + args.steps + it_, args.batch))
+        torch.cuda.synchronize()
+        set_hook(orig_call)
         m_ = summarise(p_)[2]
-        return float(d_.item()), (mfma_roofline(m_, n_) if m_ else None)
+        return float(d_.item()), (mfma_roofline(m_, 3, timed_region=False) if m_ else None)
 
     phase2 = None
     if args.workload == 'step1' and not args.no_phase2:
@@ -512,7 +513,7 @@ def main():
                               autocast_dtype=torch.bfloat16, channels_last=True)
         for it in range(max(args.warmup, 5)):
             trainer.step(data.batch(3000 + it, args.batch))
-        dt3, roof3 = timed_with_family(trainer, 4000)       # (the fp32 head's matrix family; the bf16 trunk runs library kernels)
+        dt3, roof3 = timed_with_family(trainer, 4000)       # (fp32 heads: six products per product; bf16 trunk: one - the same kernels)
         f3 = iteration_flops('step2', cfg2.to_dict()['model'], args.batch, args.size, args.objects)
         configs2 = dict(workload=f'BASELINE configs[2]: aitodv2_point_teacher_{args.percent}% phase 2 (MIL on), bf16 backbone / FPN / PSAGG (autocast) + '
                                  f'fp32 dense head, MIL head and losses, bs {args.batch}/GPU, {args.size}x{args.size}',
