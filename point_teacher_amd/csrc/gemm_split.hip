@@ -1251,6 +1251,7 @@ extern "C" int pt_conv_bf16x6(const pt_conv_desc* d, void* stream) {
   int S = d->splits;
   if (S <= 0) S = d->workspace ? conv_splits(M, d->Cout, KB, tile_rows) : 1;
   if (S > KB) S = KB;
+  if (S > 1) S = cdiv(KB, cdiv(KB, S));                  // no empty chunk (its prologue would stage a block past the operands)
   if (S > 1) {
     PT_REQUIRE(d->workspace && (((uintptr_t)d->workspace) & 15) == 0 && d->workspace_elems >= (int64_t)S * M * d->Cout, PT_EINVAL,
                "pt_conv_bf16x6: a split-k launch needs a 16-byte aligned workspace of splits * M * Cout floats");
