@@ -22,7 +22,8 @@ benchmark_init_(model, phase2=(wl == 'step2'))
 model.train()
 tr = pta.Trainer(model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config, channels_last=True)
 data = SyntheticTiles(n=8, size=1200, mean_objects=300, seed=7, device=dev, oriented=True, num_classes=9)
-for it in range(3):
+WARM = int(sys.argv[2]) if len(sys.argv) > 2 else 3        # iterations before the recorded one (the bench times iterations 5 .. 25)
+for it in range(WARM):
     tr.step(data.batch(it, 2))
 rec = []
 orig = hip.call
@@ -39,7 +40,7 @@ def spy(fn, *a):
 
 hip.call = spy
 PF.hip.call = spy
-tr.step(data.batch(3, 2))
+tr.step(data.batch(WARM, 2))
 torch.cuda.synchronize()
 for fn, rois, scale, e0, e1 in rec:
     w, h, th = rois[:, 3] * scale, rois[:, 4] * scale, rois[:, 5]
