@@ -289,10 +289,17 @@ def main():
             return orig_call(fn, *a)
         return timed_call
 
+    live = [model]                      # the detector the hooks below act on (configs[2] builds a second one)
+    side_stream = getattr(model, 'teacher_stream', False)
+
     def set_hook(h):
         hip.call = h
         PF.hip.call = h
         PPL.hip.call = h
+        # steps whose launches are bracketed by HIP events run the teacher pass inline: on its side stream (the default) its kernels
+        # would be co-scheduled with the bracketed ones and stretch them
+        if hasattr(live[0], 'teacher_stream'):
+            live[0].teacher_stream = side_stream and h is orig_call
 
     def footprint_px(r, scale, H, W):      # feature pixels an aligned RoI samples: the bilinear taps of its first and last sample
         x1, y1, x2, y2 = (r[:, i] * scale - 0.5 for i in (1, 2, 3, 4))
@@ -391,7 +398,8 @@ def main():
 
     # per-kernel table of ALL custom kernels: 3 un-timed steps after the timed region
     BREAKDOWN_STEPS = 3
-    INSTR = (f'timed region: HIP events around the launches of the dominant family (and its operand-format passes) on every '
+    INSTR = (f'teacher pass on a second HIP stream except in instrumented steps; '
+             f'timed region: HIP events around the launches of the dominant family (and its operand-format passes) on every '
              f'{EVENT_EVERY}th step ({n_event_steps} of {args.steps}); other families and custom_kernels_ms_per_step: '
              f'{BREAKDOWN_STEPS} un-timed steps after it with events around every custom call')
     full = {}
@@ -507,6 +515,7 @@ def main():
         cfg2 = pta.Config.fromfile(os.path.join(ROOT, 'point_teacher_amd', 'configs', 'point_teacher', f'aitodv2_point_teacher_{args.percent}.py'))
         cfg2.model['burn_in_step'] = -1
         model = pta.build_detector(cfg2.model).to(dev)
+        live[0] = model
         benchmark_init_(model, phase2=True)
         model.train()
         trainer = pta.Trainer(model, cfg2.optimizer, cfg2.optimizer_config, cfg2.lr_config, iters_per_epoch=5000,

@@ -114,6 +114,11 @@ class Student_FCOS(BaseDetector):
 
     backbone_autocast = None      # torch.bfloat16 = BASELINE configs[2]: bf16 backbone / necks, fp32 head (set by the Trainer)
 
+    def _plane_trunk(self):
+        """The trainable stages hand their outputs to the neck as split planes (planes.PlaneAct): no fp32 copy in between."""
+        return (self.with_neck and getattr(self.neck, 'accepts_planes', False) and getattr(self.backbone, 'plane_capable', False)
+                and self.backbone_autocast in (None, torch.bfloat16))
+
     def backbone_stem(self, img):
         """The frozen stem of the backbone (ResNet.forward_stem) under this detector's autocast setting."""
         if self.backbone_autocast is None:
@@ -124,9 +129,7 @@ class Student_FCOS(BaseDetector):
     def extract_feat(self, img, stem=None):
         """`stem`: the output of `backbone_stem` for `img` (then `img` is not read)."""
         def run():
-            if (self.with_neck and getattr(self.neck, 'accepts_planes', False) and getattr(self.backbone, 'plane_capable', False)
-                    and self.backbone_autocast in (None, torch.bfloat16)):
-                # the trainable stages hand their outputs to the neck as split planes (planes.PlaneAct): no fp32 copy in between
+            if self._plane_trunk():
                 x = self.backbone(img, planes=True) if stem is None else self.backbone(None, stem=stem, planes=True)
             else:
                 x = self.backbone(img) if stem is None else self.backbone(None, stem=stem)
@@ -230,7 +233,7 @@ class TS_P2B_FCOS(BaseDetector):
         self.student.backbone._register_load_state_dict_pre_hook(self._forget_stem_decision)
         self.teacher.backbone._register_load_state_dict_pre_hook(self._forget_stem_decision)
         self.point_stamp = {}             # image key -> iteration of its last refinement (checkpoint merges keep the newest)
-        self.teacher_stream = os.environ.get('PT_TEACHER_STREAM', '0') == '1'
+        self.teacher_stream = os.environ.get('PT_TEACHER_STREAM', '1') == '1'     # the teacher pass on a second HIP stream (_teacher_fork)
         self._side_stream = None
 
     # the reference keeps count/point dictionaries as plain attributes, so they are lost on resume
@@ -304,6 +307,9 @@ class TS_P2B_FCOS(BaseDetector):
         img = img.to(torch.float)
         num_img = len(img_metas)
         self.update_teacher_model(self.teacher, self.student, self.ema_alpha)
+        for det in (self.student, self.teacher):       # BatchNorm terms the weight planes fold in: current before the first convolution
+            if img.is_cuda and det._plane_trunk():
+                det.backbone.refresh_plane_terms()
         self.update_epoch(num_img, img_metas)
         gt_points, img_list, img = self.genrate_points(num_img, img, img_metas, gt_bboxes)
         if self.count <= self.burn_in_step:
@@ -371,13 +377,16 @@ class TS_P2B_FCOS(BaseDetector):
                                                           img_metas, img_list, gt_bboxes_ignore)
 
     def _teacher_fork(self, *args, **kw):
-        """Start the teacher pass on a second HIP stream (opt-in: PT_TEACHER_STREAM=1, -0.7 ms per iteration; off by default so that the per-kernel HIP-event timings of bench.py are not stretched by co-scheduled teacher kernels): it has no gradient and nothing of the student's
+        """Start the teacher pass on a second HIP stream (`teacher_stream`, PT_TEACHER_STREAM=0 turns it off; bench.py turns it off in the
+        steps whose launches it brackets with HIP events, so that co-scheduled teacher kernels do not stretch them; -0.3 ... -0.7 ms per
+        iteration): it has no gradient and nothing of the student's
         batched pass depends on it until the MIL stage, so its small-batch kernels (B = 2 at 25x25 / 50x50 leave most of the 256
         CUs idle) overlap the student's forward.  -> a callable that joins the stream and returns the pseudo boxes."""
         if not self.teacher_stream or not img_is_cuda(args[0]):
             res = self._teacher_pseudo(*args, **kw)
             return lambda: res
         main = torch.cuda.current_stream()
+        F.refresh_conv_weight_planes()             # both streams read the weight planes of this parameter epoch: made here, once
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream()
         side = self._side_stream

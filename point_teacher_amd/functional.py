@@ -740,20 +740,35 @@ class _ConvWeightPlanes:
         if e[4] != w._version:                                  # torch wrote the weight (load_state_dict, init, copy_): re-split
             self.epoch = -1
         if self.epoch != PARAM_EPOCH[0] or self.table is None:
-            if not all(self._alive(v) for v in self.ent.values()):
-                self.ent = {k: v for k, v in self.ent.items() if self._alive(v)}
-                self.table = None
-            if self.table is None:
-                self._build_table()
-            tab, n_items, blocks = self.table
-            hip.call('pt_conv_weight_planes_batch', tab, n_items, blocks)
-            self.epoch = PARAM_EPOCH[0]
-            for v in self.ent.values():
-                v[4] = v[0]()._version
+            self.refresh()
         return self.ent[key][2]
+
+    def refresh(self):
+        """Re-split every registered (weight, form, scale, plane count) now, on the current stream: one launch."""
+        if not all(self._alive(v) for v in self.ent.values()):
+            self.ent = {k: v for k, v in self.ent.items() if self._alive(v)}
+            self.table = None
+        if not self.ent:
+            return
+        if self.table is None:
+            self._build_table()
+        tab, n_items, blocks = self.table
+        hip.call('pt_conv_weight_planes_batch', tab, n_items, blocks)
+        self.epoch = PARAM_EPOCH[0]
+        for v in self.ent.values():
+            v[4] = v[0]()._version
 
 
 _CONV_W = _ConvWeightPlanes()
+
+
+def refresh_conv_weight_planes():
+    """Bring the cached weight planes up to the current parameter epoch NOW, on the current stream.  A caller that is about to use
+    them from two streams (the teacher pass on its side stream next to the student's, detectors._teacher_fork) calls this first, so
+    that neither stream's first convolution launches the refresh while the other reads the planes."""
+    c = _CONV_W
+    if c.ent and (c.epoch != PARAM_EPOCH[0] or c.table is None):
+        c.refresh()
 
 
 def _conv_weight_planes(w, dgrad, scale=None, np_=3):

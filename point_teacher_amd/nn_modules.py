@@ -475,14 +475,22 @@ class ResNet(nn.Module):
 
     plane_capable = True
 
+    def refresh_plane_terms(self):
+        """gamma * rstd, beta - mean * gamma * rstd and rstd of every TRAINABLE eval-mode BatchNorm (config 5), once per parameter
+        epoch.  The input-gradient weight planes fold gamma * rstd in (functional._ConvWeightPlanes reads these buffers when it
+        re-splits all weights at the first convolution of an epoch - which may be the TEACHER's), so a detector calls this for its
+        student right after the optimizer step / EMA, before any convolution of the iteration; `forward` calls it as well."""
+        if _PLANE_BN_TRAIN and getattr(self, '_bn_terms_epoch', None) != (F.PARAM_EPOCH[0], self.training):
+            refresh_bn_affines(self, trainable=True)
+            self._bn_terms_epoch = (F.PARAM_EPOCH[0], self.training)
+
     def forward(self, x, stem=None, planes=False):
         """`planes=True` (a caller whose neck reads planes.PlaneAct, i.e. FPN): the trainable stages run plane-native - their
         outputs are PlaneActs - as soon as a block qualifies (Bottleneck.plane_ok); otherwise fp32 tensors as ever."""
         x, outs = self.forward_stem(x) if stem is None else stem
         outs = list(outs)
-        if planes and _PLANE_BN_TRAIN and getattr(self, '_bn_terms_epoch', None) != (F.PARAM_EPOCH[0], self.training):
-            refresh_bn_affines(self, trainable=True)          # gamma * rstd, beta - mean * gamma * rstd, rstd of every trainable BatchNorm
-            self._bn_terms_epoch = (F.PARAM_EPOCH[0], self.training)
+        if planes:
+            self.refresh_plane_terms()
         for i in range(max(self.frozen_stages, 0), len(self.res_layers)):
             layer = getattr(self, self.res_layers[i])
             if planes:

@@ -534,3 +534,58 @@ def test_obb_full_size_iteration_properties():
     assert model.count == 4 and not torch.equal(trainer.flat.teacher_flat, t0)
     assert torch.isfinite(trainer.flat.student_flat).all() and torch.isfinite(trainer.flat.teacher_flat).all()
     assert len(trainer.flat.dead) == 8 and trainer.flat.check_views()     # shared_fcs / shared_fcs_refine left the live segment (no fc_iou in this head)
+
+
+def test_trainable_bn_terms_are_current_when_the_weight_planes_are_made():
+    """Config 5 trains the BatchNorm affines.  The input-gradient weight planes fold gamma * rstd in, and ALL planes (student and
+    teacher) are re-made by the first convolution of an iteration - the teacher's.  So the student's BatchNorm terms must have been
+    recomputed from the updated gamma BEFORE that launch: after a gamma change the student's backbone gradients must equal those of
+    a fresh model holding the same weights (whose planes are made from scratch)."""
+    from point_teacher_amd import functional as F
+    dev = torch.device('cuda:0')
+
+    def run(model, data, inject):
+        model._inject = dict(inject)
+        for p in model.parameters():
+            p.grad = None
+        out = model.train_step(data, None)
+        out['loss'].backward()
+        return {k: p.grad.clone() for k, p in model.student.named_parameters() if p.grad is not None and 'backbone' in k}
+
+    pta, cfg, model = _build(dev, phase2=True)
+    model = model.to(memory_format=torch.channels_last)       # the training layout: the trunk runs plane-native
+    img, boxes, labels, metas = _data(seed=STEP2_SEED)
+    g = torch.Generator().manual_seed(11)
+    inject = dict(neg0=torch.rand(2, 5, 200, generator=g).to(dev), aug=(['horizontal', 'None'], [5, 13], [0.9, 1.1]))
+    data = dict(img=img.to(dev).contiguous(memory_format=torch.channels_last), img_metas=metas, gt_bboxes=[b.to(dev) for b in boxes], gt_labels=[l.to(dev) for l in labels])
+    run(model, data, inject)                                   # registers every weight's planes
+    seen = {}
+    orig = F._CONV_W.refresh
+
+    def spy():
+        seen['student_terms_epoch'] = (model.student.backbone._bn_terms_epoch[0], F.PARAM_EPOCH[0])
+        return orig()
+    F._CONV_W.refresh = spy
+    try:
+        with torch.no_grad():                                  # what an optimizer step does: new gamma through .data, a new epoch
+            for m in model.student.backbone.modules():
+                if isinstance(m, torch.nn.BatchNorm2d) and m.weight.requires_grad:
+                    m.weight.data.mul_(1.3)
+        F.PARAM_EPOCH[0] += 1
+        sd = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in model.state_dict().items()}     # (incl. the iteration count)
+        got = run(model, data, inject)
+    finally:
+        F._CONV_W.refresh = orig
+    assert seen['student_terms_epoch'][0] == seen['student_terms_epoch'][1], seen
+    pta2, cfg2, fresh = _build(dev, phase2=True)
+    fresh = fresh.to(memory_format=torch.channels_last)
+    fresh.load_state_dict(sd)
+    want = run(fresh, data, inject)                             # the same iteration from the same state, planes made from scratch
+    fresh.load_state_dict(sd)
+    again = run(fresh, data, inject)                            # run-to-run noise of the same computation (float atomics, ReLU flips)
+    errs = {k: (_rel(got[k], want[k]), _rel(again[k], want[k])) for k in want}
+    top = sorted(errs.items(), key=lambda kv: -kv[1][0])[:6]
+    print('backbone gradients after a gamma change vs a fresh model with the same weights (error, run-to-run noise):',
+          [(k, f'{a:.1e}', f'{b:.1e}') for k, (a, b) in top])
+    for k, (a, b) in errs.items():
+        assert a < max(2e-3, 3 * b), (k, a, b)

@@ -671,3 +671,39 @@ def test_full_size_bf16_backbone_properties():
                 tol = 0.15 if 'mil_bags' in k else 0.10
                 assert abs(a[k] - b[k]) <= tol * max(abs(b[k]), 1e-2), (it, k, a[k], b[k])
     assert set(lv16[0]) == set(lv16[1]) == set(lv16[2])
+
+
+@pytest.mark.parametrize('phase2', [False, True])
+def test_teacher_on_a_side_stream_gives_the_same_iteration(phase2):
+    """`TS_P2B_FCOS.teacher_stream` (default on): the teacher pass runs on a second HIP stream next to the student's forward.  Same
+    loss dict and the same student weights after two `Trainer.step`s as with the teacher inline (RoIAlign's float atomics make two
+    runs agree to rounding, not bit for bit)."""
+    dev = torch.device('cuda:0')
+
+    def run(side):
+        pta, cfg, model = _build(dev, phase2=phase2)
+        model.teacher_stream = side
+        tr = pta.Trainer(model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config, channels_last=True)
+        img, boxes, labels, metas = _data(dev, seed=6 if not phase2 else 5)
+        g = torch.Generator().manual_seed(13)
+        lvs = []
+        for it in range(2):
+            inj = dict(neg0=torch.rand(2, 4, 200, generator=g).to(dev), aug=(['horizontal', 'vertical'], [0.9, 1.1]))
+            if not phase2:
+                inj['syn'] = [{n: t.to(dev) for n, t in _syn_draws(b.shape[0], 40 + i).items()} for i, b in enumerate(boxes)]
+            model._inject = inj
+            data = dict(img=img.to(dev), img_metas=metas, gt_bboxes=[b.to(dev) for b in boxes], gt_labels=[l.to(dev) for l in labels])
+            lvs.append(tr.step(data)['log_vars'].materialize())
+        used = model._side_stream is not None
+        return lvs, tr.flat.student_flat.clone(), used
+    a, wa, used_a = run(False)
+    a2, wa2, _ = run(False)                 # the inline iteration twice: what two runs of the SAME schedule differ by
+    b, wb, used_b = run(True)
+    assert not used_a and used_b
+    for it, (x, x2, y) in enumerate(zip(a, a2, b)):
+        assert set(x) == set(y)
+        for k in x:
+            noise = abs(x[k] - x2[k])
+            assert abs(x[k] - y[k]) <= max(2e-4 * max(abs(x[k]), 1e-2), 4 * noise), (it, k, x[k], x2[k], y[k])
+    noise_w = float((wa - wa2).abs().max())
+    assert float((wa - wb).abs().max()) <= max(1e-5 * float(wa.abs().max()), 4 * noise_w), (float((wa - wb).abs().max()), noise_w)
