@@ -124,3 +124,12 @@ def test_documented_build_command_works_from_a_clean_copy(tmp_path):
     os.remove(dst / 'libpt_hip.so')
     r = subprocess.run([sys.executable, '-c', 'import point_teacher_amd'], cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and 'python -m point_teacher_amd.build' in r.stderr
+
+
+def test_graft_entry_build_accepts_the_current_abi():
+    """`__graft_entry__.build()` is the driver's build check: its ABI assertion must follow the library's version."""
+    import re
+    src = open(os.path.join(ROOT, '__graft_entry__.py')).read()
+    m = re.search(r'assert hip\.ABI_VERSION == (\d+)', src)
+    from point_teacher_amd import hip
+    assert m and int(m.group(1)) == hip.ABI_VERSION
