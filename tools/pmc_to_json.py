@@ -20,8 +20,13 @@ FAMILY = {'roi_align7_fwd': ('pt_roi_align', 'roi_align.hip'), 'roi_align7_bwd':
           'affine_relu_fwd_bf16_kernel': ('pt_affine_relu', 'optim.hip'), 'affine_relu_bwd_bf16_kernel': ('pt_affine_relu', 'optim.hip'),
           'ema_kernel': ('pt_optimizer (ema + sqnorm + sgd)', 'optim.hip'), 'sgd_kernel': ('pt_optimizer (ema + sqnorm + sgd)', 'optim.hip'),
           'sqnorm_kernel': ('pt_optimizer (ema + sqnorm + sgd)', 'optim.hip'),
-          'gemm_bf16x6_kernel': ('pt_bf16x6 (gemm + conv3x3)', 'gemm_split.hip'),
-          'wgrad3x3_bf16x6_kernel': ('pt_bf16x6 (gemm + conv3x3)', 'gemm_split.hip'),
+          'gemm_bf16x6_kernel': ('pt_bf16x6 (conv + gemm + wgrad)', 'gemm_split.hip'),
+          'wgrad_bf16x6_kernel': ('pt_bf16x6 (conv + gemm + wgrad)', 'gemm_split.hip'),
+          # second halves of the same entry-point launches (split-k sum + epilogue, fixed-order sum of the pixel chunks): their bytes
+          # belong to the launch, they are not launches of their own
+          'conv_splitk_finish_kernel': ('pt_bf16x6 (conv + gemm + wgrad)', 'gemm_split.hip', False),
+          'wgrad_reduce_kernel': ('pt_bf16x6 (conv + gemm + wgrad)', 'gemm_split.hip', False),
+          'bn_wgrad_finish_kernel': ('pt_bf16x6 (conv + gemm + wgrad)', 'gemm_split.hip', False),
           'roi_align_rotated_fwd_mm': ('pt_roi_align_rotated', 'rotated.hip'), 'roi_align_rotated_bwd_mm': ('pt_roi_align_rotated', 'rotated.hip')}
 
 
@@ -38,19 +43,20 @@ def read(path):
 
 
 tag, key = sys.argv[1], sys.argv[2]
-out_path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, 'profiles', 'r03', 'pmc_traffic.json')
+out_path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, 'profiles', 'r04', 'pmc_traffic.json')
 fetch = read(os.path.join(ROOT, 'gpurun_out', f'pmc_{tag}_FETCH_SIZE.txt'))
 write = read(os.path.join(ROOT, 'gpurun_out', f'pmc_{tag}_WRITE_SIZE.txt'))
 fam = {}
 for k in fetch:
     if k not in FAMILY:
         continue
-    name, src = FAMILY[k]
+    name, src = FAMILY[k][:2]
     f = fam.setdefault(name, dict(bytes=0.0, launches=0, kernels={}, source=src))
     n = fetch[k][1]
     byts = (2.0 * fetch[k][0] + write.get(k, [0.0, 0])[0] * (n / max(write.get(k, [0, n])[1], 1))) * 1024
     f['bytes'] += byts
-    f['launches'] += n
+    if len(FAMILY[k]) < 3:
+        f['launches'] += n
     f['kernels'][k] = dict(launches=n, fetch_kib_mean=round(fetch[k][0] / n, 1),
                            write_kib_mean=round(write.get(k, [0.0, 1])[0] / max(write.get(k, [0, 1])[1], 1), 1))
 doc = json.load(open(out_path)) if os.path.exists(out_path) else {}
