@@ -419,6 +419,11 @@ int pt_affine_relu_fwd(const float* x, const float* scale, const float* shift,
                        void* stream);
 int pt_affine_relu_bwd(const float* grad_y, const float* y, const float* scale, int64_t n, int C,
                        int64_t inner, int relu, float* grad_x, float* grad_res, void* stream);
+/* The frozen stem's tail in one pass (models/backbones/resnet.py:633-640: x = conv1(x); x = norm1(x); x = relu(x); x = maxpool(x),
+ * with frozen_stages >= 0 no gradient reaches it): y[B, Ho, Wo, C] = max_pool2d(relu(x * scale[c] + shift[c]), kernel 3, stride 2,
+ * pad 1) of a channels_last map x[B, H, W, C]; Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1; C % 4 == 0; forward only. */
+int pt_affine_relu_maxpool_fwd(const float* x, const float* scale, const float* shift, int B, int H, int W,
+                               int C, float* y, void* stream);
 
 /* Top-down step of the necks on channels_last maps ([N,H,W,C], fp32 or bf16 = uint16 bit patterns when `bf16`):
  * out = a + nearest_upsample(b) with a, out [N,Ha,Wa,C] and b [N,Hb,Wb,C] - `laterals[i-1] += F.interpolate(laterals[i],

@@ -6,11 +6,10 @@ name the reference's configs use.  There is no CPU compute path."""
 import os as _os
 import sys as _sys
 
-# `python -m point_teacher_amd.build` on a clean checkout: the package is imported before its build module runs and the library
-# does not exist yet - only then the imports below are skipped (the build module needs none of them).  Any other import without
-# the library still fails loudly in .hip.
-_BUILDING = (not _os.path.exists(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), 'libpt_hip.so'))
-             and 'point_teacher_amd.build' in getattr(_sys, 'orig_argv', ()))
+# `python -m point_teacher_amd.build`: the package is imported before its build module runs, and the library may not exist yet (a
+# clean checkout) or be stale (a header that declares an entry point the old library lacks) - only then the imports below are
+# skipped (the build module needs none of them).  Any other import without a matching library still fails loudly in .hip.
+_BUILDING = 'point_teacher_amd.build' in getattr(_sys, 'orig_argv', ())
 if _BUILDING:
     __all__ = []
 else:

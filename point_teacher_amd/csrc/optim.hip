@@ -526,6 +526,54 @@ extern "C" int pt_affine_relu_fwd(const float* x, const float* scale, const floa
   return PT_OK;
 }
 
+// Frozen stem: max_pool2d(relu(x * scale + shift), 3, stride 2, pad 1) on a channels_last map in ONE pass (resnet.py:633-640:
+// norm1 -> relu -> maxpool of a stem no gradient reaches).  One thread per (output pixel, 4 channels): nine float4 taps (the window's
+// rows are contiguous 3 * C floats; neighbouring windows share taps through L2), fp32 affine + ReLU per tap exactly as the separate
+// passes compute them, maximum, one float4 store.  A padded tap never wins: every window holds its centre pixel and ReLU >= 0.
+__global__ void __launch_bounds__(256)
+    affine_relu_maxpool_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift, int B, int H,
+                               int W, int C, int Ho, int Wo, float* __restrict__ y) {
+  const int c4n = C >> 2;
+  const long total = (long)B * Ho * Wo * c4n;
+  for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(u % c4n);
+    long r = u / c4n;
+    const int ox = (int)(r % Wo);
+    r /= Wo;
+    const int oy = (int)(r % Ho), b = (int)(r / Ho);
+    const float4 sc = reinterpret_cast<const float4*>(scale)[c4], sh = reinterpret_cast<const float4*>(shift)[c4];
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int iy = 2 * oy + dy;
+      if (iy < 0 || iy >= H) continue;
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int ix = 2 * ox + dx;
+        if (ix < 0 || ix >= W) continue;
+        const float4 v = reinterpret_cast<const float4*>(x + (((long)b * H + iy) * W + ix) * C)[c4];
+        m.x = fmaxf(m.x, v.x * sc.x + sh.x); m.y = fmaxf(m.y, v.y * sc.y + sh.y);
+        m.z = fmaxf(m.z, v.z * sc.z + sh.z); m.w = fmaxf(m.w, v.w * sc.w + sh.w);
+      }
+    }
+    reinterpret_cast<float4*>(y)[u] = m;
+  }
+}
+
+extern "C" int pt_affine_relu_maxpool_fwd(const float* x, const float* scale, const float* shift, int B, int H, int W, int C, float* y,
+                                          void* stream) {
+  PT_REQUIRE(x && scale && shift && y && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, PT_EINVAL,
+             "pt_affine_relu_maxpool_fwd: NULL pointer or C not a multiple of 4");
+  PT_REQUIRE(((((uintptr_t)x) | ((uintptr_t)scale) | ((uintptr_t)shift) | ((uintptr_t)y)) & 15) == 0, PT_EINVAL,
+             "pt_affine_relu_maxpool_fwd: buffers must be 16-byte aligned");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;          // floor((H + 2 - 3) / 2) + 1
+  const long total = (long)B * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(affine_relu_maxpool_kernel, dim3(stream_blocks(total)), dim3(256), 0, as_stream(stream), x, scale, shift, B, H, W, C,
+                     Ho, Wo, y);
+  PT_LAUNCH_CHECK("pt_affine_relu_maxpool_fwd");
+  return PT_OK;
+}
+
 extern "C" int pt_affine_relu_bwd(const float* grad_y, const float* y, const float* scale, int64_t n, int C,
                                   int64_t inner, int relu, float* grad_x, float* grad_res, void* stream) {
   if (n == 0) return PT_OK;

@@ -1156,6 +1156,17 @@ def affine_relu_(x, scale, shift, residual=None, relu=True):
     return _AffineReLU.apply(x, scale, shift, residual, relu)
 
 
+def affine_relu_maxpool(x, scale, shift):
+    """max_pool2d(relu(x * scale + shift), 3, 2, 1) of a channels_last fp32 map that takes no gradient, in one pass
+    (pt_affine_relu_maxpool_fwd: the frozen stem's norm1 -> relu -> maxpool, backbones/resnet.py:633-640)."""
+    B, C, H, W = x.shape
+    assert x.dtype == f32 and x.is_cuda and C % 4 == 0 and x.permute(0, 2, 3, 1).is_contiguous() and not x.requires_grad
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((B, Ho, Wo, C), dtype=f32, device=x.device)
+    hip.call('pt_affine_relu_maxpool_fwd', x.permute(0, 2, 3, 1), scale, shift, B, H, W, C, y)
+    return y.permute(0, 3, 1, 2)
+
+
 # ------------------------------------------------------------------------ NMS --
 
 def nms(boxes, scores, iou_threshold, class_ids=None):

@@ -19,6 +19,7 @@ from .registry import BACKBONES, NECKS, ROI_EXTRACTORS
 
 
 _SPLIT_CONV = os.environ.get('PT_SPLIT_CONV', '1') != '0'
+_STEM_TAIL = os.environ.get('PT_STEM_TAIL', '1') != '0'            # 0: bn1 + ReLU and the max-pool as two passes
 _PLANE_TRUNK = _SPLIT_CONV and os.environ.get('PT_PLANE_TRUNK', '1') != '0'     # 0: the round-3 routing (3x3 only, fp32 between layers)
 _PLANE_BN_TRAIN = os.environ.get('PT_PLANE_BN_TRAIN', '1') != '0'               # 0: blocks with a trainable BatchNorm keep the round-3 routing
 _GN_CL = os.environ.get('PT_GN_CL', '1') != '0'
@@ -465,13 +466,29 @@ class ResNet(nn.Module):
         changes (frozen_stages >= 0).  -> (activation, outputs collected so far); `forward(None, stem=...)` continues from it.
         A teacher that holds the same frozen weights as its student (both load the same pretrained file and the stem never
         trains) computes the same stem on the same image: TS_P2B_FCOS evaluates it once."""
-        x = self.maxpool(conv_bn(x, self.conv1, self.bn1, True))
+        x = self._stem_head(x)
         outs = []
         for i in range(max(self.frozen_stages, 0)):
             x = getattr(self, self.res_layers[i])(x)
             if i in self.out_indices:
                 outs.append(x)
         return x, outs
+
+    def _stem_head(self, x):
+        """maxpool(relu(bn1(conv1(x)))) (resnet.py:633-640).  Frozen (frozen_stages >= 0, eval-mode BatchNorm, no gradient into the
+        image): the convolution, then norm + ReLU + max-pool in ONE pass over its output (pt_affine_relu_maxpool_fwd) instead of an
+        in-place BatchNorm pass and a pooling pass."""
+        c, bn, mp = self.conv1, self.bn1, self.maxpool
+        if (_STEM_TAIL and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled() and not bn.training
+                and not bn.weight.requires_grad and not c.weight.requires_grad and not x.requires_grad
+                and getattr(bn, 'fuse_epilogue', True) and mp.kernel_size == 3 and mp.stride == 2 and mp.padding == 1
+                and mp.dilation == 1 and not mp.ceil_mode):
+            y = c(x)
+            if y.shape[1] % 4 == 0 and y.is_contiguous(memory_format=torch.channels_last) and y.numel() > 0:
+                sc, sh = _bn_affine(bn)
+                return F.affine_relu_maxpool(y, sc, sh)
+            return mp(TF.relu(bn(y)))
+        return mp(conv_bn(x, c, bn, True))
 
     plane_capable = True
 

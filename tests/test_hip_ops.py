@@ -957,3 +957,18 @@ def test_roi_align_rotated_backward_pixel_sorted_path():
     w2 = cu(wgt[:, :1]).expand(-1, C, -1, -1).contiguous()
     (f.roi_align_rotated(fg, cu(rois), 7, 0.125, 2, True, True) * w2).sum().backward()
     close(fg.grad, g0[:, None].expand(-1, C, -1, -1), rtol=1e-4, atol=5e-4)
+
+
+@pytest.mark.parametrize('B,H,W,C', [(2, 37, 41, 64), (1, 8, 8, 4), (3, 100, 99, 64)])
+def test_affine_relu_maxpool_equals_the_three_passes(B, H, W, C):
+    """pt_affine_relu_maxpool_fwd (the frozen stem's norm1 -> relu -> maxpool, resnet.py:633-640) = the fused BatchNorm pass followed
+    by torch's max_pool2d(3, 2, 1), bit for bit (same fp32 multiply, add, maximum)."""
+    from point_teacher_amd import functional as F
+    g = torch.Generator().manual_seed(B + H)
+    x = torch.randn(B, C, H, W, generator=g).to('cuda:0').contiguous(memory_format=torch.channels_last)
+    sc = (torch.randn(C, generator=g)).to('cuda:0')              # (negative scales included)
+    sh = torch.randn(C, generator=g).to('cuda:0')
+    want = torch.nn.functional.max_pool2d(torch.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)), 3, 2, 1)
+    got = F.affine_relu_maxpool(x, sc, sh)
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, want)
