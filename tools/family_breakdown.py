@@ -25,6 +25,7 @@ torch.manual_seed(0)
 model = pta.build_detector(cfg.model).to(dev)
 benchmark_init_(model, phase2=phase2)
 model.train()
+model.teacher_stream = False      # per-launch HIP-event timings: no co-scheduled teacher kernels on a second stream
 tr = pta.Trainer(model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config, channels_last=True)
 data = SyntheticTiles(n=8, size=1200 if obb else 800, mean_objects=300, seed=7, device=dev, oriented=obb, num_classes=9 if obb else 8)
 for it in range(6):

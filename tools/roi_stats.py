@@ -22,6 +22,7 @@ cfg.model['burn_in_step'] = 10 ** 9 if wl == 'step1' else -1
 model = pta.build_detector(cfg.model).to(dev)
 benchmark_init_(model, phase2=(wl == 'step2'))
 model.train()
+model.teacher_stream = False      # per-launch HIP-event timings: no co-scheduled teacher kernels on a second stream
 tr = pta.Trainer(model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config, channels_last=True)
 data = SyntheticTiles(n=8, size=800, mean_objects=300, seed=7, device=dev)
 for it in range(3):

@@ -20,6 +20,7 @@ cfg.model['burn_in_step'] = 10 ** 9 if wl == 'step1' else -1
 model = pta.build_detector(cfg.model).to(dev)
 benchmark_init_(model, phase2=(wl == 'step2'))
 model.train()
+model.teacher_stream = False      # per-launch HIP-event timings: no co-scheduled teacher kernels on a second stream
 tr = pta.Trainer(model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config, channels_last=True)
 data = SyntheticTiles(n=8, size=1200, mean_objects=300, seed=7, device=dev, oriented=True, num_classes=9)
 WARM = int(sys.argv[2]) if len(sys.argv) > 2 else 3        # iterations before the recorded one (the bench times iterations 5 .. 25)
