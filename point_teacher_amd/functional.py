@@ -698,14 +698,14 @@ class _ConvWeightPlanes:
     def taps(w):
         return w.shape[2] * w.shape[3] if w.dim() == 4 else 1
 
-    def _build_table(self):
+    def _build_table(self, weights):
+        """`weights`: the registered weights, in the order of self.ent (strong references held by the caller)."""
         rec = np.zeros(len(self.ent), dtype=np.dtype([('w', '<u8'), ('dst', '<u8'), ('plane', '<i8'), ('O', '<i4'), ('I', '<i4'),
                                                        ('mode', '<i4'), ('first', '<i4'), ('taps', '<i4'), ('np', '<i4'),
                                                        ('scale', '<u8')]))
         first = 0
         dev = None
-        for i, ((_, mode, _sp, npl), (ref, ptr, sp, scale, _ver)) in enumerate(self.ent.items()):
-            w = ref()
+        for i, (((_, mode, _sp, npl), (_ref, ptr, sp, scale, _ver)), w) in enumerate(zip(self.ent.items(), weights)):
             O, I = w.shape[:2]
             taps = self.taps(w)
             rows, k = (I, taps * O) if mode else (O, taps * I)
@@ -745,18 +745,26 @@ class _ConvWeightPlanes:
 
     def refresh(self):
         """Re-split every registered (weight, form, scale, plane count) now, on the current stream: one launch."""
-        if not all(self._alive(v) for v in self.ent.values()):
-            self.ent = {k: v for k, v in self.ent.items() if self._alive(v)}
+        # strong references for the duration of the call: weights of a discarded model sit in reference cycles, and the cyclic
+        # collector may run at any allocation below - a weak reference that was alive a line ago can be dead the next
+        live, strong = {}, []
+        for k, v in self.ent.items():
+            w = v[0]()
+            if w is not None and w.data_ptr() == v[1]:
+                live[k] = v
+                strong.append(w)
+        if len(live) != len(self.ent):
+            self.ent = live
             self.table = None
         if not self.ent:
             return
         if self.table is None:
-            self._build_table()
+            self._build_table(strong)
         tab, n_items, blocks = self.table
         hip.call('pt_conv_weight_planes_batch', tab, n_items, blocks)
         self.epoch = PARAM_EPOCH[0]
-        for v in self.ent.values():
-            v[4] = v[0]()._version
+        for v, w in zip(self.ent.values(), strong):
+            v[4] = w._version
 
 
 _CONV_W = _ConvWeightPlanes()

@@ -571,3 +571,29 @@ def test_one_plane_bottleneck_under_autocast_vs_fp64_with_the_same_roundings():
     assert rel(out, o) < 1e-3 and rel(xin.grad, gx) < 3e-3
     for n, e in errs.items():
         assert dict(blk.named_parameters())[n].grad.dtype == torch.float32 and e < 3e-3, (n, e)
+
+
+def test_weight_plane_refresh_survives_a_collection_in_the_middle(monkeypatch):
+    """Weights of a discarded model sit in reference cycles; the cyclic collector may free them at any allocation - also between the
+    refresh's liveness check and the table it builds (seen once in a full-suite run: `ref()` returned None).  The refresh holds
+    strong references for its duration."""
+    import gc
+    from point_teacher_amd import functional as F
+    holder = {'w': (torch.randn(128, 128, 1, 1, device=DEV) * 0.05).contiguous(memory_format=torch.channels_last)}
+    keep = (torch.randn(128, 128, 3, 3, device=DEV) * 0.05).contiguous(memory_format=torch.channels_last)
+    F._conv_weight_planes(holder['w'], False)
+    want = F._conv_weight_planes(keep, False).planes.clone()
+    real_zeros = F.np.zeros
+
+    def zeros_and_collect(*a, **k):            # the allocation inside _build_table: drop the last outside reference, collect
+        holder.pop('w', None)
+        gc.collect()
+        return real_zeros(*a, **k)
+    monkeypatch.setattr(F.np, 'zeros', zeros_and_collect)
+    F.PARAM_EPOCH[0] += 1
+    F._CONV_W.table = None                      # (as after a registration: the next refresh rebuilds the table)
+    got = F._conv_weight_planes(keep, False).planes
+    assert torch.equal(got, want)
+    monkeypatch.setattr(F.np, 'zeros', real_zeros)
+    F.PARAM_EPOCH[0] += 1
+    assert torch.equal(F._conv_weight_planes(keep, False).planes, want)      # the dead entry is dropped by the next refresh
