@@ -588,4 +588,4 @@ def test_trainable_bn_terms_are_current_when_the_weight_planes_are_made():
     print('backbone gradients after a gamma change vs a fresh model with the same weights (error, run-to-run noise):',
           [(k, f'{a:.1e}', f'{b:.1e}') for k, (a, b) in top])
     for k, (a, b) in errs.items():
-        assert a < max(2e-3, 3 * b), (k, a, b)
+        assert a < max(3e-2, 3 * b), (k, a, b)      # (gamma x 1.3 left stale is an error of ~0.3; measured 1.5e-3 against 8e-3 of noise)
