@@ -706,9 +706,9 @@ def test_teacher_on_a_side_stream_gives_the_same_iteration(phase2):
     for it, (x, y) in enumerate(zip(a, b)):
         assert set(x) == set(y)
         for k in x:
-            # iteration 0: the forward pass has no atomics - the same numbers whichever stream the teacher ran on.  Iteration 1 starts
-            # from weights whose gradients went through RoIAlign's float atomics (run-to-run differences of 1e-3 on a loss key were
-            # measured between two INLINE runs): a sanity bound; a race between the streams would show in iteration 0
-            tol = 1e-6 if it == 0 else 1e-2
+            # iteration 0: the same forward pass whichever stream the teacher ran on (fp32 reduction order aside: 1e-6 measured).
+            # Iteration 1 starts from weights whose gradients went through RoIAlign's float atomics (run-to-run differences of 1e-3
+            # on a loss key were measured between two INLINE runs): a sanity bound; a race between the streams shows in iteration 0
+            tol = 1e-4 if it == 0 else 1e-2
             assert abs(x[k] - y[k]) <= tol * max(abs(x[k]), 1e-2), (it, k, x[k], y[k])
     assert float((wa - wb).abs().max()) <= 1e-3 * float(wa.abs().max())
