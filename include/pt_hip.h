@@ -240,6 +240,15 @@ int pt_gemm_bf16x6_tile_rows(int M, int N);
 int pt_gemm_bf16x6_nt(const uint16_t* a_planes, int64_t a_plane_stride, const uint16_t* b_planes,
                       int64_t b_plane_stride, float* c, int64_t ldc, const float* bias, int M, int N,
                       int K, int relu, int tile_rows, void* stream);
+/* EXPERIMENT, not on the training path: the same product from fp16 x 2 operands - x = h0 + h1 (two fp16
+ * planes in the blocked layout of pt_split_bf16x3; 22 significant bits, <= 3e-8 absolute below 0.125) and THREE fp16 MFMA products
+ * (a0 b0 + a0 b1 + a1 b0) instead of six bf16 ones.  Operands must be scaled into fp16's range by the caller.  Replaces nothing in
+ * the reference; measured against pt_gemm_bf16x6_nt by tools/gemm_bench.py. */
+int pt_split_f16x2(const float* src, int64_t ld, int R, int C, uint16_t* planes, int64_t plane_stride,
+                   void* stream);
+int pt_gemm_f16x3_nt(const uint16_t* a_planes, int64_t a_plane_stride, const uint16_t* b_planes,
+                     int64_t b_plane_stride, float* c, int64_t ldc, const float* bias, int M, int N, int K,
+                     int relu, int tile_rows, void* stream);
 
 /* The 3 x 3, stride 1, pad 1 convolutions of the dense head's towers (anchor_free_head.py:198-219; fp32 by the config) as an
  * implicit GEMM on the same kernel: out[B*H*W, Cout] (NHWC, row stride ldo) = conv(x, w) (* scale[Cout]) (+ bias[Cout]) (ReLU);

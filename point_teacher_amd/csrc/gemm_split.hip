@@ -90,6 +90,45 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// EXPERIMENT (not on the training path): fp32 -> TWO fp16 planes, x = h0 + h1 to 22 significant bits (2^-23
+// relative; <= 3e-8 absolute below 0.125, where h1 is subnormal - the matrix cores multiply subnormals exactly), same blocked layout.
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair_f16(float a, float b, unsigned& p0, unsigned& p1) {
+  f16x2_t h0;
+  h0[0] = (_Float16)a;                                  // round to nearest even
+  h0[1] = (_Float16)b;
+  f16x2_t h1;
+  h1[0] = (_Float16)(a - (float)h0[0]);                 // the residual is exact in fp32
+  h1[1] = (_Float16)(b - (float)h0[1]);
+  p0 = __builtin_bit_cast(unsigned, h0);
+  p1 = __builtin_bit_cast(unsigned, h1);
+}
+
+__global__ void __launch_bounds__(256)
+    split_f16x2_kernel(const float* __restrict__ src, long ld, int R, int C, int RB, int KB, uint16_t* __restrict__ dst, long plane) {
+  const int lane = threadIdx.x & 63, r16 = lane >> 2, q = lane & 3;
+  const long nblk = (long)RB * KB;
+  for (long blk = (long)blockIdx.x * 4 + (threadIdx.x >> 6); blk < nblk; blk += (long)gridDim.x * 4) {
+    const long rb = blk / KB, kb = blk - rb * KB;
+    const int r = (int)rb * 16 + r16, c = (int)kb * 32 + q * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (r < R) {
+      const float* sp = src + (long)r * ld + c;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (c + j < C) v[j] = sp[j];
+    }
+    uint4 o0, o1;
+    split_pair_f16(v[0], v[1], o0.x, o1.x);
+    split_pair_f16(v[2], v[3], o0.y, o1.y);
+    split_pair_f16(v[4], v[5], o0.z, o1.z);
+    split_pair_f16(v[6], v[7], o0.w, o1.w);
+    uint16_t* d = dst + block_off(rb, kb, KB, r16, q);
+    *reinterpret_cast<uint4*>(d) = o0;
+    *reinterpret_cast<uint4*>(d + plane) = o1;
+  }
+}
+
 // src [R, C] (row stride ld), transposed operand: rows = C, k = R.  64 x 64 source tiles through LDS: coalesced float4 reads
 // along C; the tile yields 4 row blocks x 2 k blocks, each written as one contiguous KiB per plane.
 __global__ void __launch_bounds__(256)
@@ -517,6 +556,15 @@ __global__ void __launch_bounds__(GTHREADS)
       }
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
+        if constexpr (NP == 2) {                        // EXPERIMENT: fp32 as two fp16 terms, three products (a1 b1 ~ 2^-22 dropped)
+          typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+          const f16x8_t a0 = __builtin_bit_cast(f16x8_t, a[0]), a1 = __builtin_bit_cast(f16x8_t, a[1]);
+          const f16x8_t b0 = __builtin_bit_cast(f16x8_t, b[c][0]), b1 = __builtin_bit_cast(f16x8_t, b[c][1]);
+          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0, cor[i][c], 0, 0, 0);
+          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1, cor[i][c], 0, 0, 0);
+          acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, acc[i][c], 0, 0, 0);
+          continue;
+        }
         if constexpr (NP == 3) {                        // fp32 as three bf16 terms: the six leading products, smallest first
           cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[c][0], cor[i][c], 0, 0, 0);
           cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[c][1], cor[i][c], 0, 0, 0);
@@ -1093,6 +1141,39 @@ extern "C" int pt_gemm_bf16x6_nt(const uint16_t* a_planes, int64_t a_plane_strid
                                        ConvGeom{}, ConvEpi{}, as_stream(stream));
   PT_REQUIRE(rc == 0, rc, "pt_gemm_bf16x6_nt: hipFuncSetAttribute failed (%d)", rc);
   PT_LAUNCH_CHECK("pt_gemm_bf16x6_nt");
+  return PT_OK;
+}
+
+// EXPERIMENT: the same GEMM on fp16 x 2 operands - three fp16 MFMA products per fp32 product instead of six
+// bf16 ones.  Measured by tools/gemm_bench.py f16; not used by the training path (operand RANGE needs per-tensor scaling first).
+extern "C" int pt_split_f16x2(const float* src, int64_t ld, int R, int C, uint16_t* planes, int64_t plane_stride, void* stream) {
+  if (R == 0 || C == 0) return PT_OK;
+  PT_REQUIRE(src && planes && R > 0 && C > 0 && ld >= C, PT_EINVAL, "pt_split_f16x2: bad argument");
+  const int RB = (R + 15) / 16, KB = (C + 31) / 32;
+  PT_REQUIRE(plane_stride >= (int64_t)RB * KB * 512 && (plane_stride & 7) == 0 && (((uintptr_t)planes) & 15) == 0, PT_EINVAL,
+             "pt_split_f16x2: plane_stride must cover pt_split_bf16x3_plane_elems(R, C) and keep planes 16-byte aligned");
+  int nb = cdiv((long)RB * KB, 4);
+  nb = nb > 16384 ? 16384 : nb;
+  hipLaunchKernelGGL(split_f16x2_kernel, dim3(nb), dim3(256), 0, as_stream(stream), src, (long)ld, R, C, RB, KB, planes, (long)plane_stride);
+  PT_LAUNCH_CHECK("pt_split_f16x2");
+  return PT_OK;
+}
+
+extern "C" int pt_gemm_f16x3_nt(const uint16_t* a_planes, int64_t a_plane_stride, const uint16_t* b_planes, int64_t b_plane_stride,
+                                float* c, int64_t ldc, const float* bias, int M, int N, int K, int relu, int tile_rows, void* stream) {
+  if (M == 0 || N == 0) return PT_OK;
+  PT_REQUIRE(a_planes && b_planes && c && M > 0 && N > 0 && K > 0 && ldc >= N, PT_EINVAL, "pt_gemm_f16x3_nt: bad argument");
+  const int Kp = (K + 31) / 32;
+  PT_REQUIRE(a_plane_stride >= pt_split_bf16x3_plane_elems(M, K) && b_plane_stride >= pt_split_bf16x3_plane_elems(N, K), PT_EINVAL,
+             "pt_gemm_f16x3_nt: plane strides too small for [M, K] / [N, K] blocked planes");
+  PT_REQUIRE(((((uintptr_t)a_planes) | ((uintptr_t)b_planes)) & 15) == 0 && (a_plane_stride & 7) == 0 && (b_plane_stride & 7) == 0, PT_EINVAL,
+             "pt_gemm_f16x3_nt: planes must be 16-byte aligned");
+  if (tile_rows <= 0) tile_rows = pt_gemm_bf16x6_tile_rows(M, N);
+  PT_REQUIRE(tile_rows % 32 == 0 && tile_rows >= 64 && tile_rows <= 256, PT_EINVAL, "pt_gemm_f16x3_nt: tile_rows in {64, 96, ..., 256}");
+  const int rc = launch_by_rows<false, 2>(tile_rows, a_planes, b_planes, c, bias, nullptr, M, N, Kp, a_plane_stride, b_plane_stride, ldc, relu,
+                                       ConvGeom{}, ConvEpi{}, as_stream(stream));
+  PT_REQUIRE(rc == 0, rc, "pt_gemm_f16x3_nt: hipFuncSetAttribute failed (%d)", rc);
+  PT_LAUNCH_CHECK("pt_gemm_f16x3_nt");
   return PT_OK;
 }
 

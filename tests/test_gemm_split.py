@@ -268,3 +268,38 @@ def test_conv_weight_planes_are_refreshed_in_one_launch_per_parameter_epoch():
     plain = torch.randn(128, 64, 3, 3, device=dev)                    # NCHW-contiguous: per-weight path
     assert not F._ConvWeightPlanes.ok(plain)
     assert torch.equal(F._conv_weight_planes(plain, True).planes, expect(plain, True).planes)
+
+
+def test_f16x3_experiment_matches_float64_inside_fp16_range():
+    """EXPERIMENT (not on the training path): the same GEMM from fp16 x 2 operands with three fp16 MFMA products
+    (pt_split_f16x2 + pt_gemm_f16x3_nt).  With operands of O(1) magnitude its error against float64 is the six-product kernel's
+    (both below the fp32 library's); operands of 1e-4 magnitude lose it unless scaled by a power of two first."""
+    from point_teacher_amd import functional as F, hip
+    dev = 'cuda:0'
+    M, N, K = 777, 300, 1000
+    g = torch.Generator().manual_seed(4)
+
+    def f16_gemm(a, b):
+        def split(x):
+            R, C = x.shape
+            n = ((R + 15) // 16) * ((C + 31) // 32) * 512
+            p = torch.empty((2, n), dtype=torch.bfloat16, device=dev)          # 16-bit storage: the header's uint16_t*
+            hip.call('pt_split_f16x2', x, x.stride(0), R, C, p, n)
+            return p
+        ap, bp = split(a), split(b)
+        out = torch.empty(a.shape[0], b.shape[0], device=dev)
+        hip.call('pt_gemm_f16x3_nt', ap, ap.shape[1], bp, bp.shape[1], out, out.stride(0), None, a.shape[0], b.shape[0], a.shape[1], 0, 0)
+        return out
+
+    def err(out, a, b):
+        ref = a.double() @ b.double().t()
+        return float(((out.double() - ref).abs() / (a.double().abs() @ b.double().abs().t())).max())
+    a = torch.randn(M, K, generator=g).to(dev)
+    b = (torch.randn(N, K, generator=g) * 0.05).to(dev)
+    e3, e6, el = err(f16_gemm(a, b), a, b), err(F.gemm_bf16x6_nt(F.split_bf16x3(a), F.split_bf16x3(b)), a, b), err(a @ b.t(), a, b)
+    print(f'f16x3 {e3:.2e}  bf16x6 {e6:.2e}  fp32 library {el:.2e}')
+    assert e3 < 3e-7 and e3 <= max(el, 2.0 ** -22)
+    small = a * 1e-4
+    assert err(f16_gemm(small, b), small, b) > 10 * e3                          # h1 of 1e-4-sized values is subnormal: the range limit
+    scaled = f16_gemm(small * 2.0 ** 13, b) * 2.0 ** -13                         # a power-of-two scale restores it
+    assert err(scaled, small, b) < 3e-7
