@@ -343,7 +343,9 @@ GRAD_KEYS = ['bbox_head.conv_cls.weight', 'bbox_head.conv_reg.weight', 'bbox_hea
              'backbone.layer3.0.bn2.weight', 'backbone.layer2.0.conv1.weight']
 
 
-def test_obb_step2_loss_dict_and_grads():
+@pytest.mark.parametrize('layout', ['nchw', 'channels_last'])
+def test_obb_step2_loss_dict_and_grads(layout):
+    """`channels_last` = the training layout: trunk (trainable eval-mode BatchNorm), necks and FC stacks plane-native."""
     dev = torch.device('cuda:0')
     pta, cfg, model = _build(dev, phase2=True)
     img, boxes, labels, metas = _data(seed=STEP2_SEED)
@@ -353,7 +355,10 @@ def test_obb_step2_loss_dict_and_grads():
     model._inject = dict(neg0=neg_u.to(dev), aug=aug)
     sd_s0 = _strip(model.state_dict(), 'student.')
     sd_t0 = _strip(model.state_dict(), 'teacher.')
-    data = dict(img=img.to(dev), img_metas=metas, gt_bboxes=[b.to(dev) for b in boxes], gt_labels=[l.to(dev) for l in labels])
+    img_dev = img.to(dev)
+    if layout == 'channels_last':
+        model, img_dev = model.to(memory_format=torch.channels_last), img_dev.contiguous(memory_format=torch.channels_last)
+    data = dict(img=img_dev, img_metas=metas, gt_bboxes=[b.to(dev) for b in boxes], gt_labels=[l.to(dev) for l in labels])
     cap, stats = {}, {}
     _spy_selection(model, cap)
     out = model.train_step(data, None)

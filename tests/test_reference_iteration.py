@@ -166,13 +166,21 @@ def _build_product(percent, G, dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('layout', ['nchw', 'channels_last'])
 @pytest.mark.parametrize('percent', [0, 100])
-def test_product_iteration_vs_reference(percent):
+def test_product_iteration_vs_reference(percent, layout):
+    """`channels_last` is the training layout (Trainer(channels_last=True), bench.py): the trainable trunk, the necks, the towers and
+    the FC stacks then run plane-native on pt_conv_bf16x6 / pt_conv_wgrad_bf16x6 (planes.py); `nchw` takes the library's
+    convolutions for the 1x1s.  Both must reproduce the reference's own two iterations."""
     dev = torch.device('cuda:0')
     G = load_golden(f'ref_iter_p{percent}')
     pta, cfg, model = _build_product(percent, G, dev)
     img, boxes, labels, metas = _inputs(G)
-    data = dict(img=img.to(dev), img_metas=metas, gt_bboxes=[b.to(dev) for b in boxes], gt_labels=[l.to(dev) for l in labels])
+    img_dev = img.to(dev)
+    if layout == 'channels_last':
+        model = model.to(memory_format=torch.channels_last)
+        img_dev = img_dev.contiguous(memory_format=torch.channels_last)
+    data = dict(img=img_dev, img_metas=metas, gt_bboxes=[b.to(dev) for b in boxes], gt_labels=[l.to(dev) for l in labels])
     seen = {}
     real_bp = model._black_paper
 

@@ -169,7 +169,9 @@ def test_oracle_obb_black_paper_vs_reference():
 
 # ------------------------------------------------------------------------ GPU: product vs the reference --
 @pytest.mark.gpu
-def test_product_obb_iteration_vs_reference():
+@pytest.mark.parametrize('layout', ['nchw', 'channels_last'])
+def test_product_obb_iteration_vs_reference(layout):
+    """`channels_last` = the training layout: the trunk (trainable eval-mode BatchNorm), necks and FC stacks plane-native."""
     import point_teacher_amd as pta
     dev = torch.device('cuda:0')
     G = load_golden('ref_iter_obb')
@@ -183,7 +185,11 @@ def test_product_obb_iteration_vs_reference():
     model.teacher.load_state_dict(sd_t, strict=False)
     model = model.to(dev).train()
     img, boxes, labels, metas = _inputs(G)
-    data = dict(img=img.to(dev), img_metas=metas, gt_bboxes=[b.to(dev) for b in boxes], gt_labels=[l.to(dev) for l in labels])
+    img_dev = img.to(dev)
+    if layout == 'channels_last':
+        model = model.to(memory_format=torch.channels_last)
+        img_dev = img_dev.contiguous(memory_format=torch.channels_last)
+    data = dict(img=img_dev, img_metas=metas, gt_bboxes=[b.to(dev) for b in boxes], gt_labels=[l.to(dev) for l in labels])
     seen = {}
     real_syn = model.genrate_syn
 

@@ -59,6 +59,17 @@ def _data(dev, size=256, n_obj=(23, 17), seed=5):
     return img, boxes, labels, metas
 
 
+def _layout(model, img, layout):
+    """`channels_last` = the training layout (Trainer(channels_last=True), bench.py): trunk, necks, towers and FC stacks run
+    plane-native on pt_conv_bf16x6 / pt_conv_wgrad_bf16x6; `nchw`: the 1x1 convolutions stay with the library."""
+    if layout == 'channels_last':
+        return model.to(memory_format=torch.channels_last), img.contiguous(memory_format=torch.channels_last)
+    return model, img
+
+
+LAYOUTS = pytest.mark.parametrize('layout', ['nchw', 'channels_last'])
+
+
 def _strip(sd, prefix):
     return {k[len(prefix):]: v.detach().cpu().clone() for k, v in sd.items() if k.startswith(prefix)}
 
@@ -91,7 +102,8 @@ GRAD_KEYS = ['bbox_head.conv_cls.weight', 'bbox_head.conv_reg.weight', 'bbox_hea
              'neck.fpn_convs.0.conv.weight', 'backbone.layer4.2.conv3.weight', 'backbone.layer2.0.conv1.weight']
 
 
-def test_step2_loss_dict_and_grads():
+@LAYOUTS
+def test_step2_loss_dict_and_grads(layout):
     dev = torch.device('cuda:0')
     pta, cfg, model = _build(dev, phase2=True)
     img, boxes, labels, metas = _data(dev)
@@ -101,7 +113,8 @@ def test_step2_loss_dict_and_grads():
     model._inject = dict(neg0=neg_u.to(dev), aug=aug)
     sd_s0 = _strip(model.state_dict(), 'student.')
     sd_t0 = _strip(model.state_dict(), 'teacher.')
-    data = dict(img=img.to(dev), img_metas=metas, gt_bboxes=[b.to(dev) for b in boxes], gt_labels=[l.to(dev) for l in labels])
+    model, img_dev = _layout(model, img.to(dev), layout)
+    data = dict(img=img_dev, img_metas=metas, gt_bboxes=[b.to(dev) for b in boxes], gt_labels=[l.to(dev) for l in labels])
     out = model.train_step(data, None)
     out['loss'].backward()
     lv = out['log_vars'].materialize()
@@ -124,7 +137,8 @@ def test_step2_loss_dict_and_grads():
         assert p.grad is None, n                                     # the teacher never receives gradients
 
 
-def test_step1_loss_dict_and_grads():
+@LAYOUTS
+def test_step1_loss_dict_and_grads(layout):
     """Burn-in step 1.  Product and oracle each run their OWN rectangle generator on the same injected draws
     (nothing the HIP path produced is handed to the oracle); loss dict 1e-3, gradients 1e-3 of their norm."""
     dev = torch.device('cuda:0')
@@ -137,7 +151,8 @@ def test_step1_loss_dict_and_grads():
     model._inject = dict(neg0=neg_u.to(dev), aug=aug, syn=[{k: v.to(dev) for k, v in d.items()} for d in syn])
     sd_s0 = _strip(model.state_dict(), 'student.')
     sd_t0 = _strip(model.state_dict(), 'teacher.')
-    data = dict(img=img.to(dev), img_metas=metas, gt_bboxes=[b.to(dev) for b in boxes], gt_labels=[l.to(dev) for l in labels])
+    model, img_dev = _layout(model, img.to(dev), layout)
+    data = dict(img=img_dev, img_metas=metas, gt_bboxes=[b.to(dev) for b in boxes], gt_labels=[l.to(dev) for l in labels])
     captured = {}
     orig = model.genrate_syn
 
@@ -556,8 +571,9 @@ def test_shared_frozen_stem(phase2, monkeypatch):
     assert shared2 is False and calls2 == 1
 
 
+@LAYOUTS
 @pytest.mark.parametrize('phase2', [False, True])
-def test_full_size_vs_oracle(phase2):
+def test_full_size_vs_oracle(phase2, layout):
     """BASELINE size - bs 2, 800x800, 300 / 280 point annotations - against the CPU oracle on the same weights, inputs and draws:
     every entry of the loss dict within 1e-3 and the gradients of the representative parameters within 3e-3 of their norm (the
     conditioning of fp32 at this size, see tests/test_reference_iteration.py), in both phases; in phase 1 also the rectangle
@@ -577,7 +593,8 @@ def test_full_size_vs_oracle(phase2):
                      for k, v in inj.items()}
     sd_s0 = _strip(model.state_dict(), 'student.')
     sd_t0 = _strip(model.state_dict(), 'teacher.')
-    data = dict(img=img.to(dev), img_metas=metas, gt_bboxes=[b.to(dev) for b in boxes], gt_labels=[l.to(dev) for l in labels])
+    model, img_dev = _layout(model, img.to(dev), layout)
+    data = dict(img=img_dev, img_metas=metas, gt_bboxes=[b.to(dev) for b in boxes], gt_labels=[l.to(dev) for l in labels])
     captured = {}
     orig = model.genrate_syn
 
