@@ -109,16 +109,20 @@ def algorithmic_flops(name, shapes):
 
 def conv_desc_shapes(d):
     """Shapes out of a pt_conv_desc / pt_conv_wgrad_desc (host struct); np: planes per operand (3: fp32 as six bf16 products,
-    1: bf16 operands, one product - the bf16 trunk of BASELINE configs[2])."""
+    1: bf16 operands, one product - the bf16 trunk of BASELINE configs[2]); f16: fp32 as two fp16 terms, three products."""
     Ho = (d.Hs + 2 * d.pad - d.KH) // d.stride + 1
     Wo = (d.Ws + 2 * d.pad - d.KW) // d.stride + 1
-    return dict(M=d.B * Ho * Wo, Cin=d.Cin, Cout=d.Cout, taps=d.KH * d.KW, np=(getattr(d, 'np', 3) or 3))
+    return dict(M=d.B * Ho * Wo, Cin=d.Cin, Cout=d.Cout, taps=d.KH * d.KW, np=(getattr(d, 'np', 3) or 3), f16=int(getattr(d, 'operand_f16', 0) or 0))
 
 
 def executed_flops(name, shapes):
     """bf16 MFMA FLOPs a matrix launch executes: six products per fp32 product (three-plane operands), one for bf16 operands."""
     f = algorithmic_flops(name, shapes)
-    return None if f is None else f * (1.0 if shapes.get('np', 3) == 1 else 6.0)
+    if f is None:
+        return None
+    if shapes.get('f16'):                # fp16 x 2 operands (the MIL head's first FC layer): three fp16 MFMA products
+        return f * 3.0
+    return f * (1.0 if shapes.get('np', 3) == 1 else 6.0)
 
 
 # the matrix kernels: every fp32 product of backbone / necks / towers / MIL FC stacks as six bf16 MFMA products (csrc/gemm_split.hip)

@@ -141,6 +141,11 @@ int pt_roi_align_fwd(const float* feat, const float* rois, int B, int C, int H, 
 int pt_roi_align_fwd_planes(const float* feat, const float* rois, int B, int C, int H, int W, int K, float spatial_scale,
                             int sampling_ratio, int aligned, int group, uint16_t* planes, int64_t plane_stride,
                             void* stream);
+/* The same block as TWO fp16 planes (value = h0 + h1, 22 significant bits; [2][(K + 1) * C * 49]): the operand of the MIL head's
+ * first FC layer on three fp16 MFMA products (pt_conv_desc.operand_f16).  RoI features are O(1) .. O(100): inside fp16's range. */
+int pt_roi_align_fwd_planes_f16(const float* feat, const float* rois, int B, int C, int H, int W, int K, float spatial_scale,
+                                int sampling_ratio, int aligned, int group, uint16_t* planes, int64_t plane_stride,
+                                void* stream);
 int pt_roi_align_bwd(const float* grad_out, const float* rois, int B, int C, int H, int W, int K,
                      int out_size, float spatial_scale, int sampling_ratio, int aligned,
                      int channels_last, int group, float* grad_feat, void* stream);
@@ -329,7 +334,12 @@ typedef struct {
   int32_t splits;
   int32_t dstride, out_H, out_W;
   int32_t np;
+  int32_t operand_f16;   /* != 0: x_planes / w_planes are TWO fp16 planes each (value = h0 + h1), three fp16 MFMA products per fp32
+                          * product instead of six bf16 ones; the epilogue's planes (res / mask / out) stay bf16 x np.  The caller
+                          * keeps the operands inside fp16's range: power-of-two scales, undone by `alpha` (see pt_planes_to_f16) */
+  float alpha;           /* the accumulator is multiplied by alpha first (0 = 1): the operands' power-of-two scales */
   int32_t reserved;
+  const float* alpha_dev; /* optional DEVICE scalar multiplied into alpha (1 / the scale pt_planes_to_f16 chose for a gradient) */
 } pt_conv_desc;
 int pt_conv_bf16x6_splits(int B, int Hs, int Ws, int Cin, int Cout, int KH, int KW, int stride, int pad, int tile_rows);
 int pt_conv_bf16x6(const pt_conv_desc* desc, void* stream);
@@ -354,6 +364,9 @@ typedef struct {
   int64_t workspace_elems;
   int32_t splits;
   int32_t np;
+  int32_t operand_f16;   /* gy_planes / x_planes are two fp16 planes each (as in pt_conv_desc) */
+  float alpha;           /* dw and dbias are multiplied by alpha (0 = 1) */
+  const float* alpha_dev; /* optional DEVICE scalar multiplied into alpha */
 } pt_conv_wgrad_desc;
 int pt_conv_wgrad_bf16x6_splits(int B, int Ho, int Wo, int KH, int KW, int Cin, int Cout);
 /* Trainable BatchNorm (eval-mode statistics) behind a convolution - OBB config 5, `norm_cfg=dict(type='BN', requires_grad=True)`,
@@ -376,6 +389,14 @@ int pt_split_bf16x3_gather(const void* src, int src_bf16, int64_t ld, int B, int
  * gradient of an activation with several consumers (a stage output feeding the next stage and an FPN lateral), or planes -> fp32. */
 int pt_planes_combine(const uint16_t* a, int64_t a_plane_stride, const uint16_t* b, int64_t b_plane_stride, const float* c,
                       const uint16_t* mask, int64_t n, int np, uint16_t* out, int64_t out_plane_stride, float* out_f32, void* stream);
+/* fp16 operands for the largest products of the path (the MIL head's first FC layer, fcos_head_p2b_ts.py:1202-1236: 12 544 -> 1 024
+ * over K RoIs): three bf16 planes (value = x0 + x1 + x2) -> TWO fp16 planes of scale * value (h0 + h1: 22
+ * significant bits, <= 3e-8 absolute below 0.125; saturated at +-60 000), same row-major layout, n elements per plane.  scale > 0: the
+ * caller's power of two.  scale == 0: chosen on the device - the power of two that brings the tensor's largest magnitude into
+ * [512, 1024) (gradient magnitudes depend on the loss normalisation: 1e-3 ... 1e-9 per element) - and written with its reciprocal to
+ * auto_scale[0], auto_scale[1] (device; the consumers' `alpha_dev` = auto_scale + 1); workspace: 1024 device floats.  Two launches. */
+int pt_planes_to_f16(const uint16_t* planes, int64_t plane_stride, int64_t n, float scale, uint16_t* out,
+                     int64_t out_stride, float* auto_scale, float* workspace, void* stream);
 
 /* GroupNorm (+ ReLU) on channels_last activations x[N, HW, C] (replaces torch.nn.GroupNorm behind the tower convolutions of the
  * oriented head: mmcv ConvModule with norm_cfg=dict(type='GN', num_groups=32) - the default of
@@ -414,6 +435,7 @@ typedef struct {
   int32_t np;
   const float* scale;
 } pt_conv_weight_item;
+#define PT_F16_WEIGHT_SCALE 16.0f   /* item.np == 2: the planes are two fp16 planes of PT_F16_WEIGHT_SCALE * w (operand_f16 consumers) */
 int pt_conv_weight_planes_batch(const pt_conv_weight_item* items, int n_items, int total_blocks, void* stream);
 
 /* Frozen BatchNorm (+ residual add) (+ ReLU) in one pass each way.  Every BatchNorm on the path

@@ -35,6 +35,7 @@
 namespace pt {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
 constexpr int GK = 32;              // k-step (bf16 elements): 64 bytes per row and plane
 constexpr int GBN = 128;            // tile columns
@@ -92,18 +93,6 @@ __global__ void __launch_bounds__(256)
 
 // EXPERIMENT (not on the training path): fp32 -> TWO fp16 planes, x = h0 + h1 to 22 significant bits (2^-23
 // relative; <= 3e-8 absolute below 0.125, where h1 is subnormal - the matrix cores multiply subnormals exactly), same blocked layout.
-typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split_pair_f16(float a, float b, unsigned& p0, unsigned& p1) {
-  f16x2_t h0;
-  h0[0] = (_Float16)a;                                  // round to nearest even
-  h0[1] = (_Float16)b;
-  f16x2_t h1;
-  h1[0] = (_Float16)(a - (float)h0[0]);                 // the residual is exact in fp32
-  h1[1] = (_Float16)(b - (float)h0[1]);
-  p0 = __builtin_bit_cast(unsigned, h0);
-  p1 = __builtin_bit_cast(unsigned, h1);
-}
-
 __global__ void __launch_bounds__(256)
     split_f16x2_kernel(const float* __restrict__ src, long ld, int R, int C, int RB, int KB, uint16_t* __restrict__ dst, long plane) {
   const int lane = threadIdx.x & 63, r16 = lane >> 2, q = lane & 3;
@@ -227,12 +216,22 @@ __global__ void __launch_bounds__(256)
       }
     }
   }
+  uint16_t* d = e.dst + block_off(rb, kb, KB, r16, q);
+  if (e.np == 2) {                                             // fp16 operand form: two planes of PT_F16_WEIGHT_SCALE * w
+    uint4 h0, h1;
+    split_pair_f16(v[0] * F16_WEIGHT_SCALE, v[1] * F16_WEIGHT_SCALE, h0.x, h1.x);
+    split_pair_f16(v[2] * F16_WEIGHT_SCALE, v[3] * F16_WEIGHT_SCALE, h0.y, h1.y);
+    split_pair_f16(v[4] * F16_WEIGHT_SCALE, v[5] * F16_WEIGHT_SCALE, h0.z, h1.z);
+    split_pair_f16(v[6] * F16_WEIGHT_SCALE, v[7] * F16_WEIGHT_SCALE, h0.w, h1.w);
+    *reinterpret_cast<uint4*>(d) = h0;
+    *reinterpret_cast<uint4*>(d + e.plane) = h1;
+    return;
+  }
   uint4 o0, o1, o2;
   split_pair(v[0], v[1], o0.x, o1.x, o2.x);
   split_pair(v[2], v[3], o0.y, o1.y, o2.y);
   split_pair(v[4], v[5], o0.z, o1.z, o2.z);
   split_pair(v[6], v[7], o0.w, o1.w, o2.w);
-  uint16_t* d = e.dst + block_off(rb, kb, KB, r16, q);
   *reinterpret_cast<uint4*>(d) = o0;
   if (e.np != 1) {
     *reinterpret_cast<uint4*>(d + e.plane) = o1;
@@ -285,6 +284,8 @@ struct ConvEpi {
   float* part;                      // splits > 1 (few output tiles, long k: the teacher's batch, layer4): workgroup (tile, s) multiplies
   int splits, ks_per;               //   k-steps [s * ks_per, (s + 1) * ks_per) and stores its raw fp32 tile to part[s][M][N];
                                     //   conv_splitk_finish_kernel adds the parts in a fixed order and runs this epilogue
+  float alpha;                      // applied to the accumulator first (fp16 operands: the power-of-two scales of the operands); 0 = 1
+  const float* alpha_dev;           // optional device scalar multiplied into alpha (the scale pt_planes_to_f16 chose on the device)
 };
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -304,6 +305,11 @@ __device__ __forceinline__ void planes_sum8(const uint4 a, const uint4 b, const 
 
 // The epilogue of one row x 8 columns (see ConvEpi); o = the accumulated products.
 __device__ __forceinline__ void conv_epilogue8(float (&o)[8], int grow, int gcol, int N, const ConvEpi& ep) {
+  if (ep.alpha != 0.f) {
+    const float al = ep.alpha_dev ? ep.alpha * *ep.alpha_dev : ep.alpha;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] *= al;
+  }
   if (ep.scale) {
     const float4 sa = *reinterpret_cast<const float4*>(ep.scale + gcol), sb = *reinterpret_cast<const float4*>(ep.scale + gcol + 4);
     o[0] *= sa.x; o[1] *= sa.y; o[2] *= sa.z; o[3] *= sa.w; o[4] *= sb.x; o[5] *= sb.y; o[6] *= sb.z; o[7] *= sb.w;
@@ -557,7 +563,6 @@ __global__ void __launch_bounds__(GTHREADS)
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         if constexpr (NP == 2) {                        // EXPERIMENT: fp32 as two fp16 terms, three products (a1 b1 ~ 2^-22 dropped)
-          typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
           const f16x8_t a0 = __builtin_bit_cast(f16x8_t, a[0]), a1 = __builtin_bit_cast(f16x8_t, a[1]);
           const f16x8_t b0 = __builtin_bit_cast(f16x8_t, b[c][0]), b1 = __builtin_bit_cast(f16x8_t, b[c][1]);
           cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0, cor[i][c], 0, 0, 0);
@@ -630,7 +635,7 @@ __global__ void __launch_bounds__(GTHREADS)
     if (ep.splits <= 1 && ep.out_planes && ep.zero_row >= 0 && m0 + BM >= M && threadIdx.x < 16 && n0 + threadIdx.x * 8 < N) {
       uint16_t* d = ep.out_planes + (long)ep.zero_row * N + n0 + threadIdx.x * 8;
       const uint4 z = make_uint4(0, 0, 0, 0);
-      for (int p = 0; p < NP; ++p) *reinterpret_cast<uint4*>(d + p * ep.out_plane) = z;
+      for (int p = 0; p < ep.np; ++p) *reinterpret_cast<uint4*>(d + p * ep.out_plane) = z;
     }
   }
 }
@@ -857,6 +862,12 @@ __global__ void __launch_bounds__(GTHREADS)
       if (more && i < NIMG) issue(i, cur ^ 1);         // wave-uniform
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
+        if constexpr (NP == 2) {                        // two fp16 terms per operand: three products (a1 b1 ~ 2^-22 dropped)
+          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a[1]), __builtin_bit_cast(f16x8_t, b[c][0]), cor[i][c], 0, 0, 0);
+          cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a[0]), __builtin_bit_cast(f16x8_t, b[c][1]), cor[i][c], 0, 0, 0);
+          acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a[0]), __builtin_bit_cast(f16x8_t, b[c][0]), acc[i][c], 0, 0, 0);
+          continue;
+        }
         if constexpr (NP == 3) {                        // smallest terms first
           cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[c][0], cor[i][c], 0, 0, 0);
           cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[c][1], cor[i][c], 0, 0, 0);
@@ -867,8 +878,16 @@ __global__ void __launch_bounds__(GTHREADS)
         acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[c][0], acc[i][c], 0, 0, 0);
       }
       if (bias_tile && (i & 3) == nb) {                 // wave-uniform
+        if constexpr (NP == 2) {
+          f16x8_t ones16;
 #pragma unroll
-        for (int p = NP - 1; p >= 0; --p) bsum[i >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[p], ones, bsum[i >> 2], 0, 0, 0);
+          for (int e = 0; e < 8; ++e) ones16[e] = (_Float16)1.0f;
+          bsum[i >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a[1]), ones16, bsum[i >> 2], 0, 0, 0);
+          bsum[i >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a[0]), ones16, bsum[i >> 2], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int p = NP - 1; p >= 0; --p) bsum[i >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[p], ones, bsum[i >> 2], 0, 0, 0);
+        }
       }
     }
   }
@@ -903,7 +922,9 @@ __global__ void __launch_bounds__(GTHREADS)
 // the items past n4 reduce the bias partials [S][O] the same way (no scale).
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float4* __restrict__ part, int S, long n4, int ld4, float4* __restrict__ out,
                                                            const float* __restrict__ row_scale, const float4* __restrict__ part_bias,
-                                                           int o4, float4* __restrict__ out_bias, int accumulate) {
+                                                           int o4, float4* __restrict__ out_bias, int accumulate, float alpha,
+                                                           const float* __restrict__ alpha_dev) {
+  if (alpha_dev) alpha *= *alpha_dev;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n4) {
     float4 a = part[i];
@@ -911,6 +932,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float4* __restr
       const float4 v = part[(long)s * n4 + i];
       a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
+    a.x *= alpha; a.y *= alpha; a.z *= alpha; a.w *= alpha;          // (fp16 operands: the power-of-two scale of the gradient; else 1)
     if (row_scale) {
       const float sc = row_scale[i / ld4];
       a.x *= sc; a.y *= sc; a.z *= sc; a.w *= sc;
@@ -927,6 +949,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float4* __restr
       const float4 v = part_bias[(long)s * o4 + j];
       a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
+    a.x *= alpha; a.y *= alpha; a.z *= alpha; a.w *= alpha;
     if (accumulate) {
       const float4 v = out_bias[j];
       a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
@@ -1076,6 +1099,58 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// largest magnitude of the planes' values per workgroup -> part[blockIdx.x] (no atomics: the consumer takes the maximum of the parts)
+__global__ void __launch_bounds__(256) planes_amax_kernel(const uint16_t* __restrict__ src, long plane, long units, float* __restrict__ part) {
+  __shared__ float sm[20];
+  float m = 0.f;
+  for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += (long)gridDim.x * blockDim.x) {
+    const long e = u << 3;
+    float v[8];
+    planes_sum8(*reinterpret_cast<const uint4*>(src + e), *reinterpret_cast<const uint4*>(src + plane + e),
+                *reinterpret_cast<const uint4*>(src + 2 * plane + e), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));
+  }
+  m = wave_max(m);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sm[w] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+
+// three bf16 planes -> two fp16 planes of scale * value (8 elements per thread); see pt_planes_to_f16.  n_part > 0: the scale is the
+// power of two that brings max(part[0 .. n_part)) into [512, 1024); workgroup 0 publishes it and its reciprocal in auto_scale[0 .. 2)
+__global__ void __launch_bounds__(256) planes_to_f16_kernel(const uint16_t* __restrict__ src, long plane, long units, float scale,
+                                                            uint16_t* __restrict__ dst, long out_plane, const float* __restrict__ part,
+                                                            int n_part, float* __restrict__ auto_scale) {
+  if (n_part > 0) {
+    __shared__ float sm[4];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n_part; i += blockDim.x) m = fmaxf(m, part[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    // finite, non-zero: 2^(9 - floor(log2 m)) puts m into [512, 1024); a zero / non-finite tensor keeps scale 1
+    scale = (m > 0.f && m < 3.0e38f) ? exp2f(9.f - floorf(log2f(m))) : 1.f;
+    scale = fminf(fmaxf(scale, 9.5367431640625e-07f), 1.099511627776e12f);      // 2^-20 ... 2^40
+    if (blockIdx.x == 0 && threadIdx.x == 0) { auto_scale[0] = scale; auto_scale[1] = 1.f / scale; }
+  }
+  for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += (long)gridDim.x * blockDim.x) {
+    const long e = u << 3;
+    float v[8];
+    planes_sum8(*reinterpret_cast<const uint4*>(src + e), *reinterpret_cast<const uint4*>(src + plane + e),
+                *reinterpret_cast<const uint4*>(src + 2 * plane + e), v);
+    uint4 h0, h1;
+    split_pair_f16(v[0] * scale, v[1] * scale, h0.x, h1.x);
+    split_pair_f16(v[2] * scale, v[3] * scale, h0.y, h1.y);
+    split_pair_f16(v[4] * scale, v[5] * scale, h0.z, h1.z);
+    split_pair_f16(v[6] * scale, v[7] * scale, h0.w, h1.w);
+    *reinterpret_cast<uint4*>(dst + e) = h0;
+    *reinterpret_cast<uint4*>(dst + out_plane + e) = h1;
+  }
+}
+
 }  // namespace pt
 
 using namespace pt;
@@ -1141,6 +1216,28 @@ extern "C" int pt_gemm_bf16x6_nt(const uint16_t* a_planes, int64_t a_plane_strid
                                        ConvGeom{}, ConvEpi{}, as_stream(stream));
   PT_REQUIRE(rc == 0, rc, "pt_gemm_bf16x6_nt: hipFuncSetAttribute failed (%d)", rc);
   PT_LAUNCH_CHECK("pt_gemm_bf16x6_nt");
+  return PT_OK;
+}
+
+extern "C" int pt_planes_to_f16(const uint16_t* planes, int64_t plane_stride, int64_t n, float scale, uint16_t* out, int64_t out_stride,
+                                float* auto_scale, float* workspace, void* stream) {
+  PT_REQUIRE(planes && out && n > 0 && (n & 7) == 0 && plane_stride >= n && out_stride >= n && (plane_stride & 7) == 0 && (out_stride & 7) == 0 &&
+                 ((((uintptr_t)planes) | ((uintptr_t)out)) & 15) == 0,
+             PT_EINVAL, "pt_planes_to_f16: n a multiple of 8, strides >= n, 16-byte aligned planes");
+  PT_REQUIRE(scale > 0.f || (scale == 0.f && auto_scale && workspace), PT_EINVAL,
+             "pt_planes_to_f16: scale > 0, or scale == 0 with auto_scale[2] and a 1024-float workspace");
+  const long units = n >> 3;
+  int nb = cdiv(units, 256);
+  nb = nb > 16384 ? 16384 : nb;
+  int n_part = 0;
+  if (scale == 0.f) {
+    n_part = nb > 1024 ? 1024 : nb;
+    hipLaunchKernelGGL(pt::planes_amax_kernel, dim3(n_part), dim3(256), 0, as_stream(stream), planes, (long)plane_stride, units, workspace);
+    PT_LAUNCH_CHECK("pt_planes_to_f16 (amax)");
+  }
+  hipLaunchKernelGGL(pt::planes_to_f16_kernel, dim3(nb), dim3(256), 0, as_stream(stream), planes, (long)plane_stride, units, scale, out,
+                     (long)out_stride, workspace, n_part, auto_scale);
+  PT_LAUNCH_CHECK("pt_planes_to_f16");
   return PT_OK;
 }
 
@@ -1340,7 +1437,13 @@ extern "C" int pt_conv_bf16x6(const pt_conv_desc* d, void* stream) {
     ep.splits = S;
     ep.ks_per = (KB + S - 1) / S;
   }
-  rc = np == 1 ? launch_by_rows<true, 1>(tile_rows, d->x_planes, d->w_planes, nullptr, nullptr, nullptr, (int)M, d->Cout, KB, d->x_plane_stride,
+  PT_REQUIRE(!d->operand_f16 || np == 3, PT_EINVAL, "pt_conv_bf16x6: operand_f16 goes with np = 3 epilogue planes");
+  ep.alpha = d->alpha;
+  ep.alpha_dev = d->alpha_dev;
+  PT_REQUIRE(!d->alpha_dev || d->alpha != 0.f, PT_EINVAL, "pt_conv_bf16x6: alpha_dev multiplies alpha (set alpha, e.g. 1)");
+  rc = d->operand_f16 ? launch_by_rows<true, 2>(tile_rows, d->x_planes, d->w_planes, nullptr, nullptr, nullptr, (int)M, d->Cout, KB,
+                                               d->x_plane_stride, d->w_plane_stride, d->Cout, 0, cg, ep, as_stream(stream))
+     : np == 1 ? launch_by_rows<true, 1>(tile_rows, d->x_planes, d->w_planes, nullptr, nullptr, nullptr, (int)M, d->Cout, KB, d->x_plane_stride,
                                          d->w_plane_stride, d->Cout, 0, cg, ep, as_stream(stream))
                : launch_by_rows<true, 3>(tile_rows, d->x_planes, d->w_planes, nullptr, nullptr, nullptr, (int)M, d->Cout, KB, d->x_plane_stride,
                                          d->w_plane_stride, d->Cout, 0, cg, ep, as_stream(stream));
@@ -1423,21 +1526,22 @@ extern "C" int pt_conv_wgrad_bf16x6(const pt_conv_wgrad_desc* d, void* stream) {
   WgradGeom wg{d->Hs, d->Ws, Ho, Wo, d->Cin, d->Cout, d->KW, taps, d->stride, d->pad, (int)P, (int)Ps, kbt, (kbt + S - 1) / S, d->Cout / bm,
                taps * d->Cin / GBN, d->dbias ? 1 : 0, (d->Cout / bm > 1 && (long)taps * d->Cin > d->Cout) ? 1 : 0};
   // one chunk and nothing to apply afterwards: the tiles ARE the result
-  const bool direct = S == 1 && !d->row_scale && !d->accumulate;
+  const float alpha = d->alpha != 0.f ? d->alpha : 1.f;
+  const bool direct = S == 1 && !d->row_scale && !d->accumulate && alpha == 1.f && !d->alpha_dev;
   float* part = direct ? d->dw : d->workspace;
   float* part_bias = direct ? d->dbias : d->workspace + (long)S * n;
   PT_REQUIRE(d->np == 0 || d->np == 1 || d->np == 3, PT_EINVAL, "pt_conv_wgrad_bf16x6: np = 3 (or 0) planes per operand, or 1");
-  const bool one = d->np == 1;
-  const int rc = bm == 256 ? (one ? launch_wgrad<8, 1>(d->gy_planes, d->x_planes, part, part_bias, d->gy_plane_stride, d->x_plane_stride, wg, S, as_stream(stream))
-                                  : launch_wgrad<8, 3>(d->gy_planes, d->x_planes, part, part_bias, d->gy_plane_stride, d->x_plane_stride, wg, S, as_stream(stream)))
-                           : (one ? launch_wgrad<4, 1>(d->gy_planes, d->x_planes, part, part_bias, d->gy_plane_stride, d->x_plane_stride, wg, S, as_stream(stream))
-                                  : launch_wgrad<4, 3>(d->gy_planes, d->x_planes, part, part_bias, d->gy_plane_stride, d->x_plane_stride, wg, S, as_stream(stream)));
+  PT_REQUIRE(!d->operand_f16 || d->np != 1, PT_EINVAL, "pt_conv_wgrad_bf16x6: operand_f16 = two fp16 planes per operand (np is not 1)");
+  const bool one = d->np == 1, f16 = d->operand_f16 != 0;
+#define PT_WG(MB_, NP_) launch_wgrad<MB_, NP_>(d->gy_planes, d->x_planes, part, part_bias, d->gy_plane_stride, d->x_plane_stride, wg, S, as_stream(stream))
+  const int rc = bm == 256 ? (f16 ? PT_WG(8, 2) : one ? PT_WG(8, 1) : PT_WG(8, 3)) : (f16 ? PT_WG(4, 2) : one ? PT_WG(4, 1) : PT_WG(4, 3));
+#undef PT_WG
   PT_REQUIRE(rc == 0, rc, "pt_conv_wgrad_bf16x6: hipFuncSetAttribute failed (%d)", rc);
   PT_LAUNCH_CHECK("pt_conv_wgrad_bf16x6");
   if (direct) return PT_OK;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n / 4 + nbias / 4, 256)), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const float4*>(d->workspace), S, n / 4, taps * d->Cin / 4, reinterpret_cast<float4*>(d->dw), d->row_scale,
-                     reinterpret_cast<const float4*>(part_bias), (int)(nbias / 4), reinterpret_cast<float4*>(d->dbias), d->accumulate);
+                     reinterpret_cast<const float4*>(part_bias), (int)(nbias / 4), reinterpret_cast<float4*>(d->dbias), d->accumulate, alpha, d->alpha_dev);
   PT_LAUNCH_CHECK("pt_conv_wgrad_bf16x6 (reduce)");
   return PT_OK;
 }

@@ -87,6 +87,26 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsig
 }
 
 
+// fp32 -> TWO fp16 terms x = h0 + h1 (11 + 11 significant bits: 2^-23 relative; <= 3e-8 absolute below 0.125, where h1 is subnormal -
+// the matrix cores multiply subnormals exactly): the operand format of the three-product fp16 instantiations of the matrix kernels
+// (csrc/gemm_split.hip; the MIL head's 12 544 -> 1 024 layer).  Tensors are scaled by powers of two into fp16's range by their producer.
+constexpr float F16_WEIGHT_SCALE = 16.f;   // weights (|w| ~ 0.01 ... 1) are stored as fp16 planes of 16 w: h1 stays a normal number down
+                                           // to |w| ~ 0.008; the consumer's alpha carries the 1 / 16 (include/pt_hip.h: PT_F16_WEIGHT_SCALE)
+constexpr float F16_SAT = 60000.f;         // magnitudes beyond fp16's range saturate instead of becoming inf
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair_f16(float a, float b, unsigned& p0, unsigned& p1) {
+  a = fminf(fmaxf(a, -F16_SAT), F16_SAT);
+  b = fminf(fmaxf(b, -F16_SAT), F16_SAT);
+  f16x2_t h0;
+  h0[0] = (_Float16)a;                                  // round to nearest even
+  h0[1] = (_Float16)b;
+  f16x2_t h1;
+  h1[0] = (_Float16)(a - (float)h0[0]);                 // the residual is exact in fp32
+  h1[1] = (_Float16)(b - (float)h0[1]);
+  p0 = __builtin_bit_cast(unsigned, h0);
+  p1 = __builtin_bit_cast(unsigned, h1);
+}
+
 // sigmoid exactly as torch's CPU/CUDA kernels compute it: 1 / (1 + exp(-x))
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 

@@ -347,9 +347,19 @@ __device__ __forceinline__ void tile_store(const float* __restrict__ tile, float
 }
 // The same block as three bf16 planes (x = x0 + x1 + x2): what the FC stack's matrix kernel stages (csrc/gemm_split.hip), so
 // neither the fp32 block nor a split pass over it ever touches HBM.  nf % 8 == 0, dst 16-byte aligned.
-__device__ __forceinline__ void tile_store_planes(const float* __restrict__ tile, uint16_t* __restrict__ dst, long plane, int nf) {
+__device__ __forceinline__ void tile_store_planes(const float* __restrict__ tile, uint16_t* __restrict__ dst, long plane, int nf, int np) {
   for (int i = threadIdx.x; i < (nf >> 3); i += blockDim.x) {
     const float4 lo = *reinterpret_cast<const float4*>(tile + 8 * i), hi = *reinterpret_cast<const float4*>(tile + 8 * i + 4);
+    if (np == 2) {                                   // two fp16 planes (pt_roi_align_fwd_planes_f16)
+      uint4 h0, h1;
+      split_pair_f16(lo.x, lo.y, h0.x, h1.x);
+      split_pair_f16(lo.z, lo.w, h0.y, h1.y);
+      split_pair_f16(hi.x, hi.y, h0.z, h1.z);
+      split_pair_f16(hi.z, hi.w, h0.w, h1.w);
+      *reinterpret_cast<uint4*>(dst + 8 * i) = h0;
+      *reinterpret_cast<uint4*>(dst + plane + 8 * i) = h1;
+      continue;
+    }
     uint4 o0, o1, o2;
     split_pair(lo.x, lo.y, o0.x, o1.x, o2.x);
     split_pair(lo.z, lo.w, o0.y, o1.y, o2.y);
@@ -498,7 +508,7 @@ __device__ void rows_path(const float* __restrict__ gout, int k0, int m, int C, 
 __global__ void __launch_bounds__(256)
     roi_align7_fwd(const float* __restrict__ feat, const float* __restrict__ rois, int B, int C, int H, int W, int K,
                    int gs, float scale, int sampling_ratio, int aligned, float* __restrict__ out, int tile_bytes,
-                   uint16_t* __restrict__ out_planes, long plane) {
+                   uint16_t* __restrict__ out_planes, long plane, int np) {
   extern __shared__ __align__(16) unsigned char smem[];
   float* tile = reinterpret_cast<float*>(smem);                       // [<=256][49]
   Roi7Lds& S = *reinterpret_cast<Roi7Lds*>(smem + tile_bytes);
@@ -506,7 +516,7 @@ __global__ void __launch_bounds__(256)
   if (out_planes && blockIdx.x == 0) {                                 // row K of the planes: the zero row the matrix kernels read
     const uint4 z = make_uint4(0, 0, 0, 0);
     for (int i = threadIdx.x; i < (C * 49) >> 3; i += blockDim.x)
-      for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(out_planes + p * plane + (size_t)K * C * 49 + 8 * i) = z;
+      for (int p = 0; p < np; ++p) *reinterpret_cast<uint4*>(out_planes + p * plane + (size_t)K * C * 49 + 8 * i) = z;
   }
   run_setup(rois, k0, n, B, H, W, scale, sampling_ratio, aligned, S);
   const bool path_a = S.ub[5] != 0;
@@ -547,7 +557,7 @@ __global__ void __launch_bounds__(256)
             }
         }
         __syncthreads();
-        if (out_planes) tile_store_planes(tile, out_planes + ((size_t)(k0 + r) * C + c0) * 49, plane, nc * 49);
+        if (out_planes) tile_store_planes(tile, out_planes + ((size_t)(k0 + r) * C + c0) * 49, plane, nc * 49, np);
         else tile_store(tile, out + ((size_t)(k0 + r) * C + c0) * 49, nc * 49);
         __syncthreads();
       }
@@ -642,7 +652,7 @@ __global__ void __launch_bounds__(256)
           }
         }
         __syncthreads();
-        if (out_planes) tile_store_planes(tile, out_planes + ((size_t)(k0 + r) * C + c0) * 49, plane, nc * 49);
+        if (out_planes) tile_store_planes(tile, out_planes + ((size_t)(k0 + r) * C + c0) * 49, plane, nc * 49, np);
         else tile_store(tile, out + ((size_t)(k0 + r) * C + c0) * 49, nc * 49);
         __syncthreads();
       }
@@ -932,7 +942,7 @@ extern "C" int pt_roi_align_fwd(const float* feat, const float* rois, int B, int
     if (e != hipSuccess) { set_error("pt_roi_align_fwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
     const int gs = run_length(group, K, 2048);
     hipLaunchKernelGGL(roi_align7_fwd, dim3(cdiv(K, gs)), dim3(256), ROI7_LDS, s, feat, rois, B, C, H, W, K, gs,
-                       spatial_scale, sampling_ratio, aligned, out, ROI7_TILE_BYTES, (uint16_t*)nullptr, 0L);
+                       spatial_scale, sampling_ratio, aligned, out, ROI7_TILE_BYTES, (uint16_t*)nullptr, 0L, 3);
   } else if (channels_last) {
     const size_t lds = (size_t)(C + 1) * out_size * out_size * sizeof(float);
     hipError_t e = roi_generic_attr();
@@ -951,26 +961,39 @@ extern "C" int pt_roi_align_fwd(const float* feat, const float* rois, int B, int
   return PT_OK;
 }
 
-extern "C" int pt_roi_align_fwd_planes(const float* feat, const float* rois, int B, int C, int H, int W, int K, float spatial_scale,
-                                       int sampling_ratio, int aligned, int group, uint16_t* planes, int64_t plane_stride,
-                                       void* stream) {
+static int roi_fwd_planes(const char* fn, int np, const float* feat, const float* rois, int B, int C, int H, int W, int K, float spatial_scale,
+                          int sampling_ratio, int aligned, int group, uint16_t* planes, int64_t plane_stride, void* stream) {
   PT_REQUIRE(planes && K >= 0 && C > 0 && (C * 49) % 8 == 0 && plane_stride >= (int64_t)(K + 1) * C * 49 && (plane_stride & 7) == 0 &&
                  (((uintptr_t)planes) & 15) == 0,
              PT_EINVAL, "pt_roi_align_fwd_planes: planes of (K + 1) * C * 49 elements each, 16-byte aligned, C * 49 a multiple of 8");
   if (K == 0) {
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < np; ++p)
       if (hipMemsetAsync(planes + p * plane_stride, 0, (size_t)C * 49 * 2, as_stream(stream)) != hipSuccess) return PT_EINVAL;
     return PT_OK;
   }
-  int rc = roi_check("pt_roi_align_fwd_planes", feat, rois, planes, B, C, H, W, K, NB, 1);
+  int rc = roi_check(fn, feat, rois, planes, B, C, H, W, K, NB, 1);
   if (rc) return rc;
   hipError_t e = roi7_attr();
   if (e != hipSuccess) { set_error("pt_roi_align_fwd_planes: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
   const int gs = run_length(group, K, 2048);
   hipLaunchKernelGGL(roi_align7_fwd, dim3(cdiv(K, gs)), dim3(256), ROI7_LDS, as_stream(stream), feat, rois, B, C, H, W, K, gs, spatial_scale,
-                     sampling_ratio, aligned, (float*)nullptr, ROI7_TILE_BYTES, planes, (long)plane_stride);
-  PT_LAUNCH_CHECK("pt_roi_align_fwd_planes");
+                     sampling_ratio, aligned, (float*)nullptr, ROI7_TILE_BYTES, planes, (long)plane_stride, np);
+  PT_LAUNCH_CHECK(fn);
   return PT_OK;
+}
+
+extern "C" int pt_roi_align_fwd_planes(const float* feat, const float* rois, int B, int C, int H, int W, int K, float spatial_scale,
+                                       int sampling_ratio, int aligned, int group, uint16_t* planes, int64_t plane_stride,
+                                       void* stream) {
+  return roi_fwd_planes("pt_roi_align_fwd_planes", 3, feat, rois, B, C, H, W, K, spatial_scale, sampling_ratio, aligned, group, planes,
+                        plane_stride, stream);
+}
+
+extern "C" int pt_roi_align_fwd_planes_f16(const float* feat, const float* rois, int B, int C, int H, int W, int K, float spatial_scale,
+                                           int sampling_ratio, int aligned, int group, uint16_t* planes, int64_t plane_stride,
+                                           void* stream) {
+  return roi_fwd_planes("pt_roi_align_fwd_planes_f16", 2, feat, rois, B, C, H, W, K, spatial_scale, sampling_ratio, aligned, group, planes,
+                        plane_stride, stream);
 }
 
 extern "C" int pt_roi_align_bwd(const float* grad_out, const float* rois, int B, int C, int H, int W, int K,

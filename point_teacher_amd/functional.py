@@ -412,15 +412,20 @@ class _RoIAlignPlanes(torch.autograd.Function):
     checks shape and dtype."""
 
     @staticmethod
-    def forward(ctx, feat, rois, scale, sampling_ratio, aligned, group):
+    def forward(ctx, feat, rois, scale, sampling_ratio, aligned, group, f16=False):
         B, C, H, W = feat.shape
         assert feat.dtype == f32 and feat.is_contiguous(memory_format=torch.channels_last)
         fbuf = feat.permute(0, 2, 3, 1)
         rois = _f(rois)
         K = rois.shape[0]
         n = (K + 1) * C * 49
-        t = torch.empty((3, n), dtype=torch.bfloat16, device=feat.device)
-        hip.call('pt_roi_align_fwd_planes', fbuf, rois, B, C, H, W, K, float(scale), sampling_ratio, int(aligned), int(group), t, n)
+        if f16:     # two fp16 planes (value = h0 + h1): the operand of the first FC layer's three-product kernels (F16_FC)
+            t = torch.empty((2, n), dtype=torch.float16, device=feat.device)
+            hip.call('pt_roi_align_fwd_planes_f16', fbuf, rois, B, C, H, W, K, float(scale), sampling_ratio, int(aligned), int(group),
+                     t.view(torch.bfloat16), n)
+        else:
+            t = torch.empty((3, n), dtype=torch.bfloat16, device=feat.device)
+            hip.call('pt_roi_align_fwd_planes', fbuf, rois, B, C, H, W, K, float(scale), sampling_ratio, int(aligned), int(group), t, n)
         ctx.save_for_backward(rois)
         ctx.cfg = (B, C, H, W, float(scale), sampling_ratio, int(aligned), int(group))
         return t
@@ -433,7 +438,7 @@ class _RoIAlignPlanes(torch.autograd.Function):
         g = carrier.contiguous().view(-1).view(f32)[:K * C * 49]
         gbuf = torch.zeros((B, H, W, C), dtype=f32, device=g.device)
         hip.call('pt_roi_align_bwd', g, rois, B, C, H, W, K, 7, scale, sr, aligned, 1, group, gbuf)
-        return gbuf.permute(0, 3, 1, 2), None, None, None, None, None
+        return gbuf.permute(0, 3, 1, 2), None, None, None, None, None, None
 
 
 def roi_align_planes_ok(feat, rois, output_size):
@@ -441,9 +446,15 @@ def roi_align_planes_ok(feat, rois, output_size):
             and feat.is_contiguous(memory_format=torch.channels_last) and not torch.is_autocast_enabled())
 
 
-def roi_align_planes(feat, rois, spatial_scale=1.0, sampling_ratio=0, aligned=True, group=1):
-    """-> bf16 [3, (K + 1) * C * 49]: row-major split planes of roi_align(...).flatten(1) (+ a zero row)."""
-    return _RoIAlignPlanes.apply(feat, rois, spatial_scale, int(sampling_ratio), bool(aligned), int(group))
+# The MIL head's first FC layer (12 544 -> 1 024 over K RoIs: the largest products of the iteration) on fp16 x 2 operands and THREE MFMA
+# products per fp32 product instead of bf16 x 3 and six (planes._PlaneConv).  PT_F16_FC=0: six products everywhere.
+F16_FC = os.environ.get('PT_F16_FC', '1') != '0'
+F16_WEIGHT_SCALE = 16.0        # csrc: PT_F16_WEIGHT_SCALE
+
+
+def roi_align_planes(feat, rois, spatial_scale=1.0, sampling_ratio=0, aligned=True, group=1, f16=False):
+    """-> bf16 [3, (K + 1) * C * 49]: row-major split planes of roi_align(...).flatten(1) (+ a zero row); f16: fp16 [2, ...]."""
+    return _RoIAlignPlanes.apply(feat, rois, spatial_scale, int(sampling_ratio), bool(aligned), int(group), bool(f16))
 
 
 def roi_align(feat, rois, output_size=7, spatial_scale=1.0, sampling_ratio=0, aligned=True, group=1):

@@ -667,7 +667,7 @@ class RoIAlign(nn.Module):
         """planes=True: the result as planes.PlaneAct [1, K, 1, C * 49] - the split planes of `.flatten(1)` - when the kernel takes the
         shape (functional.roi_align_planes_ok); the caller feeds it to planes.linear."""
         if planes and _PLANE_TRUNK and rois.shape[0] > 0 and F.roi_align_planes_ok(input, rois, self.output_size):
-            t = F.roi_align_planes(input, rois, self.spatial_scale, self.sampling_ratio, self.aligned, group)
+            t = F.roi_align_planes(input, rois, self.spatial_scale, self.sampling_ratio, self.aligned, group, f16=F.F16_FC)
             return PL.PlaneAct(t, 1, rois.shape[0], 1, input.shape[1] * self.output_size ** 2, False, gcarrier=True)
         return F.roi_align(input, rois, self.output_size, self.spatial_scale, self.sampling_ratio, self.aligned, group)
 

@@ -50,8 +50,14 @@ class PlaneAct:
     def shape(self):
         return (self.B, self.C, self.H, self.W)
 
+    @property
+    def f16(self):
+        """Two fp16 planes (value = h0 + h1): the operand format of the three-product kernels (functional.F16_FC)."""
+        return self.t.dtype == torch.float16
+
     def float(self):
         """-> fp32 [B, C, H, W] channels_last tensor (exact: x0 + x1 + x2), differentiable."""
+        assert not self.f16, 'fp16 planes feed the first FC layer only (planes.linear)'
         return _PlanesToF32.apply(self.t, self)
 
 
@@ -137,6 +143,23 @@ def to_planes(x):
     return PlaneAct((_Bf16ToPlane if x.dtype == bf16 else _F32ToPlanes).apply(x), B, H, W, C, False)
 
 
+def _u16(t):
+    """Device pointer of a 16-bit plane tensor (bf16, or fp16 planes: the header's uint16_t* is 16-bit storage)."""
+    if t is None:
+        return 0
+    return hip.dptr(t.view(bf16) if t.dtype == torch.float16 else t, 'uint16_t')
+
+
+def to_f16_planes(t):
+    """Three bf16 planes -> (two fp16 planes of s * value, device tensor [1] holding 1 / s): s = the power of two that brings the
+    tensor's largest magnitude into [512, 1024), chosen on the device (pt_planes_to_f16 with scale 0: gradient magnitudes follow the
+    loss normalisation - 1e-3 per element at K = 5 000 RoIs, 1e-8 at K = 60 750 - and fp16 keeps 22 bits only above 0.125)."""
+    out = torch.empty((2, t.shape[1]), dtype=torch.float16, device=t.device)
+    buf = torch.empty((2 + 1024,), dtype=f32, device=t.device)
+    hip.call('pt_planes_to_f16', t, t.shape[1], t.shape[1], 0.0, out.view(bf16), out.shape[1], buf, buf[2:])
+    return out, buf[1:2]
+
+
 def out_hw(H, W, K, stride, pad):
     return (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
 
@@ -160,14 +183,15 @@ def _splits(fn, *shape):
 
 def launch_conv(x_t, B, Hs, Ws, Cin, wp, Cout, K, stride, pad, scale=None, shift=None, res_planes=None, res_f32=None,
                 mask_planes=None, relu=False, want_planes=False, want_f32=False, scatter=None, tile_rows=0, splits=None, f32_out=None,
-                transposed_out=None):
+                transposed_out=None, alpha=None, alpha_dev=None):
     """pt_conv_bf16x6: x_t row-major planes of [B*Hs*Ws (+1), Cin]; wp SplitPlanes of the weight.  -> (planes or None, fp32 rows or
     None).  scatter = (H, W): a stride-2 input gradient placed at (2y, 2x) of a zeroed [B, H, W] grid."""
     Ho, Wo = out_hw(Hs, Ws, K, stride, pad) if transposed_out is None else transposed_out
     M = B * Ho * Wo
     rows = M if scatter is None else B * scatter[0] * scatter[1]
     dev = x_t.device
-    np_ = x_t.shape[0]
+    f16 = x_t.dtype == torch.float16                          # fp16 x 2 operands, three products; the epilogue's planes stay bf16 x 3
+    np_ = 3 if f16 else x_t.shape[0]
     out_p = _new_planes(rows, Cout, dev, zero=scatter is not None, np=np_) if want_planes else None
     out_f = (torch.zeros if scatter is not None else torch.empty)((rows, Cout), dtype=f32, device=dev) if want_f32 else None
     if f32_out is not None:                                   # a caller-provided fp32 buffer of rows * Cout elements
@@ -176,7 +200,11 @@ def launch_conv(x_t, B, Hs, Ws, Cin, wp, Cout, K, stride, pad, scale=None, shift
     d = hip.STRUCTS['pt_conv_desc']()
     d.B, d.Hs, d.Ws, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad, d.relu = B, Hs, Ws, Cin, Cout, K, K, stride, pad, int(bool(relu))
     d.np = np_
-    d.x_planes, d.x_plane_stride = hip.dptr(x_t, 'uint16_t'), x_t.shape[1]
+    d.operand_f16 = int(f16)
+    d.alpha = float(alpha) if alpha is not None else 0.0
+    d.alpha_dev = hip.dptr(alpha_dev, 'float')
+    assert f16 == (wp.planes.shape[0] == 2), 'fp16 activations go with fp16 weight planes'
+    d.x_planes, d.x_plane_stride = _u16(x_t), x_t.shape[1]
     d.w_planes, d.w_plane_stride = hip.dptr(wp.planes, 'uint16_t'), wp.planes.shape[1]
     d.scale, d.shift = hip.dptr(scale, 'float'), hip.dptr(shift, 'float')
     if res_planes is not None:
@@ -214,7 +242,8 @@ def wgrad_ok(Cin, Cout):
     return Cin % 128 == 0 and Cout % 128 == 0
 
 
-def launch_wgrad(gy_t, x_t, B, Hs, Ws, Cin, Cout, K, stride, pad, row_scale=None, want_bias=False, bn=None, w=None):
+def launch_wgrad(gy_t, x_t, B, Hs, Ws, Cin, Cout, K, stride, pad, row_scale=None, want_bias=False, bn=None, w=None, alpha=None,
+                 alpha_dev=None):
     """pt_conv_wgrad_bf16x6 -> (dw as a channels_last [Cout, Cin, K, K] tensor, dbias or None).
     bn = (scale, rstd, mean) of a TRAINABLE eval-mode BatchNorm behind the convolution (w = its weight): -> (dw, dbeta, dgamma)
     through pt_bn_wgrad_finish."""
@@ -229,10 +258,14 @@ def launch_wgrad(gy_t, x_t, B, Hs, Ws, Cin, Cout, K, stride, pad, row_scale=None
     db = torch.empty((Cout,), dtype=f32, device=dev) if want_bias else None
     d = hip.STRUCTS['pt_conv_wgrad_desc']()
     d.B, d.Hs, d.Ws, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad, d.accumulate = B, Hs, Ws, Cin, Cout, K, K, stride, pad, 0
-    d.np = gy_t.shape[0]
-    assert x_t.shape[0] == gy_t.shape[0]
-    d.gy_planes, d.gy_plane_stride = hip.dptr(gy_t, 'uint16_t'), gy_t.shape[1]
-    d.x_planes, d.x_plane_stride = hip.dptr(x_t, 'uint16_t'), x_t.shape[1]
+    f16 = gy_t.dtype == torch.float16
+    d.np = 3 if f16 else gy_t.shape[0]
+    d.operand_f16 = int(f16)
+    d.alpha = float(alpha) if alpha is not None else 0.0
+    d.alpha_dev = hip.dptr(alpha_dev, 'float')
+    assert x_t.shape[0] == gy_t.shape[0] and x_t.dtype == gy_t.dtype
+    d.gy_planes, d.gy_plane_stride = _u16(gy_t), gy_t.shape[1]
+    d.x_planes, d.x_plane_stride = _u16(x_t), x_t.shape[1]
     d.dw, d.dbias, d.row_scale = hip.dptr(dw, 'float'), hip.dptr(db, 'float'), hip.dptr(row_scale, 'float')
     d.workspace, d.workspace_elems, d.splits = hip.dptr(ws, 'float'), ws.numel(), S
     assert gy_t.shape[1] >= (B * Ho * Wo + 1) * Cout and x_t.shape[1] >= (B * Hs * Ws + 1) * Cin
@@ -315,13 +348,16 @@ class _PlaneConv(torch.autograd.Function):
         else:
             xt, _, _ = split_nhwc(x)                               # fp32 -> three planes, bf16 -> one
         np_ = xt.shape[0]
+        f16 = xt.dtype == torch.float16                            # fp16 x 2 operands (np_ == 2): three products, weights stored x 16
+        assert not f16 or c.scale is None
         wp = F._conv_weight_planes(w, False, None, np_)
         as_planes = c.out_planes or np_ == 1                       # (the one-plane result IS the bf16 tensor)
         yp, yf = launch_conv(xt, c.B, c.H, c.W, c.Cin, wp, c.Cout, c.K, c.stride, c.pad, scale=c.scale, shift=shift, relu=c.relu,
-                             want_planes=as_planes, want_f32=not as_planes)
+                             want_planes=as_planes, want_f32=not as_planes, alpha=1.0 / F.F16_WEIGHT_SCALE if f16 else None)
         Ho, Wo = out_hw(c.H, c.W, c.K, c.stride, c.pad)
         ctx.cfg = c
         ctx.np = np_
+        ctx.f16 = f16
         ctx.out_hw = (Ho, Wo)
         need_x_for_mask = c.x_planes and c.x_relu
         keep_y = c.relu and not c.out_planes
@@ -349,15 +385,24 @@ class _PlaneConv(torch.autograd.Function):
             rows = g.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(M, c.Cout)
             E = F._split_rows(rows, relu_of=yf)
         gx = gw = gb = None
+        f16 = ctx.f16
+        a_dx = a_dw = inv_s = None
+        if f16:
+            # fp16 x 2 operands: the gradient enters as two fp16 planes of s * g, s a power of two chosen on the device from the
+            # tensor's largest magnitude (unscaled, 1e-3 ... 1e-9 would sit in fp16's subnormal range); the kernels' alpha scales the
+            # results back (powers of two: exact)
+            E, inv_s = to_f16_planes(E)
+            a_dx, a_dw = 1.0 / F.F16_WEIGHT_SCALE, 1.0
         if ctx.needs_input_grad[0]:
             assert c.stride == 1, 'the single-consumer plane convolution back-propagates stride 1 only'
             wd = F._conv_weight_planes(w, True, c.scale, np_)
             if c.x_planes and c.x_gcarrier:
                 # the producer of x (RoIAlign) wants its gradient as fp32: it travels in the head of a tensor of x's shape
-                gx = torch.empty((3, (c.B * c.H * c.W + 1) * c.Cin), dtype=bf16, device=E.device)
+                gx = torch.empty((np_ if f16 else 3, (c.B * c.H * c.W + 1) * c.Cin), dtype=torch.float16 if f16 else bf16, device=E.device)
                 launch_conv(E, c.B, Ho, Wo, c.Cout, wd, c.Cin, c.K, 1, c.K - 1 - c.pad,
-                            f32_out=gx.view(-1).view(f32)[:c.B * c.H * c.W * c.Cin])
+                            f32_out=gx.view(-1).view(f32)[:c.B * c.H * c.W * c.Cin], alpha=a_dx, alpha_dev=inv_s)
             else:
+                assert not f16, 'fp16 operands: the first FC layer behind RoIAlign only (its gradient leaves as fp32)'
                 xp_out = c.x_planes or np_ == 1
                 gp, gf = launch_conv(E, c.B, Ho, Wo, c.Cout, wd, c.Cin, c.K, 1, c.K - 1 - c.pad,
                                      mask_planes=xt if (c.x_planes and c.x_relu) else None, want_planes=xp_out, want_f32=not xp_out)
@@ -369,7 +414,7 @@ class _PlaneConv(torch.autograd.Function):
                     gx = gf.view(c.B, c.H, c.W, c.Cin).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
             gw, gb = launch_wgrad(E, xt, c.B, c.H, c.W, c.Cin, c.Cout, c.K, c.stride, c.pad, row_scale=c.scale,
-                                  want_bias=bool(c.bias_grad and ctx.needs_input_grad[2]))
+                                  want_bias=bool(c.bias_grad and ctx.needs_input_grad[2]), alpha=a_dw, alpha_dev=inv_s)
             if w.dim() == 2:
                 gw = gw.reshape(w.shape)
         return gx, gw, gb, None

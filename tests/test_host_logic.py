@@ -204,11 +204,14 @@ def test_bench_matrix_family_accounting():
     d = hip.STRUCTS['pt_conv_desc']()
     d.B, d.Hs, d.Ws, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad = 6, 100, 100, 512, 256, 1, 1, 2, 0
     shp = bench.conv_desc_shapes(d)
-    assert shp == dict(M=6 * 50 * 50, Cin=512, Cout=256, taps=1, np=3)          # (np unset reads as the three-plane fp32 operands)
+    assert shp == dict(M=6 * 50 * 50, Cin=512, Cout=256, taps=1, np=3, f16=0)   # (np unset reads as the three-plane fp32 operands)
     assert bench.executed_flops('pt_conv_bf16x6', shp) == 6.0 * bench.algorithmic_flops('pt_conv_bf16x6', shp)
     d.np = 1                                                                     # bf16 operands (BASELINE configs[2]): one MFMA product
     assert bench.executed_flops('pt_conv_bf16x6', bench.conv_desc_shapes(d)) == bench.algorithmic_flops('pt_conv_bf16x6', shp)
     d.np = 3
+    d.operand_f16 = 1                                                            # fp16 x 2 operands: three products
+    assert bench.executed_flops('pt_conv_bf16x6', bench.conv_desc_shapes(d)) == 3.0 * bench.algorithmic_flops('pt_conv_bf16x6', shp)
+    d.operand_f16 = 0
     assert bench.algorithmic_flops('pt_conv_bf16x6', shp) == bench.algorithmic_flops('pt_conv_wgrad_bf16x6', shp) == 2.0 * 15000 * 256 * 512
     d.KH = d.KW = 3
     d.stride, d.pad = 1, 1

@@ -369,10 +369,12 @@ def test_resnet_fpn_planes_vs_fp64_and_the_fp32_routing(monkeypatch):
     assert med < 1e-4
 
 
-def test_roi_planes_and_fc_stack_vs_fp64():
+@pytest.mark.parametrize('f16', [False, True])
+def test_roi_planes_and_fc_stack_vs_fp64(f16):
     """RoIAlign writing split planes + the FC stack as 1x1 convolutions over the RoIs (fcos_head_p2b_ts.py:1202-1236): the planes sum
     to pt_roi_align_fwd's block bit for bit; Linear -> ReLU -> Linear -> ReLU and every gradient (input map through the fp32
-    carrier, weights, biases) against the same stack in float64."""
+    carrier, weights, biases) against the same stack in float64.  f16: the first layer on fp16 x 2 operands and three MFMA products
+    (RoI block as two fp16 planes within 2^-22, weights x 16, gradient planes x 2^12) - the SAME bars."""
     from point_teacher_amd import functional as F, planes as PL
     g = torch.Generator().manual_seed(4)
     B, C, H, W, K = 2, 256, 40, 36, 2500
@@ -382,8 +384,14 @@ def test_roi_planes_and_fc_stack_vs_fp64():
     rois = torch.stack([torch.randint(0, B, (K,), generator=g).float(), cx - wh[:, 0] / 2, cy - wh[:, 1] / 2, cx + wh[:, 0] / 2, cy + wh[:, 1] / 2], 1).to(DEV)
     ref_block = F.roi_align(feat.detach(), rois, 7, 0.125, 0, True, 5)
     assert F.roi_align_planes_ok(feat, rois, 7)
-    t = F.roi_align_planes(feat, rois, 0.125, 0, True, 5)
-    assert torch.equal(_planes_to_f32(t.detach(), K, C * 49), ref_block.flatten(1))
+    t = F.roi_align_planes(feat, rois, 0.125, 0, True, 5, f16=f16)
+    if f16:
+        assert t.dtype == torch.float16 and t.shape[0] == 2 and float(t[:, K * C * 49:].abs().max()) == 0
+        val = t[0, :K * C * 49].detach().float() + t[1, :K * C * 49].detach().float()
+        ref_flat = ref_block.flatten()
+        assert float((val - ref_flat).abs().max()) <= 2.0 ** -22 * float(ref_flat.abs().max()) + 3e-8
+    else:
+        assert torch.equal(_planes_to_f32(t.detach(), K, C * 49), ref_block.flatten(1))
     torch.manual_seed(1)
     fc1, fc2 = torch.nn.Linear(C * 49, 1024).to(DEV), torch.nn.Linear(1024, 1024).to(DEV)
     x = PL.PlaneAct(t, 1, K, 1, C * 49, False, gcarrier=True)
