@@ -564,9 +564,10 @@ def main():
             n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),
             higher_is_better=True, scaling='weak', vs_baseline=None,
             # arithmetic type of the path; every fp32 product of the trainable trunk, the necks, the towers and the MIL FC stacks is
-            # formed from six bf16 MFMA products with fp32 accumulation (csrc/gemm_split.hip: error vs float64 below the fp32
+            # formed from six bf16 MFMA products - three fp16 ones in the MIL head's first FC layer - with fp32 accumulation
+            # (csrc/gemm_split.hip: error vs float64 below the fp32
             # library kernels'; activations travel between the layers as exact three-term bf16 splits of their fp32 values)
-            dtype=('f32' + (' (backbone / neck / tower convolutions and MIL FC stacks: bf16x6 split MFMA, fp32 accumulate)'
+            dtype=('f32' + (' (backbone / neck / tower convolutions and MIL FC stacks: bf16x6 split MFMA - the first FC layer fp16x3 -, fp32 accumulate)'
                             if os.environ.get('PT_SPLIT_GEMM', '1') != '0' and os.environ.get('PT_SPLIT_CONV', '1') != '0' else ''))
             if args.dtype == 'fp32' else 'bf16', data='synthetic',
             config=dict(workload=(f'sodaa_fcos_pointteacher_1x (oriented) ' if obb else f'aitodv2_point_teacher_{args.percent}% ')
