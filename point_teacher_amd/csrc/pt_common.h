@@ -90,7 +90,7 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsig
 // fp32 -> TWO fp16 terms x = h0 + h1 (11 + 11 significant bits: 2^-23 relative; <= 3e-8 absolute below 0.125, where h1 is subnormal -
 // the matrix cores multiply subnormals exactly): the operand format of the three-product fp16 instantiations of the matrix kernels
 // (csrc/gemm_split.hip; the MIL head's 12 544 -> 1 024 layer).  Tensors are scaled by powers of two into fp16's range by their producer.
-constexpr float F16_WEIGHT_SCALE = 16.f;   // weights (|w| ~ 0.01 ... 1) are stored as fp16 planes of 16 w: h1 stays a normal number down
+constexpr float F16_WEIGHT_SCALE = PT_F16_WEIGHT_SCALE;   // weights (|w| ~ 0.01 ... 1) are stored as fp16 planes of 16 w: h1 stays a normal number down
                                            // to |w| ~ 0.008; the consumer's alpha carries the 1 / 16 (include/pt_hip.h: PT_F16_WEIGHT_SCALE)
 constexpr float F16_SAT = 60000.f;         // magnitudes beyond fp16's range saturate instead of becoming inf
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));

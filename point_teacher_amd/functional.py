@@ -449,7 +449,7 @@ def roi_align_planes_ok(feat, rois, output_size):
 # The MIL head's first FC layer (12 544 -> 1 024 over K RoIs: the largest products of the iteration) on fp16 x 2 operands and THREE MFMA
 # products per fp32 product instead of bf16 x 3 and six (planes._PlaneConv).  PT_F16_FC=0: six products everywhere.
 F16_FC = os.environ.get('PT_F16_FC', '1') != '0'
-F16_WEIGHT_SCALE = 16.0        # csrc: PT_F16_WEIGHT_SCALE
+F16_WEIGHT_SCALE = hip.header_constant('PT_F16_WEIGHT_SCALE')        # weight planes with np = 2 hold 16 w (include/pt_hip.h)
 
 
 def roi_align_planes(feat, rois, spatial_scale=1.0, sampling_ratio=0, aligned=True, group=1, f16=False):

@@ -82,6 +82,14 @@ for _n, (_r, _a) in PROTOS.items():
 ABI_VERSION = _lib.pt_abi_version()
 
 
+def header_constant(name):
+    """A numeric `#define` of include/pt_hip.h (one source for constants the host side and the kernels share)."""
+    m = re.search(r'^#define\s+' + name + r'\s+([0-9.eE+-]+)f?\b', open(HEADER_PATH).read(), re.M)
+    if not m:
+        raise KeyError(f'{name} is not defined in {HEADER_PATH}')
+    return float(m.group(1))
+
+
 def last_error():
     return _lib.pt_last_error().decode()
 
