@@ -340,6 +340,8 @@ typedef struct {
   float alpha;           /* the accumulator is multiplied by alpha first (0 = 1): the operands' power-of-two scales */
   int32_t reserved;
   const float* alpha_dev; /* optional DEVICE scalar multiplied into alpha (1 / the scale pt_planes_to_f16 chose for a gradient) */
+  int32_t out_f16;        /* out_planes are two fp16 planes (the next layer's fp16 operand; a gradient keeps its producer's scale) */
+  int32_t reserved2;
 } pt_conv_desc;
 int pt_conv_bf16x6_splits(int B, int Hs, int Ws, int Cin, int Cout, int KH, int KW, int stride, int pad, int tile_rows);
 int pt_conv_bf16x6(const pt_conv_desc* desc, void* stream);

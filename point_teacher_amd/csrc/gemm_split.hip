@@ -286,6 +286,7 @@ struct ConvEpi {
                                     //   conv_splitk_finish_kernel adds the parts in a fixed order and runs this epilogue
   float alpha;                      // applied to the accumulator first (fp16 operands: the power-of-two scales of the operands); 0 = 1
   const float* alpha_dev;           // optional device scalar multiplied into alpha (the scale pt_planes_to_f16 chose on the device)
+  int out_f16;                      // out_planes are TWO fp16 planes (the next layer's fp16 operand) instead of np bf16 ones
 };
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -359,7 +360,16 @@ __device__ __forceinline__ void conv_epilogue8(float (&o)[8], int grow, int gcol
     *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
     *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
   }
-  if (ep.out_planes) {
+  if (ep.out_planes && ep.out_f16) {
+    uint4 h0, h1;
+    split_pair_f16(o[0], o[1], h0.x, h1.x);
+    split_pair_f16(o[2], o[3], h0.y, h1.y);
+    split_pair_f16(o[4], o[5], h0.z, h1.z);
+    split_pair_f16(o[6], o[7], h0.w, h1.w);
+    uint16_t* d = ep.out_planes + rout;
+    *reinterpret_cast<uint4*>(d) = h0;
+    *reinterpret_cast<uint4*>(d + ep.out_plane) = h1;
+  } else if (ep.out_planes) {
     uint4 p0, p1, p2;
     split_pair(o[0], o[1], p0.x, p1.x, p2.x);
     split_pair(o[2], o[3], p0.y, p1.y, p2.y);
@@ -395,7 +405,7 @@ __global__ void __launch_bounds__(256) conv_splitk_finish_kernel(int M, int N, C
     for (int c = threadIdx.x * 8; c < N; c += blockDim.x * 8) {
       uint16_t* d = ep.out_planes + (long)ep.zero_row * N + c;
       const uint4 z = make_uint4(0, 0, 0, 0);
-      for (int p = 0; p < ep.np; ++p) *reinterpret_cast<uint4*>(d + p * ep.out_plane) = z;
+      for (int p = 0; p < (ep.out_f16 ? 2 : ep.np); ++p) *reinterpret_cast<uint4*>(d + p * ep.out_plane) = z;
     }
   }
 }
@@ -635,7 +645,7 @@ __global__ void __launch_bounds__(GTHREADS)
     if (ep.splits <= 1 && ep.out_planes && ep.zero_row >= 0 && m0 + BM >= M && threadIdx.x < 16 && n0 + threadIdx.x * 8 < N) {
       uint16_t* d = ep.out_planes + (long)ep.zero_row * N + n0 + threadIdx.x * 8;
       const uint4 z = make_uint4(0, 0, 0, 0);
-      for (int p = 0; p < ep.np; ++p) *reinterpret_cast<uint4*>(d + p * ep.out_plane) = z;
+      for (int p = 0; p < (ep.out_f16 ? 2 : ep.np); ++p) *reinterpret_cast<uint4*>(d + p * ep.out_plane) = z;
     }
   }
 }
@@ -1027,14 +1037,22 @@ __global__ void __launch_bounds__(256)
         o0 = *reinterpret_cast<const uint4*>(sp);
       } else {
         const float4 lo = *reinterpret_cast<const float4*>(sp), hi = *reinterpret_cast<const float4*>(sp + 4);
-        split_pair(lo.x, lo.y, o0.x, o1.x, o2.x);
-        split_pair(lo.z, lo.w, o0.y, o1.y, o2.y);
-        split_pair(hi.x, hi.y, o0.z, o1.z, o2.z);
-        split_pair(hi.z, hi.w, o0.w, o1.w, o2.w);
+        if (np == 2) {                                  // two fp16 planes (operand_f16 consumers)
+          split_pair_f16(lo.x, lo.y, o0.x, o1.x);
+          split_pair_f16(lo.z, lo.w, o0.y, o1.y);
+          split_pair_f16(hi.x, hi.y, o0.z, o1.z);
+          split_pair_f16(hi.z, hi.w, o0.w, o1.w);
+        } else {
+          split_pair(lo.x, lo.y, o0.x, o1.x, o2.x);
+          split_pair(lo.z, lo.w, o0.y, o1.y, o2.y);
+          split_pair(hi.x, hi.y, o0.z, o1.z, o2.z);
+          split_pair(hi.z, hi.w, o0.w, o1.w, o2.w);
+        }
       }
     }
     uint16_t* d = dst + r * C + c;
     *reinterpret_cast<uint4*>(d) = o0;
+    if (np == 2) *reinterpret_cast<uint4*>(d + plane) = o1;
     if (np == 3) {
       *reinterpret_cast<uint4*>(d + plane) = o1;
       *reinterpret_cast<uint4*>(d + 2 * plane) = o2;
@@ -1294,7 +1312,8 @@ extern "C" int pt_split_bf16x3_gather(const void* src, int src_bf16, int64_t ld,
                                       uint16_t* planes, int64_t plane_stride, void* stream) {
   PT_REQUIRE(src && planes && B > 0 && Hs > 0 && Ws > 0 && C > 0 && (C & 7) == 0 && ld >= C && (ld & 7) == 0 && (stride == 1 || stride == 2),
              PT_EINVAL, "pt_split_bf16x3_gather: bad argument (C, ld multiples of 8; stride 1 or 2)");
-  PT_REQUIRE((np == 3 && !src_bf16) || np == 1, PT_EINVAL, "pt_split_bf16x3_gather: np 3 (fp32 source) or 1 (fp32 or bf16 source)");
+  PT_REQUIRE(((np == 3 || np == 2) && !src_bf16) || np == 1, PT_EINVAL,
+             "pt_split_bf16x3_gather: np 3 (fp32 source), 2 (fp32 source -> two fp16 planes) or 1 (fp32 or bf16 source)");
   const int Ho = (Hs - 1) / stride + 1, Wo = (Ws - 1) / stride + 1;
   const long P = (long)B * Ho * Wo;
   PT_REQUIRE(P < (1L << 30), PT_ELIMIT, "pt_split_bf16x3_gather: B * Ho * Wo < 2^30");
@@ -1440,6 +1459,8 @@ extern "C" int pt_conv_bf16x6(const pt_conv_desc* d, void* stream) {
   PT_REQUIRE(!d->operand_f16 || np == 3, PT_EINVAL, "pt_conv_bf16x6: operand_f16 goes with np = 3 epilogue planes");
   ep.alpha = d->alpha;
   ep.alpha_dev = d->alpha_dev;
+  ep.out_f16 = d->out_f16;
+  PT_REQUIRE(!d->out_f16 || (d->out_planes && np == 3), PT_EINVAL, "pt_conv_bf16x6: out_f16 writes two fp16 planes to out_planes (np = 3 launches)");
   PT_REQUIRE(!d->alpha_dev || d->alpha != 0.f, PT_EINVAL, "pt_conv_bf16x6: alpha_dev multiplies alpha (set alpha, e.g. 1)");
   rc = d->operand_f16 ? launch_by_rows<true, 2>(tile_rows, d->x_planes, d->w_planes, nullptr, nullptr, nullptr, (int)M, d->Cout, KB,
                                                d->x_plane_stride, d->w_plane_stride, d->Cout, 0, cg, ep, as_stream(stream))

@@ -116,9 +116,32 @@ class _F32ToPlanes2(torch.autograd.Function):
         return of.view(B, H, W, C).permute(0, 3, 1, 2)
 
 
-def to_planes2(x):
-    """x as planes for two consumers -> (PlaneAct, PlaneAct) sharing one set of planes."""
+class _F32ToF16Planes(torch.autograd.Function):
+    """fp32 channels_last [B, C, H, W] -> two fp16 planes (value = h0 + h1) for ONE or TWO consumers whose input gradients come back
+    as fp32 CARRIERS (tensors of the planes' shape holding the fp32 gradient in their head: planes._PlaneConv with x_gcarrier)."""
+
+    @staticmethod
+    def forward(ctx, x, two):
+        t, _, _ = split_nhwc(x, f16=True)
+        ctx.shape = x.shape
+        return (t.view_as(t), t.view_as(t)) if two else t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g1, g2=None):
+        B, C, H, W = ctx.shape
+        n = B * H * W * C
+        gs = [g.contiguous().view(-1).view(f32)[:n] for g in (g1, g2) if g is not None]
+        g = gs[0] if len(gs) == 1 else gs[0] + gs[1]
+        return g.view(B, H, W, C).permute(0, 3, 1, 2), None
+
+
+def to_planes2(x, f16=False):
+    """x as planes for two consumers -> (PlaneAct, PlaneAct) sharing one set of planes.  f16: two fp16 planes - the consumers run on
+    three fp16 MFMA products (functional.F16_FC) and return their input gradients as fp32 carriers."""
     B, C, H, W = x.shape
+    if f16:
+        a, b = _F32ToF16Planes.apply(x, True)
+        return PlaneAct(a, B, H, W, C, False, gcarrier=True), PlaneAct(b, B, H, W, C, False, gcarrier=True)
     a, b = _F32ToPlanes2.apply(x)
     return PlaneAct(a, B, H, W, C, False), PlaneAct(b, B, H, W, C, False)
 
@@ -137,9 +160,12 @@ class _Bf16ToPlane(torch.autograd.Function):
         return g.contiguous()[0, :B * H * W * C].view(B, H, W, C).permute(0, 3, 1, 2)
 
 
-def to_planes(x):
-    """Differentiable entry into plane mode (relu=False: the producer of x masks its own gradient): fp32 -> three planes, bf16 -> one."""
+def to_planes(x, f16=False):
+    """Differentiable entry into plane mode (relu=False: the producer of x masks its own gradient): fp32 -> three planes, bf16 -> one;
+    f16: fp32 -> two fp16 planes (see to_planes2)."""
     B, C, H, W = x.shape
+    if f16 and x.dtype == f32:
+        return PlaneAct(_F32ToF16Planes.apply(x, False), B, H, W, C, False, gcarrier=True)
     return PlaneAct((_Bf16ToPlane if x.dtype == bf16 else _F32ToPlanes).apply(x), B, H, W, C, False)
 
 
@@ -158,6 +184,9 @@ def to_f16_planes(t):
     buf = torch.empty((2 + 1024,), dtype=f32, device=t.device)
     hip.call('pt_planes_to_f16', t, t.shape[1], t.shape[1], 0.0, out.view(bf16), out.shape[1], buf, buf[2:])
     return out, buf[1:2]
+
+
+_F16_SCALES = {}      # data_ptr of an fp16 gradient plane tensor -> device tensor [1] with 1 / its scale (from its producer to its consumer)
 
 
 def out_hw(H, W, K, stride, pad):
@@ -183,7 +212,7 @@ def _splits(fn, *shape):
 
 def launch_conv(x_t, B, Hs, Ws, Cin, wp, Cout, K, stride, pad, scale=None, shift=None, res_planes=None, res_f32=None,
                 mask_planes=None, relu=False, want_planes=False, want_f32=False, scatter=None, tile_rows=0, splits=None, f32_out=None,
-                transposed_out=None, alpha=None, alpha_dev=None):
+                transposed_out=None, alpha=None, alpha_dev=None, out_f16=False):
     """pt_conv_bf16x6: x_t row-major planes of [B*Hs*Ws (+1), Cin]; wp SplitPlanes of the weight.  -> (planes or None, fp32 rows or
     None).  scatter = (H, W): a stride-2 input gradient placed at (2y, 2x) of a zeroed [B, H, W] grid."""
     Ho, Wo = out_hw(Hs, Ws, K, stride, pad) if transposed_out is None else transposed_out
@@ -192,7 +221,11 @@ def launch_conv(x_t, B, Hs, Ws, Cin, wp, Cout, K, stride, pad, scale=None, shift
     dev = x_t.device
     f16 = x_t.dtype == torch.float16                          # fp16 x 2 operands, three products; the epilogue's planes stay bf16 x 3
     np_ = 3 if f16 else x_t.shape[0]
-    out_p = _new_planes(rows, Cout, dev, zero=scatter is not None, np=np_) if want_planes else None
+    if want_planes and out_f16:                               # the next layer's fp16 operand
+        assert f16 and scatter is None
+        out_p = torch.empty((2, (rows + 1) * Cout), dtype=torch.float16, device=dev)
+    else:
+        out_p = _new_planes(rows, Cout, dev, zero=scatter is not None, np=np_) if want_planes else None
     out_f = (torch.zeros if scatter is not None else torch.empty)((rows, Cout), dtype=f32, device=dev) if want_f32 else None
     if f32_out is not None:                                   # a caller-provided fp32 buffer of rows * Cout elements
         assert f32_out.numel() == rows * Cout and f32_out.dtype == f32 and scatter is None
@@ -210,10 +243,11 @@ def launch_conv(x_t, B, Hs, Ws, Cin, wp, Cout, K, stride, pad, scale=None, shift
     if res_planes is not None:
         d.res_planes, d.res_plane_stride = hip.dptr(res_planes, 'uint16_t'), res_planes.shape[1]
     d.res_f32 = hip.dptr(res_f32, 'float')
-    d.mask_planes = hip.dptr(mask_planes, 'uint16_t')
+    d.mask_planes = _u16(mask_planes)
     d.out_f32 = hip.dptr(out_f, 'float')
     if out_p is not None:
-        d.out_planes, d.out_plane_stride = hip.dptr(out_p, 'uint16_t'), out_p.shape[1]
+        d.out_planes, d.out_plane_stride = _u16(out_p), out_p.shape[1]
+        d.out_f16 = int(out_p.dtype == torch.float16)
     if scatter is not None:
         d.scatter_stride, d.scatter_H, d.scatter_W = 2, scatter[0], scatter[1]
     d.tile_rows = int(tile_rows)
@@ -280,7 +314,7 @@ def launch_wgrad(gy_t, x_t, B, Hs, Ws, Cin, Cout, K, stride, pad, row_scale=None
     return dw.permute(0, 3, 1, 2), db
 
 
-def split_nhwc(x, stride=1, np=None):
+def split_nhwc(x, stride=1, np=None, f16=False):
     """channels_last [B, C, H, W] (fp32, or bf16 -> np = 1) -> row-major planes of the pixels (y * stride, x * stride)
     (pt_split_bf16x3_gather).  np: 3 (fp32 as x0 + x1 + x2) or 1 (one bf16 plane); default by the dtype."""
     B, C, H, W = x.shape
@@ -289,6 +323,11 @@ def split_nhwc(x, stride=1, np=None):
     np = (1 if is16 else 3) if np is None else np
     assert rows.is_contiguous() and x.dtype in (f32, bf16) and (np == 1 or not is16)
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if f16:                                                     # two fp16 planes (value = h0 + h1)
+        assert not is16
+        t = torch.empty((2, (B * Ho * Wo + 1) * C), dtype=torch.float16, device=x.device)
+        hip.call('pt_split_bf16x3_gather', rows, 0, C, B, H, W, C, stride, 2, t.view(bf16), t.shape[1])
+        return t, Ho, Wo
     t = _new_planes(B * Ho * Wo, C, x.device, np=np)
     hip.call('pt_split_bf16x3_gather', rows, int(is16), C, B, H, W, C, stride, np, t, t.shape[1])
     return t, Ho, Wo
@@ -329,7 +368,7 @@ class _PlanesToF32(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------ single convolution --
 class ConvCfg:
     """Static description of one plane convolution call (not a tensor: autograd passes it through)."""
-    __slots__ = ('B', 'H', 'W', 'Cin', 'Cout', 'K', 'stride', 'pad', 'relu', 'x_planes', 'x_relu', 'out_planes', 'scale', 'bias_grad', 'x_gcarrier')
+    __slots__ = ('B', 'H', 'W', 'Cin', 'Cout', 'K', 'stride', 'pad', 'relu', 'x_planes', 'x_relu', 'out_planes', 'scale', 'bias_grad', 'x_gcarrier', 'f16_out')
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -353,7 +392,8 @@ class _PlaneConv(torch.autograd.Function):
         wp = F._conv_weight_planes(w, False, None, np_)
         as_planes = c.out_planes or np_ == 1                       # (the one-plane result IS the bf16 tensor)
         yp, yf = launch_conv(xt, c.B, c.H, c.W, c.Cin, wp, c.Cout, c.K, c.stride, c.pad, scale=c.scale, shift=shift, relu=c.relu,
-                             want_planes=as_planes, want_f32=not as_planes, alpha=1.0 / F.F16_WEIGHT_SCALE if f16 else None)
+                             want_planes=as_planes, want_f32=not as_planes, alpha=1.0 / F.F16_WEIGHT_SCALE if f16 else None,
+                             out_f16=bool(f16 and c.f16_out))
         Ho, Wo = out_hw(c.H, c.W, c.K, c.stride, c.pad)
         ctx.cfg = c
         ctx.np = np_
@@ -375,8 +415,11 @@ class _PlaneConv(torch.autograd.Function):
         Ho, Wo = ctx.out_hw
         M = c.B * Ho * Wo
         np_ = ctx.np
+        inv_s = None
         if c.out_planes:
             E = g.contiguous()
+            if E.dtype == torch.float16:                           # an fp16 gradient chain: the scale its first link chose travels beside it
+                inv_s = _F16_SCALES.pop(E.data_ptr())
         elif np_ == 1:                                             # a bf16 gradient tensor: behind a zero row, masked by the result's ReLU
             E, _, _ = split_nhwc(g.to(bf16).contiguous(memory_format=torch.channels_last), np=1)
             if yf is not None:
@@ -386,12 +429,13 @@ class _PlaneConv(torch.autograd.Function):
             E = F._split_rows(rows, relu_of=yf)
         gx = gw = gb = None
         f16 = ctx.f16
-        a_dx = a_dw = inv_s = None
+        a_dx = a_dw = None
         if f16:
             # fp16 x 2 operands: the gradient enters as two fp16 planes of s * g, s a power of two chosen on the device from the
             # tensor's largest magnitude (unscaled, 1e-3 ... 1e-9 would sit in fp16's subnormal range); the kernels' alpha scales the
-            # results back (powers of two: exact)
-            E, inv_s = to_f16_planes(E)
+            # results back (powers of two: exact).  A chain of fp16 layers keeps the scale of its first link (saturating at 60 000)
+            if E.dtype != torch.float16:
+                E, inv_s = to_f16_planes(E)
             a_dx, a_dw = 1.0 / F.F16_WEIGHT_SCALE, 1.0
         if ctx.needs_input_grad[0]:
             assert c.stride == 1, 'the single-consumer plane convolution back-propagates stride 1 only'
@@ -401,8 +445,13 @@ class _PlaneConv(torch.autograd.Function):
                 gx = torch.empty((np_ if f16 else 3, (c.B * c.H * c.W + 1) * c.Cin), dtype=torch.float16 if f16 else bf16, device=E.device)
                 launch_conv(E, c.B, Ho, Wo, c.Cout, wd, c.Cin, c.K, 1, c.K - 1 - c.pad,
                             f32_out=gx.view(-1).view(f32)[:c.B * c.H * c.W * c.Cin], alpha=a_dx, alpha_dev=inv_s)
+            elif f16:
+                # the producer of x is another fp16 layer: its output gradient as fp16 planes of s * g, masked by x's ReLU
+                assert c.x_planes
+                gx, _ = launch_conv(E, c.B, Ho, Wo, c.Cout, wd, c.Cin, c.K, 1, c.K - 1 - c.pad, mask_planes=xt if c.x_relu else None,
+                                    want_planes=True, out_f16=True, alpha=a_dx)
+                _F16_SCALES[gx.data_ptr()] = inv_s
             else:
-                assert not f16, 'fp16 operands: the first FC layer behind RoIAlign only (its gradient leaves as fp32)'
                 xp_out = c.x_planes or np_ == 1
                 gp, gf = launch_conv(E, c.B, Ho, Wo, c.Cout, wd, c.Cin, c.K, 1, c.K - 1 - c.pad,
                                      mask_planes=xt if (c.x_planes and c.x_relu) else None, want_planes=xp_out, want_f32=not xp_out)
@@ -437,7 +486,8 @@ def conv_module(x, conv, relu=False, out_planes=False, scale=None, shift=None):
     B, Cin, H, W = x.shape
     k = conv.kernel_size[0]
     cfg = ConvCfg(B=B, H=H, W=W, Cin=Cin, Cout=conv.out_channels, K=k, stride=1, pad=conv.padding[0], relu=bool(relu), x_planes=is_p,
-                  x_relu=bool(is_p and x.relu), out_planes=bool(out_planes), scale=scale, bias_grad=scale is None and conv.bias is not None)
+                  x_relu=bool(is_p and x.relu), out_planes=bool(out_planes), scale=scale, bias_grad=scale is None and conv.bias is not None,
+                  x_gcarrier=bool(is_p and x.gcarrier), f16_out=bool(is_p and x.f16 and out_planes))      # an fp16 chain stays in fp16 planes
     sh = shift if shift is not None else conv.bias
     y = _PlaneConv.apply(x.t if is_p else x, conv.weight, sh, cfg)
     if out_planes:

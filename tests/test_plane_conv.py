@@ -605,3 +605,46 @@ def test_weight_plane_refresh_survives_a_collection_in_the_middle(monkeypatch):
     monkeypatch.setattr(F.np, 'zeros', real_zeros)
     F.PARAM_EPOCH[0] += 1
     assert torch.equal(F._conv_weight_planes(keep, False).planes, want)      # the dead entry is dropped by the next refresh
+
+
+@pytest.mark.parametrize('two', [False, True])
+def test_fp16_operand_tower_chain_vs_fp64(two):
+    """The dense head's towers on fp16 x 2 operands (functional.F16_FC; anchor_free_head.py:198-219): the map is split ONCE into two
+    fp16 planes for one or both towers, three 3x3 convolutions + bias + ReLU pass fp16 planes to one another (three MFMA products
+    each), the last writes fp32; backward: the output gradient becomes fp16 planes with a power-of-two scale chosen on the device,
+    the chain keeps that scale, the input gradient returns as an fp32 carrier.  Everything against float64."""
+    import torch.nn.functional as TF
+    from point_teacher_amd import planes as PL
+    from point_teacher_amd.nn_modules import ConvModule
+    g = torch.Generator().manual_seed(7)
+    B, C, H, W = 2, 128, 33, 29
+    torch.manual_seed(3)
+    towers = [[ConvModule(C, C, 3, padding=1).to(DEV).to(memory_format=torch.channels_last) for _ in range(3)] for _ in range(2 if two else 1)]
+    x = torch.randn(B, C, H, W, generator=g).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gys = [(torch.randn(B, C, H, W, generator=g) * 1e-4).to(DEV).contiguous(memory_format=torch.channels_last) for _ in towers]   # gradient-sized
+    acts = PL.to_planes2(x, f16=True) if two else (PL.to_planes(x, f16=True),)
+    outs = []
+    for act, layers in zip(acts, towers):
+        assert act.f16 and act.gcarrier
+        t = act
+        for i, l in enumerate(layers):
+            t = l(t, out_planes=i + 1 < len(layers))
+            assert (i + 1 == len(layers)) or (t.f16 and t.np == 2)
+        outs.append(t)
+    params = [p for layers in towers for l in layers for p in (l.conv.weight, l.conv.bias)]
+    got = torch.autograd.grad(outs, [x] + params, gys)
+    xd = x.detach().double().requires_grad_(True)
+    refs = []
+    for layers in towers:
+        t = xd
+        for l in layers:
+            t = torch.relu(TF.conv2d(t, l.conv.weight.double(), l.conv.bias.double(), padding=1))
+        refs.append(t)
+    want = torch.autograd.grad(refs, [xd] + params, [gy.double() for gy in gys])
+    for o, r in zip(outs, refs):
+        assert o.dtype == torch.float32 and float((o.double() - r).abs().max() / r.abs().max()) < 2e-6
+    # ReLU decisions within rounding of zero differ between fp32 and float64 on a handful of elements: norm-wise bars
+    for n, a, b in zip(['x'] + [f'p{i}' for i in range(len(params))], got, want):
+        err = float((a.double() - b.double()).norm() / b.double().norm())
+        assert err < 2e-4, (n, err)
+    assert not PL._F16_SCALES                                          # every link consumed the scale handed to it
