@@ -368,7 +368,7 @@ class _PlanesToF32(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------ single convolution --
 class ConvCfg:
     """Static description of one plane convolution call (not a tensor: autograd passes it through)."""
-    __slots__ = ('B', 'H', 'W', 'Cin', 'Cout', 'K', 'stride', 'pad', 'relu', 'x_planes', 'x_relu', 'out_planes', 'scale', 'bias_grad', 'x_gcarrier', 'f16_out')
+    __slots__ = ('B', 'H', 'W', 'Cin', 'Cout', 'K', 'stride', 'pad', 'relu', 'x_planes', 'x_relu', 'out_planes', 'scale', 'bias_grad', 'x_gcarrier', 'f16_out', 'x_f16')
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -385,7 +385,7 @@ class _PlaneConv(torch.autograd.Function):
         if c.x_planes:
             xt = x
         else:
-            xt, _, _ = split_nhwc(x)                               # fp32 -> three planes, bf16 -> one
+            xt, _, _ = split_nhwc(x, f16=bool(c.x_f16))            # fp32 -> three planes (or two fp16 ones), bf16 -> one
         np_ = xt.shape[0]
         f16 = xt.dtype == torch.float16                            # fp16 x 2 operands (np_ == 2): three products, weights stored x 16
         assert not f16 or c.scale is None
@@ -445,9 +445,11 @@ class _PlaneConv(torch.autograd.Function):
                 gx = torch.empty((np_ if f16 else 3, (c.B * c.H * c.W + 1) * c.Cin), dtype=torch.float16 if f16 else bf16, device=E.device)
                 launch_conv(E, c.B, Ho, Wo, c.Cout, wd, c.Cin, c.K, 1, c.K - 1 - c.pad,
                             f32_out=gx.view(-1).view(f32)[:c.B * c.H * c.W * c.Cin], alpha=a_dx, alpha_dev=inv_s)
+            elif f16 and not c.x_planes:                           # an fp32 input split here: its gradient leaves as fp32
+                _, gf = launch_conv(E, c.B, Ho, Wo, c.Cout, wd, c.Cin, c.K, 1, c.K - 1 - c.pad, want_f32=True, alpha=a_dx, alpha_dev=inv_s)
+                gx = gf.view(c.B, c.H, c.W, c.Cin).permute(0, 3, 1, 2)
             elif f16:
                 # the producer of x is another fp16 layer: its output gradient as fp16 planes of s * g, masked by x's ReLU
-                assert c.x_planes
                 gx, _ = launch_conv(E, c.B, Ho, Wo, c.Cout, wd, c.Cin, c.K, 1, c.K - 1 - c.pad, mask_planes=xt if c.x_relu else None,
                                     want_planes=True, out_f16=True, alpha=a_dx)
                 _F16_SCALES[gx.data_ptr()] = inv_s
@@ -479,15 +481,17 @@ def plane_conv_ok(conv, x_channels_last_f32_or_planes=True):
             and autocast_ok())
 
 
-def conv_module(x, conv, relu=False, out_planes=False, scale=None, shift=None):
+def conv_module(x, conv, relu=False, out_planes=False, scale=None, shift=None, f16=False):
     """[relu](conv(x) (* scale) + bias) through the plane kernels.  x: PlaneAct or fp32 channels_last tensor.
-    -> PlaneAct (out_planes) or fp32 channels_last tensor."""
+    -> PlaneAct (out_planes) or fp32 channels_last tensor.  f16 (an fp32 tensor in, an fp32 tensor out): the operands as two fp16
+    planes, three MFMA products (functional.F16_FC: the compute-bound 3x3 convolutions of the necks)."""
     is_p = isinstance(x, PlaneAct)
     B, Cin, H, W = x.shape
     k = conv.kernel_size[0]
     cfg = ConvCfg(B=B, H=H, W=W, Cin=Cin, Cout=conv.out_channels, K=k, stride=1, pad=conv.padding[0], relu=bool(relu), x_planes=is_p,
                   x_relu=bool(is_p and x.relu), out_planes=bool(out_planes), scale=scale, bias_grad=scale is None and conv.bias is not None,
-                  x_gcarrier=bool(is_p and x.gcarrier), f16_out=bool(is_p and x.f16 and out_planes))      # an fp16 chain stays in fp16 planes
+                  x_gcarrier=bool(is_p and x.gcarrier), f16_out=bool(is_p and x.f16 and out_planes),      # an fp16 chain stays in fp16 planes
+                  x_f16=bool(f16 and not is_p and not out_planes and scale is None and x.dtype == f32))
     sh = shift if shift is not None else conv.bias
     y = _PlaneConv.apply(x.t if is_p else x, conv.weight, sh, cfg)
     if out_planes:

@@ -648,3 +648,25 @@ def test_fp16_operand_tower_chain_vs_fp64(two):
         err = float((a.double() - b.double()).norm() / b.double().norm())
         assert err < 2e-4, (n, err)
     assert not PL._F16_SCALES                                          # every link consumed the scale handed to it
+
+
+def test_fp16_operand_single_convolution_vs_fp64():
+    """An FPN output convolution (necks/fpn.py:175-177: 3x3, bias, no activation) on fp16 x 2 operands: fp32 map in, fp32 map out,
+    input / weight / bias gradients from a gradient-sized output gradient, against float64."""
+    import torch.nn.functional as TF
+    from point_teacher_amd import planes as PL
+    g = torch.Generator().manual_seed(9)
+    B, C, H, W = 2, 256, 27, 31
+    torch.manual_seed(5)
+    conv = torch.nn.Conv2d(C, C, 3, padding=1).to(DEV).to(memory_format=torch.channels_last)
+    x = torch.randn(B, C, H, W, generator=g).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gy = (torch.randn(B, C, H, W, generator=g) * 3e-6).to(DEV).contiguous(memory_format=torch.channels_last)
+    y = PL.conv_module(x, conv, relu=False, f16=True)
+    got = torch.autograd.grad(y, [x, conv.weight, conv.bias], gy)
+    xd = x.detach().double().requires_grad_(True)
+    yr = TF.conv2d(xd, conv.weight.double(), conv.bias.double(), padding=1)
+    want = torch.autograd.grad(yr, [xd, conv.weight, conv.bias], gy.double())
+    assert y.dtype == torch.float32 and float((y.double() - yr).abs().max() / yr.abs().max()) < 2e-6
+    for n, a, b in zip(('x', 'w', 'b'), got, want):
+        err = float((a.double() - b.double()).abs().max() / b.double().abs().max())
+        assert err < 5e-6, (n, err)
