@@ -222,7 +222,7 @@ def launch_conv(x_t, B, Hs, Ws, Cin, wp, Cout, K, stride, pad, scale=None, shift
     f16 = x_t.dtype == torch.float16                          # fp16 x 2 operands, three products; the epilogue's planes stay bf16 x 3
     np_ = 3 if f16 else x_t.shape[0]
     if want_planes and out_f16:                               # the next layer's fp16 operand
-        assert f16 and scatter is None
+        assert np_ == 3 and scatter is None
         out_p = torch.empty((2, (rows + 1) * Cout), dtype=torch.float16, device=dev)
     else:
         out_p = _new_planes(rows, Cout, dev, zero=scatter is not None, np=np_) if want_planes else None
@@ -609,8 +609,13 @@ class _BottleneckP(torch.autograd.Function):
         def cw(w_, dgrad, sc=None):
             return F._conv_weight_planes(w_, dgrad, sc, np_)
         S = c.bn
-        y1, _ = launch_conv(xs, c.B, xH, xW, c.Cin, cw(w1, False), p, 1, r1, 0, scale=S['1'][0], shift=S['1'][1], relu=True, want_planes=True)
-        y2, _ = launch_conv(y1, c.B, Ha, Wa, p, cw(w2, False), p, 3, s2, 1, scale=S['2'][0], shift=S['2'][1], relu=True, want_planes=True)
+        # conv2 (3x3: the block's compute-bound product) on fp16 x 2 operands / three MFMA products (functional.F16_FC): conv1's
+        # epilogue writes y1 as two fp16 planes, conv2's weights are fp16 planes of 16 w (alpha = 1 / 16 in front of its BatchNorm)
+        h16 = bool(F.F16_FC and np_ == 3)
+        y1, _ = launch_conv(xs, c.B, xH, xW, c.Cin, cw(w1, False), p, 1, r1, 0, scale=S['1'][0], shift=S['1'][1], relu=True, want_planes=True,
+                            out_f16=h16)
+        y2, _ = launch_conv(y1, c.B, Ha, Wa, p, F._conv_weight_planes(w2, False, None, 2) if h16 else cw(w2, False), p, 3, s2, 1,
+                            scale=S['2'][0], shift=S['2'][1], relu=True, want_planes=True, alpha=1.0 / F.F16_WEIGHT_SCALE if h16 else None)
         if c.has_ds and np_ == 1:                                 # bf16 trunk: the identity travels as bf16 too
             idn, _ = launch_conv(xs, c.B, xH, xW, c.Cin, cw(wd, False), 4 * p, 1, rd, 0, scale=S['d'][0], shift=S['d'][1], want_planes=True)
             out, _ = launch_conv(y2, c.B, H1, W1, p, cw(w3, False), 4 * p, 1, 1, 0, scale=S['3'][0], shift=S['3'][1], res_planes=idn, relu=True,
@@ -641,24 +646,32 @@ class _BottleneckP(torch.autograd.Function):
         need_x = ctx.needs_input_grad[0]
         gw = {}                                                   # conv -> (dw, dbeta, dgamma)
 
-        def wgrad(tag, w, gy, xin, Hs_, Ws_, Ci, Co, K, stride, pad, need):
+        def wgrad(tag, w, gy, xin, Hs_, Ws_, Ci, Co, K, stride, pad, need, alpha_dev=None):
+            a = 1.0 if alpha_dev is not None else None
             if not need:
                 gw[tag] = (None, None, None)
             elif c.bn_train:
-                gw[tag] = launch_wgrad(gy, xin, c.B, Hs_, Ws_, Ci, Co, K, stride, pad, bn=(S[tag][0], S[tag][2], S[tag][3]), w=w)
+                gw[tag] = launch_wgrad(gy, xin, c.B, Hs_, Ws_, Ci, Co, K, stride, pad, bn=(S[tag][0], S[tag][2], S[tag][3]), w=w,
+                                       alpha=a, alpha_dev=alpha_dev)
             else:
-                gw[tag] = (launch_wgrad(gy, xin, c.B, Hs_, Ws_, Ci, Co, K, stride, pad, row_scale=S[tag][0])[0], None, None)
+                gw[tag] = (launch_wgrad(gy, xin, c.B, Hs_, Ws_, Ci, Co, K, stride, pad, row_scale=S[tag][0], alpha=a,
+                                        alpha_dev=alpha_dev)[0], None, None)
         ni = ctx.needs_input_grad
         # conv3: gradient of y2 (masked by y2's ReLU), weight gradient
         E2, _ = launch_conv(E, c.B, H1, W1, 4 * p, cw(w3, True, S['3'][0]), p, 1, 1, 0, mask_planes=y2, want_planes=True)
         wgrad('3', w3, E, y2, H1, W1, p, 4 * p, 1, 1, 0, ni[3])
-        # conv2 (a stride on it makes its input gradient a transposed convolution onto y1's grid)
-        if s2 == 1:
-            E1, _ = launch_conv(E2, c.B, H1, W1, p, cw(w2, True, S['2'][0]), p, 3, 1, 1, mask_planes=y1, want_planes=True)
-        else:
-            E1, _ = launch_conv(E2, c.B, H1, W1, p, cw(w2, True, S['2'][0]), p, 3, 1, 1, mask_planes=y1, want_planes=True,
-                                transposed_out=(Ha, Wa))
-        wgrad('2', w2, E2, y1, Ha, Wa, p, p, 3, s2, 1, ni[2])
+        # conv2 (a stride on it makes its input gradient a transposed convolution onto y1's grid).  y1 in fp16 planes (forward): the
+        # product runs on fp16 x 2 operands - E2 converted with a power-of-two scale chosen on the device (two small launches against
+        # half of a 3x3 product's MFMA work), weights x 16; the epilogue's alpha undoes both, E1 leaves as bf16 x 3 planes
+        h16 = y1.dtype == torch.float16
+        E2c, inv_s, a2 = E2, None, None
+        if h16:
+            E2c, inv_s = to_f16_planes(E2)
+            a2 = 1.0 / F.F16_WEIGHT_SCALE
+        wd2 = F._conv_weight_planes(w2, True, S['2'][0], 2) if h16 else cw(w2, True, S['2'][0])
+        E1, _ = launch_conv(E2c, c.B, H1, W1, p, wd2, p, 3, 1, 1, mask_planes=y1, want_planes=True, alpha=a2, alpha_dev=inv_s,
+                            transposed_out=(Ha, Wa) if s2 != 1 else None)
+        wgrad('2', w2, E2c, y1, Ha, Wa, p, p, 3, s2, 1, ni[2], alpha_dev=inv_s)
         # conv1 (+ downsample) weights
         wgrad('1', w1, E1, xs, xH, xW, c.Cin, p, 1, r1, 0, ni[1])
         if c.has_ds:
