@@ -449,6 +449,9 @@ def roi_align_planes_ok(feat, rois, output_size):
 # The MIL head's first FC layer (12 544 -> 1 024 over K RoIs: the largest products of the iteration) on fp16 x 2 operands and THREE MFMA
 # products per fp32 product instead of bf16 x 3 and six (planes._PlaneConv).  PT_F16_FC=0: six products everywhere.
 F16_FC = os.environ.get('PT_F16_FC', '1') != '0'
+F16_TOWERS = F16_FC and os.environ.get('PT_F16_TOWERS', '1') != '0'      # the dense head's towers
+F16_NECK3 = F16_FC and os.environ.get('PT_F16_NECK3', '1') != '0'        # single 3x3 convolutions of the necks (FPN outputs)
+F16_BLOCK3 = F16_FC and os.environ.get('PT_F16_BLOCK3', '1') != '0'      # the Bottlenecks' 3x3 convolution
 F16_WEIGHT_SCALE = hip.header_constant('PT_F16_WEIGHT_SCALE')        # weight planes with np = 2 hold 16 w (include/pt_hip.h)
 
 

@@ -160,9 +160,9 @@ class TS_P2BFCOSHead(nn.Module):
             # convolutions of a tower as split planes (bias + ReLU in the epilogues, masks in the input-gradient epilogues) and
             # only the last one writes the fp32 map the 8 / 4 / 1-channel output convolutions read
             if need_cls and need_reg:
-                xa, xb = PL.to_planes2(x, f16=F.F16_FC)           # (F16_FC: the towers on fp16 x 2 operands, three MFMA products)
+                xa, xb = PL.to_planes2(x, f16=F.F16_TOWERS)           # (F16_FC: the towers on fp16 x 2 operands, three MFMA products)
             else:
-                xa = xb = PL.to_planes(x, f16=F.F16_FC)
+                xa = xb = PL.to_planes(x, f16=F.F16_TOWERS)
 
             def tower(t, layers):
                 for i, l in enumerate(layers):

@@ -121,7 +121,7 @@ class ConvModule(nn.Module):
             # 1x1 / 3x3 convolutions of necks and towers (fp32 by the config): implicit GEMM on the bf16 matrix cores with split-bf16
             # operands and fp32 accumulation, bias (+ ReLU) in its epilogue, input / weight / bias gradients on the same kernels
             # (3x3: compute-bound - fp16 x 2 operands and three products when F16_FC; the 1x1s are bound by their bytes)
-            return PL.conv_module(x, c, relu=self.with_activation, f16=F.F16_FC and c.kernel_size == (3, 3))
+            return PL.conv_module(x, c, relu=self.with_activation, f16=F.F16_NECK3 and c.kernel_size == (3, 3))
         if (_SPLIT_CONV and type(c) is nn.Conv2d and c.bias is not None and not self.with_norm and self.with_activation
                 and F.split_conv3x3_ok(x, c)):
             # the dense head's tower convolutions (fp32 by the config): implicit GEMM on the bf16 matrix cores with split-bf16

@@ -611,7 +611,7 @@ class _BottleneckP(torch.autograd.Function):
         S = c.bn
         # conv2 (3x3: the block's compute-bound product) on fp16 x 2 operands / three MFMA products (functional.F16_FC): conv1's
         # epilogue writes y1 as two fp16 planes, conv2's weights are fp16 planes of 16 w (alpha = 1 / 16 in front of its BatchNorm)
-        h16 = bool(F.F16_FC and np_ == 3)
+        h16 = bool(F.F16_BLOCK3 and np_ == 3)
         y1, _ = launch_conv(xs, c.B, xH, xW, c.Cin, cw(w1, False), p, 1, r1, 0, scale=S['1'][0], shift=S['1'][1], relu=True, want_planes=True,
                             out_f16=h16)
         y2, _ = launch_conv(y1, c.B, Ha, Wa, p, F._conv_weight_planes(w2, False, None, 2) if h16 else cw(w2, False), p, 3, s2, 1,
