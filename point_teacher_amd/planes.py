@@ -512,7 +512,10 @@ def linear(x, fc, relu=False, out_planes=False):
     rows = x.H if is_p else x.shape[0]
     cfg = ConvCfg(B=1, H=rows, W=1, Cin=fc.in_features, Cout=fc.out_features, K=1, stride=1, pad=0, relu=bool(relu), x_planes=is_p,
                   x_relu=bool(is_p and x.relu), out_planes=bool(out_planes), scale=None, bias_grad=fc.bias is not None,
-                  x_gcarrier=bool(is_p and x.gcarrier))
+                  x_gcarrier=bool(is_p and x.gcarrier),
+                  # an fp32 block (the oriented head's RoIAlignRotated output) into a layer as large as the first FC layer: split
+                  # into two fp16 planes here, three MFMA products (functional.F16_FC)
+                  x_f16=bool(F.F16_FC and not is_p and fc.in_features >= 4096 and x.dtype == f32))
     xin = x.t if is_p else x.view(1, rows, 1, fc.in_features).permute(0, 3, 1, 2)
     y = _PlaneConv.apply(xin, fc.weight, fc.bias, cfg)
     if out_planes:
