@@ -516,6 +516,7 @@ def linear(x, fc, relu=False, out_planes=False):
                   # an fp32 block (the oriented head's RoIAlignRotated output) into a layer as large as the first FC layer: split
                   # into two fp16 planes here, three MFMA products (functional.F16_FC)
                   x_f16=bool(F.F16_FC and not is_p and fc.in_features >= 4096 and x.dtype == f32))
+    cfg.f16_out = bool(out_planes and ((is_p and x.f16) or cfg.x_f16))      # the next layer of the stack stays on fp16 operands
     xin = x.t if is_p else x.view(1, rows, 1, fc.in_features).permute(0, 3, 1, 2)
     y = _PlaneConv.apply(xin, fc.weight, fc.bias, cfg)
     if out_planes:

@@ -404,7 +404,10 @@ def test_roi_planes_and_fc_stack_vs_fp64(f16):
     assert float((y.detach().double() - yr.detach()).abs().max() / yr.detach().abs().max()) < 1e-5      # (the fp32 RoIAlign feeds 12544-term sums)
     # a ReLU whose pre-activation is within rounding of zero may decide differently in fp32 and float64 (2 x 2.5 M of them here);
     # the gradient of such a RoI then differs by a whole term - rows with any such element take no gradient in this comparison
-    flip = ((_planes_to_f32(y1.t.detach(), K, 1024) > 0) != (y1r.detach() > 0)).any(1) | ((y.detach() > 0) != (yr.detach() > 0)).any(1)
+    # (f16: the first layer hands TWO fp16 planes to the second, which stays on fp16 operands as well)
+    assert y1.f16 == f16
+    y1v = (y1.t[0, :K * 1024].float() + y1.t[1, :K * 1024].float()).view(K, 1024) if f16 else _planes_to_f32(y1.t.detach(), K, 1024)
+    flip = ((y1v.detach() > 0) != (y1r.detach() > 0)).any(1) | ((y.detach() > 0) != (yr.detach() > 0)).any(1)
     print('rows with a ReLU decided differently in fp32 and float64:', int(flip.sum()))
     assert int(flip.sum()) <= 20
     gy = torch.randn(K, 1024, generator=g).to(DEV) * (~flip)[:, None]
