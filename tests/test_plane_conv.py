@@ -276,8 +276,12 @@ def _make_block(inplanes, planes, stride, ds, seed, style='caffe', train_bn=Fals
     (512, 256, 2, True, 2, 40, 37, False, 'pytorch', True),
     (512, 256, 2, True, 2, 38, 38, False, 'caffe', True),
 ])
-def test_bottleneck_planes_vs_fp64(inplanes, planes, stride, ds, B, H, W, from_stem, style, train_bn):
-    from point_teacher_amd import planes as PL
+@pytest.mark.parametrize('f16_conv2', [True, False])
+def test_bottleneck_planes_vs_fp64(inplanes, planes, stride, ds, B, H, W, from_stem, style, train_bn, f16_conv2, monkeypatch):
+    """f16_conv2: the 3x3 convolution on fp16 x 2 operands and three MFMA products (functional.F16_BLOCK3, the default) or on
+    bf16 x 3 operands and six (PT_F16_BLOCK3=0) - the same bars."""
+    from point_teacher_amd import functional as F, planes as PL
+    monkeypatch.setattr(F, 'F16_BLOCK3', f16_conv2)
     blk = _make_block(inplanes, planes, stride, ds, 11, style, train_bn)
     assert blk.plane_ok()
     g = torch.Generator().manual_seed(3)
