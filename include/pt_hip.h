@@ -340,7 +340,19 @@ typedef struct {
   float alpha;           /* the accumulator is multiplied by alpha first (0 = 1): the operands' power-of-two scales */
   int32_t reserved;
   const float* alpha_dev; /* optional DEVICE scalar multiplied into alpha (1 / the scale pt_planes_to_f16 chose for a gradient) */
-  int32_t out_f16;        /* out_planes are two fp16 planes (the next layer's fp16 operand; a gradient keeps its producer's scale) */
+  int32_t out_f16;        /* out_planes are two fp16 planes IN THE SCALED FORMAT ("H2", ABI 6): [2][out_plane_stride] fp16 with
+                          * out_plane_stride >= (rows + 1) * Cout + 8; the fp32 word at element (rows + 1) * Cout of plane 0 (the
+                          * "tail") holds 1 / s, the represented value is (h0 + h1) / s.  The launch writes the tail: a copy of
+                          * *out_inv_scale_src, or 1 when that pointer is NULL */
+  int32_t res_f16;        /* res_planes are two fp16 planes (value = (h0 + h1) * *res_alpha_dev, or h0 + h1 when that is NULL) */
+  const float* res_alpha_dev;
+  const float* out_inv_scale_src; /* a GRADIENT CHAIN keeps the scale of its first link: the caller leaves the operand's 1 / s out of
+                          * alpha (the result then IS s * gradient) and passes the operand's tail here, so the output carries it on */
+  int32_t* census;        /* optional DEVICE int32[4] of the fp16 output (out_f16): [0] += elements that saturated (|v| > 60 000),
+                          * [1] = max(bits of the largest stored magnitude), and with census_mode 2 also [2] += non-zero elements
+                          * below 0.125 (second term subnormal) and [3] += elements written.  Mode 1 costs nothing measurable: the
+                          * atomics are issued per wavefront and only when they would change the word */
+  int32_t census_mode;    /* 0 / 1: saturation + maximum; 2: all four words (a debugging census) */
   int32_t reserved2;
 } pt_conv_desc;
 int pt_conv_bf16x6_splits(int B, int Hs, int Ws, int Cin, int Cout, int KH, int KW, int stride, int pad, int tile_rows);
@@ -368,7 +380,8 @@ typedef struct {
   int32_t np;
   int32_t operand_f16;   /* gy_planes / x_planes are two fp16 planes each (as in pt_conv_desc) */
   float alpha;           /* dw and dbias are multiplied by alpha (0 = 1) */
-  const float* alpha_dev; /* optional DEVICE scalar multiplied into alpha */
+  const float* alpha_dev; /* optional DEVICE scalar multiplied into alpha (the tail of a scaled fp16 gradient: 1 / its scale) */
+  const float* alpha_dev2; /* a second one (the tail of scaled fp16 activations); ABI 6 */
 } pt_conv_wgrad_desc;
 int pt_conv_wgrad_bf16x6_splits(int B, int Ho, int Wo, int KH, int KW, int Cin, int Cout);
 /* Trainable BatchNorm (eval-mode statistics) behind a convolution - OBB config 5, `norm_cfg=dict(type='BN', requires_grad=True)`,
@@ -399,6 +412,39 @@ int pt_planes_combine(const uint16_t* a, int64_t a_plane_stride, const uint16_t*
  * auto_scale[0], auto_scale[1] (device; the consumers' `alpha_dev` = auto_scale + 1); workspace: 1024 device floats.  Two launches. */
 int pt_planes_to_f16(const uint16_t* planes, int64_t plane_stride, int64_t n, float scale, uint16_t* out,
                      int64_t out_stride, float* auto_scale, float* workspace, void* stream);
+
+/* ABI 6 - the scaled fp16 x 2 plane format ("H2") as THE activation / gradient format of the trainable trunk, necks and heads
+ * (backbones/resnet.py:262-303, necks/fpn.py:151-202, necks/ps_fpn.py:56-75, dense_heads/anchor_free_head.py:198-219,
+ * fcos_head_p2b_ts.py:1202-1256): 4 bytes per element instead of the 6 of three bf16 planes, three MFMA products instead of six.
+ *
+ * pt_planes_mix: out = fmt_out(so * m * (ia * a + ib * b + c)) element-wise over n elements (n % 8 == 0) - format conversion, the
+ * exact addition of the gradients of an activation with two consumers, the entry of a gradient into an fp16 chain.
+ *   a, b: row-major planes; *_fmt: PT_FMT_F32 (a plain fp32 array; the pointer is reinterpreted), PT_FMT_BF16 (one bf16 plane),
+ *         PT_FMT_H2 (two fp16 planes, ia / ib = *a_inv / *b_inv - their tails - or 1 when NULL), PT_FMT_BF16X3; b may be NULL.
+ *   c: fp32 or NULL.  mask: plane 0 of any 16-bit plane set (m = plane 0 > 0) or NULL; relu_of: fp32 (m = relu_of > 0) or NULL.
+ *   out (format out_fmt, may be NULL) and / or out_f32.  For out_fmt == PT_FMT_H2 the output scale `so` follows scale_mode:
+ *     PT_SCALE_ONE      so = 1;
+ *     PT_SCALE_AUTO     the power of two that brings the largest magnitude of the result into [512, 1024) (a first launch reduces
+ *                       the maximum per workgroup into `workspace`, >= 1024 floats; a zero / non-finite tensor keeps 1);
+ *     PT_SCALE_MERGE    1 / max(ia, ib): two chains meet, the result carries the smaller of their scales (no overflow);
+ *   and the tail out_plane_stride - 8 ... is written with 1 / so: out_plane_stride >= n + 8, the tail sits at element n of plane 0.
+ *   n_valid <= n (a multiple of 8): elements [n_valid, n) are written as zeros without reading any source - the zero row behind
+ *   an fp32 source that has none.  census: as in pt_conv_desc (mode 1), or NULL. */
+#define PT_FMT_F32 0
+#define PT_FMT_BF16 1
+#define PT_FMT_H2 2
+#define PT_FMT_BF16X3 3
+#define PT_SCALE_ONE 0
+#define PT_SCALE_AUTO 1
+#define PT_SCALE_MERGE 2
+int pt_planes_mix(const void* a, int a_fmt, int64_t a_plane_stride, const float* a_inv, const void* b, int b_fmt, int64_t b_plane_stride,
+                  const float* b_inv, const float* c, const uint16_t* mask, const float* relu_of, int64_t n, int64_t n_valid, void* out, int out_fmt,
+                  int64_t out_plane_stride, int scale_mode, float* out_f32, float* workspace, int32_t* census, void* stream);
+/* fp32 NHWC [B, Hs, Ws, C] (pixel stride ld) -> H2 planes of the pixels (y * stride, x * stride) with a zero last row and tail 1:
+ * the frozen stem's output entering the fp16 trunk (resnet.py:153-158 caffe style: layer2's first Bottleneck reads through its
+ * stride).  plane_stride >= (B * Ho * Wo + 1) * C + 8. */
+int pt_split_gather_h2(const float* src, int64_t ld, int B, int Hs, int Ws, int C, int stride, uint16_t* planes, int64_t plane_stride,
+                       int32_t* census, void* stream);
 
 /* GroupNorm (+ ReLU) on channels_last activations x[N, HW, C] (replaces torch.nn.GroupNorm behind the tower convolutions of the
  * oriented head: mmcv ConvModule with norm_cfg=dict(type='GN', num_groups=32) - the default of

@@ -287,7 +287,55 @@ struct ConvEpi {
   float alpha;                      // applied to the accumulator first (fp16 operands: the power-of-two scales of the operands); 0 = 1
   const float* alpha_dev;           // optional device scalar multiplied into alpha (the scale pt_planes_to_f16 chose on the device)
   int out_f16;                      // out_planes are TWO fp16 planes (the next layer's fp16 operand) instead of np bf16 ones
+  int res_f16;                      // res_planes are two fp16 planes; their value is multiplied by *res_alpha_dev (NULL: 1)
+  const float* res_alpha_dev;
+  float* out_tail;                  // out_f16: the fp32 word behind the zero row of plane 0 = 1 / (scale of the stored values)
+  const float* out_tail_src;        //   <- *out_tail_src (a gradient chain hands its scale on), or 1
+  int* census;                      // out_f16: [0] += saturated elements, [1] = max(bits of |stored|), mode 2: [2] += non-zero below
+  int census_mode;                  //   0.125, [3] += elements (see pt_conv_desc)
 };
+
+// Range census of fp16 planes: per thread, then one conditional atomic per wavefront (saturation count only when non-zero, the
+// maximum only when it raises the word - a plain load first: a handful of atomics per launch in the steady state).
+struct Census {
+  float amax;
+  int nsat, ntiny, ntot;
+  __device__ __forceinline__ void init() { amax = 0.f; nsat = ntiny = ntot = 0; }
+  __device__ __forceinline__ void add8(const float* o) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float a = fabsf(o[e]);
+      amax = fmaxf(amax, a);                            // (NaN: fmaxf keeps amax; a NaN element shows up as saturation below)
+      nsat += !(a <= F16_SAT);
+      ntiny += (a > 0.f && a < 0.125f);
+    }
+    ntot += 8;
+  }
+  __device__ __forceinline__ void flush(int* census, int mode) {
+    const float m = wave_max(amax);
+    const int ns = wave_sum(nsat);
+    if ((threadIdx.x & 63) == 0) {
+      if (ns) atomicAdd(census, ns);
+      const int mb = __float_as_int(m);                 // non-negative floats order like their bit patterns
+      if (mb > __atomic_load_n(census + 1, __ATOMIC_RELAXED)) atomicMax(census + 1, mb);
+    }
+    if (mode >= 2) {
+      const int nt = wave_sum(ntiny), na = wave_sum(ntot);
+      if ((threadIdx.x & 63) == 0) { atomicAdd(census + 2, nt); atomicAdd(census + 3, na); }
+    }
+  }
+};
+
+// the 8 values of two packed-fp16 quads summed: h0 + h1
+__device__ __forceinline__ void h2_sum8(const uint4 a, const uint4 b, float* o) {
+  const unsigned pa[4] = {a.x, a.y, a.z, a.w}, pb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f16x2_t x = __builtin_bit_cast(f16x2_t, pa[j]), y = __builtin_bit_cast(f16x2_t, pb[j]);
+    o[2 * j] = (float)x[0] + (float)y[0];
+    o[2 * j + 1] = (float)x[1] + (float)y[1];
+  }
+}
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
@@ -305,7 +353,7 @@ __device__ __forceinline__ void planes_sum8(const uint4 a, const uint4 b, const 
 
 
 // The epilogue of one row x 8 columns (see ConvEpi); o = the accumulated products.
-__device__ __forceinline__ void conv_epilogue8(float (&o)[8], int grow, int gcol, int N, const ConvEpi& ep) {
+__device__ __forceinline__ void conv_epilogue8(float (&o)[8], int grow, int gcol, int N, const ConvEpi& ep, Census& cs) {
   if (ep.alpha != 0.f) {
     const float al = ep.alpha_dev ? ep.alpha * *ep.alpha_dev : ep.alpha;
 #pragma unroll
@@ -320,7 +368,13 @@ __device__ __forceinline__ void conv_epilogue8(float (&o)[8], int grow, int gcol
     o[0] += sa.x; o[1] += sa.y; o[2] += sa.z; o[3] += sa.w; o[4] += sb.x; o[5] += sb.y; o[6] += sb.z; o[7] += sb.w;
   }
   const long rin = (long)grow * N + gcol;
-  if (ep.res_planes) {
+  if (ep.res_planes && ep.res_f16) {
+    float r[8];
+    h2_sum8(*reinterpret_cast<const uint4*>(ep.res_planes + rin), *reinterpret_cast<const uint4*>(ep.res_planes + ep.res_plane + rin), r);
+    const float ra = ep.res_alpha_dev ? *ep.res_alpha_dev : 1.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] += r[e] * ra;
+  } else if (ep.res_planes) {
     float r[8];
     const uint4 z = make_uint4(0, 0, 0, 0);
     if (ep.np == 3)
@@ -362,6 +416,7 @@ __device__ __forceinline__ void conv_epilogue8(float (&o)[8], int grow, int gcol
   }
   if (ep.out_planes && ep.out_f16) {
     uint4 h0, h1;
+    if (ep.census) cs.add8(o);
     split_pair_f16(o[0], o[1], h0.x, h1.x);
     split_pair_f16(o[2], o[3], h0.y, h1.y);
     split_pair_f16(o[4], o[5], h0.z, h1.z);
@@ -390,6 +445,8 @@ __global__ void __launch_bounds__(256) conv_splitk_finish_kernel(int M, int N, C
   const int n8 = N >> 3;
   const long items = (long)M * n8;
   const long MN = (long)M * N;
+  Census cs;
+  cs.init();
   for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < items; u += (long)gridDim.x * blockDim.x) {
     const int grow = (int)(u / n8), gcol = (int)(u - (long)grow * n8) << 3;
     const float* p = ep.part + (long)grow * N + gcol;
@@ -399,8 +456,10 @@ __global__ void __launch_bounds__(256) conv_splitk_finish_kernel(int M, int N, C
       a.x += va.x; a.y += va.y; a.z += va.z; a.w += va.w; b.x += vb.x; b.y += vb.y; b.z += vb.z; b.w += vb.w;
     }
     float o[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    conv_epilogue8(o, grow, gcol, N, ep);
+    conv_epilogue8(o, grow, gcol, N, ep, cs);
   }
+  if (ep.census && ep.out_f16) cs.flush(ep.census, ep.census_mode);
+  if (ep.out_tail && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *ep.out_tail = ep.out_tail_src ? *ep.out_tail_src : 1.f;
   if (ep.out_planes && ep.zero_row >= 0 && blockIdx.x == gridDim.x - 1) {
     for (int c = threadIdx.x * 8; c < N; c += blockDim.x * 8) {
       uint16_t* d = ep.out_planes + (long)ep.zero_row * N + c;
@@ -628,6 +687,8 @@ __global__ void __launch_bounds__(GTHREADS)
     }
   } else {
     // 8 columns per thread (N % 8 == 0): 16 lanes = one 512-byte row segment of fp32, 256 bytes of every plane
+    Census cs;
+    cs.init();
     for (int idx = threadIdx.x; idx < BM * (GBN / 8); idx += GTHREADS) {
       const int row = idx >> 4, c8 = (idx & 15) << 3;
       const int grow = m0 + row, gcol = n0 + c8;
@@ -640,8 +701,10 @@ __global__ void __launch_bounds__(GTHREADS)
         continue;
       }
       float o[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
-      conv_epilogue8(o, grow, gcol, N, ep);
+      conv_epilogue8(o, grow, gcol, N, ep, cs);
     }
+    if (ep.splits <= 1 && ep.census && ep.out_f16) cs.flush(ep.census, ep.census_mode);
+    if (ep.splits <= 1 && ep.out_tail && m0 + BM >= M && n0 == 0 && threadIdx.x == 0) *ep.out_tail = ep.out_tail_src ? *ep.out_tail_src : 1.f;
     if (ep.splits <= 1 && ep.out_planes && ep.zero_row >= 0 && m0 + BM >= M && threadIdx.x < 16 && n0 + threadIdx.x * 8 < N) {
       uint16_t* d = ep.out_planes + (long)ep.zero_row * N + n0 + threadIdx.x * 8;
       const uint4 z = make_uint4(0, 0, 0, 0);
@@ -933,8 +996,9 @@ __global__ void __launch_bounds__(GTHREADS)
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float4* __restrict__ part, int S, long n4, int ld4, float4* __restrict__ out,
                                                            const float* __restrict__ row_scale, const float4* __restrict__ part_bias,
                                                            int o4, float4* __restrict__ out_bias, int accumulate, float alpha,
-                                                           const float* __restrict__ alpha_dev) {
+                                                           const float* __restrict__ alpha_dev, const float* __restrict__ alpha_dev2) {
   if (alpha_dev) alpha *= *alpha_dev;
+  if (alpha_dev2) alpha *= *alpha_dev2;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n4) {
     float4 a = part[i];
@@ -1169,6 +1233,194 @@ __global__ void __launch_bounds__(256) planes_to_f16_kernel(const uint16_t* __re
   }
 }
 
+
+// ------------------------------------------------------------------------ the scaled fp16 x 2 format ("H2") --
+// out = fmt_out(so * m * (ia * a + ib * b + c)) over row-major planes (see pt_planes_mix in the header): conversions between the
+// plane formats, the exact addition of two gradient plane sets (with different chain scales), fp32 <-> planes.
+struct MixSrc {
+  const void* p;
+  long stride;                      // plane stride in elements (16-bit formats)
+  int fmt;                          // PT_FMT_*
+  const float* inv;                 // H2: 1 / scale (its tail), NULL = 1
+};
+struct MixArgs {
+  MixSrc a, b;
+  const float* c;
+  const uint16_t* mask;
+  const float* relu_of;
+  long n8, nv8;                     // units in total / units that read their sources (the rest is zeros)
+  void* out;
+  int out_fmt;
+  long out_stride;
+  int scale_mode;
+  float* out_f32;
+  float* out_tail;
+  int* census;
+};
+
+__device__ __forceinline__ void mix_load8(const MixSrc& s, long e, float ia, float* o) {
+  const uint4 z = make_uint4(0, 0, 0, 0);
+  if (s.fmt == PT_FMT_F32) {
+    const float* f = reinterpret_cast<const float*>(s.p) + e;
+    const float4 lo = *reinterpret_cast<const float4*>(f), hi = *reinterpret_cast<const float4*>(f + 4);
+    o[0] = lo.x; o[1] = lo.y; o[2] = lo.z; o[3] = lo.w; o[4] = hi.x; o[5] = hi.y; o[6] = hi.z; o[7] = hi.w;
+  } else {
+    const uint16_t* q = reinterpret_cast<const uint16_t*>(s.p) + e;
+    if (s.fmt == PT_FMT_H2) {
+      h2_sum8(*reinterpret_cast<const uint4*>(q), *reinterpret_cast<const uint4*>(q + s.stride), o);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] *= ia;
+    } else if (s.fmt == PT_FMT_BF16X3) {
+      planes_sum8(*reinterpret_cast<const uint4*>(q), *reinterpret_cast<const uint4*>(q + s.stride), *reinterpret_cast<const uint4*>(q + 2 * s.stride), o);
+    } else {
+      planes_sum8(*reinterpret_cast<const uint4*>(q), z, z, o);
+    }
+  }
+}
+
+__device__ __forceinline__ void mix_value8(const MixArgs& g, long u, float ia, float ib, float* o) {
+  const long e = u << 3;
+  if (u >= g.nv8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = 0.f;
+    return;
+  }
+  mix_load8(g.a, e, ia, o);
+  if (g.b.p) {
+    float r[8];
+    mix_load8(g.b, e, ib, r);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] += r[j];
+  }
+  if (g.c) {
+    const float4 ra = *reinterpret_cast<const float4*>(g.c + e), rb = *reinterpret_cast<const float4*>(g.c + e + 4);
+    o[0] += ra.x; o[1] += ra.y; o[2] += ra.z; o[3] += ra.w; o[4] += rb.x; o[5] += rb.y; o[6] += rb.z; o[7] += rb.w;
+  }
+  if (g.mask) {                                       // plane 0 of bf16 or fp16 planes: "> 0" = sign clear and not zero in both encodings
+    const uint4 mk = *reinterpret_cast<const uint4*>(g.mask + e);
+    const unsigned mm[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (!((mm[j] & 0x7fffu) != 0 && (mm[j] & 0x8000u) == 0)) o[2 * j] = 0.f;
+      if (!((mm[j] & 0x7fff0000u) != 0 && (mm[j] & 0x80000000u) == 0)) o[2 * j + 1] = 0.f;
+    }
+  }
+  if (g.relu_of) {
+    const float4 ya = *reinterpret_cast<const float4*>(g.relu_of + e), yb = *reinterpret_cast<const float4*>(g.relu_of + e + 4);
+    const float y[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = y[j] > 0.f ? o[j] : 0.f;
+  }
+}
+
+// largest magnitude of the mixed value per workgroup -> part[blockIdx.x]
+__global__ void __launch_bounds__(256) planes_mix_amax_kernel(MixArgs g, float* __restrict__ part) {
+  __shared__ float sm[4];
+  const float ia = g.a.inv ? *g.a.inv : 1.f, ib = (g.b.p && g.b.inv) ? *g.b.inv : 1.f;
+  float m = 0.f;
+  for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < g.n8; u += (long)gridDim.x * blockDim.x) {
+    float v[8];
+    mix_value8(g, u, ia, ib, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+
+__global__ void __launch_bounds__(256) planes_mix_kernel(MixArgs g, const float* __restrict__ part, int n_part) {
+  const float ia = g.a.inv ? *g.a.inv : 1.f, ib = (g.b.p && g.b.inv) ? *g.b.inv : 1.f;
+  float so = 1.f;
+  if (g.out && g.out_fmt == PT_FMT_H2) {
+    if (g.scale_mode == PT_SCALE_AUTO) {
+      __shared__ float sm[4];
+      float m = 0.f;
+      for (int i = threadIdx.x; i < n_part; i += blockDim.x) m = fmaxf(m, part[i]);
+      m = wave_max(m);
+      if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+      __syncthreads();
+      m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+      // finite, non-zero: 2^(9 - floor(log2 m)) puts m into [512, 1024); a zero / non-finite tensor keeps scale 1
+      so = (m > 0.f && m < 3.0e38f) ? exp2f(9.f - floorf(log2f(m))) : 1.f;
+      so = fminf(fmaxf(so, 9.5367431640625e-07f), 1.099511627776e12f);      // 2^-20 ... 2^40
+    } else if (g.scale_mode == PT_SCALE_MERGE) {
+      so = 1.f / (g.b.p ? fmaxf(ia, ib) : ia);          // powers of two: exact
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && g.out_tail) *g.out_tail = 1.f / so;
+  }
+  Census cs;
+  cs.init();
+  for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < g.n8; u += (long)gridDim.x * blockDim.x) {
+    const long e = u << 3;
+    float o[8];
+    mix_value8(g, u, ia, ib, o);
+    if (g.out_f32) {
+      *reinterpret_cast<float4*>(g.out_f32 + e) = make_float4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<float4*>(g.out_f32 + e + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+    if (!g.out) continue;
+    uint16_t* d = reinterpret_cast<uint16_t*>(g.out) + e;
+    if (g.out_fmt == PT_FMT_H2) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] *= so;
+      if (g.census) cs.add8(o);
+      uint4 h0, h1;
+      split_pair_f16(o[0], o[1], h0.x, h1.x);
+      split_pair_f16(o[2], o[3], h0.y, h1.y);
+      split_pair_f16(o[4], o[5], h0.z, h1.z);
+      split_pair_f16(o[6], o[7], h0.w, h1.w);
+      *reinterpret_cast<uint4*>(d) = h0;
+      *reinterpret_cast<uint4*>(d + g.out_stride) = h1;
+    } else {
+      uint4 p0, p1, p2;
+      split_pair(o[0], o[1], p0.x, p1.x, p2.x);
+      split_pair(o[2], o[3], p0.y, p1.y, p2.y);
+      split_pair(o[4], o[5], p0.z, p1.z, p2.z);
+      split_pair(o[6], o[7], p0.w, p1.w, p2.w);
+      *reinterpret_cast<uint4*>(d) = p0;
+      if (g.out_fmt == PT_FMT_BF16X3) {
+        *reinterpret_cast<uint4*>(d + g.out_stride) = p1;
+        *reinterpret_cast<uint4*>(d + 2 * g.out_stride) = p2;
+      }
+    }
+  }
+  if (g.census && g.out && g.out_fmt == PT_FMT_H2) cs.flush(g.census, 1);
+}
+
+// fp32 NHWC -> H2 planes of the stride's pixels, zero last row, tail 1 (see pt_split_gather_h2)
+__global__ void __launch_bounds__(256)
+    gather_h2_kernel(const float* __restrict__ src, long ld, int Hs, int Ws, int Ho, int Wo, int stride, int P, int C, uint16_t* __restrict__ dst,
+                     long plane, int* __restrict__ census) {
+  const int c8 = C >> 3;
+  const long units = (long)(P + 1) * c8;
+  Census cs;
+  cs.init();
+  for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += (long)gridDim.x * blockDim.x) {
+    const long r = u / c8;
+    const int c = (int)(u - r * c8) << 3;
+    uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
+    if (r < P) {
+      const int x = (int)(r % Wo), yq = (int)(r / Wo);
+      const int y = yq % Ho, b = yq / Ho;
+      const float* sp = src + (((long)b * Hs + (long)y * stride) * Ws + (long)x * stride) * ld + c;
+      const float4 lo = *reinterpret_cast<const float4*>(sp), hi = *reinterpret_cast<const float4*>(sp + 4);
+      const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      if (census) cs.add8(v);
+      split_pair_f16(v[0], v[1], o0.x, o1.x);
+      split_pair_f16(v[2], v[3], o0.y, o1.y);
+      split_pair_f16(v[4], v[5], o0.z, o1.z);
+      split_pair_f16(v[6], v[7], o0.w, o1.w);
+    }
+    uint16_t* d = dst + r * C + c;
+    *reinterpret_cast<uint4*>(d) = o0;
+    *reinterpret_cast<uint4*>(d + plane) = o1;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<float*>(dst + (long)(P + 1) * C) = 1.f;
+  if (census) cs.flush(census, 1);
+}
+
 }  // namespace pt
 
 using namespace pt;
@@ -1349,6 +1601,65 @@ extern "C" int pt_planes_combine(const uint16_t* a, int64_t a_plane_stride, cons
   return PT_OK;
 }
 
+
+static int fmt_planes(int fmt) { return fmt == PT_FMT_BF16X3 ? 3 : fmt == PT_FMT_H2 ? 2 : 1; }
+
+extern "C" int pt_planes_mix(const void* a, int a_fmt, int64_t a_plane_stride, const float* a_inv, const void* b, int b_fmt, int64_t b_plane_stride,
+                             const float* b_inv, const float* c, const uint16_t* mask, const float* relu_of, int64_t n, int64_t n_valid, void* out,
+                             int out_fmt, int64_t out_plane_stride, int scale_mode, float* out_f32, float* workspace, int32_t* census, void* stream) {
+  if (n == 0) return PT_OK;
+  PT_REQUIRE(a && n > 0 && (n & 7) == 0 && (out || out_f32) && n_valid >= 0 && n_valid <= n && (n_valid & 7) == 0, PT_EINVAL,
+             "pt_planes_mix: bad argument (n, n_valid multiples of 8, n_valid <= n, an output)");
+  PT_REQUIRE(a_fmt >= 0 && a_fmt <= 3 && (!b || (b_fmt >= 0 && b_fmt <= 3)) && (!out || (out_fmt >= 1 && out_fmt <= 3)), PT_EINVAL,
+             "pt_planes_mix: formats are PT_FMT_* (plane output formats 1 .. 3; fp32 leaves through out_f32)");
+  PT_REQUIRE(((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)mask) | ((uintptr_t)relu_of) | ((uintptr_t)out) | ((uintptr_t)out_f32) |
+               ((uintptr_t)census)) & 15) == 0 && (a_plane_stride & 7) == 0 && (b_plane_stride & 7) == 0 && (out_plane_stride & 7) == 0,
+             PT_EINVAL, "pt_planes_mix: buffers and plane strides must be 16-byte aligned");
+  PT_REQUIRE((a_fmt == PT_FMT_F32 || a_plane_stride >= n_valid) && (!b || b_fmt == PT_FMT_F32 || b_plane_stride >= n_valid), PT_EINVAL,
+             "pt_planes_mix: plane strides < n_valid");
+  PT_REQUIRE(!out || out_plane_stride >= n + (out_fmt == PT_FMT_H2 ? 8 : 0), PT_EINVAL,
+             "pt_planes_mix: out_plane_stride < n (+ 8 for the tail of scaled fp16 planes)");
+  PT_REQUIRE(scale_mode >= 0 && scale_mode <= 2 && (scale_mode != PT_SCALE_AUTO || workspace || !out || out_fmt != PT_FMT_H2), PT_EINVAL,
+             "pt_planes_mix: PT_SCALE_AUTO needs a workspace of 1024 floats");
+  MixArgs g{};
+  g.a = MixSrc{a, (long)a_plane_stride, a_fmt, a_fmt == PT_FMT_H2 ? a_inv : nullptr};
+  g.b = MixSrc{b, (long)b_plane_stride, b_fmt, (b && b_fmt == PT_FMT_H2) ? b_inv : nullptr};
+  g.c = c; g.mask = mask; g.relu_of = relu_of; g.n8 = n >> 3; g.nv8 = n_valid >> 3;
+  g.out = out; g.out_fmt = out_fmt; g.out_stride = (long)out_plane_stride; g.scale_mode = scale_mode; g.out_f32 = out_f32;
+  g.out_tail = (out && out_fmt == PT_FMT_H2) ? reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(out) + n) : nullptr;
+  g.census = census;
+  int nb = cdiv(g.n8, 256);
+  nb = nb > 16384 ? 16384 : nb;
+  int n_part = 0;
+  if (out && out_fmt == PT_FMT_H2 && scale_mode == PT_SCALE_AUTO) {
+    n_part = nb > 1024 ? 1024 : nb;
+    hipLaunchKernelGGL(pt::planes_mix_amax_kernel, dim3(n_part), dim3(256), 0, as_stream(stream), g, workspace);
+    PT_LAUNCH_CHECK("pt_planes_mix (amax)");
+  }
+  hipLaunchKernelGGL(pt::planes_mix_kernel, dim3(nb), dim3(256), 0, as_stream(stream), g, workspace, n_part);
+  PT_LAUNCH_CHECK("pt_planes_mix");
+  return PT_OK;
+}
+
+extern "C" int pt_split_gather_h2(const float* src, int64_t ld, int B, int Hs, int Ws, int C, int stride, uint16_t* planes, int64_t plane_stride,
+                                  int32_t* census, void* stream) {
+  PT_REQUIRE(src && planes && B > 0 && Hs > 0 && Ws > 0 && C > 0 && (C & 7) == 0 && ld >= C && (ld & 7) == 0 && (stride == 1 || stride == 2),
+             PT_EINVAL, "pt_split_gather_h2: bad argument (C, ld multiples of 8; stride 1 or 2)");
+  const int Ho = (Hs - 1) / stride + 1, Wo = (Ws - 1) / stride + 1;
+  const long P = (long)B * Ho * Wo;
+  PT_REQUIRE(P < (1L << 30), PT_ELIMIT, "pt_split_gather_h2: B * Ho * Wo < 2^30");
+  PT_REQUIRE(plane_stride >= (P + 1) * C + 8 && (plane_stride & 7) == 0 && (((uintptr_t)planes) & 15) == 0 && (((uintptr_t)src) & 15) == 0 &&
+                 (((uintptr_t)census) & 15) == 0,
+             PT_EINVAL, "pt_split_gather_h2: plane_stride must cover (B * Ho * Wo + 1) * C + 8, buffers 16-byte aligned");
+  const long units = (P + 1) * (C >> 3);
+  int nb = cdiv(units, 256);
+  nb = nb > 16384 ? 16384 : nb;
+  hipLaunchKernelGGL(pt::gather_h2_kernel, dim3(nb), dim3(256), 0, as_stream(stream), src, (long)ld, Hs, Ws, Ho, Wo, stride, (int)P, C, planes,
+                     (long)plane_stride, census);
+  PT_LAUNCH_CHECK("pt_split_gather_h2");
+  return PT_OK;
+}
+
 static int conv_check(const pt_conv_desc* d, const char* who) {
   PT_REQUIRE(d && d->x_planes && d->w_planes && (d->out_f32 || d->out_planes), PT_EINVAL, "%s: bad argument (operands, one output)", who);
   PT_REQUIRE(d->B > 0 && d->Hs > 0 && d->Ws > 0 && d->Cin > 0 && d->Cout > 0, PT_EINVAL, "%s: bad shape", who);
@@ -1461,6 +1772,20 @@ extern "C" int pt_conv_bf16x6(const pt_conv_desc* d, void* stream) {
   ep.alpha_dev = d->alpha_dev;
   ep.out_f16 = d->out_f16;
   PT_REQUIRE(!d->out_f16 || (d->out_planes && np == 3), PT_EINVAL, "pt_conv_bf16x6: out_f16 writes two fp16 planes to out_planes (np = 3 launches)");
+  if (d->out_f16) {
+    // the scaled fp16 format: room for the tail behind the zero row, written by this launch
+    PT_REQUIRE(d->out_plane_stride >= (rows_out + 1) * d->Cout + 8, PT_EINVAL,
+               "pt_conv_bf16x6: out_f16 planes need out_plane_stride >= (rows + 1) * Cout + 8 (the scale tail)");
+    PT_REQUIRE((((uintptr_t)d->out_inv_scale_src) & 3) == 0 && (((uintptr_t)d->census) & 15) == 0, PT_EINVAL,
+               "pt_conv_bf16x6: out_inv_scale_src / census alignment");
+    ep.out_tail = reinterpret_cast<float*>(d->out_planes + (rows_out + 1) * d->Cout);
+    ep.out_tail_src = d->out_inv_scale_src;
+    ep.census = d->census;
+    ep.census_mode = d->census_mode;
+  }
+  ep.res_f16 = d->res_f16;
+  ep.res_alpha_dev = d->res_alpha_dev;
+  PT_REQUIRE(!d->res_f16 || np == 3, PT_EINVAL, "pt_conv_bf16x6: res_f16 goes with np = 3 launches");
   PT_REQUIRE(!d->alpha_dev || d->alpha != 0.f, PT_EINVAL, "pt_conv_bf16x6: alpha_dev multiplies alpha (set alpha, e.g. 1)");
   rc = d->operand_f16 ? launch_by_rows<true, 2>(tile_rows, d->x_planes, d->w_planes, nullptr, nullptr, nullptr, (int)M, d->Cout, KB,
                                                d->x_plane_stride, d->w_plane_stride, d->Cout, 0, cg, ep, as_stream(stream))
@@ -1548,7 +1873,7 @@ extern "C" int pt_conv_wgrad_bf16x6(const pt_conv_wgrad_desc* d, void* stream) {
                taps * d->Cin / GBN, d->dbias ? 1 : 0, (d->Cout / bm > 1 && (long)taps * d->Cin > d->Cout) ? 1 : 0};
   // one chunk and nothing to apply afterwards: the tiles ARE the result
   const float alpha = d->alpha != 0.f ? d->alpha : 1.f;
-  const bool direct = S == 1 && !d->row_scale && !d->accumulate && alpha == 1.f && !d->alpha_dev;
+  const bool direct = S == 1 && !d->row_scale && !d->accumulate && alpha == 1.f && !d->alpha_dev && !d->alpha_dev2;
   float* part = direct ? d->dw : d->workspace;
   float* part_bias = direct ? d->dbias : d->workspace + (long)S * n;
   PT_REQUIRE(d->np == 0 || d->np == 1 || d->np == 3, PT_EINVAL, "pt_conv_wgrad_bf16x6: np = 3 (or 0) planes per operand, or 1");
@@ -1562,7 +1887,7 @@ extern "C" int pt_conv_wgrad_bf16x6(const pt_conv_wgrad_desc* d, void* stream) {
   if (direct) return PT_OK;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n / 4 + nbias / 4, 256)), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const float4*>(d->workspace), S, n / 4, taps * d->Cin / 4, reinterpret_cast<float4*>(d->dw), d->row_scale,
-                     reinterpret_cast<const float4*>(part_bias), (int)(nbias / 4), reinterpret_cast<float4*>(d->dbias), d->accumulate, alpha, d->alpha_dev);
+                     reinterpret_cast<const float4*>(part_bias), (int)(nbias / 4), reinterpret_cast<float4*>(d->dbias), d->accumulate, alpha, d->alpha_dev, d->alpha_dev2);
   PT_LAUNCH_CHECK("pt_conv_wgrad_bf16x6 (reduce)");
   return PT_OK;
 }

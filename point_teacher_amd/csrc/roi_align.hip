@@ -979,6 +979,13 @@ static int roi_fwd_planes(const char* fn, int np, const float* feat, const float
   hipLaunchKernelGGL(roi_align7_fwd, dim3(cdiv(K, gs)), dim3(256), ROI7_LDS, as_stream(stream), feat, rois, B, C, H, W, K, gs, spatial_scale,
                      sampling_ratio, aligned, (float*)nullptr, ROI7_TILE_BYTES, planes, (long)plane_stride, np);
   PT_LAUNCH_CHECK(fn);
+  // the scaled fp16 format (ABI 6): a plane stride with room for the tail gets 1 / scale = 1 written behind the zero row
+  if (np == 2 && plane_stride >= (int64_t)(K + 1) * C * 49 + 8) {
+    if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(planes + (int64_t)(K + 1) * C * 49), 0x3f800000, 1, as_stream(stream)) != hipSuccess) {
+      set_error("%s: tail write failed", fn);
+      return PT_EINVAL;
+    }
+  }
   return PT_OK;
 }
 

@@ -419,10 +419,10 @@ class _RoIAlignPlanes(torch.autograd.Function):
         rois = _f(rois)
         K = rois.shape[0]
         n = (K + 1) * C * 49
-        if f16:     # two fp16 planes (value = h0 + h1): the operand of the first FC layer's three-product kernels (F16_FC)
-            t = torch.empty((2, n), dtype=torch.float16, device=feat.device)
+        if f16:     # H2 planes (value = h0 + h1, tail 1): the operand of the first FC layer's three-product kernels (F16_FC)
+            t = torch.empty((2, n + 8), dtype=torch.float16, device=feat.device)
             hip.call('pt_roi_align_fwd_planes_f16', fbuf, rois, B, C, H, W, K, float(scale), sampling_ratio, int(aligned), int(group),
-                     t.view(torch.bfloat16), n)
+                     t.data_ptr(), n + 8)
         else:
             t = torch.empty((3, n), dtype=torch.bfloat16, device=feat.device)
             hip.call('pt_roi_align_fwd_planes', fbuf, rois, B, C, H, W, K, float(scale), sampling_ratio, int(aligned), int(group), t, n)
@@ -446,12 +446,18 @@ def roi_align_planes_ok(feat, rois, output_size):
             and feat.is_contiguous(memory_format=torch.channels_last) and not torch.is_autocast_enabled())
 
 
-# The MIL head's first FC layer (12 544 -> 1 024 over K RoIs: the largest products of the iteration) on fp16 x 2 operands and THREE MFMA
-# products per fp32 product instead of bf16 x 3 and six (planes._PlaneConv).  PT_F16_FC=0: six products everywhere.
-F16_FC = os.environ.get('PT_F16_FC', '1') != '0'
+# fp16 x 2 operands ("H2" planes, planes.py): three MFMA products per fp32 product instead of six, 4 bytes per element instead of 6 -
+# since round 5 THE activation / gradient format of the trainable trunk, necks, towers and FC stacks.  22
+# significant bits per stored value, fp32 accumulation; fp16's 5 exponent bits are watched by planes.CENSUS, which demotes a group to
+# bf16 x 3 planes (six products, fp32's range) when it sees saturation.  PT_F16_FC=0: bf16 x 3 everywhere - the strict 24-bit path
+# (`bench.py` times it as `strict_fp32`); the other switches turn single groups off.
+F16_FC = os.environ.get('PT_F16_FC', '1') != '0'                         # master switch + the MIL head's FC stacks
 F16_TOWERS = F16_FC and os.environ.get('PT_F16_TOWERS', '1') != '0'      # the dense head's towers
-F16_NECK3 = F16_FC and os.environ.get('PT_F16_NECK3', '1') != '0'        # single 3x3 convolutions of the necks (FPN outputs)
-F16_BLOCK3 = F16_FC and os.environ.get('PT_F16_BLOCK3', '1') != '0'      # the Bottlenecks' 3x3 convolution
+F16_NECK = F16_FC and os.environ.get('PT_F16_NECK3', '1') != '0'         # FPN's laterals / output convolutions, PSAGG
+F16_NECK3 = F16_NECK
+F16_TRUNK = F16_FC and os.environ.get('PT_F16_TRUNK', '1') != '0'        # the Bottlenecks: H2 planes between ALL their convolutions
+F16_BLOCK3 = F16_FC and os.environ.get('PT_F16_BLOCK3', '1') != '0'      # (PT_F16_TRUNK=0 only) the Bottlenecks' 3x3 alone on H2 operands
+F16_CHAIN = os.environ.get('PT_F16_CHAIN', '1') != '0'                   # one gradient scale per backward chain (0: every link re-scales)
 F16_WEIGHT_SCALE = hip.header_constant('PT_F16_WEIGHT_SCALE')        # weight planes with np = 2 hold 16 w (include/pt_hip.h)
 
 

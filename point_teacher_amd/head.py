@@ -91,6 +91,8 @@ class TS_P2BFCOSHead(nn.Module):
                                              else None) for i in range(n)])
         self.cls_convs = stack(self.stacked_convs, self.in_channels)
         self.reg_convs = stack(self.stacked_convs, self.in_channels)
+        for l in list(self.cls_convs) + list(self.reg_convs):
+            l.plane_group = 'towers'                               # census / fall-back group of their fp16 operands (planes.CENSUS)
         self.conv_cls = nn.Conv2d(self.feat_channels, self.cls_out_channels, 3, padding=1)
         self.conv_reg = nn.Conv2d(self.feat_channels, 4, 3, padding=1)
         self.conv_centerness = nn.Conv2d(self.feat_channels, 1, 3, padding=1)
@@ -160,9 +162,9 @@ class TS_P2BFCOSHead(nn.Module):
             # convolutions of a tower as split planes (bias + ReLU in the epilogues, masks in the input-gradient epilogues) and
             # only the last one writes the fp32 map the 8 / 4 / 1-channel output convolutions read
             if need_cls and need_reg:
-                xa, xb = PL.to_planes2(x, f16=F.F16_TOWERS)           # (F16_FC: the towers on fp16 x 2 operands, three MFMA products)
+                xa, xb = PL.to_planes2(x, f16=PL.use_f16('towers'))   # (the towers on fp16 x 2 operands, three MFMA products)
             else:
-                xa = xb = PL.to_planes(x, f16=F.F16_TOWERS)
+                xa = xb = PL.to_planes(x, f16=PL.use_f16('towers'))
 
             def tower(t, layers):
                 for i, l in enumerate(layers):

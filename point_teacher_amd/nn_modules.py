@@ -82,6 +82,7 @@ class ConvModule(nn.Module):
     `.conv` and `.gn` (mmcv names the norm layer after its type); bias='auto' means "no bias when a
     norm layer follows" (mmcv/cnn/bricks/conv_module.py:113-116)."""
     plane_min_pixels = int(os.environ.get('PT_PLANE_MIN_PIXELS', '2048'))     # below: the library's kernels (launch-bound shapes)
+    plane_group = 'neck'             # the census / fall-back group of its fp16 operands (planes.CENSUS); the head's towers say 'towers'
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, act=True, norm_cfg=None,
                  conv_cfg=None, dilation=1):
@@ -112,7 +113,7 @@ class ConvModule(nn.Module):
         c = self.conv
         if isinstance(x, PL.PlaneAct) or out_planes:
             if (_PLANE_TRUNK and not self.with_norm and PL.plane_conv_ok(c) and (isinstance(x, PL.PlaneAct) or PL.dense_ok(x))):
-                return PL.conv_module(x, c, relu=self.with_activation, out_planes=out_planes)
+                return PL.conv_module(x, c, relu=self.with_activation, out_planes=out_planes, group=self.plane_group)
             if isinstance(x, PL.PlaneAct):
                 x = x.tensor()
             assert not out_planes, 'this convolution cannot emit planes'
@@ -120,8 +121,8 @@ class ConvModule(nn.Module):
                 and x.shape[0] * x.shape[2] * x.shape[3] >= self.plane_min_pixels):
             # 1x1 / 3x3 convolutions of necks and towers (fp32 by the config): implicit GEMM on the bf16 matrix cores with split-bf16
             # operands and fp32 accumulation, bias (+ ReLU) in its epilogue, input / weight / bias gradients on the same kernels
-            # (3x3: compute-bound - fp16 x 2 operands and three products when F16_FC; the 1x1s are bound by their bytes)
-            return PL.conv_module(x, c, relu=self.with_activation, f16=F.F16_NECK3 and c.kernel_size == (3, 3))
+            # (fp16 x 2 operands and three products unless the group fell back: 4-byte planes for the byte-bound 1x1s as well)
+            return PL.conv_module(x, c, relu=self.with_activation, f16=PL.use_f16(self.plane_group), group=self.plane_group)
         if (_SPLIT_CONV and type(c) is nn.Conv2d and c.bias is not None and not self.with_norm and self.with_activation
                 and F.split_conv3x3_ok(x, c)):
             # the dense head's tower convolutions (fp32 by the config): implicit GEMM on the bf16 matrix cores with split-bf16
@@ -373,7 +374,7 @@ class Bottleneck(nn.Module):
             terms['d'] = (None, None, None, None)
         p = self.conv1.out_channels
         cfg = PL.BottleneckCfg(B=B, H=H, W=W, Cin=Cin, planes=p, s1=s1, s2=s2, x_planes=is_p, x_relu=bool(is_p and x.relu),
-                               bn=terms, has_ds=ds is not None, bn_train=train)
+                               bn=terms, has_ds=ds is not None, bn_train=train, name=getattr(self, 'plane_name', 'block'))
         gb = [(bn.weight, bn.bias) if train else (None, None) for bn in (self.bn1, self.bn2, self.bn3)]
         gb.append((ds[1].weight, ds[1].bias) if (train and ds is not None) else (None, None))
         t = PL._BottleneckP.apply(x.t if is_p else x, self.conv1.weight, self.conv2.weight, self.conv3.weight,
@@ -422,6 +423,7 @@ class ResNet(nn.Module):
                     ds = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False),
                                        nn.BatchNorm2d(planes * 4))
                 layers.append(Bottleneck(inplanes, planes, stride, dilations[i], ds, style))
+                layers[-1].plane_name = f'layer{i + 1}.{j}'            # (the census' name of the block's tensors)
                 inplanes = planes * 4
             name = f'layer{i + 1}'
             self.add_module(name, nn.Sequential(*layers))
@@ -516,7 +518,7 @@ class ResNet(nn.Module):
                     if not isinstance(x, PL.PlaneAct) and PL.dense_ok(x) and blk.plane_ok():
                         # enter plane mode: the frozen stem's output is read where the block's stride samples it; an input that takes
                         # a gradient goes through a differentiable split first
-                        x = blk.forward_planes(PL.to_planes(x) if x.requires_grad else x)
+                        x = blk.forward_planes(PL.to_planes(x, f16=PL.use_f16('trunk'), group='trunk', carrier=False) if x.requires_grad else x)
                     else:
                         x = blk(x)                            # (a PlaneAct stays plane-native while the blocks qualify)
             else:
@@ -668,7 +670,7 @@ class RoIAlign(nn.Module):
         """planes=True: the result as planes.PlaneAct [1, K, 1, C * 49] - the split planes of `.flatten(1)` - when the kernel takes the
         shape (functional.roi_align_planes_ok); the caller feeds it to planes.linear."""
         if planes and _PLANE_TRUNK and rois.shape[0] > 0 and F.roi_align_planes_ok(input, rois, self.output_size):
-            t = F.roi_align_planes(input, rois, self.spatial_scale, self.sampling_ratio, self.aligned, group, f16=F.F16_FC)
+            t = F.roi_align_planes(input, rois, self.spatial_scale, self.sampling_ratio, self.aligned, group, f16=PL.use_f16('fc'))
             return PL.PlaneAct(t, 1, rois.shape[0], 1, input.shape[1] * self.output_size ** 2, False, gcarrier=True)
         return F.roi_align(input, rois, self.output_size, self.spatial_scale, self.sampling_ratio, self.aligned, group)
 

@@ -231,9 +231,15 @@ class FlatParams:
         return out
 
     def add_to_grad(self, name, g):
-        """Add `g` to the flat gradient slice of the (live) parameter `name`."""
+        """Add `g` (logical [O, I, KH, KW] order) to the flat gradient slice of the (live) parameter `name`.  Under channels_last the
+        slot of a 4-D weight is stored as (O, KH, KW, I): the addition goes through the permuted view the parameter's `.grad` is."""
         off, n = self.slices[name]
-        self.grad_flat[off:off + n].add_(g.reshape(-1).to(self.grad_flat.dtype))
+        flat = self.grad_flat[off:off + n]
+        if self.channels_last and g.dim() == 4:
+            O, I, KH, KW = g.shape
+            flat.view(O, KH, KW, I).permute(0, 3, 1, 2).add_(g.to(flat.dtype))
+        else:
+            flat.add_(g.reshape(-1).to(flat.dtype))
 
     def gather_grads(self, seen=None):
         """Copy the gradients autograd left in `.grad` into the flat buffer with multi-tensor copies (segments of
@@ -551,8 +557,8 @@ class Trainer:
         has ever reached (TS_P2BFCOSHead.shared_fcs / shared_fcs_refine / fc_iou: 31 % of the student) leave the live groups.
         First step: dead = trainable parameters without a gradient on ANY rank.  Later: a dead parameter that received a
         gradient is revived (N == 1: in the same step, before the update, WITH that gradient; N > 1: at the next agreement point,
-        so that every rank re-lays its buffers in the same step - the gradients of the steps in between are summed and enter
-        the update of the revival step, averaged over the ranks)."""
+        so that every rank re-lays its buffers in the same step - the latest gradient seen in between enters the update of the
+        revival step, averaged over the ranks by one all-reduce)."""
         f = self.flat
         trainable = [n for n, p in f.order if p.requires_grad]
         if not self.dead_known:
@@ -560,25 +566,38 @@ class Trainer:
             self.dead_known = True
             self._relayout(set(trainable) - live)
             return
-        self._revived.update(f.take_revived(self._revived_grads))
         if self.world == 1:
+            self._revived.update(f.take_revived(self._revived_grads))
             if self._revived:
                 self._relayout(set(f.dead) - self._revived)
                 for n, g in self._revived_grads.items():           # the gradient that revived it takes part in THIS update
                     self.flat.add_to_grad(n, g)
                 self._revived, self._revived_grads = set(), {}
-        elif (self.iter + 1) % self.revive_interval == 0 and f.dead:
+            return
+        # N > 1: only the LATEST gradient of a revived parameter is kept (round-4 advice: the sum of up to `revive_interval` steps'
+        # gradients in one update would dominate that step's clip norm and shrink every other parameter's update)
+        fresh = {}
+        self._revived.update(f.take_revived(fresh))
+        self._revived_grads.update(fresh)
+        if (self.iter + 1) % self.revive_interval == 0 and f.dead:
             rev = self._agree(self._revived, sorted(f.dead))
             if rev:
                 self._relayout(set(f.dead) - rev)
-                # the gradients the ranks saw since the last agreement point (summed per rank, averaged over the ranks here - the
-                # one collective of a revival) enter this update instead of being dropped
-                for n in sorted(rev):
-                    off, cnt = self.flat.slices[n]
-                    g = self._revived_grads.get(n)
-                    buf = (g.reshape(-1).float() if g is not None else torch.zeros(cnt, device=self.flat.grad_flat.device)).contiguous()
-                    dist.all_reduce(buf)
-                    self.flat.add_to_grad(n, buf / self.world)
+                # the latest gradient each rank saw since the last agreement point, averaged over the ranks by ONE all-reduce of
+                # their concatenation (a rank that saw none contributes zeros), enters this update instead of being dropped
+                names = sorted(rev)
+                shapes = {n: dict(f.order)[n].shape for n in names}
+                dev = self.flat.grad_flat.device
+                parts = [(self._revived_grads[n].reshape(-1).float() if n in self._revived_grads
+                          else torch.zeros(self.flat.slices[n][1], device=dev)) for n in names]
+                buf = torch.cat(parts).contiguous()
+                dist.all_reduce(buf)
+                buf /= self.world
+                o = 0
+                for n in names:
+                    cnt = self.flat.slices[n][1]
+                    self.flat.add_to_grad(n, buf[o:o + cnt].view(shapes[n]))
+                    o += cnt
             self._revived, self._revived_grads = set(), {}
 
     def _relayout(self, dead):

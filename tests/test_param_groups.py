@@ -124,6 +124,31 @@ def test_dead_segment_and_relayout():
     assert torch.equal(flat.grad_flat[off:off + k], torch.full((7,), 2.5)) and torch.equal(net[1].bias.grad, torch.full((7,), 2.5))
 
 
+def test_revived_3x3_conv_gradient_lands_in_channels_last_order():
+    """Round-4 advice: under channels_last the flat slot of a 4-D weight is stored as (O, KH, KW, I); the gradient that revives a
+    dead 3x3 convolution arrives in logical [O, I, KH, KW] order and must be added through the permuted view, not the raw slice."""
+    from point_teacher_amd.runtime import FlatParams
+    torch.manual_seed(1)
+    net = torch.nn.Sequential(torch.nn.Conv2d(4, 6, 3, padding=1), torch.nn.Conv2d(6, 5, 3, padding=1), torch.nn.Conv2d(5, 2, 1))
+    flat = FlatParams(net, channels_last=True, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.), dead={'1.weight', '1.bias'})
+    assert net[1].weight.grad is None and net[1].weight.is_contiguous(memory_format=torch.channels_last)
+    g = torch.randn(5, 6, 3, 3)
+    net[1].weight.grad = g.clone()
+    keep = {}
+    assert flat.take_revived(keep) == ['1.weight']
+    assert flat.relayout({'1.bias'})
+    flat.add_to_grad('1.weight', keep['1.weight'])
+    assert torch.equal(net[1].weight.grad, g), 'the kept gradient must appear, element for element, in the parameter\'s .grad view'
+    off, n = flat.slices['1.weight']
+    assert torch.equal(flat.grad_flat[off:off + n], g.permute(0, 2, 3, 1).reshape(-1))       # (O, KH, KW, I) storage order
+    flat.add_to_grad('1.weight', keep['1.weight'])                                           # and it accumulates
+    assert torch.equal(net[1].weight.grad, 2 * g)
+    g1 = torch.randn(2, 5, 1, 1)                                                             # 1x1: both orders coincide
+    flat.grad_flat.zero_()
+    flat.add_to_grad('2.weight', g1)
+    assert torch.equal(net[2].weight.grad, g1)
+
+
 def test_retinanet_baseline_config_groups():
     import point_teacher_amd as pta
     from point_teacher_amd.runtime import FlatParams

@@ -10,9 +10,10 @@ DEV = 'cuda:0'
 
 
 def _planes_to_f32(t, rows, C):
-    p = t.float().view(3, -1, C)
-    assert float(p[:, rows].abs().max()) == 0, 'the zero row'
-    return (p[0, :rows] + p[1, :rows]) + p[2, :rows]
+    from point_teacher_amd import planes as PL
+    n = PL.n_of(t)
+    assert float(t[:, rows * C:n].float().abs().max()) == 0, 'the zero row'
+    return PL.planes_to_f32(t, rows, C)
 
 
 def _rows(x):                                        # [B, C, H, W] -> [B*H*W, C]
@@ -276,12 +277,19 @@ def _make_block(inplanes, planes, stride, ds, seed, style='caffe', train_bn=Fals
     (512, 256, 2, True, 2, 40, 37, False, 'pytorch', True),
     (512, 256, 2, True, 2, 38, 38, False, 'caffe', True),
 ])
-@pytest.mark.parametrize('f16_conv2', [True, False])
-def test_bottleneck_planes_vs_fp64(inplanes, planes, stride, ds, B, H, W, from_stem, style, train_bn, f16_conv2, monkeypatch):
-    """f16_conv2: the 3x3 convolution on fp16 x 2 operands and three MFMA products (functional.F16_BLOCK3, the default) or on
-    bf16 x 3 operands and six (PT_F16_BLOCK3=0) - the same bars."""
+@pytest.mark.parametrize('mode', ['h2', 'h2_relink', 'b3_f16conv2', 'b3'])
+def test_bottleneck_planes_vs_fp64(inplanes, planes, stride, ds, B, H, W, from_stem, style, train_bn, mode, monkeypatch):
+    """The three operand modes of the trunk - the same bars:
+    h2: every activation and gradient of the block as scaled fp16 x 2 planes, three MFMA products, one gradient scale for the chain
+        (functional.F16_TRUNK, the default); h2_relink: the same with a fresh scale at every link (the census' fall-back for a chain
+        that left fp16's range: PT_F16_CHAIN=0);
+    b3_f16conv2: bf16 x 3 planes between the layers, the 3x3 alone on fp16 operands (PT_F16_TRUNK=0: round 4's default);
+    b3: bf16 x 3 operands and six products everywhere (PT_F16_FC=0: the strict 24-bit path)."""
     from point_teacher_amd import functional as F, planes as PL
-    monkeypatch.setattr(F, 'F16_BLOCK3', f16_conv2)
+    PL.CENSUS.reset()
+    monkeypatch.setattr(F, 'F16_TRUNK', mode.startswith('h2'))
+    monkeypatch.setattr(F, 'F16_CHAIN', mode != 'h2_relink')
+    monkeypatch.setattr(F, 'F16_BLOCK3', mode == 'b3_f16conv2')
     blk = _make_block(inplanes, planes, stride, ds, 11, style, train_bn)
     assert blk.plane_ok()
     g = torch.Generator().manual_seed(3)
@@ -290,9 +298,10 @@ def test_bottleneck_planes_vs_fp64(inplanes, planes, stride, ds, B, H, W, from_s
         out = blk.forward_planes(x)
     else:
         x.requires_grad_(True)
-        xa = PL.to_planes(x)
+        xa = PL.to_planes(x, f16=mode.startswith('h2'), group='trunk', carrier=False)
         xa.relu = True                              # (x is a ReLU output; the test plays its producer)
         out = blk.forward_planes(xa)
+    assert out.f16 == mode.startswith('h2')
     y = out.float()
     xr = x.detach().double().requires_grad_(not from_stem)
     ref = _ref_bottleneck(blk, xr)
@@ -314,6 +323,9 @@ def test_bottleneck_planes_vs_fp64(inplanes, planes, stride, ds, B, H, W, from_s
         err = float((a.double() - b).abs().max() / b.abs().max())
         print(name, f'{err:.3e}')
         assert err < 5e-6, (name, err)
+    if mode.startswith('h2'):
+        cen = PL.CENSUS.poll(sync=True)
+        assert cen and all(d['saturated'] == 0 for d in cen.values()) and not PL.CENSUS.demoted, (cen, PL.CENSUS.demoted)
 
 
 def test_resnet_fpn_planes_vs_fp64_and_the_fp32_routing(monkeypatch):
@@ -390,7 +402,9 @@ def test_roi_planes_and_fc_stack_vs_fp64(f16):
     assert F.roi_align_planes_ok(feat, rois, 7)
     t = F.roi_align_planes(feat, rois, 0.125, 0, True, 5, f16=f16)
     if f16:
-        assert t.dtype == torch.float16 and t.shape[0] == 2 and float(t[:, K * C * 49:].abs().max()) == 0
+        n = (K + 1) * C * 49
+        assert t.dtype == torch.float16 and tuple(t.shape) == (2, n + 8) and float(t[:, K * C * 49:n].abs().max()) == 0
+        assert PL.tail_value(t.detach()) == 1.0                           # forward activations are stored unscaled
         val = t[0, :K * C * 49].detach().float() + t[1, :K * C * 49].detach().float()
         ref_flat = ref_block.flatten()
         assert float((val - ref_flat).abs().max()) <= 2.0 ** -22 * float(ref_flat.abs().max()) + 3e-8
@@ -629,7 +643,11 @@ def test_fp16_operand_tower_chain_vs_fp64(two):
     towers = [[ConvModule(C, C, 3, padding=1).to(DEV).to(memory_format=torch.channels_last) for _ in range(3)] for _ in range(2 if two else 1)]
     x = torch.randn(B, C, H, W, generator=g).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     gys = [(torch.randn(B, C, H, W, generator=g) * 1e-4).to(DEV).contiguous(memory_format=torch.channels_last) for _ in towers]   # gradient-sized
+    PL.CENSUS.reset()
     acts = PL.to_planes2(x, f16=True) if two else (PL.to_planes(x, f16=True),)
+    for layers in towers:
+        for l in layers:
+            l.plane_group = 'towers'
     outs = []
     for act, layers in zip(acts, towers):
         assert act.f16 and act.gcarrier
@@ -654,7 +672,9 @@ def test_fp16_operand_tower_chain_vs_fp64(two):
     for n, a, b in zip(['x'] + [f'p{i}' for i in range(len(params))], got, want):
         err = float((a.double() - b.double()).norm() / b.double().norm())
         assert err < 2e-4, (n, err)
-    assert not PL._F16_SCALES                                          # every link consumed the scale handed to it
+    cen = PL.CENSUS.poll(sync=True)                                    # the chain's scale: every gradient tensor's largest stored
+    grads = {k: d for k, d in cen.items() if k[0] == 'towers_grad'}    # magnitude sits inside fp16's comfortable range
+    assert grads and all(d['saturated'] == 0 and 1.0 <= d['amax_stored'] < 60000 for d in grads.values()), grads
 
 
 def test_fp16_operand_single_convolution_vs_fp64():
