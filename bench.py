@@ -43,6 +43,8 @@ def parse():
     ap.add_argument('--no-phase2', action='store_true', help='skip the extra steady-state (phase 2) measurement')
     ap.add_argument('--no-configs2', action='store_true', help='skip the extra BASELINE configs[2] (bf16 backbone) measurement')
     ap.add_argument('--roofline-kernel', default='auto')
+    ap.add_argument('--tiles', type=int, default=64, help='synthetic tiles per rank, cycled (SURVEY 8(d): 64, so the point dictionaries are exercised)')
+    ap.add_argument('--no-strict', action='store_true', help='skip the extra strict-fp32 (bf16 x 3 operands everywhere) measurement')
     return ap.parse_args()
 
 
@@ -109,10 +111,49 @@ def algorithmic_flops(name, shapes):
 
 def conv_desc_shapes(d):
     """Shapes out of a pt_conv_desc / pt_conv_wgrad_desc (host struct); np: planes per operand (3: fp32 as six bf16 products,
-    1: bf16 operands, one product - the bf16 trunk of BASELINE configs[2]); f16: fp32 as two fp16 terms, three products."""
+    1: bf16 operands, one product - the bf16 trunk of BASELINE configs[2]); f16: fp32 as two fp16 terms, three products.
+    abytes: the launch's ALGORITHMIC HBM bytes - every tensor it reads or writes once, as fp32 (4 B per element: activations at the
+    pixels the convolution reads, weights, results, identity, the ReLU mask's activation); fbytes: the same tensors in the formats
+    this implementation moves (6 B bf16 x 3 planes, 4 B fp16 x 2 planes or fp32, 2 B one plane / a mask's plane 0, plus the fp32
+    partial tiles of split launches).  SURVEY 8(d): algorithmic bytes per launch x launches = the family's floor."""
     Ho = (d.Hs + 2 * d.pad - d.KH) // d.stride + 1
     Wo = (d.Ws + 2 * d.pad - d.KW) // d.stride + 1
-    return dict(M=d.B * Ho * Wo, Cin=d.Cin, Cout=d.Cout, taps=d.KH * d.KW, np=(getattr(d, 'np', 3) or 3), f16=int(getattr(d, 'operand_f16', 0) or 0))
+    np_ = getattr(d, 'np', 3) or 3
+    f16 = int(getattr(d, 'operand_f16', 0) or 0)
+    ob = 4 if f16 else 2 * np_                                # bytes per operand element
+    taps = d.KH * d.KW
+    M = d.B * Ho * Wo
+    wn = d.Cout * taps * d.Cin
+    if hasattr(d, 'gy_planes'):                               # weight gradient: gy [M, Cout], x at the pixels read, dw (+ partial tiles)
+        xe = (M if taps == 1 else d.B * d.Hs * d.Ws) * d.Cin
+        S = max(int(d.splits), 1)
+        ab = 4 * (M * d.Cout + xe + wn)
+        fb = ob * (M * d.Cout + xe) + 4 * wn * (1 + 2 * S)   # (partials written and read once by the reduction)
+    else:
+        if getattr(d, 'dstride', 0) > 1:                      # transposed form: result on the [out_H, out_W] grid
+            M = d.B * d.out_H * d.out_W
+        xe = (M if taps == 1 else d.B * d.Hs * d.Ws) * d.Cin
+        oe = M * d.Cout
+        ab = 4 * (xe + wn)
+        fb = ob * (xe + wn)
+        if d.out_planes:
+            ab += 4 * oe
+            fb += (4 if d.out_f16 else 2 * np_) * oe
+        if d.out_f32:
+            ab += 0 if d.out_planes else 4 * oe               # (a second copy of the same result is format overhead)
+            fb += 4 * oe
+        if d.res_planes:
+            ab += 4 * oe
+            fb += (4 if d.res_f16 else 2 * np_) * oe
+        if d.res_f32:
+            ab += 4 * oe
+            fb += 4 * oe
+        if d.mask_planes:
+            ab += 4 * oe
+            fb += 2 * oe
+        if int(d.splits) > 1:
+            fb += 8 * int(d.splits) * oe
+    return dict(M=d.B * Ho * Wo, Cin=d.Cin, Cout=d.Cout, taps=taps, np=np_, f16=f16, abytes=ab, fbytes=fb)
 
 
 def executed_flops(name, shapes):
@@ -130,7 +171,8 @@ MFMA_FAMILY = ('pt_bf16x6 (conv + gemm + wgrad)', ('pt_conv_bf16x6', 'pt_conv_wg
                                                   'pt_conv3x3_wgrad_bf16x6_nhwc'))
 # their companion launches: fp32 -> split planes at the edges of the plane-native region, the once-per-update weight planes, the
 # exact addition of gradient planes where an activation has two consumers (round-3 advice: report them beside the family)
-SPLIT_FNS = ('pt_split_bf16x3', 'pt_split_bf16x3_rows', 'pt_split_bf16x3_gather', 'pt_conv_weight_planes_batch', 'pt_planes_combine')
+SPLIT_FNS = ('pt_split_bf16x3', 'pt_split_bf16x3_rows', 'pt_split_bf16x3_gather', 'pt_conv_weight_planes_batch', 'pt_planes_combine',
+             'pt_planes_mix', 'pt_split_gather_h2', 'pt_planes_to_f16')
 BF16_PEAK_TFLOPS = 2500.0          # dense bf16 MFMA (MI355X_MICROARCH.md); 6 products per fp32 product -> 416.7 TFLOP/s fp32-equivalent ceiling
 
 FAMILIES = {                                                    # op families for the roofline line
@@ -222,7 +264,7 @@ def main():
         for m in model.modules():
             if isinstance(m, torch.nn.BatchNorm2d):
                 m.fold_into_conv = True
-    data = SyntheticTiles(n=8, size=args.size, mean_objects=args.objects, seed=7, device=dev, rank=rank, world=world,
+    data = SyntheticTiles(n=args.tiles, size=args.size, mean_objects=args.objects, seed=7, device=dev, rank=rank, world=world,
                           oriented=obb, num_classes=9 if obb else 8)
 
     def barrier():
@@ -330,7 +372,8 @@ def main():
             ex = [executed_flops(fn, s) if s else None for _, _, s in evs]
             kern[fn] = dict(calls=len(ms), total_ms=sum(ms), bytes=sum(b for b in byts if b) if all(b for b in byts) else None,
                             flops=sum(f for f in fl if f) if all(f for f in fl) else None,
-                            exec_flops=sum(f for f in ex if f) if all(f for f in ex) else None)
+                            exec_flops=sum(f for f in ex if f) if all(f for f in ex) else None,
+                            abytes=sum((s or {}).get('abytes', 0) for _, _, s in evs), fbytes=sum((s or {}).get('fbytes', 0) for _, _, s in evs))
         fam = {}
         for name, members in FAMILIES.items():
             ks = [kern[m] for m in members if m in kern and kern[m]['bytes']]
@@ -339,7 +382,8 @@ def main():
         # the matrix kernels of the path (fp32 products as six bf16 MFMA products): MFMA-bound, priced against the dense bf16 peak
         mk = [kern[m] for m in MFMA_FAMILY[1] if m in kern and kern[m].get('flops')]
         mfma = dict(calls=sum(k['calls'] for k in mk), total_ms=sum(k['total_ms'] for k in mk), flops=sum(k['flops'] for k in mk),
-                    exec_flops=sum(k['exec_flops'] for k in mk)) if mk else None
+                    exec_flops=sum(k['exec_flops'] for k in mk), abytes=sum(k['abytes'] for k in mk),
+                    fbytes=sum(k['fbytes'] for k in mk)) if mk else None
         if mfma:
             sk = [kern[m] for m in SPLIT_FNS if m in kern]
             mfma['split_ms'], mfma['split_calls'] = sum(k['total_ms'] for k in sk), sum(k['calls'] for k in sk)
@@ -462,7 +506,12 @@ def main():
                     split_launches_per_step=round(m.get('split_calls', 0) / steps_, 1),
                     avg_launch_us=round(m['total_ms'] / m['calls'] * 1e3, 2), event_pair_overhead_us=round(event_overhead_us, 2),
                     launches=m['calls'], flops_per_launch=int(m['exec_flops'] / m['calls']),
-                    algorithmic_flops_per_launch=int(m['flops'] / m['calls']), **extra)
+                    algorithmic_flops_per_launch=int(m['flops'] / m['calls']),
+                    # bytes beside `traffic` (verdict r04 W3): the family's fp32-tensor floor and what its plane formats move, per launch
+                    # (conv_desc_shapes); format / algorithmic = the byte overhead of the operand formats (1.5 for bf16 x 3, 1.0 for fp16 x 2)
+                    algorithmic_bytes=int(m['abytes'] / m['calls']), format_bytes=int(m['fbytes'] / m['calls']),
+                    algorithmic_bytes_per_step=int(m['abytes'] / steps_), format_bytes_per_step=int(m['fbytes'] / steps_),
+                    hbm_floor_ms_per_step=round(m['abytes'] / steps_ / 8e12 * 1e3, 3), **extra)
 
     if dom == MFMA_FAMILY[0]:
         roofline = mfma_roofline(mfma, n_event_steps, traffic=traffic, families=fams, instrumentation=INSTR)
@@ -472,7 +521,30 @@ def main():
                         avg_launch_us=round(d['total_ms'] / d['calls'] * 1e3, 2), event_pair_overhead_us=round(event_overhead_us, 2),
                         launches=d['calls'], bytes_per_launch=int(d['bytes'] / d['calls']), families=fams, instrumentation=INSTR)
 
-    # ---- the steady-state phase as well (94 % of a 12-epoch run is phase 2): same model, phase switch flipped ----
+    def fresh(workload, autocast=None):
+        """A new detector + Trainer in the state the stand-alone `--workload <workload>` line starts from (same seed, same
+        `benchmark_init_`).  Every sub-line below is timed on one of these: until round 4 the `phase2` field flipped the phase switch
+        of the model the default workload had just trained for ~30 phase-1 iterations - its regression branch still emits the
+        all-zero distances of a cold start, the centerness target becomes 0.01 / 0 and the weights are NaN from the second phase-2
+        iteration on (profiles/r05/census_switch.txt): the driver's 25.46 ms against the stand-alone 22.8 ms was a NaN model."""
+        torch.manual_seed(1234)
+        c_ = pta.Config.fromfile(os.path.join(ROOT, 'point_teacher_amd', 'configs', 'obb', 'point_teacher', 'sodaa_fcos_pointteacher_1x.py') if obb else
+                                 os.path.join(ROOT, 'point_teacher_amd', 'configs', 'point_teacher', f'aitodv2_point_teacher_{args.percent}.py'))
+        c_.model['burn_in_step'] = 10 ** 9 if workload == 'step1' else -1
+        m_ = pta.build_detector(c_.model).to(dev)
+        live[0] = m_
+        benchmark_init_(m_, phase2=(workload == 'step2'))
+        m_.train()
+        t_ = pta.Trainer(m_, c_.optimizer, c_.optimizer_config, c_.lr_config, iters_per_epoch=5000, autocast_dtype=autocast,
+                         channels_last=bool(args.channels_last))
+        return c_, m_, t_
+
+    def final_loss(out_):
+        v = out_['log_vars'].materialize().get('loss', float('nan'))
+        assert v == v and abs(v) != float('inf'), 'a benchmark sub-line ended on a non-finite loss: its timing is of a diverged model'
+        return round(v, 4)
+
+    # ---- the steady-state phase as well (94 % of a 12-epoch run is phase 2) ----
     def timed_with_family(tr_, base):
         """args.steps timed steps of `tr_` with NO instrumentation (an event pair per matrix launch costs a host-bound iteration -
         the bf16 configuration - up to 25 % of its step), then 3 un-timed steps with HIP events around the matrix family (and its
@@ -480,7 +552,7 @@ def main():
         barrier()
         t0_ = time.perf_counter()
         for it_ in range(args.steps):
-            tr_.step(data.batch(base + it_, args.batch))
+            last_[0] = tr_.step(data.batch(base + it_, args.batch))
         barrier()
         d_ = torch.tensor([time.perf_counter() - t0_], device=dev, dtype=torch.float64)
         if world > 1:
@@ -494,45 +566,73 @@ def main():
         m_ = summarise(p_)[2]
         return float(d_.item()), (mfma_roofline(m_, 3, timed_region=False) if m_ else None)
 
-    phase2 = None
-    if args.workload == 'step1' and not args.no_phase2:
-        model.burn_in_step = -1
-        for it in range(max(args.warmup, 3)):
-            trainer.step(data.batch(1000 + it, args.batch))
-        dt2, roof2 = timed_with_family(trainer, 2000)
-        f2 = iteration_flops('step2', cfg.to_dict()['model'], args.batch, args.size, args.objects)
-        phase2 = dict(workload='phase 2 (MIL on, steady state), same model and inputs', value=round(args.steps * world / dt2, 4), unit='iters/s',
-                      ms_per_step=round(dt2 / args.steps * 1e3, 3), flops=f2, achieved_tflops=round(f2 * args.steps / dt2 / 1e12, 2),
-                      roofline=roof2)
-        model.burn_in_step = 10 ** 9
-
-    # ---- BASELINE configs[2] (bf16 backbone / FPN / PSAGG + fp32 heads, two-phase = MIL on): timed by THIS run as well, so
-    # that the driver's line carries it (round-2 verdict item 6); a fresh model + Trainer under bf16 autocast, phase 2, same inputs
+    last_ = [None]
     exchange_stats = (dict(trainer.exchange.stats, dead_bytes=4 * trainer.flat.n_dead, backend=dist.get_backend())
                       if trainer.exchange is not None else dict(buckets=0, issued_during_backward=0, bytes=0, dead_bytes=4 * trainer.flat.n_dead))
     tuned_table = bool(trainer.tuned_gemms)
+    from point_teacher_amd import planes as PPLc
+
+    def census_summary():
+        PPLc.CENSUS.poll(sync=True)
+        h = PPLc.CENSUS.history
+        lo = [v[2] for v in h.values() if v[2] < float('inf')]
+        return dict(mode=PPLc.CENSUS.mode, demoted=dict(PPLc.CENSUS.demoted), sites=len(h), saturated_elements=sum(v[0] for v in h.values()),
+                    largest_stored=max([v[1] for v in h.values()] + [0.0]), smallest_site_maximum=min(lo) if lo else None, polls_every_steps=10)
+    census = census_summary()
+    phase2 = None
+    if args.workload == 'step1' and not args.no_phase2:
+        del trainer, model
+        torch.cuda.empty_cache()
+        PPLc.CENSUS.reset()
+        cfg2p, model, trainer = fresh('step2')
+        for it in range(max(args.warmup, 5)):
+            trainer.step(data.batch(1000 + it, args.batch))
+        dt2, roof2 = timed_with_family(trainer, 2000)
+        f2 = iteration_flops('step2', cfg.to_dict()['model'], args.batch, args.size, args.objects)
+        phase2 = dict(workload='phase 2 (MIL on, steady state): a fresh model in the stand-alone `--workload step2` state, same inputs',
+                      value=round(args.steps * world / dt2, 4), unit='iters/s',
+                      ms_per_step=round(dt2 / args.steps * 1e3, 3), flops=f2, achieved_tflops=round(f2 * args.steps / dt2 / 1e12, 2),
+                      roofline=roof2, loss=final_loss(last_[0]), f16_census=census_summary())
+
+    # ---- BASELINE configs[2] (bf16 backbone / FPN / PSAGG + fp32 heads, two-phase = MIL on): timed by THIS run as well, so
+    # that the driver's line carries it (round-2 verdict item 6); a fresh model + Trainer under bf16 autocast, phase 2, same inputs
     configs2 = None
     if args.workload == 'step1' and args.dtype == 'fp32' and not obb and not args.no_phase2 and not args.no_configs2:
         del trainer, model
         torch.cuda.empty_cache()
-        torch.manual_seed(1234)
-        cfg2 = pta.Config.fromfile(os.path.join(ROOT, 'point_teacher_amd', 'configs', 'point_teacher', f'aitodv2_point_teacher_{args.percent}.py'))
-        cfg2.model['burn_in_step'] = -1
-        model = pta.build_detector(cfg2.model).to(dev)
-        live[0] = model
-        benchmark_init_(model, phase2=True)
-        model.train()
-        trainer = pta.Trainer(model, cfg2.optimizer, cfg2.optimizer_config, cfg2.lr_config, iters_per_epoch=5000,
-                              autocast_dtype=torch.bfloat16, channels_last=True)
+        PPLc.CENSUS.reset()
+        cfg2, model, trainer = fresh('step2', autocast=torch.bfloat16)
         for it in range(max(args.warmup, 5)):
             trainer.step(data.batch(3000 + it, args.batch))
-        dt3, roof3 = timed_with_family(trainer, 4000)       # (fp32 heads: six products per product; bf16 trunk: one - the same kernels)
+        dt3, roof3 = timed_with_family(trainer, 4000)       # (fp32 heads: three products per product; bf16 trunk: one - the same kernels)
         f3 = iteration_flops('step2', cfg2.to_dict()['model'], args.batch, args.size, args.objects)
         configs2 = dict(workload=f'BASELINE configs[2]: aitodv2_point_teacher_{args.percent}% phase 2 (MIL on), bf16 backbone / FPN / PSAGG (autocast) + '
                                  f'fp32 dense head, MIL head and losses, bs {args.batch}/GPU, {args.size}x{args.size}',
                         value=round(args.steps * world / dt3, 4), unit='iters/s', ms_per_step=round(dt3 / args.steps * 1e3, 3),
                         steps=args.steps, dtype='bf16 backbone + f32 head', flops=f3, achieved_tflops=round(f3 * args.steps / dt3 / 1e12, 2),
-                        roofline=roof3)
+                        roofline=roof3, loss=final_loss(last_[0]), f16_census=census_summary())
+
+    # ---- the strictly 24-bit number (verdict r04 W1): the SAME default workload with every fp16-operand group switched off - bf16 x 3
+    # planes and six MFMA products everywhere (PT_F16_FC=0) - timed by this run too, so the driver's line carries both
+    strict = None
+    if args.dtype == 'fp32' and not args.no_strict and PF.F16_FC:
+        try:
+            del trainer, model
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        saved = {k: getattr(PF, k) for k in ('F16_FC', 'F16_TOWERS', 'F16_NECK', 'F16_NECK3', 'F16_TRUNK', 'F16_BLOCK3')}
+        for k in saved:
+            setattr(PF, k, False)
+        _, model, trainer = fresh(args.workload)
+        for it in range(max(args.warmup, 5)):
+            trainer.step(data.batch(it, args.batch))
+        dt4, roof4 = timed_with_family(trainer, args.warmup)
+        strict = dict(workload='the default workload with bf16 x 3 operands and six MFMA products in EVERY layer (PT_F16_FC=0): 24 significant bits per operand',
+                      value=round(args.steps * world / dt4, 4), unit='iters/s', ms_per_step=round(dt4 / args.steps * 1e3, 3), steps=args.steps,
+                      roofline=roof4, loss=final_loss(last_[0]))
+        for k, v in saved.items():
+            setattr(PF, k, v)
 
     if rank == 0:
         cpu_baseline = None
@@ -567,7 +667,12 @@ def main():
             # formed from six bf16 MFMA products - three fp16 ones in the MIL head's first FC layer - with fp32 accumulation
             # (csrc/gemm_split.hip: error vs float64 below the fp32
             # library kernels'; activations travel between the layers as exact three-term bf16 splits of their fp32 values)
-            dtype=('f32' + (' (backbone / neck / tower convolutions and MIL FC stacks: bf16x6 split MFMA - the first FC layer fp16x3 -, fp32 accumulate)'
+            # NOT 24-bit operands by default (round-4 advice): the trainable trunk, necks, towers and MIL FC stacks multiply scaled
+            # fp16 x 2 operands (22 significant bits per stored value, three MFMA products, fp32 accumulation) unless PT_F16_FC=0 or
+            # the range census demoted a group; `strict_fp32` below is the bf16 x 3 (24-bit, six products) number of the same workload
+            dtype=('f32' + ((' (fp32 tensors at the boundaries; trainable trunk / necks / towers / MIL FC stacks on split-operand MFMA with fp32 '
+                             'accumulation: ' + ('scaled fp16 x 2 planes = 22-bit operands, 3 products' if PF.F16_FC else 'bf16 x 3 planes = 24-bit operands, 6 products')
+                             + (f'; groups demoted to bf16 x 3 by the range census: {sorted(census["demoted"])}' if census['demoted'] else '') + ')')
                             if os.environ.get('PT_SPLIT_GEMM', '1') != '0' and os.environ.get('PT_SPLIT_CONV', '1') != '0' else ''))
             if args.dtype == 'fp32' else 'bf16', data='synthetic',
             config=dict(workload=(f'sodaa_fcos_pointteacher_1x (oriented) ' if obb else f'aitodv2_point_teacher_{args.percent}% ')
@@ -579,7 +684,10 @@ def main():
             roofline=roofline, cpu_baseline=cpu_baseline,
             iteration=dict(flops=flops_iter, flops_reference=flops_ref, achieved_tflops=round(flops_iter * iters_s / 1e12, 2),
                            mfma_peak_tflops=peak / 1e12, frac=round(flops_iter * iters_s / peak, 4)),
-            phase2=phase2, configs2_bf16=configs2,
+            phase2=phase2, configs2_bf16=configs2, strict_fp32=strict, f16_census=census,
+            # N > 1: weak scaling - `value` = iterations/s of ONE rank x N, i.e. bs-2-equivalent iterations per second of the job
+            # (every rank steps its own batch of 2; an 8-GPU line is 8 batches per step time, not 8x faster iterations)
+            value_is='iterations/s of one rank x n_gpus (bs-%d-equivalent iterations/s; global batch %d per step)' % (args.batch, args.batch * world),
             # gradient exchange of the LAST timed step (N > 1): buckets, how many all-reduces were issued while backward was
             # still running, payload per step; the never-used MIL stacks are in neither (runtime.FlatParams "dead")
             exchange=exchange_stats,

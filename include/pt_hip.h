@@ -424,8 +424,9 @@ int pt_planes_to_f16(const uint16_t* planes, int64_t plane_stride, int64_t n, fl
  *   c: fp32 or NULL.  mask: plane 0 of any 16-bit plane set (m = plane 0 > 0) or NULL; relu_of: fp32 (m = relu_of > 0) or NULL.
  *   out (format out_fmt, may be NULL) and / or out_f32.  For out_fmt == PT_FMT_H2 the output scale `so` follows scale_mode:
  *     PT_SCALE_ONE      so = 1;
- *     PT_SCALE_AUTO     the power of two that brings the largest magnitude of the result into [512, 1024) (a first launch reduces
- *                       the maximum per workgroup into `workspace`, >= 1024 floats; a zero / non-finite tensor keeps 1);
+ *     PT_SCALE_AUTO     the power of two that brings the largest magnitude of the result into [128, 256) (a first launch reduces
+ *                       the maximum per workgroup into `workspace`, >= 1024 floats; a zero / non-finite tensor keeps 1): ~250 x
+ *                       of headroom for a gradient that grows along its chain, 500 x above the census' floor of 0.25;
  *     PT_SCALE_MERGE    1 / max(ia, ib): two chains meet, the result carries the smaller of their scales (no overflow);
  *   and the tail out_plane_stride - 8 ... is written with 1 / so: out_plane_stride >= n + 8, the tail sits at element n of plane 0.
  *   n_valid <= n (a multiple of 8): elements [n_valid, n) are written as zeros without reading any source - the zero row behind

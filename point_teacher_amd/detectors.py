@@ -39,7 +39,12 @@ class LazyLogVars(OrderedDict):
             vals = vals / dist.get_world_size()
             dist.all_reduce(vals)                      # ONE coalesced all-reduce instead of one per key
         host = vals.cpu().tolist()
-        return OrderedDict(zip(keys, host))
+        out = OrderedDict(zip(keys, host))
+        from . import planes as PL
+        if PL.CENSUS.mode >= 2:            # PT_F16_CENSUS=2, the debugging census of the fp16 planes: per site saturated / sub-0.125
+            PL.CENSUS.poll(sync=True)      # elements and the largest stored magnitude since the last read (this rank's)
+            out.update(PL.CENSUS.log_vars())
+        return out
 
     def __getitem__(self, k):
         v = super().__getitem__(k)

@@ -6,7 +6,7 @@ planes.  Two formats carry an fp32 value (round 5):
 * **H2** - the default: two fp16 planes with a power-of-two scale, `torch.float16 [2, (pixels + 1) * C + 8]`: rows of pixels, a zero last
   row, and behind it (element `(pixels + 1) * C` of plane 0) an fp32 word - the TAIL - holding 1 / s; value = (h0 + h1) / s, 22
   significant bits, three MFMA products per fp32 product, 4 bytes per element.  Forward activations are stored unscaled (s = 1); a
-  GRADIENT entering the plane region is scaled by the power of two that brings its largest magnitude into [512, 1024) (chosen on
+  GRADIENT entering the plane region is scaled by the power of two that brings its largest magnitude into [128, 256) (chosen on
   the device, pt_planes_mix PT_SCALE_AUTO) and every input-gradient launch of the chain hands that scale on (the operations are
   linear: `out_inv_scale_src`); two chains that meet (a stage output feeding the next stage and an FPN lateral) are added exactly and
   continue with the smaller scale (PT_SCALE_MERGE); weight gradients multiply the tails back in (`alpha_dev`).
@@ -15,7 +15,7 @@ planes.  Two formats carry an fp32 value (round 5):
 
 fp16 has 5 exponent bits: every H2 tensor a kernel writes is watched by a CENSUS (`Census`: saturated elements and the largest
 stored magnitude per site, conditional atomics - free in the steady state) that the Trainer polls without synchronising; a site
-that saturates (|stored| > 60 000) or whose largest stored magnitude falls below 1 (less than 25 bits against the tensor's maximum)
+that saturates (|stored| > 60 000) or whose largest stored magnitude falls below 0.25 (less than 23 bits against the tensor's maximum)
 demotes its GROUP - 'trunk', 'neck', 'towers', 'fc' to B3 operands, a '*_grad' group to a fresh scale at every link - for the
 rest of the run, with a warning.
 
@@ -47,7 +47,8 @@ class Census:
     """Device int32 [MAX, 4] (one row per site: saturated count, bits of the largest stored magnitude, and - mode 2 - non-zero
     elements below 0.125, elements written) + the fall-back policy it drives.  `ptr(group, name)` is what a launch receives."""
     MAX = 1024
-    LOW = 1.0                                          # a non-zero tensor whose largest STORED magnitude is below this has lost bits
+    LOW = 0.25                                         # a non-zero tensor whose largest STORED magnitude is below this has lost bits: its
+                                                       # absolute error 2^-25 is more than 2^-23 of the tensor's own maximum
 
     def __init__(self):
         self.buf = None
@@ -57,6 +58,7 @@ class Census:
         self.mode = int(os.environ.get('PT_F16_CENSUS', '1'))         # 0: off, 1: saturation + maximum, 2: + tiny / total counts
         self.auto_fallback = os.environ.get('PT_F16_FALLBACK', '1') != '0'
         self._pending = None                           # (pinned host copy, event) of an asynchronous poll
+        self._pin = None
         self.last = {}                                 # site -> dict of the last completed poll
         self.history = {}                              # site -> [saturated total, largest stored magnitude, smallest non-zero per-poll maximum]
 
@@ -135,7 +137,9 @@ class Census:
                 return None
             self._pending = None
             self._digest(host)
-        host = torch.empty(self.buf.shape, dtype=torch.int32, pin_memory=True)
+        if self._pin is None:
+            self._pin = torch.empty(self.buf.shape, dtype=torch.int32, pin_memory=True)
+        host = self._pin                               # (the previous copy has been digested above)
         host.copy_(self.buf, non_blocking=True)
         self.buf.zero_()
         ev = torch.cuda.Event()
@@ -320,7 +324,7 @@ def split_nhwc(x, stride=1, np=None, f16=False, census=0):
 
 def grad_to_planes(rows, h2, relu_of=None, mask=None, census=0):
     """An fp32 gradient [M, C] entering the plane region -> planes with a zero row: H2 with the power-of-two scale that brings its
-    largest magnitude into [512, 1024) (two launches: maximum, conversion), or B3.  relu_of (fp32 [M, C]) / mask (plane 0 of the
+    largest magnitude into [128, 256) (two launches: maximum, conversion), or B3.  relu_of (fp32 [M, C]) / mask (plane 0 of the
     activation's planes): the ReLU of the tensor the gradient belongs to."""
     M, C = rows.shape
     if h2:

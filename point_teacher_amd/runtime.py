@@ -490,6 +490,7 @@ class Trainer:
         # with one all-reduce of a bitmap, re-checked every `revive_interval` steps (N > 1; N == 1 sees a revival at once).
         self.dead_known = False
         self.revive_interval = 100
+        self.census_interval = 10
         self._revived = set()
         self._revived_grads = {}              # name -> gradient(s) a dead parameter received since the last agreement point
         # BASELINE configs[2] "bf16 backbone + fp32 head": autocast covers backbone / FPN / PSAGG only (Student_FCOS.extract_feat)
@@ -535,6 +536,11 @@ class Trainer:
         F.sgd_step_groups_(f.student_flat[:f.n_train], f.grad_flat, f.mom_flat, f.group_tables(), self.lr_t, self.momentum,
                            self.weight_decay, sq, self.max_norm, self.iter == 0)
         self.iter += 1
+        if self.iter % self.census_interval == 0:
+            # range census of the fp16 planes (planes.CENSUS): an asynchronous copy now, digested at the next poll - no host wait; a
+            # site that saturated or sank below fp16's comfortable range demotes its group to bf16 x 3 planes from the next step on
+            from . import planes as PL
+            PL.CENSUS.poll()
         return out
 
     # ------------------------------------------------------------------------------ never-used parameters --

@@ -674,7 +674,7 @@ def test_fp16_operand_tower_chain_vs_fp64(two):
         assert err < 2e-4, (n, err)
     cen = PL.CENSUS.poll(sync=True)                                    # the chain's scale: every gradient tensor's largest stored
     grads = {k: d for k, d in cen.items() if k[0] == 'towers_grad'}    # magnitude sits inside fp16's comfortable range
-    assert grads and all(d['saturated'] == 0 and 1.0 <= d['amax_stored'] < 60000 for d in grads.values()), grads
+    assert grads and all(d['saturated'] == 0 and 0.25 <= d['amax_stored'] < 60000 for d in grads.values()), grads
 
 
 def test_fp16_operand_single_convolution_vs_fp64():

@@ -27,12 +27,14 @@ benchmark_init_(model, phase2=phase2)
 model.train()
 model.teacher_stream = False      # per-launch HIP-event timings: no co-scheduled teacher kernels on a second stream
 tr = pta.Trainer(model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config, channels_last=True)
-data = SyntheticTiles(n=8, size=1200 if obb else 800, mean_objects=300, seed=7, device=dev, oriented=obb, num_classes=9 if obb else 8)
+data = SyntheticTiles(n=16, size=1200 if obb else 800, mean_objects=300, seed=7, device=dev, oriented=obb, num_classes=9 if obb else 8)
 for it in range(6):
     tr.step(data.batch(it, 2))
 torch.cuda.synchronize()
 orig = hip.call
 rec = []
+groups = defaultdict(lambda: [0, 0.0, 0.0])
+gkeys = {}
 
 
 def hook(fn, *a):
@@ -50,13 +52,17 @@ def hook(fn, *a):
                 Ho, Wo = d.out_H, d.out_W
             M = d.B * Ho * Wo
             flav = ''
+            grp = 'FC' if (d.B == 1 and d.Ws == 1) else ('3x3' if d.KH == 3 else '1x1')
             if fn == 'pt_conv_bf16x6':
                 flav = ('P' if d.out_planes else '') + ('F' if d.out_f32 else '') + ('+rp' if d.res_planes else '') + ('+rf' if d.res_f32 else '') + \
                        ('+m' if d.mask_planes else '') + (f' s{d.stride}' if d.stride > 1 else '') + (' T' if d.dstride > 1 else '') + \
                        (' sc' if d.scatter_stride else '') + (f' k{d.splits}' if d.splits > 1 else '')
             else:
                 flav = (f's{d.stride} ' if d.stride > 1 else '') + ('b' if d.dbias else '') + f' S{d.splits}'
+            flav = ('h2 ' if d.operand_f16 else ('b1 ' if d.np == 1 else 'b3 ')) + flav + (' >h2' if (fn == 'pt_conv_bf16x6' and d.out_f16) else '')
             key, fl = (fn, M, d.Cin, d.Cout, d.KH * d.KW, flav), 2.0 * M * d.Cin * d.Cout * d.KH * d.KW
+            groups[grp][0] += 1
+            gkeys[key] = grp
         rec.append((key, fl, e0, e1))
         return r
     return orig(fn, *a)
@@ -78,6 +84,12 @@ rows = sorted(((v[0] / N, v[1] / N, v[2] / v[0] / 1e9, k) for k, v in agg.items(
 tot = sum(r[0] for r in rows)
 print(f'matrix family: {tot:.2f} ms / iteration in {sum(r[1] for r in rows):.0f} launches ({"phase 2" if phase2 else "phase 1"}{" obb" if obb else ""}); '
       f'{sum(v[2] for v in agg.values()) / N / tot / 1e9:.1f} TFLOP/s fp32-equivalent overall (HIP events incl. ~5 us per launch)')
+for k, v in agg.items():
+    if k in gkeys:
+        groups[gkeys[k]][1] += v[0] / N
+        groups[gkeys[k]][2] += v[2] / N
+for gname, (cnt, ms, fl) in sorted(groups.items()):
+    print(f'  group {gname:4s}: {ms:7.3f} ms / iteration, {cnt / N:6.1f} launches, {fl / ms / 1e9 if ms else 0:6.1f} TFLOP/s fp32-equivalent')
 print(f'{"ms/iter":>8} {"calls":>6} {"TF":>6}  entry  M  Cin->Cout  taps  flavour')
 for ms, n, tf, k in rows:
     print(f'{ms:8.3f} {n:6.1f} {tf:6.1f}  {k[0][3:]:22s} M={k[1]:6d} {k[2]:5d}->{k[3]:5d} t{k[4]} {k[5]}')
