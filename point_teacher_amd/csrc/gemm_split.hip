@@ -1753,9 +1753,18 @@ extern "C" int pt_conv_bf16x6(const pt_conv_desc* d, void* stream) {
     if (tile_rows <= 0 || tile_rows > 128) tile_rows = M >= 32768 ? 128 : 64;
   } else if (tile_rows <= 0) {
     tile_rows = pt_gemm_bf16x6_tile_rows((int)M, d->Cout);
-    // a reduce dimension of <= 128 with many rows (a Bottleneck's expanding 1 x 1, the input gradient of its reducing one) is bound
-    // by its epilogue's HBM traffic: 64-row tiles fit two workgroups per CU, one's stores overlap the other's products
-    if (taps * (d->Cin / 32) <= 4 && M >= 16384 && d->Cout >= 256) tile_rows = 64;
+    if (d->operand_f16 && taps == 1 && d->Cin <= 2048) {
+      // the trunk's 1 x 1 convolutions on 4-byte planes are bound by their bytes: the tallest tile of 128 / 96 / 64 rows that still
+      // leaves >= 400 tiles (two to three workgroups per CU overlap one another's loads, products and stores; beyond 128 rows a CU
+      // holds one workgroup less and the launch slows by a third) - measured per shape, tools/h2_tile_sweep.py, profiles/r05
+      tile_rows = 64;
+      if ((long)cdiv(M, 128) * cdiv(d->Cout, GBN) >= 400) tile_rows = 128;
+      else if ((long)cdiv(M, 96) * cdiv(d->Cout, GBN) >= 400) tile_rows = 96;
+    } else if (taps * (d->Cin / 32) <= 4 && M >= 16384 && d->Cout >= 256) {
+      // a reduce dimension of <= 128 with many rows (a Bottleneck's expanding 1 x 1, the input gradient of its reducing one) is bound
+      // by its epilogue's HBM traffic: 64-row tiles fit two workgroups per CU, one's stores overlap the other's products
+      tile_rows = 64;
+    }
   }
   PT_REQUIRE(tile_rows % 32 == 0 && tile_rows >= 64 && tile_rows <= 256, PT_EINVAL, "pt_conv_bf16x6: tile_rows in {64, 96, ..., 256}");
   const ConvGeom cg{d->Hs, d->Ws, Ho, Wo, d->Cin, d->Cin / 32, d->KW, taps, d->stride, d->pad, (int)Ps, d->dstride > 1 ? 2 : 1};

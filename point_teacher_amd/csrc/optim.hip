@@ -552,8 +552,10 @@ __global__ void __launch_bounds__(256)
         const int ix = 2 * ox + dx;
         if (ix < 0 || ix >= W) continue;
         const float4 v = reinterpret_cast<const float4*>(x + (((long)b * H + iy) * W + ix) * C)[c4];
-        m.x = fmaxf(m.x, v.x * sc.x + sh.x); m.y = fmaxf(m.y, v.y * sc.y + sh.y);
-        m.z = fmaxf(m.z, v.z * sc.z + sh.z); m.w = fmaxf(m.w, v.w * sc.w + sh.w);
+        // (torch's relu and max_pool2d propagate NaN; fmaxf would drop it - round-4 advice: a NaN maximum stays, a NaN tap wins)
+        const float tx = v.x * sc.x + sh.x, ty = v.y * sc.y + sh.y, tz = v.z * sc.z + sh.z, tw = v.w * sc.w + sh.w;
+        m.x = (m.x != m.x || tx <= m.x) ? m.x : tx; m.y = (m.y != m.y || ty <= m.y) ? m.y : ty;
+        m.z = (m.z != m.z || tz <= m.z) ? m.z : tz; m.w = (m.w != m.w || tw <= m.w) ? m.w : tw;
       }
     }
     reinterpret_cast<float4*>(y)[u] = m;

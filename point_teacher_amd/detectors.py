@@ -13,6 +13,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from . import functional as F
+from . import planes as PL
 from .core import bbox2result, bbox_overlaps, bbox_xyxy_to_cxcywh, mean0
 from .proposals import (MIL_gen_proposals_from_cfg, gen_negative_proposals, generate_black_paper_batch,
                         load_basic_shape, random_point_in_quadrilateral, strong_augmentation_images,
@@ -23,6 +24,14 @@ def img_is_cuda(t):
 
 
 from .registry import DETECTORS, build_backbone, build_detector, build_head, build_neck
+
+
+def _first_images(t, B):
+    """The first B images of a batched stem output: a view of a tensor, or - plane activations (planes.PlaneAct, the plane-native
+    frozen stage) - a copy of their rows behind a zero row of their own (the 3 x 3 taps of the consumer read it)."""
+    if isinstance(t, PL.PlaneAct):
+        return PL.first_images(t, B)
+    return t[:B]
 
 
 class LazyLogVars(OrderedDict):
@@ -127,7 +136,7 @@ class Student_FCOS(BaseDetector):
     def backbone_stem(self, img):
         """The frozen stem of the backbone (ResNet.forward_stem) under this detector's autocast setting."""
         if self.backbone_autocast is None:
-            return self.backbone.forward_stem(img)
+            return self.backbone.forward_stem(img, planes=True) if self._plane_trunk() else self.backbone.forward_stem(img)
         with torch.autocast('cuda', dtype=self.backbone_autocast):
             return self.backbone.forward_stem(img)
 
@@ -399,16 +408,23 @@ class TS_P2B_FCOS(BaseDetector):
         stem = kw.get('stem')
         if stem is not None:                       # views of a tensor the main stream allocated and will free
             for t in [stem[0]] + list(stem[1]):
-                t.record_stream(side)
+                (t.t if isinstance(t, PL.PlaneAct) else t).record_stream(side)
         with torch.cuda.stream(side):
             res = self._teacher_pseudo(*args, **kw)
 
+        def record(obj):                           # every tensor of the (nested) result is used by the main stream from here on
+            if torch.is_tensor(obj):
+                obj.record_stream(main)
+            elif isinstance(obj, (list, tuple)):
+                for o in obj:
+                    record(o)
+            elif isinstance(obj, dict):
+                for o in obj.values():
+                    record(o)
+
         def join():
             main.wait_stream(side)
-            for item in res:
-                for t in (item if isinstance(item, (list, tuple)) else [item]):
-                    if torch.is_tensor(t):
-                        t.record_stream(main)
+            record(res)
             return res
         return join
 
@@ -432,7 +448,7 @@ class TS_P2B_FCOS(BaseDetector):
             with torch.no_grad():                      # no trainable parameter, no input that requires a gradient
                 stem = self.student.backbone_stem(batch)
             B = img.shape[0]
-            t_stem = (stem[0][:B], [o[:B] for o in stem[1]])
+            t_stem = (_first_images(stem[0], B), [_first_images(o, B) for o in stem[1]])
         return (params, aug_imgs), parts, batch, stem, t_stem
 
     def _student_passes(self, img, extra=None, inputs=None):

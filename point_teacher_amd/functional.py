@@ -705,6 +705,7 @@ class _ConvWeightPlanes:
         self.ent = {}            # (id(w), mode, scale ptr) -> [weakref(w), data_ptr, SplitPlanes, scale tensor or None, version]
         self.table = None        # (device uint8 tensor of pt_conv_weight_item, n_items, total_blocks)
         self.epoch = -1
+        self._retired = []       # device tables replaced since the last full refresh: a launch on ANOTHER stream may still read them
 
     @staticmethod
     def ok(w):
@@ -718,21 +719,25 @@ class _ConvWeightPlanes:
     def taps(w):
         return w.shape[2] * w.shape[3] if w.dim() == 4 else 1
 
-    def _build_table(self, weights):
-        """`weights`: the registered weights, in the order of self.ent (strong references held by the caller)."""
-        rec = np.zeros(len(self.ent), dtype=np.dtype([('w', '<u8'), ('dst', '<u8'), ('plane', '<i8'), ('O', '<i4'), ('I', '<i4'),
-                                                       ('mode', '<i4'), ('first', '<i4'), ('taps', '<i4'), ('np', '<i4'),
-                                                       ('scale', '<u8')]))
+    def _records(self, items, weights):
+        """Device table (pt_conv_weight_item records) of `items` = [(key, entry)], `weights` their tensors -> (table, n, blocks)."""
+        rec = np.zeros(len(items), dtype=np.dtype([('w', '<u8'), ('dst', '<u8'), ('plane', '<i8'), ('O', '<i4'), ('I', '<i4'),
+                                                    ('mode', '<i4'), ('first', '<i4'), ('taps', '<i4'), ('np', '<i4'),
+                                                    ('scale', '<u8')]))
         first = 0
         dev = None
-        for i, (((_, mode, _sp, npl), (_ref, ptr, sp, scale, _ver)), w) in enumerate(zip(self.ent.items(), weights)):
+        for i, (((_, mode, _sp, npl), (_ref, ptr, sp, scale, _ver)), w) in enumerate(zip(items, weights)):
             O, I = w.shape[:2]
             taps = self.taps(w)
             rows, k = (I, taps * O) if mode else (O, taps * I)
             rec[i] = (ptr, sp.planes.data_ptr(), sp.planes.shape[1], O, I, mode, first, taps, npl, scale.data_ptr() if scale is not None else 0)
             first += ((rows + 15) // 16) * (k // 32)
             dev = w.device
-        self.table = (torch.from_numpy(rec.view(np.uint8)).to(dev), len(self.ent), first)
+        return torch.from_numpy(rec.view(np.uint8)).to(dev), len(items), first
+
+    def _build_table(self, weights):
+        """`weights`: the registered weights, in the order of self.ent (strong references held by the caller)."""
+        self.table = self._records(list(self.ent.items()), weights)
 
     @staticmethod
     def _alive(v):
@@ -755,11 +760,27 @@ class _ConvWeightPlanes:
             n = ((rows + 15) // 16) * ((k + 31) // 32) * 512
             sp = SplitPlanes(torch.empty((np_, n), dtype=torch.bfloat16, device=w.device), rows, k)
             e = self.ent[key] = [weakref.ref(w), w.data_ptr(), sp, scale, -1]
+            if self.table is not None:
+                self._retired.append(self.table)                # (a refresh on the other stream may still be reading it)
             self.table = None
+            if self.epoch == PARAM_EPOCH[0]:
+                # the other entries are current (a weight's first use in the middle of an iteration - the first iteration, the switch
+                # of the burn-in phase - possibly while the OTHER stream reads their planes, round-4 advice): split this entry alone
+                # instead of re-splitting every registered plane under the reader
+                one = self._records([(key, e)], [w])
+                self._retired.append(one)
+                hip.call('pt_conv_weight_planes_batch', one[0], one[1], one[2])
+                e[4] = w._version
+                # the full table for the NEXT epoch's refresh is uploaded now (a blocking upload: registrations happen in the first
+                # iteration of a phase, a steady-state iteration never synchronises)
+                strong = [v[0]() for v in self.ent.values()]
+                if all(x is not None for x in strong):
+                    self._build_table(strong)
+                return sp
             self.epoch = -1
         if e[4] != w._version:                                  # torch wrote the weight (load_state_dict, init, copy_): re-split
             self.epoch = -1
-        if self.epoch != PARAM_EPOCH[0] or self.table is None:
+        if self.epoch != PARAM_EPOCH[0]:                        # (a table dropped by a mid-epoch registration is rebuilt by the next refresh)
             self.refresh()
         return self.ent[key][2]
 
@@ -780,6 +801,7 @@ class _ConvWeightPlanes:
             return
         if self.table is None:
             self._build_table(strong)
+        self._retired.clear()                                   # (a full refresh runs between iterations: both streams have joined)
         tab, n_items, blocks = self.table
         hip.call('pt_conv_weight_planes_batch', tab, n_items, blocks)
         self.epoch = PARAM_EPOCH[0]
@@ -795,7 +817,7 @@ def refresh_conv_weight_planes():
     them from two streams (the teacher pass on its side stream next to the student's, detectors._teacher_fork) calls this first, so
     that neither stream's first convolution launches the refresh while the other reads the planes."""
     c = _CONV_W
-    if c.ent and (c.epoch != PARAM_EPOCH[0] or c.table is None):
+    if c.ent and c.epoch != PARAM_EPOCH[0]:
         c.refresh()
 
 
@@ -806,7 +828,7 @@ def _conv_weight_planes(w, dgrad, scale=None, np_=3):
     refresh (_ConvWeightPlanes); any other layout is split on its own."""
     c = _CONV_W
     e = c.ent.get((id(w), 1 if dgrad else 0, scale.data_ptr() if scale is not None else 0, np_))
-    if (e is not None and c.epoch == PARAM_EPOCH[0] and c.table is not None and e[0]() is w and e[1] == w.data_ptr()
+    if (e is not None and c.epoch == PARAM_EPOCH[0] and e[0]() is w and e[1] == w.data_ptr()
             and e[4] == w._version):
         return e[2]                                              # (the steady state: a registered weight, planes of this parameter epoch)
     if _ConvWeightPlanes.ok(w):

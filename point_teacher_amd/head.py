@@ -22,6 +22,7 @@ from .registry import HEADS, build_assigner, build_bbox_coder, build_loss, build
 
 _SPLIT_GEMM = os.environ.get('PT_SPLIT_GEMM', '1') != '0'
 _PLANE_FC = _SPLIT_GEMM and os.environ.get('PT_PLANE_FC', '1') != '0'       # 0: the round-3 routing (fp32 RoI blocks, blocked-plane GEMMs)
+_MERGE_NEG = os.environ.get('PT_MERGE_NEG', '1') != '0'                     # 0: the negatives' 400 RoIs in a pass of their own (round 4)
 
 INF = 1e8
 
@@ -411,13 +412,21 @@ class TS_P2BFCOSHead(nn.Module):
         bbox_results['extensive_bags_reference'] = ext_ref
         bbox_results['extensive_bags_real'] = ext_real
 
-    def mil_bag_classifier(self, num_gt, x, bbox_results, stage):
-        """:1240-1256"""
+    def mil_bag_classifier(self, num_gt, x, bbox_results, stage, neg_rois=None):
+        """:1240-1256.  neg_rois: the negative proposals of :1266-1271 ride along - they pass through the SAME RoIAlign, FC stack
+        (`shared_fcs_bag`) and `fc_cls` as the bags, row by row, so their 400 rows are appended to the K bag rows of one launch each
+        (forward, input and weight gradients) instead of a second, launch-bound pass through library GEMMs."""
         rois = bbox2roi(bbox_results['extensive_bags'])
         U1, U2 = bbox_results['base_shaking_num'], bbox_results['extensive_shaking_num']
+        K = rois.shape[0]
+        if neg_rois is not None:
+            rois = torch.cat([rois, neg_rois], 0)
         feats = self._fc_stack(self.shared_fcs_bag[stage], self._roi_feats(x, rois, group=self._bag_group(U1, U2)))
-        bbox_results['cls_score'] = self.fc_cls[stage](feats).view(num_gt, U1, U2, self.num_classes)
-        bbox_results['ins_score'] = self.fc_ins[stage](feats).view(num_gt, U1, U2, self.num_classes)
+        cls = self.fc_cls[stage](feats)
+        bbox_results['cls_score'] = cls[:K].view(num_gt, U1, U2, self.num_classes)
+        bbox_results['ins_score'] = self.fc_ins[stage](feats[:K]).view(num_gt, U1, U2, self.num_classes)
+        if neg_rois is not None:
+            bbox_results['neg_cls_score'] = cls[K:]
 
     def forward_mil_head(self, num_gt, num_gt_pre_image, x, proposals_list, proposals_valid_list,
                          proposals_reference_list, proposals_real_list, img_metas, fine_proposal_cfg, stage,
@@ -432,9 +441,10 @@ class TS_P2BFCOSHead(nn.Module):
         self.mil_bag_extensive(num_gt, num_gt_pre_image, x, img_metas, proposals_list, proposals_valid_list,
                                proposals_reference_list, proposals_real_list, bbox_results, fine_proposal_cfg, stage,
                                bag_weight=bag_weight)
+        merge_neg = need_classifier and neg_proposal_list is not None and _MERGE_NEG
         if need_classifier:
-            self.mil_bag_classifier(num_gt, x, bbox_results, stage)
-        if neg_proposal_list is not None:
+            self.mil_bag_classifier(num_gt, x, bbox_results, stage, neg_rois=bbox2roi(neg_proposal_list) if merge_neg else None)
+        if neg_proposal_list is not None and not merge_neg:
             rois = bbox2roi(neg_proposal_list)
             feats = self._fc_stack(self.shared_fcs_bag[stage],
                                    self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois).flatten(1))

@@ -22,6 +22,7 @@ _SPLIT_CONV = os.environ.get('PT_SPLIT_CONV', '1') != '0'
 _STEM_TAIL = os.environ.get('PT_STEM_TAIL', '1') != '0'            # 0: bn1 + ReLU and the max-pool as two passes
 _PLANE_TRUNK = _SPLIT_CONV and os.environ.get('PT_PLANE_TRUNK', '1') != '0'     # 0: the round-3 routing (3x3 only, fp32 between layers)
 _PLANE_BN_TRAIN = os.environ.get('PT_PLANE_BN_TRAIN', '1') != '0'               # 0: blocks with a trainable BatchNorm keep the round-3 routing
+_PLANE_STEM = _PLANE_TRUNK and os.environ.get('PT_PLANE_STEM', '1') != '0'      # 0: the frozen stages (layer1) stay library convolutions + BatchNorm passes
 _GN_CL = os.environ.get('PT_GN_CL', '1') != '0'
 
 
@@ -352,8 +353,11 @@ class Bottleneck(nn.Module):
                 and self.conv2.dilation == (1, 1) and s1 in (1, 2) and s2 in (1, 2) and s1 * s2 in (1, 2)
                 and (self.downsample is None or self.downsample[0].stride[0] == s1 * s2)
                 and (self.downsample is not None or s1 * s2 == 1)
-                and all(c.in_channels % 128 == 0 and c.out_channels % 128 == 0 and c.weight.is_cuda and c.weight.dtype == torch.float32
-                        and F._ConvWeightPlanes.ok(c.weight) for c in convs))
+                # the weight-gradient kernel tiles 128 channels; a FROZEN block (layer1: 64 channels) has no weight gradient and only
+                # needs whole 32-channel k-steps
+                and all(((c.in_channels % 128 == 0 and c.out_channels % 128 == 0) or
+                         (not c.weight.requires_grad and not any(train) and c.in_channels % 32 == 0 and c.out_channels % 32 == 0))
+                        and c.weight.is_cuda and c.weight.dtype == torch.float32 and F._ConvWeightPlanes.ok(c.weight) for c in convs))
 
     def forward_planes(self, x):
         """x: planes.PlaneAct (a ReLU output) or the fp32 channels_last output of the frozen stem -> PlaneAct."""
@@ -464,15 +468,28 @@ class ResNet(nn.Module):
             for p in m.parameters():
                 p.requires_grad = False
 
-    def forward_stem(self, x):
+    def forward_stem(self, x, planes=False):
         """conv1 / bn1 / maxpool and the frozen stages: the part of the network no gradient reaches and no optimizer step
         changes (frozen_stages >= 0).  -> (activation, outputs collected so far); `forward(None, stem=...)` continues from it.
         A teacher that holds the same frozen weights as its student (both load the same pretrained file and the stem never
         trains) computes the same stem on the same image: TS_P2B_FCOS evaluates it once."""
         x = self._stem_head(x)
         outs = []
+        # the frozen stages plane-native too (round 5): H2 planes (4 bytes per element) between their convolutions, BatchNorm + ReLU +
+        # identity in the epilogues - no library convolution + separate BatchNorm pass per layer (layer1 at 200 x 200 is bound by
+        # its bytes: ~3.1 GB per pass of six images instead of ~5.5); fp32 mode only (under bf16 autocast the library path stays)
+        plane = bool(planes and _PLANE_STEM and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
+                     and PL.use_f16('trunk') and not x.requires_grad)
         for i in range(max(self.frozen_stages, 0)):
-            x = getattr(self, self.res_layers[i])(x)
+            layer = getattr(self, self.res_layers[i])
+            if plane:
+                for blk in layer:
+                    if isinstance(x, PL.PlaneAct) or (PL.dense_ok(x) and blk.plane_ok()):
+                        x = blk(x) if isinstance(x, PL.PlaneAct) else blk.forward_planes(x)
+                    else:
+                        x = blk(x)
+            else:
+                x = layer(x)
             if i in self.out_indices:
                 outs.append(x)
         return x, outs
@@ -507,7 +524,7 @@ class ResNet(nn.Module):
     def forward(self, x, stem=None, planes=False):
         """`planes=True` (a caller whose neck reads planes.PlaneAct, i.e. FPN): the trainable stages run plane-native - their
         outputs are PlaneActs - as soon as a block qualifies (Bottleneck.plane_ok); otherwise fp32 tensors as ever."""
-        x, outs = self.forward_stem(x) if stem is None else stem
+        x, outs = self.forward_stem(x, planes=planes) if stem is None else stem
         outs = list(outs)
         if planes:
             self.refresh_plane_terms()

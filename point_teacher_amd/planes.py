@@ -468,6 +468,17 @@ def to_planes(x, f16=False, group='towers', carrier=True):
     return PlaneAct(_F32ToPlanes.apply(x, bool(f16)), B, H, W, C, False)
 
 
+def first_images(act, B):
+    """The first B images of a plane activation as a PlaneAct of their own (one copy pass: rows, a zero row, the tail) - no gradient
+    (the frozen stem shared between the student's batched pass and the teacher)."""
+    assert B <= act.B and not act.t.requires_grad
+    if B == act.B:
+        return act
+    rows = B * act.H * act.W
+    t, _ = mix(act.t, n=(rows + 1) * act.C, n_valid=rows * act.C, out_fmt=fmt_of(act.t), scale=SCALE_MERGE)
+    return PlaneAct(t, B, act.H, act.W, act.C, act.relu)
+
+
 def out_hw(H, W, K, stride, pad):
     return (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
 

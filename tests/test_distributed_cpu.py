@@ -100,6 +100,30 @@ def _worker(rank, world, port, q):
         torch.testing.assert_close(per_rank[0], per_rank[1], rtol=0, atol=0)     # identical reduced gradient on both ranks
         off0, n0 = flat.slices['0.weight']
         assert float(flat.grad_flat[off0:off0 + n0].abs().sum()) > 0              # rank 1's contribution / world arrived
+        # bf16 on the wire (PT_GRAD_WIRE=bf16 / wire='bf16', SURVEY 8(e): half the payload over xGMI): every bucket is rounded to bf16 on
+        # its rank, reduced in bf16 and widened back - both ranks end with the SAME fp32 gradient (bit-identical ranks kept), which is
+        # the mean of the bf16-rounded per-rank gradients within bf16's rounding
+        ex.remove()
+        ex = BucketedGradExchange(flat, n_buckets=3, device=None, small=0, wire='bf16')
+        assert ex.stats['bytes'] == 2 * flat.n_train and ex.stats['wire'] == 'bf16'
+        flat.zero_grad(); flat.detach_grads()
+        ex.begin()
+        pair.student[:5](x).pow(2).mean().backward()
+        ex.finish()
+        assert ex.stats['overlap_ms'] >= 0.0 and ex.issued == ex.issue_order
+        per_rank = [torch.empty_like(flat.grad_flat) for _ in range(world)]
+        dist.all_gather(per_rank, flat.grad_flat.clone())
+        assert torch.equal(per_rank[0], per_rank[1])
+        ref = Pair(); ref.load_state_dict(pair.state_dict())
+        ref.student[:5](x).pow(2).mean().backward()
+        for name, p in ref.student.named_parameters():
+            if p.grad is not None:
+                mine = [torch.empty_like(p.grad) for _ in range(world)]
+                dist.all_gather(mine, p.grad)
+                off, n = flat.slices[name]
+                want = (sum(mine) / world).reshape(-1)
+                torch.testing.assert_close(flat.grad_flat[off:off + n], want, rtol=2e-2, atol=1e-3 * float(want.abs().max()))
+                assert torch.equal(flat.grad_flat[off:off + n], flat.grad_flat[off:off + n].to(torch.bfloat16).float())   # bf16 values
         # a detector without a teacher (the supervised baselines of row N4): same flat layout, same exchange
         torch.manual_seed(9)
         solo = torch.nn.Sequential(torch.nn.Linear(11, 20), torch.nn.ReLU(), torch.nn.Linear(20, 4))

@@ -972,3 +972,10 @@ def test_affine_relu_maxpool_equals_the_three_passes(B, H, W, C):
     got = F.affine_relu_maxpool(x, sc, sh)
     assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
     assert torch.equal(got, want)
+    # NaN propagates as in torch's relu + max_pool2d (round-4 advice: fmaxf dropped it)
+    xn = x.clone()
+    xn[0, 1, H // 2, W // 2] = float('nan')
+    want = torch.nn.functional.max_pool2d(torch.relu(xn * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)), 3, 2, 1)
+    got = F.affine_relu_maxpool(xn, sc, sh)
+    assert bool(torch.isnan(want).any()) and torch.equal(torch.isnan(got), torch.isnan(want))
+    assert torch.equal(torch.nan_to_num(got), torch.nan_to_num(want))

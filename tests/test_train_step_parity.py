@@ -327,7 +327,9 @@ def test_full_size_noisy_point_configs(percent):
     hook.remove()
     assert {'stage0_loss_mil_bbox', 'stage0_loss_mil_bags', 'loss_cls', 'loss_bbox', 'loss_centerness', 'refined_points_distance'} <= keys
     U = 9 * 45
-    assert max(ks) == 2 * 75 * U, (max(ks), 2 * 75 * U)             # every real-bag RoIAlign call sees the whole 60 750-box batch
+    # every real-bag RoIAlign call sees the whole 60 750-box batch; the bag classifier's call also carries the 2 x 200 negative
+    # proposals (round 5: they ride through the same RoIAlign / FC launches instead of a pass of their own)
+    assert max(ks) == 2 * 75 * U + 400 and 2 * 75 * U in ks, (sorted(set(ks)), 2 * 75 * U)
     assert model.count == 4 and len(model.gt_bboxes_point) == 2
     first = torch.cat([v for _, v in sorted(model.gt_bboxes_point.items())])
     assert float((pts_seen[-1] - first).abs().max()) > 0.1           # lamda 0.5: refined points left the first-visit points ...
