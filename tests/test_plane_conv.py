@@ -669,9 +669,12 @@ def test_fp16_operand_tower_chain_vs_fp64(two):
     for o, r in zip(outs, refs):
         assert o.dtype == torch.float32 and float((o.double() - r).abs().max() / r.abs().max()) < 2e-6
     # ReLU decisions within rounding of zero differ between fp32 and float64 on a handful of elements: norm-wise bars
+    # round 4: 2e-4 (the chain kept a scale in [512, 1024) chosen from plane values, ReLU flips un-masked); round 5, with the gradient
+    # entering the chain from fp32 at a scale in [128, 256): measured 1.2e-7 ... 2.8e-7 - the bar is the bf16 x 3 path's 5e-6
     for n, a, b in zip(['x'] + [f'p{i}' for i in range(len(params))], got, want):
         err = float((a.double() - b.double()).norm() / b.double().norm())
-        assert err < 2e-4, (n, err)
+        print(n, f'{err:.3e}')
+        assert err < 5e-6, (n, err)
     cen = PL.CENSUS.poll(sync=True)                                    # the chain's scale: every gradient tensor's largest stored
     grads = {k: d for k, d in cen.items() if k[0] == 'towers_grad'}    # magnitude sits inside fp16's comfortable range
     assert grads and all(d['saturated'] == 0 and 0.25 <= d['amax_stored'] < 60000 for d in grads.values()), grads
