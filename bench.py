@@ -52,6 +52,8 @@ def parse():
 def algorithmic_bytes(name, shapes):
     if name == 'pt_roi_align_fwd_planes':   # the same block written as three bf16 planes (6 B per element instead of 4)
         return shapes['K'] * shapes['C'] * 49 * 6 + shapes.get('footprint_px', 9 * shapes['K']) * shapes['C'] * 4
+    if name == 'pt_roi_align_fwd_planes_f16':   # ... as two fp16 planes: 4 B per element, the fp32 block's size
+        return shapes['K'] * shapes['C'] * 49 * 4 + shapes.get('footprint_px', 9 * shapes['K']) * shapes['C'] * 4
     if name in ('pt_roi_align_fwd', 'pt_roi_align_bwd', 'pt_roi_align_rotated_fwd', 'pt_roi_align_rotated_bwd'):
         K, C, o = shapes['K'], shapes['C'], shapes['out']
         # "K*256*49*4 B written (fwd) / read (bwd) + <= 9 feature pixels x 1 KB read per RoI": `footprint_px` is
@@ -176,7 +178,7 @@ SPLIT_FNS = ('pt_split_bf16x3', 'pt_split_bf16x3_rows', 'pt_split_bf16x3_gather'
 BF16_PEAK_TFLOPS = 2500.0          # dense bf16 MFMA (MI355X_MICROARCH.md); 6 products per fp32 product -> 416.7 TFLOP/s fp32-equivalent ceiling
 
 FAMILIES = {                                                    # op families for the roofline line
-    'pt_roi_align': ('pt_roi_align_fwd', 'pt_roi_align_fwd_planes', 'pt_roi_align_bwd'),
+    'pt_roi_align': ('pt_roi_align_fwd', 'pt_roi_align_fwd_planes', 'pt_roi_align_fwd_planes_f16', 'pt_roi_align_bwd'),
     'pt_roi_align_rotated': ('pt_roi_align_rotated_fwd', 'pt_roi_align_rotated_bwd'),
     'pt_affine_relu': ('pt_affine_relu_fwd', 'pt_affine_relu_bwd', 'pt_affine_relu_bwd_train'),
     'pt_optimizer (ema + sqnorm + sgd)': ('pt_ema_update', 'pt_sqnorm_partial', 'pt_sgd_step', 'pt_sgd_step_groups'),
@@ -310,7 +312,7 @@ def main():
                 shp = None
                 if fn in ('pt_roi_align_fwd', 'pt_roi_align_bwd'):
                     shp = dict(K=a[6], C=a[3], out=a[7], rois=a[1], scale=a[8], H=a[4], W=a[5])    # footprints are counted afterwards
-                elif fn == 'pt_roi_align_fwd_planes':
+                elif fn in ('pt_roi_align_fwd_planes', 'pt_roi_align_fwd_planes_f16'):
                     shp = dict(K=a[6], C=a[3], out=7, rois=a[1], scale=a[7], H=a[4], W=a[5])
                 elif fn in ('pt_roi_align_rotated_fwd', 'pt_roi_align_rotated_bwd'):
                     shp = dict(K=a[6], C=a[3], out=a[7])
@@ -469,7 +471,7 @@ def main():
     traffic = None
     try:
         import hashlib
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r04', 'pmc_traffic.json')))
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r05', 'pmc_traffic.json')))
         ent = pmc.get(('obb_' if obb else '') + args.workload + ('_bf16' if args.dtype == 'bf16' else ''), {}).get(dom)
         if ent:
             src = os.path.join(ROOT, 'point_teacher_amd', 'csrc', ent['source'])

@@ -27,6 +27,8 @@ FAMILY = {'roi_align7_fwd': ('pt_roi_align', 'roi_align.hip'), 'roi_align7_bwd':
           'conv_splitk_finish_kernel': ('pt_bf16x6 (conv + gemm + wgrad)', 'gemm_split.hip', False),
           'wgrad_reduce_kernel': ('pt_bf16x6 (conv + gemm + wgrad)', 'gemm_split.hip', False),
           'bn_wgrad_finish_kernel': ('pt_bf16x6 (conv + gemm + wgrad)', 'gemm_split.hip', False),
+          'planes_mix_kernel': ('pt_bf16x6 (conv + gemm + wgrad)', 'gemm_split.hip', False),
+          'gather_h2_kernel': ('pt_bf16x6 (conv + gemm + wgrad)', 'gemm_split.hip', False),
           'roi_align_rotated_fwd_mm': ('pt_roi_align_rotated', 'rotated.hip'), 'roi_align_rotated_bwd_mm': ('pt_roi_align_rotated', 'rotated.hip')}
 
 
@@ -43,7 +45,7 @@ def read(path):
 
 
 tag, key = sys.argv[1], sys.argv[2]
-out_path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, 'profiles', 'r04', 'pmc_traffic.json')
+out_path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, 'profiles', 'r05', 'pmc_traffic.json')
 fetch = read(os.path.join(ROOT, 'gpurun_out', f'pmc_{tag}_FETCH_SIZE.txt'))
 write = read(os.path.join(ROOT, 'gpurun_out', f'pmc_{tag}_WRITE_SIZE.txt'))
 fam = {}
