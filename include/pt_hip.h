@@ -467,7 +467,9 @@ int pt_group_norm_cl_bwd(const float* grad_y, const float* x, const float* y, co
  * of a split - and, for the input-gradient form, a flip and a copy - per weight and form).  `items`: DEVICE array; every item = a
  * channels_last fp32 weight [Cout][KH][KW][Cin] (taps = KH * KW = 1 or 9; Cin % 32 == 0, Cout % 32 == 0), 16-byte aligned planes of
  * pt_split_bf16x3_plane_elems(rows, k) elements each (plane stride `plane`), and the form: mode 0 = rows Cout, k = (ky, kx, cin) - what
- * pt_conv_bf16x6's forward takes; mode 1 = rows cin, k = (KH - 1 - ky, KW - 1 - kx, cout) - its input gradient.  scale (NULL or
+ * pt_conv_bf16x6's forward takes; mode 1 = rows cin, k = (KH - 1 - ky, KW - 1 - kx, cout) - its input gradient; mode 2 (ABI 6) =
+ * rows (ky, kx, cin), k = cout - the transpose of the forward matrix: d col = g W of a convolution evaluated as a GEMM over gathered
+ * columns (the deformable convolutions of `dcn_on_last_conv`, dense_heads/anchor_free_head.py:101-102).  scale (NULL or
  * [Cout], device): w[o] * scale[o] is what gets split - the scale of the frozen BatchNorm behind the convolution folded into the
  * input-gradient weights (backbones/resnet.py:262-303: dx = (g * scale) W = g (diag(scale) W)).  first_block = number of 16 x 32 blocks
  * of the items before this one (blocks of an item = ceil(rows / 16) * (taps * cols / 32)); total_blocks = their sum over all items.

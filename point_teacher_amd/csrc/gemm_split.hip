@@ -169,7 +169,7 @@ struct ConvWItem {
   uint16_t* dst;
   long plane;                       // plane stride in elements
   int O, I;
-  int mode;                         // 0: rows = Cout, k = (tap, cin);  1: rows = cin, k = (flipped tap, cout)
+  int mode;                         // 0: rows = Cout, k = (tap, cin);  1: rows = cin, k = (flipped tap, cout);  2: rows = (tap, cin), k = cout
   int first_block;
   int taps;                         // KH * KW (1 or 9)
   int np;                           // planes written: 3, or 1 (= the bf16 rounding of the weight: the bf16 trunk of configs[2])
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(256)
   }
   const ConvWItem e = items[it];
   const int T = e.taps;
-  const int rows = e.mode ? e.I : e.O, kdim = T * (e.mode ? e.O : e.I);
+  const int rows = e.mode == 2 ? T * e.I : (e.mode ? e.I : e.O), kdim = e.mode == 2 ? e.O : T * (e.mode ? e.O : e.I);
   const int KB = kdim >> 5;
   const int blk = gb - e.first_block;
   const int rb = blk / KB, kb = blk - rb * KB;
@@ -204,6 +204,17 @@ __global__ void __launch_bounds__(256)
         const float sc = e.scale[r];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] *= sc;
+      }
+    } else if (e.mode == 2) {
+      // rows = (tap, cin), k = cout: the transpose of the forward matrix - the input gradient of a convolution evaluated as a GEMM
+      // over gathered columns (deformable convolution: d col = g W)
+      const int t = r / e.I, i = r - t * e.I;
+      const float* sp = e.w + ((long)kk * T + t) * e.I + i;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = sp[(long)j * T * e.I];
+      if (e.scale) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= e.scale[kk + j];
       }
     } else {
       const int tapf = kk / e.O, o = kk - tapf * e.O;        // (T - 1 - tapf) = the tap flipped in both directions

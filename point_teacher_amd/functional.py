@@ -729,7 +729,7 @@ class _ConvWeightPlanes:
         for i, (((_, mode, _sp, npl), (_ref, ptr, sp, scale, _ver)), w) in enumerate(zip(items, weights)):
             O, I = w.shape[:2]
             taps = self.taps(w)
-            rows, k = (I, taps * O) if mode else (O, taps * I)
+            rows, k = self._dims(mode, O, I, taps)
             rec[i] = (ptr, sp.planes.data_ptr(), sp.planes.shape[1], O, I, mode, first, taps, npl, scale.data_ptr() if scale is not None else 0)
             first += ((rows + 15) // 16) * (k // 32)
             dev = w.device
@@ -744,9 +744,15 @@ class _ConvWeightPlanes:
         w = v[0]()
         return w is not None and w.data_ptr() == v[1]
 
+    @staticmethod
+    def _dims(mode, O, I, taps):
+        """(rows, k) of the operand matrix: mode 0 [O][taps I] (forward), 1 [I][taps O] (input gradient of the convolution),
+        2 [taps I][O] (the forward matrix transposed: d col = g W of a convolution over gathered columns)."""
+        return (taps * I, O) if mode == 2 else ((I, taps * O) if mode else (O, taps * I))
+
     def get(self, w, dgrad, scale=None, np_=3):
         import weakref
-        mode = int(bool(dgrad))
+        mode = 2 if dgrad == 2 else int(bool(dgrad))
         key = (id(w), mode, scale.data_ptr() if scale is not None else 0, np_)
         e = self.ent.get(key)
         if e is not None and (e[0]() is not w or e[1] != w.data_ptr()):
@@ -756,7 +762,7 @@ class _ConvWeightPlanes:
             self.ent = {k: v for k, v in self.ent.items() if self._alive(v) and k != key}
             O, I = w.shape[:2]
             taps = self.taps(w)
-            rows, k = (I, taps * O) if mode else (O, taps * I)
+            rows, k = self._dims(mode, O, I, taps)
             n = ((rows + 15) // 16) * ((k + 31) // 32) * 512
             sp = SplitPlanes(torch.empty((np_, n), dtype=torch.bfloat16, device=w.device), rows, k)
             e = self.ent[key] = [weakref.ref(w), w.data_ptr(), sp, scale, -1]
@@ -827,7 +833,7 @@ def _conv_weight_planes(w, dgrad, scale=None, np_=3):
     cached until the parameters change (PARAM_EPOCH / the weight's version counter).  Channels_last weights go through the batched
     refresh (_ConvWeightPlanes); any other layout is split on its own."""
     c = _CONV_W
-    e = c.ent.get((id(w), 1 if dgrad else 0, scale.data_ptr() if scale is not None else 0, np_))
+    e = c.ent.get((id(w), 2 if dgrad == 2 else (1 if dgrad else 0), scale.data_ptr() if scale is not None else 0, np_))
     if (e is not None and c.epoch == PARAM_EPOCH[0] and e[0]() is w and e[1] == w.data_ptr()
             and e[4] == w._version):
         return e[2]                                              # (the steady state: a registered weight, planes of this parameter epoch)
@@ -1422,8 +1428,13 @@ def roi_align_rotated(feat, rois, out_size, spatial_scale, sample_num=0, aligned
 
 
 # ------------------------------------------------------ (modulated) deformable conv --
+_DCN_PLANES = os.environ.get('PT_DCN_PLANES', '1') != '0'      # 0: the deformable convolution's GEMMs stay with hipBLASLt (round 4)
+
+
 class _DeformConv(torch.autograd.Function):
-    """mmcv.ops.(modulated_)deform_conv2d, groups = 1: gather (HIP) -> GEMM (hipBLASLt) and the mirrored backward.
+    """mmcv.ops.(modulated_)deform_conv2d, groups = 1: gather (HIP) -> contraction and the mirrored backward.  channels_last with
+    channel counts the matrix kernels tile: the contraction, its weight / bias gradient and d col run on pt_conv_bf16x6 /
+    pt_conv_wgrad_bf16x6 (round 5); otherwise a library GEMM.
     A channels_last input (the training layout) stays NHWC end to end (pt_deform_*_cl: wave-wide contiguous gathers, col
     [B*L, K*C], output written as NHWC by the GEMM); an NCHW input takes the NCHW kernels."""
 
@@ -1445,6 +1456,22 @@ class _DeformConv(torch.autograd.Function):
             col = torch.empty((B * Ho * Wo, kh * kw * C), dtype=f32, device=x.device)
             hip.call('pt_deform_im2col_cl', x.permute(0, 2, 3, 1), offset.permute(0, 2, 3, 1),
                      mask.permute(0, 2, 3, 1) if mask is not None else None, *geo, col)
+            M, KC = B * Ho * Wo, kh * kw * C
+            ctx.planes = bool(_DCN_PLANES and KC % 128 == 0 and O % 128 == 0 and C % 32 == 0 and weight.dtype == f32
+                              and _ConvWeightPlanes.ok(weight) and not torch.is_autocast_enabled() and M > 0)
+            if ctx.planes:
+                # the contraction on the path's own matrix kernels (round 5; until round 4 a hipBLASLt GEMM): the gathered columns
+                # become split planes (H2, or bf16 x 3 when the group fell back), the 3x3 weight's forward planes ARE the
+                # [O][(ky, kx, c)] matrix of the column order, bias in the epilogue
+                from . import planes as PL
+                h2 = PL.use_f16('towers')
+                colp, _, _ = PL.split_nhwc(col.view(1, M, 1, KC).permute(0, 3, 1, 2), f16=h2,
+                                           census=PL.CENSUS.ptr('towers', f'dcn{C}>{O}:col', x.device) if h2 else 0)
+                del col
+                _, out = PL.launch_conv(colp, 1, M, 1, KC, _conv_weight_planes(weight, False, None, 2 if h2 else 3), O, 1, 1, 0,
+                                        shift=bias.float() if bias is not None else None, want_f32=True)
+                ctx.save_for_backward(x, offset, mask, weight, colp)
+                return out.view(B, Ho, Wo, O).permute(0, 3, 1, 2)
             wm = weight.float().permute(0, 2, 3, 1).reshape(O, -1)                     # [O, kh*kw*C]: a view of a channels_last weight
             out = torch.nn.functional.linear(col, wm, bias.float() if bias is not None else None)
             ctx.save_for_backward(x, offset, mask, weight, col)
@@ -1469,12 +1496,32 @@ class _DeformConv(torch.autograd.Function):
         need_in = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or (mask is not None and ctx.needs_input_grad[2])
         if ctx.cl:
             g2 = g.float().contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(-1, O)     # [B*L, O]
-            if ctx.needs_input_grad[3]:
-                gw = torch.matmul(g2.t(), col).view(O, kh, kw, C).permute(0, 3, 1, 2)
-            if ctx.has_bias and ctx.needs_input_grad[4]:
-                gb = g2.sum(0)
+            gcol = None
+            if ctx.planes:
+                # weight / bias gradient and d col on the plane kernels: the output gradient enters as planes (H2: with the
+                # power-of-two scale of its largest magnitude), d W = g^T col from the two plane sets, d col = g W through the
+                # transposed weight planes (mode 2)
+                from . import planes as PL
+                M, KC = g2.shape[0], kh * kw * C
+                h2 = PL.is_h2(col)
+                E = PL.grad_to_planes(g2, h2, census=PL.CENSUS.ptr('towers_grad', f'dcn{C}>{O}:gy', g.device) if h2 else 0)
+                if ctx.needs_input_grad[3]:
+                    dw, db = PL.launch_wgrad(E, col, 1, M, 1, KC, O, 1, 1, 0, want_bias=bool(ctx.has_bias and ctx.needs_input_grad[4]))
+                    gw = dw.reshape(O, kh, kw, C).permute(0, 3, 1, 2)
+                    gb = db
+                elif ctx.has_bias and ctx.needs_input_grad[4]:
+                    gb = g2.sum(0)
+                if need_in:
+                    _, gcol = PL.launch_conv(E, 1, M, 1, O, _conv_weight_planes(weight, 2, None, 2 if h2 else 3), KC, 1, 1, 0,
+                                             want_f32=True, x_inv=PL.tail_ptr(E))
+            else:
+                if ctx.needs_input_grad[3]:
+                    gw = torch.matmul(g2.t(), col).view(O, kh, kw, C).permute(0, 3, 1, 2)
+                if ctx.has_bias and ctx.needs_input_grad[4]:
+                    gb = g2.sum(0)
             if need_in:
-                gcol = torch.matmul(g2, weight.float().permute(0, 2, 3, 1).reshape(O, -1))                      # [B*L, K*C]
+                if gcol is None:
+                    gcol = torch.matmul(g2, weight.float().permute(0, 2, 3, 1).reshape(O, -1))                  # [B*L, K*C]
                 gx = torch.zeros_like(x) if ctx.needs_input_grad[0] else None                                    # channels_last
                 goff = torch.empty_like(offset)
                 gmask = torch.empty_like(mask) if mask is not None else None
