@@ -37,6 +37,12 @@ namespace pt {
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
+// (measured, profiles/r05/h2_tile_sweep_k3_oneacc.txt: one accumulator frees 16 - 64 registers but LDS, not registers, limits the
+//  workgroups per CU at every tile height above 64 rows - no gain where the tiles are chosen; the two-accumulator error stays)
+#ifndef PT_H2_ONE_ACC
+#define PT_H2_ONE_ACC 0
+#endif
+constexpr bool H2_ONE_ACC = PT_H2_ONE_ACC != 0;   // fp16 x 2 operands (NP = 2) of gemm_bf16x6_kernel: one accumulator instead of two
 constexpr int GK = 32;              // k-step (bf16 elements): 64 bytes per row and plane
 constexpr int GBN = 128;            // tile columns
 constexpr int GTHREADS = 512;
@@ -646,6 +652,14 @@ __global__ void __launch_bounds__(GTHREADS)
         if constexpr (NP == 2) {                        // EXPERIMENT: fp32 as two fp16 terms, three products (a1 b1 ~ 2^-22 dropped)
           const f16x8_t a0 = __builtin_bit_cast(f16x8_t, a[0]), a1 = __builtin_bit_cast(f16x8_t, a[1]);
           const f16x8_t b0 = __builtin_bit_cast(f16x8_t, b[c][0]), b1 = __builtin_bit_cast(f16x8_t, b[c][1]);
+          if constexpr (H2_ONE_ACC) {
+            // one accumulator for the three products (the operands carry 22 bits: the 2^-23 truncation of a stored value, not the
+            // accumulation order, bounds the error) - 8 MB fewer live registers: 160- and 192-row tiles fit two workgroups per CU
+            acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0, acc[i][c], 0, 0, 0);
+            acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1, acc[i][c], 0, 0, 0);
+            acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, acc[i][c], 0, 0, 0);
+            continue;
+          }
           cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0, cor[i][c], 0, 0, 0);
           cor[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1, cor[i][c], 0, 0, 0);
           acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, acc[i][c], 0, 0, 0);

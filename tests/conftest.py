@@ -37,3 +37,13 @@ def load_golden(name):
 @pytest.fixture
 def golden():
     return load_golden
+
+
+@pytest.fixture(autouse=True)
+def _fresh_f16_census(request):
+    """The range census of the fp16 planes (point_teacher_amd.planes.CENSUS) is process-wide state: a group demoted by one GPU test
+    (on purpose, or by a diverging toy model) must not decide the operand format of the next test."""
+    if 'gpu' in request.keywords and torch.cuda.is_available():
+        from point_teacher_amd import planes
+        planes.CENSUS.reset()
+    yield

@@ -9,7 +9,7 @@ dev = torch.device('cuda:0')
 torch.backends.cudnn.benchmark = True
 cfg = pta.Config.fromfile(os.path.join(ROOT, 'point_teacher_amd', 'configs', 'point_teacher', 'aitodv2_point_teacher_0.py'))
 cfg.model['burn_in_step'] = -1
-torch.manual_seed(0)
+torch.manual_seed(1234)
 model = pta.build_detector(cfg.model).to(dev)
 benchmark_init_(model, phase2=True)
 model.train()
@@ -26,7 +26,9 @@ for it in range(10):
 t_issue = time.perf_counter() - t0
 torch.cuda.synchronize()
 t_all = time.perf_counter() - t0
-print(f'un-profiled: host issue {t_issue * 100:.2f} ms/iter, with the GPU drained {t_all * 100:.2f} ms/iter')
+from point_teacher_amd import planes as _PL
+_PL.CENSUS.poll(sync=True)
+print(f'un-profiled: host issue {t_issue * 100:.2f} ms/iter, with the GPU drained {t_all * 100:.2f} ms/iter; census demotions: {dict(_PL.CENSUS.demoted)}')
 pr = cProfile.Profile()
 pr.enable()
 for it in range(10):
