@@ -204,7 +204,14 @@ def test_bench_matrix_family_accounting():
     d = hip.STRUCTS['pt_conv_desc']()
     d.B, d.Hs, d.Ws, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad = 6, 100, 100, 512, 256, 1, 1, 2, 0
     shp = bench.conv_desc_shapes(d)
-    assert shp == dict(M=6 * 50 * 50, Cin=512, Cout=256, taps=1, np=3, f16=0)   # (np unset reads as the three-plane fp32 operands)
+    assert {k: shp[k] for k in ('M', 'Cin', 'Cout', 'taps', 'np', 'f16')} == dict(M=6 * 50 * 50, Cin=512, Cout=256, taps=1, np=3, f16=0)   # (np unset: three planes)
+    # algorithmic bytes = every tensor once as fp32 (a strided 1x1 reads only the pixels it needs), format bytes = the same in 6-byte planes
+    assert shp['abytes'] == 4 * (15000 * 512 + 256 * 512) and shp['fbytes'] == 6 * (15000 * 512 + 256 * 512)
+    d.out_planes, d.out_f16, d.operand_f16, d.res_planes, d.res_f16, d.mask_planes = 1, 1, 1, 1, 1, 1
+    s2 = bench.conv_desc_shapes(d)                                               # H2 operands, H2 result + identity, a ReLU mask
+    assert s2['abytes'] == 4 * (15000 * 512 + 256 * 512 + 3 * 15000 * 256)
+    assert s2['fbytes'] == 4 * (15000 * 512 + 256 * 512 + 2 * 15000 * 256) + 2 * 15000 * 256
+    d.out_planes = d.out_f16 = d.operand_f16 = d.res_planes = d.res_f16 = d.mask_planes = 0
     assert bench.executed_flops('pt_conv_bf16x6', shp) == 6.0 * bench.algorithmic_flops('pt_conv_bf16x6', shp)
     d.np = 1                                                                     # bf16 operands (BASELINE configs[2]): one MFMA product
     assert bench.executed_flops('pt_conv_bf16x6', bench.conv_desc_shapes(d)) == bench.algorithmic_flops('pt_conv_bf16x6', shp)
