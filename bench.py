@@ -590,7 +590,7 @@ def main():
         del trainer, model
         torch.cuda.empty_cache()
         PPLc.CENSUS.reset()
-        cfg2p, model, trainer = fresh('step2')
+        _, model, trainer = fresh('step2')
         for it in range(max(args.warmup, 5)):
             trainer.step(data.batch(1000 + it, args.batch))
         dt2, roof2 = timed_with_family(trainer, 2000)

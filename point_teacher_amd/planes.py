@@ -624,16 +624,6 @@ def launch_wgrad(gy_t, x_t, B, Hs, Ws, Cin, Cout, K, stride, pad, row_scale=None
     return dw.permute(0, 3, 1, 2), db
 
 
-def same_format(gy_t, x_t, census=0):
-    """The weight gradient multiplies two operands of one format: bring the gradient into the activations' (a group that fell back
-    in the middle of an iteration, or a B3 activation under an H2 gradient)."""
-    if fmt_of(gy_t) == fmt_of(x_t):
-        return gy_t
-    if is_h2(x_t):
-        return rescale_h2(gy_t, census=census)
-    return mix(gy_t, out_fmt=fmt_of(x_t))[0]
-
-
 # ------------------------------------------------------------------------------------------------ single convolution --
 class ConvCfg:
     """Static description of one plane convolution call (not a tensor: autograd passes it through)."""
@@ -1000,10 +990,9 @@ class _BottleneckP(torch.autograd.Function):
                 assert c.x_planes, 'a trainable stage behind an fp32 input is not plane-native'
                 mask = xs if c.x_relu else None
                 if not c.has_ds:
-                    if chain:                                     # E by-passes the block on the identity path: the same chain, added raw
-                        gx, _ = dgrad('gx', E1, Ha, Wa, p, cw(w1, True, S['1'][0]), c.Cin, 1, 0, mask, res_planes=E, want_planes=True)
-                    else:                                         # E1 was re-scaled: both terms in natural units
-                        gx, _ = dgrad('gx', E1, Ha, Wa, p, cw(w1, True, S['1'][0]), c.Cin, 1, 0, mask, res_planes=E, want_planes=True)
+                    # E by-passes the block on the identity path: in chain mode the same chain, added raw; in the fall-back E1 was
+                    # re-scaled and `dgrad` adds both terms in natural units (res_inv = E's tail)
+                    gx, _ = dgrad('gx', E1, Ha, Wa, p, cw(w1, True, S['1'][0]), c.Cin, 1, 0, mask, res_planes=E, want_planes=True)
                 else:
                     # the downsample path's gradient as fp32 in the chain's units (chain) or in natural units (fall-back: E and E1
                     # carry different scales), added in conv1's input-gradient epilogue; `caffe`: the sum is scattered to the
