@@ -292,17 +292,18 @@ class BucketedGradExchange:
     still enqueue the same sequence of equally sized all-reduces; `finish()` issues whatever is left in the same order
     and asserts the sequence.  `stats` = what the last iteration did (buckets, how many went out during backward, bytes)."""
 
-    def __init__(self, flat, n_buckets=6, device=None, small=1 << 16, wire=None):
+    def __init__(self, flat, n_buckets=6, device=None, small=1 << 16, wire=None, force=False):
         """wire: 'fp32' (default) or 'bf16' (PT_GRAD_WIRE=bf16; SURVEY 8(e): 120 MB instead of 240 MB per step over xGMI): a bucket is
         rounded to bf16 on this rank, all-reduced in bf16, and widened back into the flat fp32 gradient - every rank receives the
         same reduced values, so the ranks stay bit-identical; the optimizer still steps fp32 master weights with fp32 momentum."""
         self.flat = flat
+        self.force = bool(force)          # issue the collectives with ONE rank too (a 1-rank RCCL communicator: exercises the real path)
         self.wire = (wire or os.environ.get('PT_GRAD_WIRE', 'fp32')).lower()
         assert self.wire in ('fp32', 'bf16'), self.wire
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         self.stream = torch.cuda.Stream(device=device) if (device is not None and device.type == 'cuda') else None
         self.avg = None
-        if self.world > 1 and dist.get_backend() == 'nccl':
+        if (self.world > 1 or self.force) and dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl':
             self.avg = dist.ReduceOp.AVG                    # RCCL divides inside the collective: one launch less per bucket
         total = flat.n_train
         target = max(total // max(int(n_buckets), 1), 1)
@@ -394,7 +395,7 @@ class BucketedGradExchange:
             else:
                 t.div_(self.world)
                 dist.all_reduce(t)
-        if self.world > 1:
+        if self.world > 1 or self.force:
             if self.stream is None:
                 if self.wire == 'bf16':
                     w16 = g.to(torch.bfloat16)
@@ -483,7 +484,7 @@ class Trainer:
     """One object = model + flat storage + optimizer + (optional) data-parallel exchange."""
 
     def __init__(self, model, optimizer_cfg, optimizer_config=None, lr_config=None, iters_per_epoch=1000,
-                 grad_chunks=4, autocast_dtype=None, channels_last=False):
+                 grad_chunks=4, autocast_dtype=None, channels_last=False, force_exchange=False):
         assert optimizer_cfg.get('type', 'SGD') == 'SGD', 'the Point-Teacher recipe is SGD'
         self.model = model
         if autocast_dtype is not None and not channels_last:
@@ -510,7 +511,11 @@ class Trainer:
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         # N > 1: bucketed exchange overlapped with backward; N == 1: nothing to exchange, one gather after backward
         self.n_buckets = max(grad_chunks, 1) + 2
-        self.exchange = BucketedGradExchange(self.flat, self.n_buckets, dev) if self.world > 1 else None
+        # force_exchange: run the bucketed exchange with a single rank as well (a 1-rank process group: the RCCL code path - AVG
+        # all-reduce on the side stream, bf16 wire - executes on a one-GPU box; tests/test_rccl_single_rank.py)
+        self.force_exchange = bool(force_exchange and dist.is_available() and dist.is_initialized())
+        self.exchange = (BucketedGradExchange(self.flat, self.n_buckets, dev, force=self.force_exchange)
+                         if (self.world > 1 or self.force_exchange) else None)
         # Parameters that never receive a gradient (FlatParams "dead"): discovered at the first step, agreed between the ranks
         # with one all-reduce of a bitmap, re-checked every `revive_interval` steps (N > 1; N == 1 sees a revival at once).
         self.dead_known = False
@@ -527,7 +532,7 @@ class Trainer:
         self._broadcast_initial_state()
 
     def _broadcast_initial_state(self):
-        if self.world > 1:                     # identical initial weights on every rank, as DDP does
+        if self.world > 1 or self.force_exchange:   # identical initial weights on every rank, as DDP does
             dist.broadcast(self.flat.student_flat, src=0)
             if self.flat.teacher_flat is not None:
                 dist.broadcast(self.flat.teacher_flat, src=0)
@@ -634,7 +639,7 @@ class Trainer:
     def _relayout(self, dead):
         if self.flat.relayout(dead) and self.exchange is not None:
             self.exchange.remove()
-            self.exchange = BucketedGradExchange(self.flat, self.n_buckets, self.flat.student_flat.device)
+            self.exchange = BucketedGradExchange(self.flat, self.n_buckets, self.flat.student_flat.device, force=self.force_exchange)
 
     def state_dict(self):
         return dict(model=self.model.state_dict(), momentum=self.flat.mom_flat.clone(), iter=self.iter,

@@ -1,0 +1,71 @@
+"""Worker of tests/test_rccl_single_rank.py: a ONE-rank `nccl` (= RCCL) process group on the box's single MI355X, so that the code the
+8-GPU job will run - `init_process_group('nccl', device_id=...)`, the initial broadcast, the bucketed AVG all-reduces issued on a side
+stream while backward runs, the bf16 wire, the coalesced normaliser / log-var all-reduces - executes on real RCCL at least once
+before the driver's scaling run.  With one rank every collective is the identity: the trained weights must equal a run without the
+exchange."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def run(force, wire, steps=3):
+    import point_teacher_amd as pta
+    from point_teacher_amd.synthetic import SyntheticTiles, benchmark_init_
+    dev = torch.device('cuda:0')
+    torch.manual_seed(77)
+    cfg = pta.Config.fromfile(os.path.join(ROOT, 'point_teacher_amd', 'configs', 'point_teacher', 'aitodv2_point_teacher_0.py'))
+    cfg.model['burn_in_step'] = 1                                     # steps 0, 1 = phase 1; step 2 = phase 2
+    model = pta.build_detector(cfg.model).to(dev)
+    benchmark_init_(model, phase2=True)
+    model.train()
+    os.environ['PT_GRAD_WIRE'] = wire
+    tr = pta.Trainer(model, cfg.optimizer, cfg.optimizer_config, cfg.lr_config, channels_last=True, force_exchange=force)
+    data = SyntheticTiles(n=4, size=256, mean_objects=20, seed=11, device=dev)
+    g = torch.Generator().manual_seed(5)
+    stats, lvs = [], []
+    for it in range(steps):
+        model._inject = dict(neg0=torch.rand(2, 4, 200, generator=g).to(dev), aug=(['horizontal', 'None'], [0.9, 1.1]))
+        out = tr.step(data.batch(it, 2))
+        lvs.append(out['log_vars'].materialize())                      # (one coalesced all-reduce when a process group exists)
+        if tr.exchange is not None:
+            stats.append(dict(tr.exchange.stats))
+    torch.cuda.synchronize()
+    return tr.flat.student_flat.detach().clone(), tr.flat.teacher_flat.detach().clone(), stats, lvs, tr
+
+
+def main():
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda:0')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        assert dist.get_backend() == 'nccl'
+        s1, t1, stats, lv1, tr = run(True, 'fp32')
+        assert tr.exchange is not None and tr.exchange.avg is not None and tr.exchange.stream is not None      # RCCL AVG on the side stream
+        assert all(st['buckets'] >= 6 for st in stats), stats
+        assert stats[-1]['issued_during_backward'] >= stats[-1]['buckets'] - 2, stats     # issued WHILE backward ran
+        assert stats[-1]['overlap_ms'] > 0 and stats[-1]['wire'] == 'fp32'
+        s0, t0, _, lv0, tr0 = run(False, 'fp32')
+        assert tr0.exchange is None
+        for a, b, n in ((s1, s0, 'student'), (t1, t0, 'teacher')):
+            assert torch.isfinite(a).all(), n
+            d = float((a.double() - b.double()).norm() / b.double().norm())
+            print(f'{n}: |with exchange - without| / |without| = {d:.2e}')
+            assert d < 1e-5, (n, d)                                     # (RoIAlign's atomics make two runs differ in the last bits)
+        for a, b in zip(lv1, lv0):
+            assert set(a) == set(b)
+            for k in a:
+                assert abs(a[k] - b[k]) <= 2e-3 * max(abs(b[k]), 1e-2), (k, a[k], b[k])
+        s2, _, stats2, lv2, _ = run(True, 'bf16', steps=2)
+        assert stats2[-1]['wire'] == 'bf16' and stats2[-1]['bytes'] * 2 == stats[-1]['bytes'] and torch.isfinite(s2).all()
+        assert all(v == v for v in lv2[-1].values())
+        print('rccl single rank ok', stats[-1], stats2[-1])
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
