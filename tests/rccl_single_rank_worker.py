@@ -55,10 +55,13 @@ def main():
             d = float((a.double() - b.double()).norm() / b.double().norm())
             print(f'{n}: |with exchange - without| / |without| = {d:.2e}')
             assert d < 1e-5, (n, d)                                     # (RoIAlign's atomics make two runs differ in the last bits)
-        for a, b in zip(lv1, lv0):
+        for it, (a, b) in enumerate(zip(lv1, lv0)):
             assert set(a) == set(b)
+            # step 0: the same weights and inputs - only the atomics of RoIAlign's backward differ between two runs; later steps train
+            # on random labels, where a last-bit difference can flip an assignment (the chaotic map of tests/test_trajectory.py)
+            tol = 1e-3 if it == 0 else 5e-2
             for k in a:
-                assert abs(a[k] - b[k]) <= 2e-3 * max(abs(b[k]), 1e-2), (k, a[k], b[k])
+                assert abs(a[k] - b[k]) <= tol * max(abs(b[k]), 1e-2), (it, k, a[k], b[k])
         s2, _, stats2, lv2, _ = run(True, 'bf16', steps=2)
         assert stats2[-1]['wire'] == 'bf16' and stats2[-1]['bytes'] * 2 == stats[-1]['bytes'] and torch.isfinite(s2).all()
         assert all(v == v for v in lv2[-1].values())
