@@ -67,7 +67,7 @@ def sweep(name, B, H, W, Cin, Cout, res, mask, wgrad=False):
 
 
 print('operands:', 'H2 (fp16 x 2)' if H2 else 'B3 (bf16 x 3)')
-for B in (() if 'k3' in sys.argv[1:] else (6, 2)):
+for B in (() if ('k3' in sys.argv[1:] or 'b4' in sys.argv[1:]) else (6, 2)):
     sweep(f'layer2 conv3 +res (B={B})', B, 100, 100, 128, 512, True, False)
     sweep(f'layer2 conv3^T +mask', B, 100, 100, 512, 128, False, True)
     sweep(f'layer2 conv1 (B={B})', B, 100, 100, 512, 128, False, False)
@@ -111,3 +111,13 @@ if 'k3' in sys.argv[1:]:
     sweep_k('FC1 5000 rows', 1, 5000, 1, 12544, 1024, 1)
     sweep_k('FC1 dgrad 5000 rows', 1, 5000, 1, 1024, 12544, 1, planes_out=False)
     sweep_k('FC2 5000 rows', 1, 5000, 1, 1024, 1024, 1)
+
+if 'b4' in sys.argv[1:]:            # the phase-2 student batch (clean + augmented = 4 images)
+    sweep('layer3 conv1 (B=4)', 4, 50, 50, 1024, 256, False, False)
+    sweep('layer3 conv3^T +mask (B=4)', 4, 50, 50, 1024, 256, False, True)
+    sweep('layer3 conv3 +res (B=4)', 4, 50, 50, 256, 1024, True, False)
+    sweep('layer2 conv1 (B=4)', 4, 100, 100, 512, 128, False, False)
+    sweep('layer2 conv3^T +mask (B=4)', 4, 100, 100, 512, 128, False, True)
+    sweep('layer2 conv3 +res (B=4)', 4, 100, 100, 128, 512, True, False)
+    sweep('layer4 conv1 (B=4)', 4, 25, 25, 2048, 512, False, False)
+    sweep('layer4 conv3 +res (B=4)', 4, 25, 25, 512, 2048, True, False)
