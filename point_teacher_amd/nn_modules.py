@@ -138,8 +138,13 @@ class ConvModule(nn.Module):
             if F.bias_relu_ok(y, c.bias):
                 return F.bias_relu_(y, c.bias, True)          # bias + ReLU in one pass; backward: grad_x + bias gradient in one
             return TF.relu(y + c.bias.view(1, -1, 1, 1), inplace=True)
-        if _SPLIT_CONV and type(c) is nn.Conv2d and c.bias is None and self.with_norm and F.split_conv3x3_ok(x, c):
-            x = F.split_conv3x3(x, c.weight, None, False)     # towers with GroupNorm (config 5): the convolution alone, then the norm
+        if (_PLANE_TRUNK and self.with_norm and c.bias is None and PL.plane_conv_ok(c) and PL.dense_ok(x) and PL.use_f16(self.plane_group)
+                and x.shape[0] * x.shape[2] * x.shape[3] >= self.plane_min_pixels):
+            # towers with GroupNorm (config 5), round 5: the convolution alone on fp16 x 2 operands / three MFMA products (fp32 map in,
+            # split once, fp32 map out; input / weight gradients on the same kernels), then the norm
+            x = PL.conv_module(x, c, relu=False, f16=True, group=self.plane_group)
+        elif _SPLIT_CONV and type(c) is nn.Conv2d and c.bias is None and self.with_norm and F.split_conv3x3_ok(x, c):
+            x = F.split_conv3x3(x, c.weight, None, False)     # ... on bf16 x 3 operands / six products (the group fell back, PT_F16_FC=0)
         else:
             x = c(x)
         if self.with_norm:
