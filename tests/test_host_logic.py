@@ -243,3 +243,47 @@ def test_black_paper_batches_beyond_one_segmented_launch_are_grouped():
         g = plan_black_paper_groups(counts, [sh] * len(counts))
         assert [i for a, b in g for i in range(a, b)] == list(range(len(counts)))                       # a partition, in order
         assert all(b - a <= 16 and (b - a == 1 or max(2 * c + 10 for c in counts[a:b]) <= 8192) for a, b in g)
+
+
+def test_f16_census_policy_digest():
+    """planes.Census turns the device counters into fall-back decisions on the host (no GPU needed for the rule itself): a site that
+    saturated demotes its group; so does a non-zero tensor whose largest STORED magnitude sank below 0.25; an all-zero tensor (a masked
+    gradient, a pass that did not run) and a healthy one do nothing; '<group>_grad' demotions switch chains to per-link re-scaling."""
+    import struct
+    import warnings
+    from point_teacher_amd import planes as PL
+    c = PL.Census()
+    c.mode = 2
+    c.names = [('trunk', 'layer2.0:y1'), ('towers', 'conv:y'), ('fc', 'fc1:y'), ('trunk_grad', 'layer3.1:E2'), ('neck', 'zero')]
+    c.index = {k: i for i, k in enumerate(c.names)}
+    bits = lambda v: struct.unpack('<i', struct.pack('<f', v))[0]       # noqa: E731
+    host = torch.zeros((8, 4), dtype=torch.int32)
+    host[0] = torch.tensor([0, bits(37.5), 10, 1000])                    # healthy
+    host[1] = torch.tensor([3, bits(60000.0), 0, 1000])                  # saturated
+    host[2] = torch.tensor([0, bits(0.1), 900, 1000])                    # sank below the floor
+    host[3] = torch.tensor([0, bits(20000.0), 0, 1000])                  # a chain that grew, still inside the range
+    host[4] = torch.tensor([0, 0, 0, 1000])                              # all zeros: no information
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        out = c._digest(host)
+    assert set(c.demoted) == {'towers', 'fc'} and len(w) == 2
+    assert out[('towers', 'conv:y')]['saturated'] == 3 and abs(out[('fc', 'fc1:y')]['amax_stored'] - 0.1) < 1e-7
+    assert ('neck', 'zero') in out and c.ok('trunk') and c.ok('trunk_grad') and not c.ok('fc')
+    lv = c.log_vars()
+    assert lv['census/towers/conv:y/sat'] == 3.0 and lv['census/fc/fc1:y/tiny_frac'] == 0.9 and lv['census/trunk/layer2.0:y1/amax'] == 37.5
+    assert c.history[('trunk_grad', 'layer3.1:E2')][1] == 20000.0
+    # a saturating gradient site demotes the '<group>_grad' policy only
+    host.zero_()
+    host[3] = torch.tensor([5, bits(60000.0), 0, 1000])
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter('always')
+        c._digest(host)
+    assert 'trunk_grad' in c.demoted and 'trunk' not in c.demoted
+    # PT_F16_FALLBACK=0: the census still reports, nothing is demoted
+    c2 = PL.Census()
+    c2.auto_fallback = False
+    c2.names, c2.index = list(c.names), dict(c.index)
+    host[1] = torch.tensor([3, bits(60000.0), 0, 1000])
+    assert c2._digest(host)[('towers', 'conv:y')]['saturated'] == 3 and not c2.demoted
+    c.reset()
+    assert not c.demoted and not c.history
