@@ -487,6 +487,31 @@ __global__ void __launch_bounds__(256) conv_splitk_finish_kernel(int M, int N, C
   }
 }
 
+// Stages of the LDS ring.  Two (one k-step of loads in flight behind one barrier per k-step) everywhere until round 5.  With fp16 x 2
+// operands a k-step holds HALF the MFMA work of the bf16 x 3 form but its global -> LDS loads take the same ~1 us round trip: PMC says
+// the waves wait 40 - 52 % of their cycles and the matrix pipes are 34 % busy (profiles/r05/h2_pmc_*.txt; bf16 x 3: 58 - 67 %).  Tiles
+// of 160 rows and up (one workgroup per CU: nobody else hides the latency) therefore keep TWO k-steps of loads in flight: three
+// stages, `s_waitcnt vmcnt(N)` with N = this wave's loads of the younger stage instead of the barrier's vmcnt(0).
+#ifndef PT_NSTAGE3_MIN_MB
+#define PT_NSTAGE3_MIN_MB 5
+#endif
+#ifndef PT_NSTAGE_MAX
+#define PT_NSTAGE_MAX 4
+#endif
+template <int MB, bool CONV, int NP>
+__host__ __device__ constexpr int n_stages() {
+  if (!(CONV && NP == 2 && MB >= PT_NSTAGE3_MIN_MB)) return 2;
+  const int stage = (32 * MB + GBN) * NP * 64;
+  int n = (160 * 1024) / stage;                        // what the CU's LDS holds
+  n = n > PT_NSTAGE_MAX ? PT_NSTAGE_MAX : n;
+  return n < 2 ? 2 : n;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_barrier() {   // (the "memory" clobber keeps the compiler's LDS reads behind it)
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
 template <int MB, bool CONV, int NP>
 __global__ void __launch_bounds__(GTHREADS)
     gemm_bf16x6_kernel(const uint16_t* __restrict__ Ap, const uint16_t* __restrict__ Bp, float* __restrict__ C,
@@ -497,6 +522,7 @@ __global__ void __launch_bounds__(GTHREADS)
   constexpr int NI = ROWS * NP / 16;                   // staging instructions (one 1-KiB block each) per stage
   constexpr int NJ = (NI + 7) / 8;                     // per wave
   constexpr int PER = (NJ + MB - 1) / MB;              // staging instructions issued behind each row block's MFMAs
+  constexpr int NST = n_stages<MB, CONV, NP>();        // stages of the LDS ring (2, or 3: two k-steps of loads in flight)
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
   // XCD-aware block -> tile (bijective for any tile count): blocks b, b + 8, ... share an XCD and take consecutive tiles
@@ -625,13 +651,36 @@ __global__ void __launch_bounds__(GTHREADS)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[i][c][e] = cor[i][c][e] = 0.f;
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) issue1(j, 0);
-  next_stage();
+  for (int sidx = 0; sidx < NST - 1; ++sidx) {          // the first NST - 1 stages
+    if (kb0 + sidx < kb1) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) issue1(j, sidx);
+    }
+    next_stage();
+  }
+  // (this wave's loads per stage: NJ, or NJ - 1 when its last slot lies beyond the stage's NI instructions - wave-uniform)
+  const bool full_wave = __builtin_amdgcn_readfirstlane(w) + 8 * (NJ - 1) < NI;
+  int cur = 0;                                          // ring slot of stage ks
   for (int ks = kb0; ks < kb1; ++ks) {
-    __syncthreads();          // (emits s_waitcnt vmcnt(0)): stage ks has landed, every wave is done reading the other buffer
-    const bool more = ks + 1 < kb1;
-    const int nbuf = (ks - kb0 + 1) & 1;
-    const unsigned char* st = smem + ((ks - kb0) & 1) * STAGE;
+    if constexpr (NST == 2) {
+      __syncthreads();        // (emits s_waitcnt vmcnt(0)): stage ks has landed, every wave is done reading the other buffer
+    } else {
+      // stage ks has landed when at most the loads of the NST - 2 younger stages are still in flight (fewer at the last k-steps); the
+      // barrier then also says that every wave is done reading the slot the next loads overwrite
+      constexpr int NL = NJ > 1 ? NJ - 1 : 0;
+      const int ahead = min(NST - 2, kb1 - 1 - ks);      // younger stages whose loads may stay in flight
+      if (ahead >= 2) {
+        if (full_wave) wait_vmcnt_barrier<2 * NJ>(); else wait_vmcnt_barrier<2 * NL>();
+      } else if (ahead == 1) {
+        if (full_wave) wait_vmcnt_barrier<NJ>(); else wait_vmcnt_barrier<NL>();
+      } else {
+        wait_vmcnt_barrier<0>();
+      }
+    }
+    const bool more = ks + NST - 1 < kb1;
+    const int nbuf = cur + NST - 1 >= NST ? cur - 1 : cur + NST - 1;      // slot of stage ks + NST - 1 = the slot stage ks - 1 left
+    const unsigned char* st = smem + cur * STAGE;
+    cur = cur + 1 == NST ? 0 : cur + 1;
     bf16x8_t b[2][NP];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -743,7 +792,7 @@ template <int MB, bool CONV, int NP>
 static int launch_gemm(const uint16_t* Ap, const uint16_t* Bp, float* C, const float* bias, const float* scale, int M, int N, int KB,
                        long a_plane, long b_plane, long ldc, int relu, ConvGeom cg, ConvEpi ep, hipStream_t s) {
   constexpr int BM = 32 * MB;
-  constexpr int STAGES = (BM + GBN) * NP * 64 * 2;
+  constexpr int STAGES = (BM + GBN) * NP * 64 * n_stages<MB, CONV, NP>();
   constexpr int LDS = STAGES > BM * (GBN + 4) * 4 ? STAGES : BM * (GBN + 4) * 4;      // the output tile [BM][132] fp32 reuses the stages
   static_assert(LDS <= 160 * 1024, "the stages must fit the CU's LDS");
   const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, GBN);
