@@ -898,6 +898,27 @@ __device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* lo, const unsig
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
+// Stages of the weight gradient's LDS ring: what fits the CU's LDS, at most PT_WG_NSTAGE_MAX.  A k-step of a [256][128] tile is
+// 0.64 us of fp16 x 2 MFMA work behind 48 KB of loads whose round trip under load is ~2.8 us: with two stages (one k-step in flight)
+// the launch ran at the latency, 3 us per k-step (FC1: 159 TFLOP/s fp32-equivalent); see DESIGN.md section 5.000.
+#ifndef PT_WG_NSTAGE_MAX
+#define PT_WG_NSTAGE_MAX 4
+#endif
+// The same LDS-DMA as glds16, issued from inline assembly: the compiler puts `s_waitcnt vmcnt(0)` in front of every
+// `ds_read_b64_tr_b16` that follows an LDS-DMA it knows about (the transposed read is an intrinsic it takes for a possible alias of the
+// DMA's LDS write) - which would drain the ring at every row block.  The waits of these loads are the counted ones at the stage barrier.
+__device__ __forceinline__ void glds16_untracked(const void* g, unsigned lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_wave_base) : "memory", "m0");
+}
+
+template <int MB, int NP>
+__host__ __device__ constexpr int wg_stages() {
+  const int stage = (32 * MB / 128 + 1) * NP * 8192;
+  int n = (160 * 1024) / stage;
+  n = n > PT_WG_NSTAGE_MAX ? PT_WG_NSTAGE_MAX : n;
+  return n < 2 ? 2 : n;
+}
+
 template <int MB, int NP>
 __global__ void __launch_bounds__(GTHREADS)
     wgrad_bf16x6_kernel(const uint16_t* __restrict__ Gp, const uint16_t* __restrict__ Xp, float* __restrict__ part,
@@ -934,8 +955,15 @@ __global__ void __launch_bounds__(GTHREADS)
   const uint16_t* ga = Gp + m0 + lc * 8;
   const uint16_t* xb = Xp + c0 + lc * 8;
   long arow = 0, brow = 0;
+  // a 1 x 1 stride-1 product (the FC stacks run as B = rows, 1 x 1 pixels: the walk below would take 32 turns per k-step): source = pixel
+  const bool flat = wg.taps == 1 && wg.stride == 1 && wg.pad == 0;
   auto next_rows = [&]() {                             // rows of the stage at `pix`, then advance one k-step
     arow = (long)(pix < wg.P ? pix : wg.P) * wg.O;
+    if (flat) {
+      brow = (long)(pix < wg.P ? pix : wg.Ps) * wg.C;
+      pix += 32;
+      return;
+    }
     const int yy = py * wg.stride - wg.pad + ky, xx = px * wg.stride - wg.pad + kx;
     const bool ok = pix < wg.P && yy >= 0 && yy < wg.Hs && xx >= 0 && xx < wg.Ws;
     brow = (long)(ok ? sbase + yy * wg.Ws + xx : wg.Ps) * wg.C;
@@ -944,12 +972,13 @@ __global__ void __launch_bounds__(GTHREADS)
     while (px >= wg.Wo) { px -= wg.Wo; ++py; }
     while (py >= wg.Ho) { py -= wg.Ho; sbase += wg.Hs * wg.Ws; }
   };
-  auto issue = [&](int img, int buf) {                 // the three planes of one image
-    unsigned char* dst = smem + buf * STAGE + img * NP * IMG + w * 1024;
+  const unsigned smem_lds = (unsigned)(uintptr_t)smem;   // (the low word of a flat LDS address is the LDS offset)
+  auto issue = [&](int img, int buf) {                 // the planes of one image
+    const unsigned dst = smem_lds + buf * STAGE + img * NP * IMG + w * 1024;
     const uint16_t* src = img < IMG_A ? ga + arow + img * 128 : xb + brow;
     const long plane = img < IMG_A ? g_plane : x_plane;
 #pragma unroll
-    for (int p = 0; p < NP; ++p) glds16(src + p * plane, dst + p * IMG);
+    for (int p = 0; p < NP; ++p) glds16_untracked(src + p * plane, dst + p * IMG);
   };
 
   // fragments: lane 16 g + 4 q + p2 supplies row 8 g + q (+ 4 for the second read), 8-byte half p2 & 1 of chunk c0 + (p2 >> 1)
@@ -986,15 +1015,30 @@ __global__ void __launch_bounds__(GTHREADS)
   bf16x8_t ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
-  if (k_begin < k_end) {
-    next_rows();
+  constexpr int NST = wg_stages<MB, NP>();             // ring slots; NST - 1 k-steps of loads in flight
+  constexpr int NL = NIMG * NP;                        // this wave's loads per stage
+  static_assert(NST <= 4 && 2 * NL < 64, "the wait dispatch below covers two younger stages; vmcnt is a 6-bit counter");
 #pragma unroll
-    for (int img = 0; img < NIMG; ++img) issue(img, 0);
-  }
-  for (int ks = k_begin; ks < k_end; ++ks) {
-    __syncthreads();          // the stage has landed (s_waitcnt vmcnt(0)) and every wave has left the other buffer
-    const bool more = ks + 1 < k_end;
-    const int cur = (ks - k_begin) & 1;
+  for (int j = 0; j < NST - 1; ++j)
+    if (k_begin + j < k_end) {
+      next_rows();
+#pragma unroll
+      for (int img = 0; img < NIMG; ++img) issue(img, j);
+    }
+  int cur = 0;
+  for (int ks = k_begin; ks < k_end; ++ks, cur = cur + 1 == NST ? 0 : cur + 1) {
+    // stage ks has landed - for this wave: all but the loads of the (up to NST - 2) younger stages; behind the barrier: for every
+    // wave - and every wave has left slot cur - 1, the one this k-step refills
+    if constexpr (NST == 2) {
+      wait_vmcnt_barrier<0>();
+    } else {
+      const int ahead = min(NST - 2, k_end - 1 - ks);
+      if (ahead >= 2) wait_vmcnt_barrier<2 * NL>();
+      else if (ahead == 1) wait_vmcnt_barrier<NL>();
+      else wait_vmcnt_barrier<0>();
+    }
+    const bool more = ks + NST - 1 < k_end;
+    const int nbuf = cur == 0 ? NST - 1 : cur - 1;
     const unsigned char* st = smem + cur * STAGE;
     if (more) next_rows();
     bf16x8_t b[2][NP];
@@ -1007,7 +1051,7 @@ __global__ void __launch_bounds__(GTHREADS)
       bf16x8_t a[NP];
 #pragma unroll
       for (int p = 0; p < NP; ++p) a[p] = tr_frag(st + a_off[i][0] + p * IMG, st + a_off[i][1] + p * IMG);
-      if (more && i < NIMG) issue(i, cur ^ 1);         // wave-uniform
+      if (more && i < NIMG) issue(i, nbuf);            // wave-uniform
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         if constexpr (NP == 2) {                        // two fp16 terms per operand: three products (a1 b1 ~ 2^-22 dropped)
@@ -1107,6 +1151,50 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float4* __restr
   }
 }
 
+// The same sum for SMALL results behind MANY chunks (a 1 x 1 convolution of the trunk: 64 K weights, up to 125 chunks): the kernel
+// above gives every float4 of the result ONE thread that walks the S partials - 64 workgroups and a chain of S loads each (33 us
+// measured for 16 384 float4 x 125).  Here the eight waves of a workgroup take the chunks s = t, t + 8, ... of 64 consecutive float4
+// and wave 0 adds the eight sums in the order t = 0 .. 7: fixed order (run-to-run identical bits), an eighth of the chain.
+__global__ void __launch_bounds__(512) wgrad_reduce_sliced_kernel(const float4* __restrict__ part, int S, long n4, int ld4, float4* __restrict__ out,
+                                                                  const float* __restrict__ row_scale, const float4* __restrict__ part_bias,
+                                                                  int o4, float4* __restrict__ out_bias, int accumulate, float alpha,
+                                                                  const float* __restrict__ alpha_dev, const float* __restrict__ alpha_dev2) {
+  __shared__ float4 sm[8][64];
+  const int t = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const long i = (long)blockIdx.x * 64 + l;
+  const bool w = i < n4, b = !w && i < n4 + o4;
+  const float4* src = w ? part + i : part_bias + (i - n4);
+  const long step = w ? n4 : (long)o4;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (w || b)
+    for (int s = t; s < S; s += 8) {
+      const float4 v = src[(long)s * step];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  sm[t][l] = a;
+  __syncthreads();
+  if (t != 0 || !(w || b)) return;
+  a = sm[0][l];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) {
+    const float4 v = sm[k][l];
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  if (alpha_dev) alpha *= *alpha_dev;
+  if (alpha_dev2) alpha *= *alpha_dev2;
+  a.x *= alpha; a.y *= alpha; a.z *= alpha; a.w *= alpha;
+  if (w && row_scale) {
+    const float sc = row_scale[i / ld4];
+    a.x *= sc; a.y *= sc; a.z *= sc; a.w *= sc;
+  }
+  float4* dst = w ? out + i : out_bias + (i - n4);
+  if (accumulate) {
+    const float4 v = *dst;
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  *dst = a;
+}
+
 // Trainable BatchNorm behind a convolution (eval-mode statistics; OBB config 5: norm_cfg requires_grad=True, norm_eval=True):
 // y = gamma * rstd * (conv - mean) + beta.  With G[o][:] = sum_p e[p][o] x[src(p)][:] (the raw weight gradient) and
 // sum_e[o] = sum_p e[p][o] (the bias sums of the same launch):
@@ -1140,7 +1228,7 @@ __global__ void __launch_bounds__(256)
 template <int MB, int NP>
 static int launch_wgrad(const uint16_t* Gp, const uint16_t* Xp, float* part, float* part_bias, long g_plane, long x_plane, WgradGeom wg, int S,
                         hipStream_t s) {
-  constexpr int STAGES = (32 * MB / 128 + 1) * NP * 8192 * 2;
+  constexpr int STAGES = (32 * MB / 128 + 1) * NP * 8192 * wg_stages<MB, NP>();
   constexpr int LDS = STAGES > 32 * MB * (GBN + 4) * 4 ? STAGES : 32 * MB * (GBN + 4) * 4;   // the output tile reuses the stages
   static_assert(LDS <= 160 * 1024, "the stages must fit the CU's LDS");
   static bool once = false;
@@ -1972,9 +2060,14 @@ extern "C" int pt_conv_wgrad_bf16x6(const pt_conv_wgrad_desc* d, void* stream) {
   PT_REQUIRE(rc == 0, rc, "pt_conv_wgrad_bf16x6: hipFuncSetAttribute failed (%d)", rc);
   PT_LAUNCH_CHECK("pt_conv_wgrad_bf16x6");
   if (direct) return PT_OK;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n / 4 + nbias / 4, 256)), dim3(256), 0, as_stream(stream),
-                     reinterpret_cast<const float4*>(d->workspace), S, n / 4, taps * d->Cin / 4, reinterpret_cast<float4*>(d->dw), d->row_scale,
-                     reinterpret_cast<const float4*>(part_bias), (int)(nbias / 4), reinterpret_cast<float4*>(d->dbias), d->accumulate, alpha, d->alpha_dev, d->alpha_dev2);
+  if (S >= 8 && n / 4 + nbias / 4 <= (1L << 17))
+    hipLaunchKernelGGL(wgrad_reduce_sliced_kernel, dim3(cdiv(n / 4 + nbias / 4, 64)), dim3(512), 0, as_stream(stream),
+                       reinterpret_cast<const float4*>(d->workspace), S, n / 4, taps * d->Cin / 4, reinterpret_cast<float4*>(d->dw), d->row_scale,
+                       reinterpret_cast<const float4*>(part_bias), (int)(nbias / 4), reinterpret_cast<float4*>(d->dbias), d->accumulate, alpha, d->alpha_dev, d->alpha_dev2);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n / 4 + nbias / 4, 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4*>(d->workspace), S, n / 4, taps * d->Cin / 4, reinterpret_cast<float4*>(d->dw), d->row_scale,
+                       reinterpret_cast<const float4*>(part_bias), (int)(nbias / 4), reinterpret_cast<float4*>(d->dbias), d->accumulate, alpha, d->alpha_dev, d->alpha_dev2);
   PT_LAUNCH_CHECK("pt_conv_wgrad_bf16x6 (reduce)");
   return PT_OK;
 }
