@@ -498,9 +498,11 @@ __global__ void __launch_bounds__(256) conv_splitk_finish_kernel(int M, int N, C
 #ifndef PT_NSTAGE_MAX
 #define PT_NSTAGE_MAX 4
 #endif
-template <int MB, bool CONV, int NP>
+// DEEP: the launch has no more workgroups than the chip has CUs (a k-split 3 x 3 of layer3 / layer4, 236 tiles of layer3's 3 x 3): a
+// second workgroup per CU - what the two-stage form leaves LDS for - never comes, so the ring takes the LDS instead.
+template <int MB, bool CONV, int NP, bool DEEP = false>
 __host__ __device__ constexpr int n_stages() {
-  if (!(CONV && NP == 2 && MB >= PT_NSTAGE3_MIN_MB)) return 2;
+  if (!(CONV && NP == 2 && (MB >= PT_NSTAGE3_MIN_MB || DEEP))) return 2;
   const int stage = (32 * MB + GBN) * NP * 64;
   int n = (160 * 1024) / stage;                        // what the CU's LDS holds
   n = n > PT_NSTAGE_MAX ? PT_NSTAGE_MAX : n;
@@ -512,7 +514,7 @@ __device__ __forceinline__ void wait_vmcnt_barrier() {   // (the "memory" clobbe
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <int MB, bool CONV, int NP>
+template <int MB, bool CONV, int NP, bool DEEP = false>
 __global__ void __launch_bounds__(GTHREADS)
     gemm_bf16x6_kernel(const uint16_t* __restrict__ Ap, const uint16_t* __restrict__ Bp, float* __restrict__ C,
                        const float* __restrict__ bias, const float* __restrict__ scale, int M, int N, int KB, long a_plane, long b_plane,
@@ -522,7 +524,7 @@ __global__ void __launch_bounds__(GTHREADS)
   constexpr int NI = ROWS * NP / 16;                   // staging instructions (one 1-KiB block each) per stage
   constexpr int NJ = (NI + 7) / 8;                     // per wave
   constexpr int PER = (NJ + MB - 1) / MB;              // staging instructions issued behind each row block's MFMAs
-  constexpr int NST = n_stages<MB, CONV, NP>();        // stages of the LDS ring (2, or 3: two k-steps of loads in flight)
+  constexpr int NST = n_stages<MB, CONV, NP, DEEP>();  // stages of the LDS ring (2, or 3: two k-steps of loads in flight)
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
   // XCD-aware block -> tile (bijective for any tile count): blocks b, b + 8, ... share an XCD and take consecutive tiles
@@ -788,29 +790,38 @@ __global__ void __launch_bounds__(GTHREADS)
   }
 }
 
-template <int MB, bool CONV, int NP>
+template <int MB, bool CONV, int NP, bool DEEP = false>
 static int launch_gemm(const uint16_t* Ap, const uint16_t* Bp, float* C, const float* bias, const float* scale, int M, int N, int KB,
                        long a_plane, long b_plane, long ldc, int relu, ConvGeom cg, ConvEpi ep, hipStream_t s) {
   constexpr int BM = 32 * MB;
-  constexpr int STAGES = (BM + GBN) * NP * 64 * n_stages<MB, CONV, NP>();
+  constexpr int STAGES = (BM + GBN) * NP * 64 * n_stages<MB, CONV, NP, DEEP>();
   constexpr int LDS = STAGES > BM * (GBN + 4) * 4 ? STAGES : BM * (GBN + 4) * 4;      // the output tile [BM][132] fp32 reuses the stages
   static_assert(LDS <= 160 * 1024, "the stages must fit the CU's LDS");
   const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, GBN);
   const int items = tiles_m * tiles_n * ((CONV && ep.splits > 1) ? ep.splits : 1);
   static bool once = false;
   if (!once) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x6_kernel<MB, CONV, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x6_kernel<MB, CONV, NP, DEEP>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
     once = true;
   }
-  hipLaunchKernelGGL((gemm_bf16x6_kernel<MB, CONV, NP>), dim3(items), dim3(GTHREADS), LDS, s, Ap, Bp, C, bias, scale, M, N, KB,
+  hipLaunchKernelGGL((gemm_bf16x6_kernel<MB, CONV, NP, DEEP>), dim3(items), dim3(GTHREADS), LDS, s, Ap, Bp, C, bias, scale, M, N, KB,
                      a_plane, b_plane, ldc, relu, tiles_n, items, cg, ep);
   return 0;
 }
 
 template <bool CONV, int NP>
 static int launch_by_rows(int tile_rows, const uint16_t* Ap, const uint16_t* Bp, float* C, const float* bias, const float* scale, int M,
-                          int N, int KB, long a_plane, long b_plane, long ldc, int relu, ConvGeom cg, ConvEpi ep, hipStream_t s) {
+                          int N, int KB, long a_plane, long b_plane, long ldc, int relu, ConvGeom cg, ConvEpi ep, hipStream_t s,
+                          bool deep = false) {
+  if constexpr (CONV && NP == 2) {
+    if (deep) switch (tile_rows / 32) {
+        case 2: return launch_gemm<2, CONV, NP, true>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
+        case 3: return launch_gemm<3, CONV, NP, true>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
+        case 4: return launch_gemm<4, CONV, NP, true>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
+        default: break;                                  // 160 rows and up: the ring is the only form
+      }
+  }
   switch (tile_rows / 32) {
     case 2: return launch_gemm<2, CONV, NP>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
     case 3: return launch_gemm<3, CONV, NP>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
@@ -1835,6 +1846,16 @@ static int conv_check(const pt_conv_desc* d, const char* who) {
   return PT_OK;
 }
 
+static int device_cus() {                               // compute units of the current device (256 on MI355X)
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
+}
+
 // k-splits of a convolution with M x N results and KB k-steps at tile height tile_rows: 1 while the tiles fill the chip; else the
 // count (each chunk at least 8 k-steps) that minimises rounds-of-256-workgroups x work per workgroup.
 static int conv_splits(long M, int N, int KB, int tile_rows) {
@@ -1962,8 +1983,10 @@ extern "C" int pt_conv_bf16x6(const pt_conv_desc* d, void* stream) {
   ep.res_alpha_dev = d->res_alpha_dev;
   PT_REQUIRE(!d->res_f16 || np == 3, PT_EINVAL, "pt_conv_bf16x6: res_f16 goes with np = 3 launches");
   PT_REQUIRE(!d->alpha_dev || d->alpha != 0.f, PT_EINVAL, "pt_conv_bf16x6: alpha_dev multiplies alpha (set alpha, e.g. 1)");
+  // no more workgroups than CUs (and a k-loop long enough to fill a ring): the deep-ring form of the 64 .. 128-row tiles
+  const bool deep = d->operand_f16 && (long)cdiv(M, tile_rows) * cdiv(d->Cout, GBN) * S <= device_cus() && cdiv(KB, S) >= 8;
   rc = d->operand_f16 ? launch_by_rows<true, 2>(tile_rows, d->x_planes, d->w_planes, nullptr, nullptr, nullptr, (int)M, d->Cout, KB,
-                                               d->x_plane_stride, d->w_plane_stride, d->Cout, 0, cg, ep, as_stream(stream))
+                                               d->x_plane_stride, d->w_plane_stride, d->Cout, 0, cg, ep, as_stream(stream), deep)
      : np == 1 ? launch_by_rows<true, 1>(tile_rows, d->x_planes, d->w_planes, nullptr, nullptr, nullptr, (int)M, d->Cout, KB, d->x_plane_stride,
                                          d->w_plane_stride, d->Cout, 0, cg, ep, as_stream(stream))
                : launch_by_rows<true, 3>(tile_rows, d->x_planes, d->w_planes, nullptr, nullptr, nullptr, (int)M, d->Cout, KB, d->x_plane_stride,
