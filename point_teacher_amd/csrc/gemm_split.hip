@@ -543,17 +543,26 @@ __global__ void __launch_bounds__(GTHREADS)
   }
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   const int m0 = tm * BM, n0 = tn * GBN;
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // (the wave index as a SCALAR: see below)
 
-  // global source of every staging instruction this wave issues: one contiguous KiB block of the blocked planes per instruction
-  // (advances by one block = 1 KiB per k-step)
+  // Global source of every staging instruction this wave issues = a WAVE-UNIFORM 64-bit base (scalar registers, advanced by scalar
+  // adds) + a 32-bit per-lane byte offset: the `global_load_lds ... v, s[..]` form.  Round 5: the per-lane 64-bit multiply-adds, the
+  // divergent branches around the masked taps and the scalar-register spills they caused were ~2/3 of the instructions between two
+  // row blocks' MFMAs (profiles/r05/README.md, "issue code").
+  //   blocked planes (weights; the GEMM's A): one contiguous KiB block per instruction, lane * 16 inside it, + 1 KiB per k-step;
+  //   CONV activations: voff = ((source pixel under tap (0, 0)) + bias) * Cin * 2 + slot * 16 >= 0 with bias = pad * (Ws + 1); the tap's
+  //   shift, the channel block and - bias live in the uniform part; a lane whose tap leaves the image reads the zero row instead
+  //   (`zoff`, uniform: (Ps - shift + bias) * Cin * 2 behind the same uniform base).
   const int RBA = (M + 15) >> 4, RBN = (N + 15) >> 4;
-  const unsigned char* gsrc[NJ];
+  const unsigned char* ubase[NJ];
+  unsigned voff[NJ];
   int cpix[NJ], cmask[NJ];                              // CONV: source pixel of this lane's row under tap (0, 0), "tap stays inside" mask
+  const int bias_pix = CONV ? cg.pad * (cg.Ws + 1) : 0;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int i = w + 8 * j;                            // staging instruction = block index within the stage
-    gsrc[j] = nullptr;
+    ubase[j] = nullptr;
+    voff[j] = lane * 16;
     cpix[j] = cmask[j] = 0;
     if (i < NI) {
       const bool isA = i < NP * (BM / 16);
@@ -594,10 +603,13 @@ __global__ void __launch_bounds__(GTHREADS)
           }
           cpix[j] = (bi * cg.Hs + yb) * cg.Ws + xb;
           cmask[j] = mask;
+          // (rows past M have mask 0 and never use voff; the host checks that (Ps + 2 * bias + 2) * Cin * 2 fits 32 bits)
+          voff[j] = (unsigned)(cpix[j] + bias_pix) * (unsigned)(cg.Cin * 2) + sl * 16;
         }
-        gsrc[j] = reinterpret_cast<const unsigned char*>(base) + sl * 16;
+        ubase[j] = reinterpret_cast<const unsigned char*>(base);
+        if (cg.dstride > 1) voff[j] = sl * 16;
       } else {
-        gsrc[j] = reinterpret_cast<const unsigned char*>(base + (((long)rb * KB + kb0) << 9)) + lane * 16;
+        ubase[j] = reinterpret_cast<const unsigned char*>(base + (((long)rb * KB + kb0) << 9));
       }
     }
   }
@@ -610,26 +622,37 @@ __global__ void __launch_bounds__(GTHREADS)
     s_kx = s_tap - s_ky * cg.KW;
     s_off = s_ky * cg.Ws + s_kx;
   }
+  long u_blk = 0;                                       // uniform byte offset of the blocked pieces: 1 KiB per issued stage
+  long u_act = CONV ? ((long)(s_off - bias_pix) * cg.Cin + s_cb * 32) * 2 : 0;   // ... of the activation pieces (may start negative)
+  unsigned z_off = CONV ? (unsigned)(cg.Ps - s_off + bias_pix) * (unsigned)(cg.Cin * 2) : 0u;   // the zero row behind u_act - 64 s_cb
   auto issue1 = [&](int j, int buf) {                   // one 1-KiB block of the next stage
     if (j < NJ && w + 8 * j < NI) {                     // wave-uniform
       if (CONV && w + 8 * j < NP * (BM / 16)) {         // wave-uniform: an activation piece
-        int pix = cg.Ps;
-        if ((cmask[j] >> s_tap) & 1)
-          pix = cg.dstride > 1 ? cpix[j] + ((s_ky - ((cmask[j] >> 9) & 1)) >> 1) * cg.Ws + ((s_kx - ((cmask[j] >> 10) & 1)) >> 1) : cpix[j] + s_off;
-        glds16(gsrc[j] + ((long)pix * cg.Cin + s_cb * 32) * 2, smem + buf * STAGE + (w + 8 * j) * 1024);
+        if (cg.dstride > 1) {
+          int pix = cg.Ps;
+          if ((cmask[j] >> s_tap) & 1)
+            pix = cpix[j] + ((s_ky - ((cmask[j] >> 9) & 1)) >> 1) * cg.Ws + ((s_kx - ((cmask[j] >> 10) & 1)) >> 1);
+          glds16(ubase[j] + voff[j] + ((long)pix * cg.Cin + s_cb * 32) * 2, smem + buf * STAGE + (w + 8 * j) * 1024);
+        } else {
+          const unsigned vo = ((cmask[j] >> s_tap) & 1) ? voff[j] : z_off;
+          glds16(ubase[j] + u_act + vo, smem + buf * STAGE + (w + 8 * j) * 1024);
+        }
       } else {
-        glds16(gsrc[j], smem + buf * STAGE + (w + 8 * j) * 1024);
-        gsrc[j] += 1024;
+        glds16(ubase[j] + u_blk + voff[j], smem + buf * STAGE + (w + 8 * j) * 1024);
       }
     }
   };
   auto next_stage = [&]() {                             // advance the counters once every piece of a stage has been issued
+    u_blk += 1024;
     if (CONV) {
+      u_act += 64;
       if (++s_cb == cg.CB) {
         s_cb = 0;
         ++s_tap;
         ++s_off;
         if (++s_kx == cg.KW) { s_kx = 0; ++s_ky; s_off += cg.Ws - cg.KW; }
+        u_act = (long)(s_off - bias_pix) * cg.Cin * 2;
+        z_off = (unsigned)(cg.Ps - s_off + bias_pix) * (unsigned)(cg.Cin * 2);
       }
     }
   };
@@ -1901,7 +1924,8 @@ extern "C" int pt_conv_bf16x6(const pt_conv_desc* d, void* stream) {
   }
   PT_REQUIRE(Ho > 0 && Wo > 0, PT_EINVAL, "pt_conv_bf16x6: empty output");
   const long Ps = (long)d->B * d->Hs * d->Ws, M = (long)d->B * Ho * Wo;
-  PT_REQUIRE(Ps < (1L << 30) && Ps * d->Cin < (1L << 40), PT_ELIMIT, "pt_conv_bf16x6: B * Hs * Ws < 2^30");
+  PT_REQUIRE(Ps < (1L << 30) && (Ps + 2L * d->pad * (d->Ws + 1) + 2) * d->Cin * 2 < (1L << 32), PT_ELIMIT,
+             "pt_conv_bf16x6: B * Hs * Ws < 2^30 and one activation plane < 4 GiB (32-bit lane offsets)");
   const int taps = d->KH * d->KW;
   PT_REQUIRE(d->x_plane_stride >= (Ps + 1) * d->Cin && d->w_plane_stride >= pt_split_bf16x3_plane_elems(d->Cout, taps * d->Cin), PT_EINVAL,
              "pt_conv_bf16x6: plane strides too small ([Ps + 1][Cin] row-major activations, blocked [Cout][taps Cin] weights)");
