@@ -298,7 +298,7 @@ def main():
     orig_call = hip.call
     import point_teacher_amd.functional as PF
     SKIP = ('pt_focal_nblocks', 'pt_sqnorm_nblocks', 'pt_abi_version', 'pt_affine_train_rows', 'pt_gemm_bf16x6_tile_rows',
-            'pt_conv3x3_wgrad_bf16x6_splits', 'pt_group_norm_cl_workspace_bytes', 'pt_split_bf16x3_plane_elems', 'pt_conv_bf16x6_splits',
+            'pt_conv3x3_wgrad_bf16x6_splits', 'pt_group_norm_cl_workspace_bytes', 'pt_split_bf16x3_plane_elems', 'pt_conv_bf16x6_splits', 'pt_conv_bf16x6_plan',
             'pt_conv_wgrad_bf16x6_splits')
     import point_teacher_amd.planes as PPL
 

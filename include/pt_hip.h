@@ -356,6 +356,9 @@ typedef struct {
   int32_t reserved2;
 } pt_conv_desc;
 int pt_conv_bf16x6_splits(int B, int Hs, int Ws, int Cin, int Cout, int KH, int KW, int stride, int pad, int tile_rows);
+/* ABI 7: the chunk count the launch takes for THIS descriptor when it is given a workspace and splits <= 0 (the tile height and the
+ * k-step costs depend on np / operand_f16, which the shape-only query above cannot see): size the workspace with it. */
+int pt_conv_bf16x6_plan(const pt_conv_desc* desc);
 int pt_conv_bf16x6(const pt_conv_desc* desc, void* stream);
 
 /* Weight (and bias) gradient of the same convolutions: dw[Cout][KH][KW][Cin] (+)= row_scale[o] * sum over output pixels p of

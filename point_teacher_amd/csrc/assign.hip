@@ -456,7 +456,7 @@ __global__ void __launch_bounds__(256)
 using namespace pt;
 
 extern "C" const char* pt_last_error(void) { return pt::g_err; }
-extern "C" int pt_abi_version(void) { return 6; }   // 2: pt_roi_align_* lost their workspace argument; 3: r03 additions (pt_sgd_step_groups, ...); 4: pt_conv_weight_item grew taps / scale, plane-native convolutions; 5: fp16 operands (operand_f16 / alpha in the descriptors); 6: the scaled fp16 plane format (tails, pt_planes_mix, census)
+extern "C" int pt_abi_version(void) { return 7; }   // 2: pt_roi_align_* lost their workspace argument; 3: r03 additions (pt_sgd_step_groups, ...); 4: pt_conv_weight_item grew taps / scale, plane-native convolutions; 5: fp16 operands (operand_f16 / alpha in the descriptors); 6: the scaled fp16 plane format (tails, pt_planes_mix, census); 7: pt_conv_bf16x6_plan
 
 extern "C" int pt_topk_assign(const float* points, int P, const float* gt_xy, const uint8_t* gt_valid,
                               const int32_t* off, int B, int sumG, int num_pre, int32_t* gt_inds, int32_t* cand,

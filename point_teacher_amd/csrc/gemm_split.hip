@@ -371,7 +371,27 @@ __device__ __forceinline__ void planes_sum8(const uint4 a, const uint4 b, const 
 
 
 // The epilogue of one row x 8 columns (see ConvEpi); o = the accumulated products.
-__device__ __forceinline__ void conv_epilogue8(float (&o)[8], int grow, int gcol, int N, const ConvEpi& ep, Census& cs) {
+// The residual / mask chunks of one epilogue item, loaded ahead of the item (the tile kernel issues the loads of ALL its items before
+// the barrier behind the accumulator transposition: one HBM round trip per tile instead of one per item).
+struct EpiPre {
+  uint4 r0 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0}, r2 = {0, 0, 0, 0}, m = {0, 0, 0, 0};
+  bool have = false;                                         // the chunks above were loaded (same addresses conv_epilogue8 would read)
+};
+
+__device__ __forceinline__ void epi_preload(EpiPre& pr, int grow, int gcol, int N, const ConvEpi& ep) {
+  pr.have = !ep.sc_stride;                              // (a scattered result reads its mask at the scattered row: not preloaded)
+  if (!pr.have) return;
+  const long rin = (long)grow * N + gcol;
+  if (ep.res_planes) {
+    pr.r0 = *reinterpret_cast<const uint4*>(ep.res_planes + rin);
+    if (ep.res_f16 || ep.np == 3) pr.r1 = *reinterpret_cast<const uint4*>(ep.res_planes + ep.res_plane + rin);
+    if (!ep.res_f16 && ep.np == 3) pr.r2 = *reinterpret_cast<const uint4*>(ep.res_planes + 2 * ep.res_plane + rin);
+  }
+  if (ep.mask_planes) pr.m = *reinterpret_cast<const uint4*>(ep.mask_planes + rin);
+}
+
+__device__ __forceinline__ void conv_epilogue8(float (&o)[8], int grow, int gcol, int N, const ConvEpi& ep, Census& cs,
+                                               const EpiPre pr = EpiPre{}) {
   if (ep.alpha != 0.f) {
     const float al = ep.alpha_dev ? ep.alpha * *ep.alpha_dev : ep.alpha;
 #pragma unroll
@@ -386,16 +406,19 @@ __device__ __forceinline__ void conv_epilogue8(float (&o)[8], int grow, int gcol
     o[0] += sa.x; o[1] += sa.y; o[2] += sa.z; o[3] += sa.w; o[4] += sb.x; o[5] += sb.y; o[6] += sb.z; o[7] += sb.w;
   }
   const long rin = (long)grow * N + gcol;
+  const bool pre = pr.have;
   if (ep.res_planes && ep.res_f16) {
     float r[8];
-    h2_sum8(*reinterpret_cast<const uint4*>(ep.res_planes + rin), *reinterpret_cast<const uint4*>(ep.res_planes + ep.res_plane + rin), r);
+    if (pre) h2_sum8(pr.r0, pr.r1, r);
+    else h2_sum8(*reinterpret_cast<const uint4*>(ep.res_planes + rin), *reinterpret_cast<const uint4*>(ep.res_planes + ep.res_plane + rin), r);
     const float ra = ep.res_alpha_dev ? *ep.res_alpha_dev : 1.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] += r[e] * ra;
   } else if (ep.res_planes) {
     float r[8];
     const uint4 z = make_uint4(0, 0, 0, 0);
-    if (ep.np == 3)
+    if (pre) planes_sum8(pr.r0, ep.np == 3 ? pr.r1 : z, ep.np == 3 ? pr.r2 : z, r);
+    else if (ep.np == 3)
       planes_sum8(*reinterpret_cast<const uint4*>(ep.res_planes + rin), *reinterpret_cast<const uint4*>(ep.res_planes + ep.res_plane + rin),
                   *reinterpret_cast<const uint4*>(ep.res_planes + 2 * ep.res_plane + rin), r);
     else
@@ -419,7 +442,7 @@ __device__ __forceinline__ void conv_epilogue8(float (&o)[8], int grow, int gcol
   }
   const long rout = orow * N + gcol;
   if (ep.mask_planes) {
-    const uint4 mk = *reinterpret_cast<const uint4*>(ep.mask_planes + rout);
+    const uint4 mk = pre ? pr.m : *reinterpret_cast<const uint4*>(ep.mask_planes + rout);
     const unsigned mm[4] = {mk.x, mk.y, mk.z, mk.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {                   // bf16 > 0: sign clear and not zero
@@ -761,6 +784,20 @@ __global__ void __launch_bounds__(GTHREADS)
 #pragma unroll
       for (int e = 0; e < 4; ++e)         // C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
         otile[(rg * MB * 16 + i * 16 + sq * 4 + e) * TLD + nb * 32 + c * 16 + r16] = acc[i][c][e] + cor[i][c][e];
+  // CONV: the residual / mask chunks of this thread's MB items start their round trip now (the accumulators are in LDS: their
+  // registers are free) and land behind the barrier and the tile reads
+  uint4 pr0[CONV ? MB : 1], pr1[CONV ? MB : 1], pr2[CONV ? MB : 1], prm[CONV ? MB : 1];
+  const bool have_pre = CONV && ep.splits <= 1 && !ep.sc_stride && (ep.res_planes || ep.mask_planes);   // block-uniform
+  if constexpr (CONV) {
+#pragma unroll
+    for (int q = 0; q < MB; ++q) {
+      const int idx = threadIdx.x + q * GTHREADS, row = idx >> 4, c8 = (idx & 15) << 3;
+      EpiPre e;
+      e.r0 = e.r1 = e.r2 = e.m = make_uint4(0, 0, 0, 0);
+      if (have_pre && m0 + row < M && n0 + c8 < N) epi_preload(e, m0 + row, n0 + c8, N, ep);
+      pr0[q] = e.r0; pr1[q] = e.r1; pr2[q] = e.r2; prm[q] = e.m;
+    }
+  }
   __syncthreads();
   if constexpr (!CONV) {
     // whole rows of the tile leave as 16-byte stores: 32 lanes = one 512-byte row segment
@@ -789,7 +826,10 @@ __global__ void __launch_bounds__(GTHREADS)
     // 8 columns per thread (N % 8 == 0): 16 lanes = one 512-byte row segment of fp32, 256 bytes of every plane
     Census cs;
     cs.init();
-    for (int idx = threadIdx.x; idx < BM * (GBN / 8); idx += GTHREADS) {
+    static_assert(BM * (GBN / 8) == MB * GTHREADS, "MB items of 8 columns per thread");
+#pragma unroll
+    for (int q = 0; q < MB; ++q) {
+      const int idx = threadIdx.x + q * GTHREADS;
       const int row = idx >> 4, c8 = (idx & 15) << 3;
       const int grow = m0 + row, gcol = n0 + c8;
       if (grow >= M || gcol >= N) continue;
@@ -801,7 +841,10 @@ __global__ void __launch_bounds__(GTHREADS)
         continue;
       }
       float o[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
-      conv_epilogue8(o, grow, gcol, N, ep, cs);
+      EpiPre e;
+      e.r0 = pr0[q]; e.r1 = pr1[q]; e.r2 = pr2[q]; e.m = prm[q];
+      e.have = have_pre;
+      conv_epilogue8(o, grow, gcol, N, ep, cs, e);
     }
     if (ep.splits <= 1 && ep.census && ep.out_f16) cs.flush(ep.census, ep.census_mode);
     if (ep.splits <= 1 && ep.out_tail && m0 + BM >= M && n0 == 0 && threadIdx.x == 0) *ep.out_tail = ep.out_tail_src ? *ep.out_tail_src : 1.f;
@@ -1881,7 +1924,7 @@ static int device_cus() {                               // compute units of the 
 
 // k-splits of a convolution with M x N results and KB k-steps at tile height tile_rows: 1 while the tiles fill the chip; else the
 // count (each chunk at least 8 k-steps) that minimises rounds-of-256-workgroups x work per workgroup.
-static int conv_splits(long M, int N, int KB, int tile_rows) {
+static int conv_splits(long M, int N, int KB, int tile_rows, bool f16 = false) {
   static int off = -1;
   if (off < 0) {
     const char* e = getenv("PT_CONV_SPLITK");             // PT_CONV_SPLITK=0: never split (measurements)
@@ -1889,7 +1932,32 @@ static int conv_splits(long M, int N, int KB, int tile_rows) {
   }
   if (off) return 1;
   const long tiles = (long)cdiv(M, tile_rows) * cdiv(N, GBN);
-  if (tiles >= 256 || KB < 16) return 1;
+  const int cus = device_cus();
+  if (tiles >= cus || KB < 16) return 1;
+  if (f16) {
+    // fp16 x 2 operands, measured per k-step of one workgroup (profiles/r05: h2_tile_sweep_*): 0.67 us in the deep-ring form (a launch
+    // of <= one workgroup per CU), 1.48 us for each of two co-resident workgroups of the two-stage form (64 - 128-row tiles), 1.2 us
+    // for a lone two-stage workgroup (160 rows and up keep their ring: 0.67); ~4 us of prologue + epilogue per workgroup; a split
+    // adds its partial tiles (written, then read by the finish launch, ~4 TB/s) and the finish launch (~6 us).
+    int best = 1;
+    double best_t = -1.0;
+    const bool pair = tile_rows <= 128;
+    for (int S = 1; S <= 16 && (S == 1 || S * 8 <= KB); ++S) {
+      const long items = tiles * S;
+      const double ks = (double)((KB + S - 1) / S);
+      double t;
+      if (items <= cus) t = ks * (ks >= 8 || !pair ? 0.67 : 1.2) + 4.0;
+      else if (pair) {
+        const long full = items / (2L * cus), rest = items - full * 2L * cus;
+        t = full * (ks * 1.48 + 4.0) + (rest > cus ? ks * 1.48 + 4.0 : rest > 0 ? ks * 1.2 + 4.0 : 0.0);
+      } else {
+        t = (double)((items + cus - 1) / cus) * (ks * 0.67 + 4.0);
+      }
+      if (S > 1) t += 6.0 + (double)S * (double)M * N * 8.0 / 4e6;
+      if (best_t < 0 || t < best_t) { best_t = t; best = S; }
+    }
+    return best;
+  }
   // rounds of 256 workgroups x (k-steps per workgroup + ~6 k-steps' worth of prologue / epilogue / part traffic)
   int best = 1;
   long best_cost = -1;
@@ -1907,6 +1975,45 @@ extern "C" int pt_conv_bf16x6_splits(int B, int Hs, int Ws, int Cin, int Cout, i
   const long M = (long)B * Ho * Wo;
   if (tile_rows <= 0) tile_rows = pt_gemm_bf16x6_tile_rows((int)M, Cout);
   return conv_splits(M, Cout, KH * KW * (Cin / 32), tile_rows);
+}
+
+// Tile height of a pt_conv_bf16x6 launch (d->tile_rows > 0: the caller's choice).
+static int conv_tile_rows(const pt_conv_desc* d, long M, int taps, int np) {
+  int tile_rows = d->tile_rows;
+  if (np == 1) {
+    // one bf16 plane: a sixth of the products - the convolutions are bound by their bytes; 64-row tiles keep the fp32 output tile
+    // (the LDS a workgroup needs) at 34 KB: four workgroups per CU overlap one another's loads, products and stores
+    if (tile_rows <= 0 || tile_rows > 128) tile_rows = M >= 32768 ? 128 : 64;
+  } else if (tile_rows <= 0) {
+    tile_rows = pt_gemm_bf16x6_tile_rows((int)M, d->Cout);
+    if (d->operand_f16 && taps == 1 && d->Cin <= 2048) {
+      // the trunk's 1 x 1 convolutions on 4-byte planes are bound by their bytes: the tallest tile of 128 / 96 / 64 rows that still
+      // leaves >= 400 tiles (two to three workgroups per CU overlap one another's loads, products and stores; beyond 128 rows a CU
+      // holds one workgroup less and the launch slows by a third) - measured per shape, tools/h2_tile_sweep.py, profiles/r05
+      tile_rows = 64;
+      if ((long)cdiv(M, 128) * cdiv(d->Cout, GBN) >= 400) tile_rows = 128;
+      else if ((long)cdiv(M, 96) * cdiv(d->Cout, GBN) >= 400) tile_rows = 96;
+    } else if (taps * (d->Cin / 32) <= 4 && M >= 16384 && d->Cout >= 256) {
+      // a reduce dimension of <= 128 with many rows (a Bottleneck's expanding 1 x 1, the input gradient of its reducing one) is bound
+      // by its epilogue's HBM traffic: 64-row tiles fit two workgroups per CU, one's stores overlap the other's products
+      tile_rows = 64;
+    }
+  }
+  return tile_rows;
+}
+
+// The chunk count pt_conv_bf16x6 takes for this descriptor when it is given a workspace (d->splits <= 0): what the caller sizes the
+// workspace with (splits * M * Cout floats).  Pure function of the shape fields, np, operand_f16 and tile_rows.
+extern "C" int pt_conv_bf16x6_plan(const pt_conv_desc* d) {
+  if (!d || d->B <= 0 || d->Hs <= 0 || d->Ws <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0) return 1;
+  if (d->dstride > 1) return 1;
+  const int Ho = (d->Hs + 2 * d->pad - d->KH) / d->stride + 1, Wo = (d->Ws + 2 * d->pad - d->KW) / d->stride + 1;
+  if (Ho <= 0 || Wo <= 0) return 1;
+  const long M = (long)d->B * Ho * Wo;
+  const int taps = d->KH * d->KW, np = d->np == 1 ? 1 : 3;
+  const int tile_rows = conv_tile_rows(d, M, taps, np);
+  if (tile_rows % 32 != 0 || tile_rows < 64 || tile_rows > 256) return 1;
+  return conv_splits(M, d->Cout, taps * (d->Cin / 32), tile_rows, d->operand_f16 != 0);
 }
 
 extern "C" int pt_conv_bf16x6(const pt_conv_desc* d, void* stream) {
@@ -1953,31 +2060,12 @@ extern "C" int pt_conv_bf16x6(const pt_conv_desc* d, void* stream) {
   ep.out_planes = d->out_planes; ep.out_plane = d->out_plane_stride;
   ep.relu = d->relu;
   ep.zero_row = (d->out_planes && !d->scatter_stride) ? (int)M : -1;      // (a scattered result lands in a buffer the caller zeroed)
-  int tile_rows = d->tile_rows;
-  if (np == 1) {
-    // one bf16 plane: a sixth of the products - the convolutions are bound by their bytes; 64-row tiles keep the fp32 output tile
-    // (the LDS a workgroup needs) at 34 KB: four workgroups per CU overlap one another's loads, products and stores
-    if (tile_rows <= 0 || tile_rows > 128) tile_rows = M >= 32768 ? 128 : 64;
-  } else if (tile_rows <= 0) {
-    tile_rows = pt_gemm_bf16x6_tile_rows((int)M, d->Cout);
-    if (d->operand_f16 && taps == 1 && d->Cin <= 2048) {
-      // the trunk's 1 x 1 convolutions on 4-byte planes are bound by their bytes: the tallest tile of 128 / 96 / 64 rows that still
-      // leaves >= 400 tiles (two to three workgroups per CU overlap one another's loads, products and stores; beyond 128 rows a CU
-      // holds one workgroup less and the launch slows by a third) - measured per shape, tools/h2_tile_sweep.py, profiles/r05
-      tile_rows = 64;
-      if ((long)cdiv(M, 128) * cdiv(d->Cout, GBN) >= 400) tile_rows = 128;
-      else if ((long)cdiv(M, 96) * cdiv(d->Cout, GBN) >= 400) tile_rows = 96;
-    } else if (taps * (d->Cin / 32) <= 4 && M >= 16384 && d->Cout >= 256) {
-      // a reduce dimension of <= 128 with many rows (a Bottleneck's expanding 1 x 1, the input gradient of its reducing one) is bound
-      // by its epilogue's HBM traffic: 64-row tiles fit two workgroups per CU, one's stores overlap the other's products
-      tile_rows = 64;
-    }
-  }
+  const int tile_rows = conv_tile_rows(d, M, taps, np);
   PT_REQUIRE(tile_rows % 32 == 0 && tile_rows >= 64 && tile_rows <= 256, PT_EINVAL, "pt_conv_bf16x6: tile_rows in {64, 96, ..., 256}");
   const ConvGeom cg{d->Hs, d->Ws, Ho, Wo, d->Cin, d->Cin / 32, d->KW, taps, d->stride, d->pad, (int)Ps, d->dstride > 1 ? 2 : 1};
   const int KB = taps * (d->Cin / 32);
   int S = d->splits;
-  if (S <= 0) S = d->workspace ? conv_splits(M, d->Cout, KB, tile_rows) : 1;
+  if (S <= 0) S = d->workspace ? conv_splits(M, d->Cout, KB, tile_rows, d->operand_f16 != 0) : 1;
   if (S > KB) S = KB;
   if (S > 1) S = cdiv(KB, cdiv(KB, S));                  // no empty chunk (its prologue would stage a block past the operands)
   if (S > 1) {

@@ -120,7 +120,7 @@ def _ptr(x, name, ctype=None):
 
 
 _NO_RC_CHECK = ('pt_abi_version', 'pt_focal_nblocks', 'pt_sqnorm_nblocks', 'pt_affine_train_rows', 'pt_gemm_bf16x6_tile_rows',
-                'pt_conv3x3_wgrad_bf16x6_splits', 'pt_conv_wgrad_bf16x6_splits', 'pt_conv_bf16x6_splits')
+                'pt_conv3x3_wgrad_bf16x6_splits', 'pt_conv_wgrad_bf16x6_splits', 'pt_conv_bf16x6_splits', 'pt_conv_bf16x6_plan')
 _PLANS = {}
 
 

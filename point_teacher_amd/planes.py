@@ -560,7 +560,13 @@ def launch_conv(x_t, B, Hs, Ws, Cin, wp, Cout, K, stride, pad, scale=None, shift
     if transposed_out is not None:            # the input gradient of a 3x3 stride-2 convolution onto its input grid (Ho, Wo)
         d.dstride, d.out_H, d.out_W = 2, Ho, Wo
         splits = 1
-    S = _splits('pt_conv_bf16x6_splits', B, Hs, Ws, Cin, Cout, K, K, stride, pad, int(tile_rows)) if splits is None else int(splits)
+    if splits is None:                          # the library's choice for this descriptor (a pure function of the key: asked once)
+        k = ('plan', B, Hs, Ws, Cin, Cout, K, stride, pad, int(tile_rows), np_, h2)
+        S = _SPLITS.get(k)
+        if S is None:
+            S = _SPLITS[k] = hip.call('pt_conv_bf16x6_plan', d)
+    else:
+        S = int(splits)
     if S > 1:
         ws = torch.empty((S * M * Cout,), dtype=f32, device=dev)
         d.workspace, d.workspace_elems, d.splits = hip.dptr(ws, 'float'), ws.numel(), S

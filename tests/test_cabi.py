@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     out = subprocess.run(['nm', '-D', '--defined-only', hip.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r' T (pt_\w+)', out))
     assert exported == declared, exported ^ declared
-    assert hip.ABI_VERSION == 6
+    assert hip.ABI_VERSION == 7
 
 
 def test_no_cpu_fallback():

@@ -82,3 +82,36 @@ for e in prof.events():
 print(f'\nlaunch-bound torch kernels: {tot_ms / N:.2f} ms / iteration in {tot_n / N:.0f} launches / iteration; by (op, shapes):')
 for (name, shapes), (ms, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:
     print(f'{ms / N:8.3f} ms {n / N:7.1f} x  {name:32s} {shapes}')
+
+# ---- GPU time per call site: HIP events around every dispatched op (one more iteration; the events add host time, not GPU time) ----
+timed = collections.defaultdict(list)
+
+
+class Timed(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        full = str(func)
+        if any(v in full.split('.')[-2] if full.count('.') >= 2 else v in full for v in VIEW):
+            return func(*args, **(kwargs or {}))
+        frame = 'autograd engine / other'
+        for fs in reversed(traceback.extract_stack(limit=40)):
+            if 'point_teacher_amd' in fs.filename and not fs.filename.endswith(('hip.py', 'launch_sites.py')):
+                frame = f'{os.path.relpath(fs.filename, ROOT)}:{fs.lineno} {fs.name}'
+                break
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = func(*args, **(kwargs or {}))
+        b.record()
+        timed[frame].append((a, b, full.replace('aten.', '')))
+        return out
+
+
+with Timed():
+    tr.step(data.batch(1, 2))
+torch.cuda.synchronize()
+rows = []
+for frame, evs in timed.items():
+    ops = collections.Counter(o for _, _, o in evs)
+    rows.append((sum(a.elapsed_time(b) for a, b, _ in evs), len(evs), frame, ops))
+print('\nGPU ms per call site (HIP events around each aten op; includes our own kernels when the site calls them through torch ops):')
+for ms, n, frame, ops in sorted(rows, key=lambda r: -r[0])[:70]:
+    print(f'{ms:8.3f} ms {n:5d} x  {frame[:90]:90s} [' + ', '.join(f'{k}x{v}' for k, v in ops.most_common(4)) + ']')
