@@ -263,6 +263,14 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// The same LDS-DMA with the address split the way the instruction takes it: a wave-uniform 64-bit base in scalar registers + a 32-bit
+// per-lane byte offset (`global_load_lds_dwordx4 v, s[..]`) - no per-lane 64-bit add.  Issued from inline assembly, so the compiler
+// does not count it: the kernel waits for these loads itself (`wait_vmcnt_barrier`).
+__device__ __forceinline__ void glds16_saddr(const void* uniform_base, unsigned lane_off, unsigned lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(uniform_base), "s"(lds_wave_base)
+               : "memory", "m0");
+}
+
 // CONV = true: the same product as an implicit GEMM of a KH x KW convolution (1 x 1 or 3 x 3, stride 1 or 2) over [B, Hs, Ws, Cin]
 // activations (the dense head's towers, anchor_free_head.py:198-219; the Bottlenecks of backbones/resnet.py:262-303; the laterals
 // and output convolutions of necks/fpn.py:151-202 and necks/ps_fpn.py:56-75): row = output pixel, k = (tap, input channel).  The A
@@ -648,21 +656,25 @@ __global__ void __launch_bounds__(GTHREADS)
   long u_blk = 0;                                       // uniform byte offset of the blocked pieces: 1 KiB per issued stage
   long u_act = CONV ? ((long)(s_off - bias_pix) * cg.Cin + s_cb * 32) * 2 : 0;   // ... of the activation pieces (may start negative)
   unsigned z_off = CONV ? (unsigned)(cg.Ps - s_off + bias_pix) * (unsigned)(cg.Cin * 2) : 0u;   // the zero row behind u_act - 64 s_cb
-  auto issue1 = [&](int j, int buf) {                   // one 1-KiB block of the next stage
-    if (j < NJ && w + 8 * j < NI) {                     // wave-uniform
-      if (CONV && w + 8 * j < NP * (BM / 16)) {         // wave-uniform: an activation piece
-        if (cg.dstride > 1) {
-          int pix = cg.Ps;
-          if ((cmask[j] >> s_tap) & 1)
-            pix = cpix[j] + ((s_ky - ((cmask[j] >> 9) & 1)) >> 1) * cg.Ws + ((s_kx - ((cmask[j] >> 10) & 1)) >> 1);
-          glds16(ubase[j] + voff[j] + ((long)pix * cg.Cin + s_cb * 32) * 2, smem + buf * STAGE + (w + 8 * j) * 1024);
-        } else {
-          const unsigned vo = ((cmask[j] >> s_tap) & 1) ? voff[j] : z_off;
-          glds16(ubase[j] + u_act + vo, smem + buf * STAGE + (w + 8 * j) * 1024);
-        }
+  const unsigned smem_lds = (unsigned)(uintptr_t)smem;    // (the low word of a flat LDS address is the LDS offset)
+  constexpr int NA = NP * (BM / 16);                    // activation (A) pieces of a stage; the rest are weight (B) pieces
+  auto issue1 = [&](int j, int buf) {                   // one 1-KiB block of the next stage (j is a constant once unrolled)
+    if (j >= NJ) return;
+    if (!(8 * j + 7 < NI) && !(w + 8 * j < NI)) return;                  // wave-uniform; folds away for all but the last j
+    const unsigned lds = smem_lds + buf * STAGE + (w + 8 * j) * 1024;
+    const bool isA = (8 * j + 7 < NA) || (8 * j < NA && w + 8 * j < NA);   // wave-uniform; a compile-time constant for most j
+    if (CONV && isA) {
+      if (cg.dstride > 1) {
+        int pix = cg.Ps;
+        if ((cmask[j] >> s_tap) & 1)
+          pix = cpix[j] + ((s_ky - ((cmask[j] >> 9) & 1)) >> 1) * cg.Ws + ((s_kx - ((cmask[j] >> 10) & 1)) >> 1);
+        glds16_saddr(ubase[j] + s_cb * 64, voff[j] + (unsigned)pix * (unsigned)(cg.Cin * 2), lds);
       } else {
-        glds16(ubase[j] + u_blk + voff[j], smem + buf * STAGE + (w + 8 * j) * 1024);
+        const unsigned vo = ((cmask[j] >> s_tap) & 1) ? voff[j] : z_off;
+        glds16_saddr(ubase[j] + u_act, vo, lds);
       }
+    } else {
+      glds16_saddr(ubase[j] + u_blk, voff[j], lds);
     }
   };
   auto next_stage = [&]() {                             // advance the counters once every piece of a stage has been issued
@@ -711,7 +723,7 @@ __global__ void __launch_bounds__(GTHREADS)
   int cur = 0;                                          // ring slot of stage ks
   for (int ks = kb0; ks < kb1; ++ks) {
     if constexpr (NST == 2) {
-      __syncthreads();        // (emits s_waitcnt vmcnt(0)): stage ks has landed, every wave is done reading the other buffer
+      wait_vmcnt_barrier<0>();   // stage ks has landed, every wave is done reading the other buffer
     } else {
       // stage ks has landed when at most the loads of the NST - 2 younger stages are still in flight (fewer at the last k-steps); the
       // barrier then also says that every wave is done reading the slot the next loads overwrite
@@ -740,7 +752,7 @@ __global__ void __launch_bounds__(GTHREADS)
       bf16x8_t a[NP];
 #pragma unroll
       for (int p = 0; p < NP; ++p) a[p] = *reinterpret_cast<const bf16x8_t*>(ap + p * BM * 64);
-      if (more) {
+      if (more) {             // (all the pieces in one burst behind the barrier measured 5 - 13 % slower on 160-row tiles and up)
 #pragma unroll
         for (int q = 0; q < PER; ++q) issue1(i * PER + q, nbuf);
       }
