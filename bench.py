@@ -348,6 +348,8 @@ def main():
         # would be co-scheduled with the bracketed ones and stretch them
         if hasattr(live[0], 'teacher_stream'):
             live[0].teacher_stream = side_stream and h is orig_call
+            # ... and eagerly: the launches of a replayed HIP graph (graphs.py) cannot be bracketed one by one
+            live[0].teacher_graph_off = h is not orig_call
 
     def footprint_px(r, scale, H, W):      # feature pixels an aligned RoI samples: the bilinear taps of its first and last sample
         x1, y1, x2, y2 = (r[:, i] * scale - 0.5 for i in (1, 2, 3, 4))

@@ -249,6 +249,8 @@ class TS_P2B_FCOS(BaseDetector):
         self.point_stamp = {}             # image key -> iteration of its last refinement (checkpoint merges keep the newest)
         self.teacher_stream = os.environ.get('PT_TEACHER_STREAM', '1') == '1'     # the teacher pass on a second HIP stream (_teacher_fork)
         self._side_stream = None
+        self._teacher_graph = None                 # graphs.GraphedNoGrad of _teacher_trunk (PT_TEACHER_GRAPH=0 turns it off)
+        self.teacher_graph_off = False
 
     # the reference keeps count/point dictionaries as plain attributes, so they are lost on resume
     # (SURVEY section 5); persisting them is a documented deviation.
@@ -383,10 +385,30 @@ class TS_P2B_FCOS(BaseDetector):
             img_list.append(img[i])
         return gt_points, img_list, img
 
+    def _teacher_trunk(self, img, stem):
+        """The fixed-shape part of the teacher pass: backbone, necks and the dense head's maps (no ground truth involved)."""
+        feat = self.extract_feat(img, self.teacher, stem=stem)
+        return self.teacher.bbox_head(feat)
+
+    def _teacher_graph_state(self):
+        """What a captured teacher trunk depends on besides its inputs (graphs.GraphedNoGrad): the teacher itself and its mode, the
+        registrations of the weight-plane cache, the persistent BatchNorm affine buffers, the fp16 groups the census demoted."""
+        t = self.teacher
+        buf = getattr(t, '_bn_affine_buf', None)
+        return (id(t), t.training, F._CONV_W.generation, buf[0].data_ptr() if buf is not None else 0,
+                tuple(sorted(PL.CENSUS.demoted)), torch.is_autocast_enabled(), getattr(t, 'backbone_autocast', None))
+
     def _teacher_pseudo(self, img, img_metas, img_list, gt_points, gt_labels, gt_bboxes, gt_bboxes_ignore, stem=None):
         with torch.no_grad():
-            feat = self.extract_feat(img, self.teacher, stem=stem)
-            outs = self.teacher.bbox_head(feat)
+            if self._teacher_graph is None:
+                from .graphs import GraphedNoGrad
+                self._teacher_graph = GraphedNoGrad(self._teacher_trunk, self._teacher_graph_state, name='the teacher pass')
+            if self.teacher_graph_off:    # (a measurement that brackets single launches with events)
+                outs = self._teacher_trunk(img, stem)
+            elif stem is not None:        # (the images are not read then: keep them out of the segment's static inputs)
+                outs = self._teacher_graph(None, stem)
+            else:
+                outs = self._teacher_graph(img, None)
             return self.teacher.bbox_head.get_pseudo_bbox(*outs, gt_points, gt_labels, gt_bboxes, self.filter_score,
                                                           img_metas, img_list, gt_bboxes_ignore)
 

@@ -706,6 +706,7 @@ class _ConvWeightPlanes:
         self.table = None        # (device uint8 tensor of pt_conv_weight_item, n_items, total_blocks)
         self.epoch = -1
         self._retired = []       # device tables replaced since the last full refresh: a launch on ANOTHER stream may still read them
+        self.generation = 0      # bumped by every (re-)registration: captured HIP graphs hold the planes' addresses (graphs.py)
 
     @staticmethod
     def ok(w):
@@ -766,6 +767,7 @@ class _ConvWeightPlanes:
             n = ((rows + 15) // 16) * ((k + 31) // 32) * 512
             sp = SplitPlanes(torch.empty((np_, n), dtype=torch.bfloat16, device=w.device), rows, k)
             e = self.ent[key] = [weakref.ref(w), w.data_ptr(), sp, scale, -1]
+            self.generation += 1
             if self.table is not None:
                 self._retired.append(self.table)                # (a refresh on the other stream may still be reading it)
             self.table = None

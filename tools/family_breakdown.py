@@ -69,6 +69,7 @@ def hook(fn, *a):
 
 
 hip.call = PF.hip.call = PPL.hip.call = hook
+model.teacher_graph_off = True          # (the launches of a replayed HIP graph cannot be bracketed one by one)
 N = 3
 for it in range(N):
     tr.step(data.batch(10 + it, 2))
