@@ -93,7 +93,10 @@ class BaseDetector(nn.Module):
                 log_vars[name] = sum(v.mean() for v in value)
             else:
                 raise TypeError(f'{name} is not a tensor or list of tensors')
-        loss = sum(v for k, v in OrderedDict.items(log_vars) if 'loss' in k)
+        terms = [v for k, v in OrderedDict.items(log_vars) if 'loss' in k]
+        # (python's sum() is one launch per term - it starts with `0 + term` -; one stack + one sum here.  The summation order of the
+        #  total differs from the reference's left-to-right one by rounding only; every term's gradient is 1 either way)
+        loss = terms[0] if len(terms) == 1 else torch.stack([t.reshape(()) for t in terms]).sum()
         log_vars['loss'] = loss
         return loss, log_vars
 
@@ -452,7 +455,8 @@ class TS_P2B_FCOS(BaseDetector):
 
     def _refined_points_distance(self, gt_points, gt_bboxes):
         real = self._cxcywh(torch.cat(gt_bboxes, dim=0))
-        return mean0(torch.sqrt((torch.cat(gt_points) - real[:, :2]) ** 2) / torch.sqrt((real[:, 2:4] / 2) ** 2))
+        # sqrt(x ** 2) of the reference (:291) is |x| exactly in binary floating point (no overflow at pixel scale)
+        return mean0((torch.cat(gt_points) - real[:, :2]).abs() / (real[:, 2:4] / 2).abs())
 
     def _student_inputs(self, img, extra=None):
         """The batch of ONE student pass, [clean images | extra (synthetic) images | strongly augmented images], and - when the

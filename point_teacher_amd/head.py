@@ -269,7 +269,7 @@ class TS_P2BFCOSHead(nn.Module):
         else:
             loss_bbox = diou_forward_masked(loss_mod, pred, tgt, pos, ctr_t, ctr_den)
         bce = TF.binary_cross_entropy_with_logits(ft.reshape(-1), ctr_t, reduction='none')
-        loss_ctr = self.loss_centerness.loss_weight * torch.where(pos, bce, torch.zeros_like(bce)).sum() / num_pos
+        loss_ctr = self.loss_centerness.loss_weight * torch.where(pos, bce, 0.0).sum() / num_pos
         if cls_pos is not None:
             return loss_bbox, loss_ctr, norms[2].clamp(min=1.0)
         return loss_bbox, loss_ctr
