@@ -32,6 +32,19 @@ def reduce_mean(tensor):
     return tensor
 
 
+_ZEROS = {}
+
+
+def zero_like_scalar(t):
+    """A cached 0-dim zero of t's dtype on t's device: `torch.where(mask, x, zero_like_scalar(x))` is ONE launch (a python scalar
+    there costs a `scalar_tensor` fill per call, `zeros_like(x)` a full-size one)."""
+    k = (t.device, t.dtype)
+    z = _ZEROS.get(k)
+    if z is None:
+        z = _ZEROS[k] = torch.zeros((), dtype=t.dtype, device=t.device)
+    return z
+
+
 def mean0(t):
     """t.mean() that is 0 (not NaN) for an empty tensor: a batch without any object logs zeros (the reference
     never sees one: its datasets filter empty images)."""

@@ -605,6 +605,19 @@ class TS_P2B_FCOS(BaseDetector):
             w.index_copy_(0, idx, take.to(w.dtype))
         return out[:n].contiguous(), w[:n].contiguous()
 
+    def _compact_alive_batch(self, boxes, alive, n):
+        """`_compact_alive` for a [B, N, 4] stack / [B, N] masks -> ([B, n, 4], [B, n]); row for row the same values."""
+        B, N = alive.shape
+        rank = torch.cumsum(alive.int(), 1) - 1
+        take = alive & (rank < n)
+        idx = torch.where(take, rank, n).long() + torch.arange(B, device=boxes.device).view(B, 1) * (n + 1)
+        out = boxes.new_zeros((B * (n + 1), boxes.shape[2]))
+        out[:, 2:4] = 8.0
+        w = boxes.new_zeros(B * (n + 1))
+        out.index_copy_(0, idx.reshape(-1), boxes.reshape(B * N, -1))
+        w.index_copy_(0, idx.reshape(-1), take.reshape(-1).to(w.dtype))
+        return out.view(B, n + 1, -1)[:, :n].contiguous(), w.view(B, n + 1)[:, :n].contiguous()
+
     def forward_mil_head_burn_in_step1(self, num_img, synthetic_bboxes, synthetic_alive, pseudo_bboxes, pseudo_points,
                                        pseudo_labels, gt_bboxes, img_metas, x_synthetic, x_ori, img):
         """:365-423.  Deviation (documented): when an image ends with zero synthetic boxes the
@@ -612,8 +625,13 @@ class TS_P2B_FCOS(BaseDetector):
         the keys are always present and such an image simply contributes zero-weight bags."""
         n = self.num_training_burninstep1
         losses = {}
-        syn_t, syn_w = zip(*[self._compact_alive(b, a, n) for b, a in zip(synthetic_bboxes, synthetic_alive)])
-        syn_t, syn_w = list(syn_t), list(syn_w)
+        if len({(b.shape, a.shape) for b, a in zip(synthetic_bboxes, synthetic_alive)}) == 1 and synthetic_bboxes[0].shape[0]:
+            # the fixed-size lists of the batch in one pass (the same per-image arithmetic on a [B, N] stack)
+            st, sw = self._compact_alive_batch(torch.stack(list(synthetic_bboxes)), torch.stack(list(synthetic_alive)), n)
+            syn_t, syn_w = list(st.unbind(0)), list(sw.unbind(0))
+        else:
+            syn_t, syn_w = zip(*[self._compact_alive(b, a, n) for b, a in zip(synthetic_bboxes, synthetic_alive)])
+            syn_t, syn_w = list(syn_t), list(syn_w)
         syn_p = [self._cxcywh(b)[:, :2] for b in syn_t]
         pb_t = [b[:n] for b in pseudo_bboxes]
         gb_t = [b[:n] for b in gt_bboxes]

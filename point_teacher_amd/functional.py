@@ -107,11 +107,25 @@ def upload_f32(values, device):
     return _ring.upload(np.asarray(values, dtype=np.float32), device, torch.float32)
 
 
+_OFFSETS = {}
+
+
 def make_offsets(counts, device):
-    """Host list of per-image counts -> (off int32 [B+1] on device, total)."""
+    """Host list of per-image counts -> (off int32 [B+1] on device, total).  A pure function of the counts: the device tensor is kept
+    per (counts, device, stream) - an iteration asks for the same offsets several times (the assigners, the pseudo boxes, the MIL
+    stages), and a data set cycles through the same count tuples; per STREAM, because an upload is ordered only on the stream that
+    issued it (the teacher pass runs beside the student's)."""
+    device = torch.device(device)
+    key = (tuple(int(c) for c in counts), device, torch.cuda.current_stream(device).stream_id if device.type == 'cuda' else 0)
+    hit = _OFFSETS.get(key)
+    if hit is not None:
+        return hit
     off = np.zeros(len(counts) + 1, np.int32)
     off[1:] = np.cumsum(counts)
-    return upload_i32(off, device), int(off[-1])
+    if len(_OFFSETS) >= 512:
+        _OFFSETS.clear()
+    hit = _OFFSETS[key] = (upload_i32(off, device), int(off[-1]))
+    return hit
 
 
 # ------------------------------------------------------------------ assigners --

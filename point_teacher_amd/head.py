@@ -13,7 +13,7 @@ import torch.nn.functional as TF
 
 from . import functional as F
 from . import planes as PL
-from .core import (bbox2roi, bbox_cxcywh_to_xyxy, bbox_overlaps, bbox_xyxy_to_cxcywh, distance2bbox, mean0, multi_apply,
+from .core import (bbox2roi, bbox_cxcywh_to_xyxy, bbox_overlaps, bbox_xyxy_to_cxcywh, distance2bbox, mean0, multi_apply, zero_like_scalar,
                    multiclass_nms, reduce_mean, reduce_mean_many)
 from .losses import diou_forward_masked
 from .nn_modules import ConvModule, Scale
@@ -269,7 +269,7 @@ class TS_P2BFCOSHead(nn.Module):
         else:
             loss_bbox = diou_forward_masked(loss_mod, pred, tgt, pos, ctr_t, ctr_den)
         bce = TF.binary_cross_entropy_with_logits(ft.reshape(-1), ctr_t, reduction='none')
-        loss_ctr = self.loss_centerness.loss_weight * torch.where(pos, bce, 0.0).sum() / num_pos
+        loss_ctr = self.loss_centerness.loss_weight * torch.where(pos, bce, zero_like_scalar(bce)).sum() / num_pos
         if cls_pos is not None:
             return loss_bbox, loss_ctr, norms[2].clamp(min=1.0)
         return loss_bbox, loss_ctr

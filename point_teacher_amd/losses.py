@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as TF
 
+from .core import zero_like_scalar
 from . import functional as F
 from .registry import LOSSES
 
@@ -101,20 +102,20 @@ class DN_DIoULoss(_IoULossBase):
         if base_mask is None:
             base = diou.mean()
         else:   # dense-with-mask form used by the head: mean over the rows that exist in the reference
-            base = torch.where(base_mask, diou, 0.0).sum() / base_mask.sum().clamp(min=1)   # (a scalar `other`: no fill launch)
+            base = torch.where(base_mask, diou, zero_like_scalar(diou)).sum() / base_mask.sum().clamp(min=1)   # (a cached 0-dim `other`: no fill launch)
         return (base + dnmin) / 2
 
     def forward_masked(self, pred, target, mask, weight, avg_factor):
         """Same value/gradients as forward(pred[mask], target[mask], weight[mask], avg_factor) but
         without the boolean gather (no host sync): rows outside `mask` contribute exactly 0."""
         elem = self._elem(pred, target, base_mask=mask)
-        elem = torch.where(mask, elem * weight, 0.0)
+        elem = torch.where(mask, elem * weight, zero_like_scalar(elem))
         return self.loss_weight * elem.sum() / avg_factor
 
 
 def diou_forward_masked(loss_mod, pred, target, mask, weight, avg_factor):
     elem = loss_mod._elem(pred, target)
-    elem = torch.where(mask, elem * weight, 0.0)
+    elem = torch.where(mask, elem * weight, zero_like_scalar(elem))
     return loss_mod.loss_weight * elem.sum() / avg_factor
 
 

@@ -30,7 +30,7 @@ def fine_proposals_from_cfg(pseudo_boxes, fine_proposal_cfg, img_meta):
     props, valid = F.fine_proposals(torch.cat(pseudo_boxes), ratios, shake, fine_proposal_cfg['min_scale'], (h, w))
     U = len(ratios) ** 2 * (1 + 4 * len(shake or []))
     sizes = [c * U for c in counts]
-    return _split(props, sizes), [v.bool().reshape(-1, 1) for v in _split(valid, sizes)]
+    return _split(props, sizes), [v.reshape(-1, 1) for v in _split(valid.bool(), sizes)]      # (one conversion for the batch)
 
 
 def MIL_gen_proposals_from_cfg(pseudo_points, pseudo_boxes, fine_proposal_cfg, gt_boxes, img_meta):

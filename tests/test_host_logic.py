@@ -287,3 +287,16 @@ def test_f16_census_policy_digest():
     assert c2._digest(host)[('towers', 'conv:y')]['saturated'] == 3 and not c2.demoted
     c.reset()
     assert not c.demoted and not c.history
+
+
+def test_compact_alive_batch_matches_per_image():
+    """detectors._compact_alive_batch (the batch's fixed-size synthetic lists in one pass) = _compact_alive image by image."""
+    from point_teacher_amd.detectors import TS_P2B_FCOS
+    g = torch.Generator().manual_seed(11)
+    for B, N, n in ((2, 37, 20), (3, 8, 20), (1, 50, 5)):
+        boxes = torch.rand(B, N, 4, generator=g) * 100
+        alive = torch.rand(B, N, generator=g) > 0.4
+        bt, bw = TS_P2B_FCOS._compact_alive_batch(None, boxes, alive, n)
+        for i in range(B):
+            t, w = TS_P2B_FCOS._compact_alive(None, boxes[i], alive[i], n)
+            assert torch.equal(bt[i], t) and torch.equal(bw[i], w)
