@@ -700,3 +700,97 @@ def test_fp16_operand_single_convolution_vs_fp64():
     for n, a, b in zip(('x', 'w', 'b'), got, want):
         err = float((a.double() - b.double()).abs().max() / b.double().abs().max())
         assert err < 5e-6, (n, err)
+
+
+def _h2_conv_ref(x, w, K):
+    import torch.nn.functional as TF
+    return TF.conv2d(x.double(), w.double(), None, 1, (K - 1) // 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,H,W,Cin,Cout,K', [(2, 40, 37, 256, 256, 3), (1, 700, 1, 2048, 256, 1), (3, 50, 50, 128, 384, 1)])
+def test_h2_every_tile_height_and_ring_depth_gives_the_same_product(B, H, W, Cin, Cout, K):
+    """fp16 x 2 operands through every instantiation of the k-loop: 64 ... 256-row tiles = the two-stage form (64 - 128 rows, many
+    workgroups), the deep-ring form of the same tiles (no more workgroups than CUs), the three / four-stage ring (160 rows and up),
+    with and without a k-split.  The ring changes WHEN a stage is loaded, never what is multiplied: every variant gives the bits of
+    the 64-row launch, and that launch is float64-close."""
+    from point_teacher_amd import functional as F, planes as PL
+    g = torch.Generator().manual_seed(Cin + K + H)
+    pad = (K - 1) // 2
+    x = torch.relu(torch.randn(B, Cin, H, W, generator=g)).to(DEV).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, K, K, generator=g) * (2.0 / (Cin * K * K)) ** 0.5).to(DEV).contiguous(memory_format=torch.channels_last)
+    xt = PL.split_nhwc(x, f16=True)[0]
+    wp = F._conv_weight_planes(w, False, None, 2)
+    ref = _h2_conv_ref(x, w, K)
+    base = None
+    for rows in (64, 96, 128, 160, 192, 224, 256):
+        _, y = PL.launch_conv(xt, B, H, W, Cin, wp, Cout, K, 1, pad, want_f32=True, tile_rows=rows, splits=1)
+        if base is None:
+            base = y
+            err = float((_nchw(y, B, H, W).double() - ref).abs().max() / ref.abs().max())
+            assert err < 2e-6, err
+        else:
+            assert torch.equal(y, base), rows
+    # a k-split: a different summation order (the chunks are added by the finish launch), not a different product
+    KB = K * K * Cin // 32
+    if KB >= 32:
+        _, ys = PL.launch_conv(xt, B, H, W, Cin, wp, Cout, K, 1, pad, want_f32=True, tile_rows=64, splits=2)
+        assert float((ys.double() - base.double()).abs().max() / base.double().abs().max()) < 1e-6
+    # the library's own plan: the workspace it asks for is the one the launch takes
+    _, ya = PL.launch_conv(xt, B, H, W, Cin, wp, Cout, K, 1, pad, want_f32=True)
+    assert float((ya.double() - base.double()).abs().max() / base.double().abs().max()) < 1e-6
+
+
+@pytest.mark.gpu
+def test_h2_many_workgroups_take_the_two_stage_form_and_agree():
+    """More tiles than CUs at 64 - 128 rows (the two-stage form with two workgroups per CU) against the 160-row ring on the same
+    operands: a layer2-sized 3x3."""
+    from point_teacher_amd import functional as F, planes as PL
+    g = torch.Generator().manual_seed(77)
+    B, H, W, Cin, Cout, K = 4, 100, 100, 128, 128, 3
+    x = torch.relu(torch.randn(B, Cin, H, W, generator=g)).to(DEV).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, K, K, generator=g) * 0.03).to(DEV).contiguous(memory_format=torch.channels_last)
+    xt = PL.split_nhwc(x, f16=True)[0]
+    wp = F._conv_weight_planes(w, False, None, 2)
+    ys = [PL.launch_conv(xt, B, H, W, Cin, wp, Cout, K, 1, 1, want_f32=True, tile_rows=r, splits=1)[1] for r in (64, 128, 160)]
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+    ref = _h2_conv_ref(x, w, K)
+    assert float((_nchw(ys[0], B, H, W).double() - ref).abs().max() / ref.abs().max()) < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,H,W,Cin,Cout,K', [(3, 64, 64, 128, 256, 1), (5000, 1, 1, 1024, 128, 1), (2, 30, 30, 128, 128, 3)])
+def test_weight_gradient_ring_and_sliced_reduction_vs_fp64(B, H, W, Cin, Cout, K):
+    """pt_conv_wgrad_bf16x6 on fp16 x 2 operands: the LDS ring, the flat row walk of B = rows x 1 x 1 pixels (the FC stacks) and the
+    sliced reduction of a small result behind many chunks (S >= 8) against float64; the chunk count only changes the summation order."""
+    from point_teacher_amd import hip, planes as PL
+    g = torch.Generator().manual_seed(B + Cin + K)
+    pad = (K - 1) // 2
+    x = torch.randn(B, Cin, H, W, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(B, Cout, H, W, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    xt, gt = PL.split_nhwc(x, f16=True)[0], PL.split_nhwc(gy, f16=True)[0]
+    want = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, K, K), gy.double(), padding=pad)
+    wb = gy.double().sum((0, 2, 3))
+    M = B * H * W
+    n = Cout * K * K * Cin
+    outs = []
+    for S in (1, 3, 8, 24):
+        if S * 4 * 32 > M:
+            continue
+        ws = torch.empty(S * (n + Cout), device=DEV)
+        dw, db = torch.empty(n, device=DEV), torch.empty(Cout, device=DEV)
+        d = hip.STRUCTS['pt_conv_wgrad_desc']()
+        d.B, d.Hs, d.Ws, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad = B, H, W, Cin, Cout, K, K, 1, pad
+        d.np, d.operand_f16, d.alpha = 3, 1, 1.0
+        d.alpha_dev, d.alpha_dev2 = PL.tail_ptr(gt), PL.tail_ptr(xt)
+        d.gy_planes, d.gy_plane_stride = PL._p16(gt), gt.shape[1]
+        d.x_planes, d.x_plane_stride = PL._p16(xt), xt.shape[1]
+        d.dw, d.dbias = hip.dptr(dw, 'float'), hip.dptr(db, 'float')
+        d.workspace, d.workspace_elems, d.splits = hip.dptr(ws, 'float'), ws.numel(), S
+        hip.call('pt_conv_wgrad_bf16x6', d)
+        got = dw.view(Cout, K, K, Cin).permute(0, 3, 1, 2).double()
+        err = float((got - want).abs().max() / want.abs().max())
+        eb = float((db.double() - wb).abs().max() / wb.abs().max())
+        assert err < 2e-6 and eb < 2e-6, (S, err, eb)
+        outs.append(got)
+    assert len(outs) >= 2
