@@ -506,6 +506,9 @@ def main():
                     products_per_algorithmic_product=round(ppp, 3),
                     scheme_ceiling_tflops=round(BF16_PEAK_TFLOPS / ppp, 1), fp32_equivalent_tflops=round(ex / ppp, 1),
                     fp32_equivalent_incl_split_tflops=round(incl, 1), fp32_mfma_peak_tflops=157.3,
+                    # `peak` is the dense MFMA figure at the 2.4 GHz boost clock; under this family's load the shader clock measured
+                    # 1.98 GHz (GRBM_GUI_ACTIVE / kernel time of FC1, profiles/r05/h2_pmc_fc1_ring.txt): a sustained peak of ~2 060
+                    sustained_clock_ghz=1.98, frac_of_sustained_peak=round(ex / (BF16_PEAK_TFLOPS * 1.98 / 2.4), 4),
                     ms_per_step=round(m['total_ms'] / steps_, 3), split_overhead_ms=round(m.get('split_ms', 0.0) / steps_, 3),
                     split_launches_per_step=round(m.get('split_calls', 0) / steps_, 1),
                     avg_launch_us=round(m['total_ms'] / m['calls'] * 1e3, 2), event_pair_overhead_us=round(event_overhead_us, 2),
