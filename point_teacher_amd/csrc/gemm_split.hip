@@ -531,10 +531,10 @@ __global__ void __launch_bounds__(256) conv_splitk_finish_kernel(int M, int N, C
 #endif
 // DEEP: the launch has no more workgroups than the chip has CUs (a k-split 3 x 3 of layer3 / layer4, 236 tiles of layer3's 3 x 3): a
 // second workgroup per CU - what the two-stage form leaves LDS for - never comes, so the ring takes the LDS instead.
-template <int MB, bool CONV, int NP, bool DEEP = false>
+template <int MB, bool CONV, int NP, bool DEEP = false, int BN = GBN>
 __host__ __device__ constexpr int n_stages() {
   if (!(CONV && NP == 2 && (MB >= PT_NSTAGE3_MIN_MB || DEEP))) return 2;
-  const int stage = (32 * MB + GBN) * NP * 64;
+  const int stage = (32 * MB + BN) * NP * 64;
   int n = (160 * 1024) / stage;                        // what the CU's LDS holds
   n = n > PT_NSTAGE_MAX ? PT_NSTAGE_MAX : n;
   return n < 2 ? 2 : n;
@@ -545,17 +545,21 @@ __device__ __forceinline__ void wait_vmcnt_barrier() {   // (the "memory" clobbe
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <int MB, bool CONV, int NP, bool DEEP = false>
+// BN = 64 (round 5): tile columns for results of <= 64 channels (the frozen layer1's 64-channel convolutions: with 128 columns half
+// of every B stage, MFMA and output tile was padding) - each of the four column waves takes ONE 16-column block instead of two.
+template <int MB, bool CONV, int NP, bool DEEP = false, int BN = GBN>
 __global__ void __launch_bounds__(GTHREADS)
     gemm_bf16x6_kernel(const uint16_t* __restrict__ Ap, const uint16_t* __restrict__ Bp, float* __restrict__ C,
                        const float* __restrict__ bias, const float* __restrict__ scale, int M, int N, int KB, long a_plane, long b_plane,
                        long ldc, int relu, int tiles_n, int n_tiles, ConvGeom cg, ConvEpi ep) {
-  constexpr int BM = 32 * MB, ROWS = BM + GBN;
+  static_assert(BN == 128 || BN == 64, "tile columns");
+  constexpr int NC = BN / 64;                          // 16-column blocks per wave (four column waves)
+  constexpr int BM = 32 * MB, ROWS = BM + BN;
   constexpr int STAGE = ROWS * NP * 64;                // bytes: A planes [NP][BM][64] then B planes [NP][128][64]
   constexpr int NI = ROWS * NP / 16;                   // staging instructions (one 1-KiB block each) per stage
   constexpr int NJ = (NI + 7) / 8;                     // per wave
   constexpr int PER = (NJ + MB - 1) / MB;              // staging instructions issued behind each row block's MFMAs
-  constexpr int NST = n_stages<MB, CONV, NP, DEEP>();  // stages of the LDS ring (2, or 3: two k-steps of loads in flight)
+  constexpr int NST = n_stages<MB, CONV, NP, DEEP, BN>();  // stages of the LDS ring (2, or 3: two k-steps of loads in flight)
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
   // XCD-aware block -> tile (bijective for any tile count): blocks b, b + 8, ... share an XCD and take consecutive tiles
@@ -573,7 +577,7 @@ __global__ void __launch_bounds__(GTHREADS)
     kb1 = min(KB, kb0 + ep.ks_per);
   }
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-  const int m0 = tm * BM, n0 = tn * GBN;
+  const int m0 = tm * BM, n0 = tn * BN;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // (the wave index as a SCALAR: see below)
 
   // Global source of every staging instruction this wave issues = a WAVE-UNIFORM 64-bit base (scalar registers, advanced by scalar
@@ -598,7 +602,7 @@ __global__ void __launch_bounds__(GTHREADS)
     if (i < NI) {
       const bool isA = i < NP * (BM / 16);
       const int i2 = isA ? i : i - NP * (BM / 16);
-      const int rbs = isA ? BM / 16 : GBN / 16;
+      const int rbs = isA ? BM / 16 : BN / 16;
       const int p = i2 / rbs, rbi = i2 - p * rbs;
       const int lim = isA ? RBA : RBN;
       int rb = (isA ? m0 : n0) / 16 + rbi;
@@ -699,15 +703,15 @@ __global__ void __launch_bounds__(GTHREADS)
   const int r16 = lane & 15, sq = lane >> 4;
   const int phys = (sq ^ slot_swz(r16)) * 16;
   const int a_off = (rg * MB * 16 + r16) * 64 + phys;                  // + p * BM * 64 + i * 16 * 64
-  const int b_off = NP * BM * 64 + (nb * 32 + r16) * 64 + phys;        // + p * 128 * 64 + c * 16 * 64
+  const int b_off = NP * BM * 64 + (nb * (BN / 4) + r16) * 64 + phys;  // + p * BN * 64 + c * 16 * 64
   // Two accumulators per output tile: the leading product a0 b0 and the five correction products (2^-8 ... 2^-16 of it).  Every
   // MFMA rounds the running fp32 sum once; kept apart, the long chain of corrections rounds at ITS magnitude and the leading
   // chain is 6x shorter - the error against float64 drops below the 32x32x16 form's (which sums two k-halves) again.
-  f32x4_t acc[MB][2], cor[MB][2];
+  f32x4_t acc[MB][NC], cor[MB][NC];
 #pragma unroll
   for (int i = 0; i < MB; ++i)
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[i][c][e] = cor[i][c][e] = 0.f;
 #pragma unroll
@@ -741,11 +745,11 @@ __global__ void __launch_bounds__(GTHREADS)
     const int nbuf = cur + NST - 1 >= NST ? cur - 1 : cur + NST - 1;      // slot of stage ks + NST - 1 = the slot stage ks - 1 left
     const unsigned char* st = smem + cur * STAGE;
     cur = cur + 1 == NST ? 0 : cur + 1;
-    bf16x8_t b[2][NP];
+    bf16x8_t b[NC][NP];
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
-      for (int p = 0; p < NP; ++p) b[c][p] = *reinterpret_cast<const bf16x8_t*>(st + b_off + p * GBN * 64 + c * 16 * 64);
+      for (int p = 0; p < NP; ++p) b[c][p] = *reinterpret_cast<const bf16x8_t*>(st + b_off + p * BN * 64 + c * 16 * 64);
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
       const unsigned char* ap = st + a_off + i * 16 * 64;
@@ -757,7 +761,7 @@ __global__ void __launch_bounds__(GTHREADS)
         for (int q = 0; q < PER; ++q) issue1(i * PER + q, nbuf);
       }
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
+      for (int c = 0; c < NC; ++c) {
         if constexpr (NP == 2) {                        // EXPERIMENT: fp32 as two fp16 terms, three products (a1 b1 ~ 2^-22 dropped)
           const f16x8_t a0 = __builtin_bit_cast(f16x8_t, a[0]), a1 = __builtin_bit_cast(f16x8_t, a[1]);
           const f16x8_t b0 = __builtin_bit_cast(f16x8_t, b[c][0]), b1 = __builtin_bit_cast(f16x8_t, b[c][1]);
@@ -787,34 +791,36 @@ __global__ void __launch_bounds__(GTHREADS)
     next_stage();
   }
   __syncthreads();            // everyone is done with the staging buffers: they become the output tile [BM][132] (fp32)
-  constexpr int TLD = GBN + 4;
+  constexpr int TLD = BN + 4;
   float* otile = reinterpret_cast<float*>(smem);
 #pragma unroll
   for (int i = 0; i < MB; ++i)
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int e = 0; e < 4; ++e)         // C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
-        otile[(rg * MB * 16 + i * 16 + sq * 4 + e) * TLD + nb * 32 + c * 16 + r16] = acc[i][c][e] + cor[i][c][e];
+        otile[(rg * MB * 16 + i * 16 + sq * 4 + e) * TLD + nb * (BN / 4) + c * 16 + r16] = acc[i][c][e] + cor[i][c][e];
   // CONV: the residual / mask chunks of this thread's MB items start their round trip now (the accumulators are in LDS: their
   // registers are free) and land behind the barrier and the tile reads
-  uint4 pr0[CONV ? MB : 1], pr1[CONV ? MB : 1], pr2[CONV ? MB : 1], prm[CONV ? MB : 1];
+  constexpr int C8 = BN / 8;                           // 8-column items per tile row
+  constexpr int NQ = (BM * C8 + GTHREADS - 1) / GTHREADS;   // items per thread (MB at 128 columns)
+  uint4 pr0[CONV ? NQ : 1], pr1[CONV ? NQ : 1], pr2[CONV ? NQ : 1], prm[CONV ? NQ : 1];
   const bool have_pre = CONV && ep.splits <= 1 && !ep.sc_stride && (ep.res_planes || ep.mask_planes);   // block-uniform
   if constexpr (CONV) {
 #pragma unroll
-    for (int q = 0; q < MB; ++q) {
-      const int idx = threadIdx.x + q * GTHREADS, row = idx >> 4, c8 = (idx & 15) << 3;
+    for (int q = 0; q < NQ; ++q) {
+      const int idx = threadIdx.x + q * GTHREADS, row = idx / C8, c8 = (idx % C8) << 3;
       EpiPre e;
       e.r0 = e.r1 = e.r2 = e.m = make_uint4(0, 0, 0, 0);
-      if (have_pre && m0 + row < M && n0 + c8 < N) epi_preload(e, m0 + row, n0 + c8, N, ep);
+      if (have_pre && idx < BM * C8 && m0 + row < M && n0 + c8 < N) epi_preload(e, m0 + row, n0 + c8, N, ep);
       pr0[q] = e.r0; pr1[q] = e.r1; pr2[q] = e.r2; prm[q] = e.m;
     }
   }
   __syncthreads();
   if constexpr (!CONV) {
     // whole rows of the tile leave as 16-byte stores: 32 lanes = one 512-byte row segment
-    for (int idx = threadIdx.x; idx < BM * (GBN / 4); idx += GTHREADS) {
-      const int row = idx >> 5, c4 = (idx & 31) << 2;
+    for (int idx = threadIdx.x; idx < BM * (BN / 4); idx += GTHREADS) {
+      const int row = idx / (BN / 4), c4 = (idx % (BN / 4)) << 2;
       const int grow = m0 + row, gcol = n0 + c4;
       if (grow >= M || gcol >= N) continue;
       float4 v = *reinterpret_cast<const float4*>(otile + row * TLD + c4);
@@ -838,13 +844,12 @@ __global__ void __launch_bounds__(GTHREADS)
     // 8 columns per thread (N % 8 == 0): 16 lanes = one 512-byte row segment of fp32, 256 bytes of every plane
     Census cs;
     cs.init();
-    static_assert(BM * (GBN / 8) == MB * GTHREADS, "MB items of 8 columns per thread");
 #pragma unroll
-    for (int q = 0; q < MB; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       const int idx = threadIdx.x + q * GTHREADS;
-      const int row = idx >> 4, c8 = (idx & 15) << 3;
+      const int row = idx / C8, c8 = (idx % C8) << 3;
       const int grow = m0 + row, gcol = n0 + c8;
-      if (grow >= M || gcol >= N) continue;
+      if (idx >= BM * C8 || grow >= M || gcol >= N) continue;
       const float4 va = *reinterpret_cast<const float4*>(otile + row * TLD + c8), vb = *reinterpret_cast<const float4*>(otile + row * TLD + c8 + 4);
       if (ep.splits > 1) {                              // a raw part of a split-k product
         float* dst = ep.part + ((long)sp * M + grow) * N + gcol;
@@ -860,7 +865,7 @@ __global__ void __launch_bounds__(GTHREADS)
     }
     if (ep.splits <= 1 && ep.census && ep.out_f16) cs.flush(ep.census, ep.census_mode);
     if (ep.splits <= 1 && ep.out_tail && m0 + BM >= M && n0 == 0 && threadIdx.x == 0) *ep.out_tail = ep.out_tail_src ? *ep.out_tail_src : 1.f;
-    if (ep.splits <= 1 && ep.out_planes && ep.zero_row >= 0 && m0 + BM >= M && threadIdx.x < 16 && n0 + threadIdx.x * 8 < N) {
+    if (ep.splits <= 1 && ep.out_planes && ep.zero_row >= 0 && m0 + BM >= M && (int)threadIdx.x < C8 && n0 + threadIdx.x * 8 < N) {
       uint16_t* d = ep.out_planes + (long)ep.zero_row * N + n0 + threadIdx.x * 8;
       const uint4 z = make_uint4(0, 0, 0, 0);
       for (int p = 0; p < (ep.out_f16 ? 2 : ep.np); ++p) *reinterpret_cast<uint4*>(d + p * ep.out_plane) = z;
@@ -868,22 +873,22 @@ __global__ void __launch_bounds__(GTHREADS)
   }
 }
 
-template <int MB, bool CONV, int NP, bool DEEP = false>
+template <int MB, bool CONV, int NP, bool DEEP = false, int BN = GBN>
 static int launch_gemm(const uint16_t* Ap, const uint16_t* Bp, float* C, const float* bias, const float* scale, int M, int N, int KB,
                        long a_plane, long b_plane, long ldc, int relu, ConvGeom cg, ConvEpi ep, hipStream_t s) {
   constexpr int BM = 32 * MB;
-  constexpr int STAGES = (BM + GBN) * NP * 64 * n_stages<MB, CONV, NP, DEEP>();
-  constexpr int LDS = STAGES > BM * (GBN + 4) * 4 ? STAGES : BM * (GBN + 4) * 4;      // the output tile [BM][132] fp32 reuses the stages
+  constexpr int STAGES = (BM + BN) * NP * 64 * n_stages<MB, CONV, NP, DEEP, BN>();
+  constexpr int LDS = STAGES > BM * (BN + 4) * 4 ? STAGES : BM * (BN + 4) * 4;        // the output tile [BM][BN + 4] fp32 reuses the stages
   static_assert(LDS <= 160 * 1024, "the stages must fit the CU's LDS");
-  const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, GBN);
+  const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
   const int items = tiles_m * tiles_n * ((CONV && ep.splits > 1) ? ep.splits : 1);
   static bool once = false;
   if (!once) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x6_kernel<MB, CONV, NP, DEEP>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x6_kernel<MB, CONV, NP, DEEP, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
     once = true;
   }
-  hipLaunchKernelGGL((gemm_bf16x6_kernel<MB, CONV, NP, DEEP>), dim3(items), dim3(GTHREADS), LDS, s, Ap, Bp, C, bias, scale, M, N, KB,
+  hipLaunchKernelGGL((gemm_bf16x6_kernel<MB, CONV, NP, DEEP, BN>), dim3(items), dim3(GTHREADS), LDS, s, Ap, Bp, C, bias, scale, M, N, KB,
                      a_plane, b_plane, ldc, relu, tiles_n, items, cg, ep);
   return 0;
 }
@@ -891,8 +896,15 @@ static int launch_gemm(const uint16_t* Ap, const uint16_t* Bp, float* C, const f
 template <bool CONV, int NP>
 static int launch_by_rows(int tile_rows, const uint16_t* Ap, const uint16_t* Bp, float* C, const float* bias, const float* scale, int M,
                           int N, int KB, long a_plane, long b_plane, long ldc, int relu, ConvGeom cg, ConvEpi ep, hipStream_t s,
-                          bool deep = false) {
+                          bool deep = false, bool narrow = false) {
   if constexpr (CONV && NP == 2) {
+    if (narrow) switch (tile_rows / 32) {                // results of <= 64 channels: 64-column tiles (128 / 64-row forms)
+        case 2: return deep ? launch_gemm<2, CONV, NP, true, 64>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s)
+                            : launch_gemm<2, CONV, NP, false, 64>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
+        case 4: return deep ? launch_gemm<4, CONV, NP, true, 64>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s)
+                            : launch_gemm<4, CONV, NP, false, 64>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
+        default: break;
+      }
     if (deep) switch (tile_rows / 32) {
         case 2: return launch_gemm<2, CONV, NP, true>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
         case 3: return launch_gemm<3, CONV, NP, true>(Ap, Bp, C, bias, scale, M, N, KB, a_plane, b_plane, ldc, relu, cg, ep, s);
@@ -1998,7 +2010,10 @@ static int conv_tile_rows(const pt_conv_desc* d, long M, int taps, int np) {
     if (tile_rows <= 0 || tile_rows > 128) tile_rows = M >= 32768 ? 128 : 64;
   } else if (tile_rows <= 0) {
     tile_rows = pt_gemm_bf16x6_tile_rows((int)M, d->Cout);
-    if (d->operand_f16 && taps == 1 && d->Cin <= 2048) {
+    if (d->operand_f16 && d->Cout <= 64) {
+      // the 64-column form (launch_by_rows, `narrow`) exists at 128 and 64 rows: three workgroups per CU at 128 rows
+      tile_rows = cdiv(M, 128) >= 2 * device_cus() ? 128 : 64;
+    } else if (d->operand_f16 && taps == 1 && d->Cin <= 2048) {
       // the trunk's 1 x 1 convolutions on 4-byte planes are bound by their bytes: the tallest tile of 128 / 96 / 64 rows that still
       // leaves >= 400 tiles (two to three workgroups per CU overlap one another's loads, products and stores; beyond 128 rows a CU
       // holds one workgroup less and the launch slows by a third) - measured per shape, tools/h2_tile_sweep.py, profiles/r05
@@ -2110,7 +2125,8 @@ extern "C" int pt_conv_bf16x6(const pt_conv_desc* d, void* stream) {
   // no more workgroups than CUs (and a k-loop long enough to fill a ring): the deep-ring form of the 64 .. 128-row tiles
   const bool deep = d->operand_f16 && (long)cdiv(M, tile_rows) * cdiv(d->Cout, GBN) * S <= device_cus() && cdiv(KB, S) >= 8;
   rc = d->operand_f16 ? launch_by_rows<true, 2>(tile_rows, d->x_planes, d->w_planes, nullptr, nullptr, nullptr, (int)M, d->Cout, KB,
-                                               d->x_plane_stride, d->w_plane_stride, d->Cout, 0, cg, ep, as_stream(stream), deep)
+                                               d->x_plane_stride, d->w_plane_stride, d->Cout, 0, cg, ep, as_stream(stream), deep,
+                                               d->Cout <= 64 && (tile_rows == 64 || tile_rows == 128))
      : np == 1 ? launch_by_rows<true, 1>(tile_rows, d->x_planes, d->w_planes, nullptr, nullptr, nullptr, (int)M, d->Cout, KB, d->x_plane_stride,
                                          d->w_plane_stride, d->Cout, 0, cg, ep, as_stream(stream))
                : launch_by_rows<true, 3>(tile_rows, d->x_planes, d->w_planes, nullptr, nullptr, nullptr, (int)M, d->Cout, KB, d->x_plane_stride,

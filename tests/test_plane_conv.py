@@ -794,3 +794,29 @@ def test_weight_gradient_ring_and_sliced_reduction_vs_fp64(B, H, W, Cin, Cout, K
         assert err < 2e-6 and eb < 2e-6, (S, err, eb)
         outs.append(got)
     assert len(outs) >= 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,H,W,Cin,Cout,K', [(2, 60, 50, 64, 64, 3), (3, 41, 37, 256, 64, 1), (6, 200, 200, 64, 64, 1)])
+def test_h2_64_column_tiles_vs_fp64_and_the_128_column_form(B, H, W, Cin, Cout, K):
+    """Results of <= 64 channels (the frozen layer1) take 64-column tiles at 64 / 128 rows: same products as the 128-column form of
+    another tile height (bit-identical), float64-close, epilogue with BatchNorm terms, identity planes and ReLU included."""
+    from point_teacher_amd import functional as F, planes as PL
+    g = torch.Generator().manual_seed(Cin + Cout + K + H)
+    pad = (K - 1) // 2
+    x = torch.relu(torch.randn(B, Cin, H, W, generator=g)).to(DEV).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, K, K, generator=g) * (2.0 / (Cin * K * K)) ** 0.5).to(DEV).contiguous(memory_format=torch.channels_last)
+    r = torch.relu(torch.randn(B, Cout, H, W, generator=g)).to(DEV).contiguous(memory_format=torch.channels_last)
+    sc, sh = (torch.rand(Cout, generator=g) + 0.5).to(DEV), torch.randn(Cout, generator=g).to(DEV)
+    xt, rt = PL.split_nhwc(x, f16=True)[0], PL.split_nhwc(r, f16=True)[0]
+    wp = F._conv_weight_planes(w, False, None, 2)
+    kw = dict(scale=sc, shift=sh, res_planes=rt, relu=True, want_planes=True, want_f32=True, splits=1)
+    outs = [PL.launch_conv(xt, B, H, W, Cin, wp, Cout, K, 1, pad, tile_rows=rows, **kw) for rows in (64, 128, 96, 160)]
+    for p, f in outs[1:]:                      # 64 / 128 rows: 64 columns; 96 / 160 rows: the 128-column kernels
+        n = (B * H * W + 1) * Cout               # (behind the zero row: the fp32 tail word, then uninitialised padding)
+        assert torch.equal(f, outs[0][1]) and torch.equal(p[:, :n], outs[0][0][:, :n]) and PL.tail_value(p) == PL.tail_value(outs[0][0])
+    ref = torch.relu(_h2_conv_ref(x, w, K) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1) + r.double())
+    err = float((_nchw(outs[0][1], B, H, W).double() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-6, err
+    pa, fa = PL.launch_conv(xt, B, H, W, Cin, wp, Cout, K, 1, pad, **dict(kw, splits=None))     # the library's own choice
+    assert torch.equal(fa, outs[0][1])
