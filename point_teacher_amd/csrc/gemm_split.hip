@@ -2018,8 +2018,22 @@ static int conv_tile_rows(const pt_conv_desc* d, long M, int taps, int np) {
       // leaves >= 400 tiles (two to three workgroups per CU overlap one another's loads, products and stores; beyond 128 rows a CU
       // holds one workgroup less and the launch slows by a third) - measured per shape, tools/h2_tile_sweep.py, profiles/r05
       tile_rows = 64;
-      if ((long)cdiv(M, 128) * cdiv(d->Cout, GBN) >= 400) tile_rows = 128;
-      else if ((long)cdiv(M, 96) * cdiv(d->Cout, GBN) >= 400) tile_rows = 96;
+      const long tn = cdiv(d->Cout, GBN);
+      if ((long)cdiv(M, 128) * tn >= 400) tile_rows = 128;
+      else {
+        // fewer tiles than that: if some height gives ONE deep-ring workgroup per CU (<= CUs tiles, >= 8 k-steps), take the height
+        // that keeps the most CUs busy (layer3's 1024 -> 256 at B = 6: 236 tiles of 128 rows, 33 us against 38 with 470 two-stage
+        // tiles of 64; layer4's 2048 -> 512: 236 tiles of 64 rows, 34 us against 50 with 120 of 128)
+        int best = 0;
+        long best_t = 0;
+        if (d->Cin / 32 >= 8)
+          for (int rows = 64; rows <= 128; rows += 32) {
+            const long t = (long)cdiv(M, rows) * tn;
+            if (t <= device_cus() && t >= best_t) { best_t = t; best = rows; }
+          }
+        if (best) tile_rows = best;
+        else if ((long)cdiv(M, 96) * tn >= 400) tile_rows = 96;
+      }
     } else if (taps * (d->Cin / 32) <= 4 && M >= 16384 && d->Cout >= 256) {
       // a reduce dimension of <= 128 with many rows (a Bottleneck's expanding 1 x 1, the input gradient of its reducing one) is bound
       // by its epilogue's HBM traffic: 64-row tiles fit two workgroups per CU, one's stores overlap the other's products
