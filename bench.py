@@ -285,8 +285,21 @@ def main():
             big = max([float(p.abs().max()) for p in pts if p.numel()] + [0.0])
             print(f'[trace] it {it} non-finite points {bad} max |coord| {big:.1f} ' + ' '.join(f'{k}={v:.4g}' for k, v in lv.items()), file=sys.stderr, flush=True)
 
+    def settle(tr_, model_, base):
+        """Un-timed extra steps (at most 6) until the teacher pass of this model replays as a HIP graph (graphs.py: the capture needs
+        a stable signature - every weight form registered - plus two eager calls; its one-off cost, tens of ms of graph
+        instantiation, must not fall into the timed region whatever --warmup says)."""
+        for k in range(6):
+            g = getattr(model_, '_teacher_graph', None)
+            if g is not None and (g.disabled or g.replays > 0):
+                break
+            if g is None and k >= 1:                   # a model without a graphed teacher pass
+                break
+            tr_.step(data.batch(base + k, args.batch))
+
     for it in range(args.warmup):
         traced(it, trainer.step(data.batch(it, args.batch)))
+    settle(trainer, model, 500)
     barrier()
 
     # HIP-event timing of the custom kernels (torch's current stream is the stream every libpt_hip kernel is launched on).
@@ -598,6 +611,7 @@ def main():
         _, model, trainer = fresh('step2')
         for it in range(max(args.warmup, 5)):
             trainer.step(data.batch(1000 + it, args.batch))
+        settle(trainer, model, 1500)
         dt2, roof2 = timed_with_family(trainer, 2000)
         f2 = iteration_flops('step2', cfg.to_dict()['model'], args.batch, args.size, args.objects)
         phase2 = dict(workload='phase 2 (MIL on, steady state): a fresh model in the stand-alone `--workload step2` state, same inputs',
@@ -615,6 +629,7 @@ def main():
         cfg2, model, trainer = fresh('step2', autocast=torch.bfloat16)
         for it in range(max(args.warmup, 5)):
             trainer.step(data.batch(3000 + it, args.batch))
+        settle(trainer, model, 3500)
         dt3, roof3 = timed_with_family(trainer, 4000)       # (fp32 heads: three products per product; bf16 trunk: one - the same kernels)
         f3 = iteration_flops('step2', cfg2.to_dict()['model'], args.batch, args.size, args.objects)
         configs2 = dict(workload=f'BASELINE configs[2]: aitodv2_point_teacher_{args.percent}% phase 2 (MIL on), bf16 backbone / FPN / PSAGG (autocast) + '
@@ -638,6 +653,7 @@ def main():
         _, model, trainer = fresh(args.workload)
         for it in range(max(args.warmup, 5)):
             trainer.step(data.batch(it, args.batch))
+        settle(trainer, model, 5500)
         dt4, roof4 = timed_with_family(trainer, args.warmup)
         strict = dict(workload='the default workload with bf16 x 3 operands and six MFMA products in EVERY layer (PT_F16_FC=0): 24 significant bits per operand',
                       value=round(args.steps * world / dt4, 4), unit='iters/s', ms_per_step=round(dt4 / args.steps * 1e3, 3), steps=args.steps,
