@@ -474,7 +474,13 @@ class TS_P2B_FCOS(BaseDetector):
             with torch.no_grad():                      # no trainable parameter, no input that requires a gradient
                 stem = self.student.backbone_stem(batch)
             B = img.shape[0]
-            t_stem = (_first_images(stem[0], B), [_first_images(o, B) for o in stem[1]])
+            memo = {}                                  # (the last frozen stage's output is both `stem[0]` and an entry of `stem[1]`)
+
+            def first(o):
+                if id(o) not in memo:
+                    memo[id(o)] = _first_images(o, B)
+                return memo[id(o)]
+            t_stem = (first(stem[0]), [first(o) for o in stem[1]])
         return (params, aug_imgs), parts, batch, stem, t_stem
 
     def _student_passes(self, img, extra=None, inputs=None):
