@@ -1936,6 +1936,15 @@ static int conv_check(const pt_conv_desc* d, const char* who) {
   return PT_OK;
 }
 
+static bool narrow_ok() {                                // PT_CONV_NARROW=0: results of <= 64 channels on the 128-column kernels (measurements)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("PT_CONV_NARROW");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v != 0;
+}
+
 static int device_cus() {                               // compute units of the current device (256 on MI355X)
   static int n = 0;
   if (n == 0) {
@@ -2140,7 +2149,7 @@ extern "C" int pt_conv_bf16x6(const pt_conv_desc* d, void* stream) {
   const bool deep = d->operand_f16 && (long)cdiv(M, tile_rows) * cdiv(d->Cout, GBN) * S <= device_cus() && cdiv(KB, S) >= 8;
   rc = d->operand_f16 ? launch_by_rows<true, 2>(tile_rows, d->x_planes, d->w_planes, nullptr, nullptr, nullptr, (int)M, d->Cout, KB,
                                                d->x_plane_stride, d->w_plane_stride, d->Cout, 0, cg, ep, as_stream(stream), deep,
-                                               d->Cout <= 64 && (tile_rows == 64 || tile_rows == 128))
+                                               narrow_ok() && d->Cout <= 64 && (tile_rows == 64 || tile_rows == 128))
      : np == 1 ? launch_by_rows<true, 1>(tile_rows, d->x_planes, d->w_planes, nullptr, nullptr, nullptr, (int)M, d->Cout, KB, d->x_plane_stride,
                                          d->w_plane_stride, d->Cout, 0, cg, ep, as_stream(stream))
                : launch_by_rows<true, 3>(tile_rows, d->x_planes, d->w_planes, nullptr, nullptr, nullptr, (int)M, d->Cout, KB, d->x_plane_stride,
