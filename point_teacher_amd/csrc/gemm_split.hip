@@ -533,6 +533,9 @@ __global__ void __launch_bounds__(256) conv_splitk_finish_kernel(int M, int N, C
 // second workgroup per CU - what the two-stage form leaves LDS for - never comes, so the ring takes the LDS instead.
 template <int MB, bool CONV, int NP, bool DEEP = false, int BN = GBN>
 __host__ __device__ constexpr int n_stages() {
+  // bf16 x 3 operands (the strict form and the census' fall-back): a 96 / 128-row tile's two stages already leave no room for a second
+  // workgroup per CU (2 x 86 / 98 KB > 160 KB), so a third stage is free there
+  if (CONV && NP == 3 && BN == GBN && (MB == 3 || MB == 4)) return 3;
   if (!(CONV && NP == 2 && (MB >= PT_NSTAGE3_MIN_MB || DEEP))) return 2;
   const int stage = (32 * MB + BN) * NP * 64;
   int n = (160 * 1024) / stage;                        // what the CU's LDS holds
