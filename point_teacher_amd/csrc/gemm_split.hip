@@ -536,6 +536,12 @@ __host__ __device__ constexpr int n_stages() {
   // bf16 x 3 operands (the strict form and the census' fall-back): a 96 / 128-row tile's two stages already leave no room for a second
   // workgroup per CU (2 x 86 / 98 KB > 160 KB), so a third stage is free there
   if (CONV && NP == 3 && BN == GBN && (MB == 3 || MB == 4)) return 3;
+  // one bf16 plane (the autocast trunk): the stages are small - as many as fit UNDER the fp32 output tile the workgroup needs anyway
+  // (128 rows: four 16 KB stages in 66 KB; 96 rows: three), so the ring costs no workgroup per CU
+  if (CONV && NP == 1 && BN == GBN) {
+    const int fit = (32 * MB * (GBN + 4) * 4) / ((32 * MB + GBN) * 64);
+    return fit > 4 ? 4 : fit < 2 ? 2 : fit;
+  }
   if (!(CONV && NP == 2 && (MB >= PT_NSTAGE3_MIN_MB || DEEP))) return 2;
   const int stage = (32 * MB + BN) * NP * 64;
   int n = (160 * 1024) / stage;                        // what the CU's LDS holds
