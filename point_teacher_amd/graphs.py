@@ -97,7 +97,8 @@ class GraphedNoGrad:
                     self._stream = torch.cuda.Stream()
                 self._stream.wait_stream(cur)
                 with torch.cuda.stream(self._stream):
-                    g.capture_begin()
+                    # thread_local: calls of OTHER threads (RCCL's watchdog of a multi-rank run) do not invalidate this capture
+                    g.capture_begin(capture_error_mode='thread_local')
                     try:
                         out = self.fn(*_rebuild(spec, static))
                     finally:
