@@ -426,33 +426,42 @@ class _RoIAlignPlanes(torch.autograd.Function):
     checks shape and dtype."""
 
     @staticmethod
-    def forward(ctx, feat, rois, scale, sampling_ratio, aligned, group, f16=False):
+    def forward(ctx, feat, rois, scale, sampling_ratio, aligned, group, f16=False, tail=0):
+        """`tail`: the last `tail` RoIs are not members of `group`-sized bags (the negative proposals appended to the bag rows):
+        they run as a launch of their own with runs of one - inside a bag launch 25 scattered negatives would be taken for one run
+        whose union spans the image, the slowest path of the backward (364 us for 5 000 + 400 rows against 104 + 45)."""
         B, C, H, W = feat.shape
         assert feat.dtype == f32 and feat.is_contiguous(memory_format=torch.channels_last)
         fbuf = feat.permute(0, 2, 3, 1)
         rois = _f(rois)
         K = rois.shape[0]
+        tail = int(tail) if 0 < int(tail) < K and int(group) > 1 else 0
         n = (K + 1) * C * 49
+        parts = [(0, K - tail, int(group))] + ([(K - tail, tail, 1)] if tail else [])
         if f16:     # H2 planes (value = h0 + h1, tail 1): the operand of the first FC layer's three-product kernels (F16_FC)
             t = torch.empty((2, n + 8), dtype=torch.float16, device=feat.device)
-            hip.call('pt_roi_align_fwd_planes_f16', fbuf, rois, B, C, H, W, K, float(scale), sampling_ratio, int(aligned), int(group),
-                     t.data_ptr(), n + 8)
+            for k0, kn, g in parts:       # (each launch ends its rows with the zero row and the scale word: the last one's stay)
+                hip.call('pt_roi_align_fwd_planes_f16', fbuf, rois[k0:k0 + kn], B, C, H, W, kn, float(scale), sampling_ratio, int(aligned), g,
+                         t.data_ptr() + k0 * C * 49 * 2, n + 8)
         else:
             t = torch.empty((3, n), dtype=torch.bfloat16, device=feat.device)
-            hip.call('pt_roi_align_fwd_planes', fbuf, rois, B, C, H, W, K, float(scale), sampling_ratio, int(aligned), int(group), t, n)
+            for k0, kn, g in parts:
+                hip.call('pt_roi_align_fwd_planes', fbuf, rois[k0:k0 + kn], B, C, H, W, kn, float(scale), sampling_ratio, int(aligned), g,
+                         t.data_ptr() + k0 * C * 49 * 2, n)
         ctx.save_for_backward(rois)
-        ctx.cfg = (B, C, H, W, float(scale), sampling_ratio, int(aligned), int(group))
+        ctx.cfg = (B, C, H, W, float(scale), sampling_ratio, int(aligned), parts)
         return t
 
     @staticmethod
     def backward(ctx, carrier):
         rois, = ctx.saved_tensors
-        B, C, H, W, scale, sr, aligned, group = ctx.cfg
+        B, C, H, W, scale, sr, aligned, parts = ctx.cfg
         K = rois.shape[0]
         g = carrier.contiguous().view(-1).view(f32)[:K * C * 49]
         gbuf = torch.zeros((B, H, W, C), dtype=f32, device=g.device)
-        hip.call('pt_roi_align_bwd', g, rois, B, C, H, W, K, 7, scale, sr, aligned, 1, group, gbuf)
-        return gbuf.permute(0, 3, 1, 2), None, None, None, None, None, None
+        for k0, kn, grp in parts:
+            hip.call('pt_roi_align_bwd', g[k0 * C * 49:(k0 + kn) * C * 49], rois[k0:k0 + kn], B, C, H, W, kn, 7, scale, sr, aligned, 1, grp, gbuf)
+        return gbuf.permute(0, 3, 1, 2), None, None, None, None, None, None, None
 
 
 def roi_align_planes_ok(feat, rois, output_size):
@@ -475,9 +484,10 @@ F16_CHAIN = os.environ.get('PT_F16_CHAIN', '1') != '0'                   # one g
 F16_WEIGHT_SCALE = hip.header_constant('PT_F16_WEIGHT_SCALE')        # weight planes with np = 2 hold 16 w (include/pt_hip.h)
 
 
-def roi_align_planes(feat, rois, spatial_scale=1.0, sampling_ratio=0, aligned=True, group=1, f16=False):
-    """-> bf16 [3, (K + 1) * C * 49]: row-major split planes of roi_align(...).flatten(1) (+ a zero row); f16: fp16 [2, ...]."""
-    return _RoIAlignPlanes.apply(feat, rois, spatial_scale, int(sampling_ratio), bool(aligned), int(group), bool(f16))
+def roi_align_planes(feat, rois, spatial_scale=1.0, sampling_ratio=0, aligned=True, group=1, f16=False, tail=0):
+    """-> bf16 [3, (K + 1) * C * 49]: row-major split planes of roi_align(...).flatten(1) (+ a zero row); f16: fp16 [2, ...].
+    `tail`: trailing RoIs outside the `group`-sized bags (see _RoIAlignPlanes)."""
+    return _RoIAlignPlanes.apply(feat, rois, spatial_scale, int(sampling_ratio), bool(aligned), int(group), bool(f16), int(tail))
 
 
 def roi_align(feat, rois, output_size=7, spatial_scale=1.0, sampling_ratio=0, aligned=True, group=1):

@@ -351,13 +351,13 @@ class TS_P2BFCOSHead(nn.Module):
                 x = TF.relu(fc(x), inplace=True)
         return x
 
-    def _roi_feats(self, x, rois, group=1):
+    def _roi_feats(self, x, rois, group=1, tail=0):
         """RoI blocks [K, C * 49] for an FC stack: as split planes straight from RoIAlign when the stack runs on the plane kernels
         (K >= SPLIT_GEMM_MIN_ROWS on the MI355X), else the flattened fp32 block."""
         ext = self.bbox_roi_extractor
         if (_PLANE_FC and rois.shape[0] >= self.SPLIT_GEMM_MIN_ROWS and ext.num_inputs == 1 and type(ext).__name__ == 'SingleRoIExtractor'
                 and x[0].is_cuda and not torch.is_autocast_enabled()):
-            f = ext(x[:1], rois, group=group, planes=True)
+            f = ext(x[:1], rois, group=group, planes=True, tail=tail)
             return f if isinstance(f, PL.PlaneAct) else f.flatten(1)
         return ext(x[:ext.num_inputs], rois, group=group).flatten(1)
 
@@ -421,7 +421,8 @@ class TS_P2BFCOSHead(nn.Module):
         K = rois.shape[0]
         if neg_rois is not None:
             rois = torch.cat([rois, neg_rois], 0)
-        feats = self._fc_stack(self.shared_fcs_bag[stage], self._roi_feats(x, rois, group=self._bag_group(U1, U2)))
+        feats = self._fc_stack(self.shared_fcs_bag[stage], self._roi_feats(x, rois, group=self._bag_group(U1, U2),
+                                                                            tail=rois.shape[0] - K))
         cls = self.fc_cls[stage](feats)
         bbox_results['cls_score'] = cls[:K].view(num_gt, U1, U2, self.num_classes)
         bbox_results['ins_score'] = self.fc_ins[stage](feats[:K]).view(num_gt, U1, U2, self.num_classes)

@@ -688,11 +688,11 @@ class RoIAlign(nn.Module):
         self.output_size = output_size if isinstance(output_size, int) else output_size[0]
         self.spatial_scale, self.sampling_ratio, self.aligned = float(spatial_scale), int(sampling_ratio), aligned
 
-    def forward(self, input, rois, group=1, planes=False):
+    def forward(self, input, rois, group=1, planes=False, tail=0):
         """planes=True: the result as planes.PlaneAct [1, K, 1, C * 49] - the split planes of `.flatten(1)` - when the kernel takes the
         shape (functional.roi_align_planes_ok); the caller feeds it to planes.linear."""
         if planes and _PLANE_TRUNK and rois.shape[0] > 0 and F.roi_align_planes_ok(input, rois, self.output_size):
-            t = F.roi_align_planes(input, rois, self.spatial_scale, self.sampling_ratio, self.aligned, group, f16=PL.use_f16('fc'))
+            t = F.roi_align_planes(input, rois, self.spatial_scale, self.sampling_ratio, self.aligned, group, f16=PL.use_f16('fc'), tail=tail)
             return PL.PlaneAct(t, 1, rois.shape[0], 1, input.shape[1] * self.output_size ** 2, False, gcarrier=True)
         return F.roi_align(input, rois, self.output_size, self.spatial_scale, self.sampling_ratio, self.aligned, group)
 
@@ -720,7 +720,7 @@ class SingleRoIExtractor(nn.Module):
         lvls = torch.floor(torch.log2(scale / self.finest_scale + 1e-6))
         return lvls.clamp(min=0, max=num_levels - 1).long()
 
-    def forward(self, feats, rois, roi_scale_factor=None, group=1, planes=False):
+    def forward(self, feats, rois, roi_scale_factor=None, group=1, planes=False, tail=0):
         """`group`: how many consecutive RoIs overlap (one MIL bag) - a locality hint for the backward.
         `planes`: a single-level extractor may return planes.PlaneAct (see RoIAlign.forward)."""
         assert roi_scale_factor is None
@@ -729,7 +729,7 @@ class SingleRoIExtractor(nn.Module):
                 o = self.roi_layers[0].output_size
                 return feats[0].new_zeros(0, self.out_channels, o, o)
             if planes:
-                return self.roi_layers[0](feats[0], rois, group, planes=True)
+                return self.roi_layers[0](feats[0], rois, group, planes=True, tail=tail)
             return self.roi_layers[0](feats[0], rois, group)
         out_size = self.roi_layers[0].output_size
         roi_feats = feats[0].new_zeros(rois.size(0), self.out_channels, out_size, out_size)
